@@ -1,0 +1,271 @@
+"""Generate the golden vectors that pin oracle/ against the REAL reference.
+
+Run ONLY in the build container (needs /root/reference):   python tests/golden/make_golden.py
+It imports the reference's own modules (third-party packages that are absent offline are stubbed:
+pytorch_lightning -> nn.Module base with save_hyperparameters, torchaudio/numba/soxbindings/
+pymixconsole -> minimal stand-ins that carry NO arithmetic of the hot path), feeds them seeded
+inputs + key-hashed synthetic weights, and stores inputs/outputs as small .npz fixtures next to
+this script.  Nothing from the reference is copied; the fixtures are data only.
+
+Fixtures:
+  nets_tiny.npz     tiny FXencoder / TCNModel configs, full tensors (even-kernel asymmetric pad,
+                    strides, grouped res of block 0, list-cond branch)
+  nets_full.npz     default configs.yaml nets on x[1,2,131072]: embedding[2048], TCN output on a
+                    strided index set + fp64 checksums, per-block probes
+  bookkeeping.npz   batchwise_segmentization tables for edge-case lengths
+  fx.npz            compressor / imager / gain / haas / panner / rms-normalise vectors
+"""
+import os
+import sys
+import types
+import inspect
+
+import numpy as np
+import torch
+import torch.nn as nn
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from music_mixing_style_transfer_amd.utils import synth  # noqa: E402
+
+
+# ------------------------------------------------------------------ stubs for absent third parties
+def install_stubs():
+    pl = types.ModuleType("pytorch_lightning")
+
+    class _HP(dict):
+        __getattr__ = dict.__getitem__
+
+    class LightningModule(nn.Module):
+        def save_hyperparameters(self):
+            frame = inspect.currentframe().f_back
+            args, _, _, values = inspect.getargvalues(frame)
+            self.hparams = _HP({a: values[a] for a in args if a != "self"})
+
+    pl.LightningModule = LightningModule
+    sys.modules["pytorch_lightning"] = pl
+    sys.modules["torchaudio"] = types.ModuleType("torchaudio")
+
+    nb = types.ModuleType("numba")
+    nb.jit = lambda *a, **k: (lambda f: f)
+    sys.modules["numba"] = nb
+    sys.modules["soxbindings"] = types.ModuleType("soxbindings")
+
+    pymc = types.ModuleType("pymixconsole")
+    par = types.ModuleType("pymixconsole.parameter")
+    plist = types.ModuleType("pymixconsole.parameter_list")
+    proc = types.ModuleType("pymixconsole.processor")
+
+    class Parameter:
+        def __init__(self, name, value, kind, **kw):
+            self.name, self.value, self.kind = name, value, kind
+            self.__dict__.update(kw)
+
+    class ParameterList:
+        def add(self, p):
+            setattr(self, p.name, p)
+
+    class Processor:
+        pass
+
+    par.Parameter, plist.ParameterList, proc.Processor = Parameter, ParameterList, Processor
+    pymc.parameter, pymc.parameter_list, pymc.processor = par, plist, proc
+    sys.modules.update({"pymixconsole": pymc, "pymixconsole.parameter": par,
+                        "pymixconsole.parameter_list": plist, "pymixconsole.processor": proc})
+    sys.modules["data_loader"] = types.ModuleType("data_loader")
+
+
+def probe_index(length, n=1024):
+    idx = np.unique(np.concatenate([np.arange(0, 64), np.arange(length - 64, length),
+                                    np.linspace(0, length - 1, n).astype(np.int64)]))
+    return idx
+
+
+def main():
+    install_stubs()
+    sys.path.insert(0, os.path.join(REF, "mixing_style_transfer"))
+    from networks.architectures import FXencoder, TCNModel  # the reference
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+
+    # ---------------------------------------------------------------- tiny nets (full tensors)
+    out = {}
+    tiny_enc_cfg = {"channels": [4, 8, 8], "kernels": [5, 4, 3], "strides": [2, 2, 1], "dilation": [1, 1, 1],
+                    "bias": True, "norm": "batch", "conv_block": "res", "activation": "relu"}
+    sd = synth.fxencoder_state_dict(tiny_enc_cfg, seed=3)
+    enc = FXencoder({k: (list(v) if isinstance(v, list) else v) for k, v in tiny_enc_cfg.items()})
+    enc.load_state_dict(sd)
+    enc.eval()
+    x = synth.synth_audio((3, 2, 203), seed=11)
+    with torch.no_grad():
+        e = enc(x)
+    out["tiny_enc_x"], out["tiny_enc_out"] = x.numpy(), e.numpy()
+    out["tiny_enc_keys"] = np.array(list(enc.state_dict().keys()))
+
+    tk = dict(nblocks=4, kernel_size=5, channel_width=8, cond_dim=16)
+    tsd = synth.tcn_state_dict(ninputs=2, noutputs=2, seed=5, **tk)
+    tcn = TCNModel(nparams=16, ninputs=2, noutputs=2, nblocks=4, dilation_growth=2, kernel_size=5,
+                   channel_width=8, stack_size=15, cond_dim=16, causal=False)
+    tcn.load_state_dict(tsd)
+    tcn.eval()
+    xt = synth.synth_audio((2, 2, 157), seed=12)
+    cond = synth.synth_audio((1, 16), seed=13)
+    condB = synth.synth_audio((2, 16), seed=14)
+    condL = [synth.synth_audio((1, 16), seed=20 + i) for i in range(4)]
+    with torch.no_grad():
+        out["tiny_tcn_out"] = tcn(xt, cond).numpy()
+        out["tiny_tcn_out_condB"] = tcn(xt, condB).numpy()
+        out["tiny_tcn_out_condL"] = tcn(xt, condL).numpy()
+    out["tiny_tcn_x"], out["tiny_tcn_cond"], out["tiny_tcn_condB"] = xt.numpy(), cond.numpy(), condB.numpy()
+    out["tiny_tcn_condL"] = np.stack([c.numpy() for c in condL])
+    out["tiny_tcn_rf"] = np.int64(tcn.compute_receptive_field())
+    out["tiny_tcn_keys"] = np.array(list(tcn.state_dict().keys()))
+    np.savez_compressed(os.path.join(HERE, "nets_tiny.npz"), **out)
+
+    # ---------------------------------------------------------------- full default nets
+    with open(os.path.join(REF, "inference", "configs.yaml")) as f:
+        cfgs = yaml.full_load(f)
+    enc_cfg = cfgs["Effects_Encoder"]["default"]
+    tcn_cfg = cfgs["TCN"]["default"]
+    full = {}
+    esd = synth.fxencoder_state_dict(enc_cfg, seed=0)
+    enc = FXencoder({k: (list(v) if isinstance(v, list) else v) for k, v in enc_cfg.items()})
+    enc.load_state_dict(esd)
+    enc.eval()
+    L = 131072
+    x = synth.synth_audio((1, 2, L), seed=0)
+    probes = {}
+    hooks = []
+    for i, blk in enumerate(enc.encoder):
+        hooks.append(blk.register_forward_hook(lambda m, a, o, i=i: probes.__setitem__(i, o.detach())))
+    with torch.no_grad():
+        emb = enc(x)
+    for h in hooks:
+        h.remove()
+    full["enc_emb"] = emb.numpy()
+    for i, o in probes.items():
+        full[f"enc_blk{i}_sum"] = np.float64(o.double().sum().item())
+        full[f"enc_blk{i}_abs"] = np.float64(o.double().abs().sum().item())
+        full[f"enc_blk{i}_shape"] = np.array(o.shape)
+    full["enc_nkeys"] = np.int64(len(enc.state_dict()))
+    full["enc_nparams"] = np.int64(sum(p.numel() for p in enc.parameters()))
+
+    tsd = synth.tcn_state_dict(seed=0)
+    tcn = TCNModel(nparams=tcn_cfg["condition_dimension"], ninputs=2, noutputs=2, nblocks=tcn_cfg["nblocks"],
+                   dilation_growth=tcn_cfg["dilation_growth"], kernel_size=tcn_cfg["kernel_size"],
+                   channel_width=tcn_cfg["channel_width"], stack_size=tcn_cfg["stack_size"],
+                   cond_dim=tcn_cfg["condition_dimension"], causal=tcn_cfg["causal"])
+    tcn.load_state_dict(tsd)
+    tcn.eval()
+    probes = {}
+    hooks = []
+    for i, blk in enumerate(tcn.blocks):
+        hooks.append(blk.register_forward_hook(lambda m, a, o, i=i: probes.__setitem__(i, o.detach().clone())))
+    with torch.no_grad():
+        y = tcn(x, emb)
+    for h in hooks:
+        h.remove()
+    idx = probe_index(L)
+    full["probe_idx"] = idx
+    full["tcn_out_probe"] = y[0][:, idx].numpy()
+    full["tcn_out_sum"] = np.float64(y.double().sum().item())
+    full["tcn_out_abs"] = np.float64(y.double().abs().sum().item())
+    full["tcn_out_clamped"] = np.int64((y.abs() >= 1.0).sum().item())
+    for i, o in probes.items():
+        full[f"tcn_blk{i}_probe"] = o[0][[0, 17, 64, 127]][:, idx].numpy()
+        full[f"tcn_blk{i}_abs"] = np.float64(o.double().abs().sum().item())
+    full["tcn_rf"] = np.int64(tcn.compute_receptive_field())
+    full["tcn_nkeys"] = np.int64(len(tcn.state_dict()))
+    full["tcn_nparams"] = np.int64(sum(p.numel() for p in tcn.parameters()))
+    np.savez_compressed(os.path.join(HERE, "nets_full.npz"), **full)
+
+    # ---------------------------------------------------------------- bookkeeping
+    sys.path.insert(0, os.path.join(REF, "inference"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_style_transfer", os.path.join(REF, "inference", "style_transfer.py"))
+    st = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(st)
+    seg_fn = st.Mixing_Style_Transfer_Inference.batchwise_segmentization
+    rows = []
+    examples = {}
+    for seg in (8, 12):
+        for bs in (1, 3, 4):
+            for Lx in (seg, seg + 1, 2 * seg, 2 * seg + 1, 5 * seg - 1, 7 * seg, 61):
+                fake = types.SimpleNamespace(args=types.SimpleNamespace(segment_length=seg, batch_size=bs))
+                song = torch.arange(2 * Lx, dtype=torch.float32).reshape(2, Lx) + 1.0
+                batches = seg_fn(fake, song, "song", seg, False)
+                n_seg = sum(b.shape[0] for b in batches)
+                rows.append([Lx, seg, bs, n_seg * seg - Lx, n_seg, len(batches), batches[-1].shape[0]])
+                if seg == 8 and bs == 3:
+                    cat = torch.cat([torch.cat(torch.unbind(b, 0), -1) for b in batches], -1)
+                    examples[f"cat_L{Lx}"] = cat.numpy()
+    bk = {"table": np.array(rows, dtype=np.int64),
+          "table_cols": np.array(["L", "seg", "batch", "pad", "n_seg", "n_batches", "last_batch"])}
+    bk.update(examples)
+    # the duration assert (style_transfer.py:275) compares with args.segment_length
+    fake = types.SimpleNamespace(args=types.SimpleNamespace(segment_length=16, batch_size=2))
+    try:
+        seg_fn(fake, torch.zeros(2, 10), "s", 4, False)
+        bk["assert_short"] = np.int64(0)
+    except AssertionError:
+        bk["assert_short"] = np.int64(1)
+    np.savez_compressed(os.path.join(HERE, "bookkeeping.npz"), **bk)
+
+    # ---------------------------------------------------------------- FX processors
+    sys.path.insert(0, os.path.join(REF, "mixing_style_transfer", "mixing_manipulator"))
+    spec = importlib.util.spec_from_file_location(
+        "ref_fx", os.path.join(REF, "mixing_style_transfer", "mixing_manipulator", "common_audioeffects.py"))
+    fxm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fxm)
+    fx = {}
+    Lf = 4096
+    xs = (0.25 * synth.synth_music(2, Lf, seed=4).numpy().T
+          + 0.05 * synth.synth_audio((Lf, 2), seed=5).numpy()).astype(np.float32)
+    xs[100:110] = 0.0            # exercises |x| < 1e-6 -> -120 dB
+    xs[200:204] = 5e-7
+    fx["x"] = xs
+    comp_cases = [(-20.0, 2.0, 100.0, 4.0), (-35.0, 1.0, 50.0, 40.0), (-10.0, 20.0, 500.0, 0.5),
+                  (-25.0, 5.0, 200.0, 1.0)]
+    fx["comp_cases"] = np.array(comp_cases)
+    for i, (th, at, rt, ra) in enumerate(comp_cases):
+        c = fxm.Compressor(sample_rate=44100)
+        c.parameters.threshold.value = th
+        c.parameters.attack_time.value = at
+        c.parameters.release_time.value = rt
+        c.parameters.ratio.value = ra
+        fx[f"comp_f32in_{i}"] = c.process(xs.copy())
+        c.update()
+        fx[f"comp_f64in_{i}"] = c.process(xs.astype(np.float64))
+    for i, bal in enumerate((0.0, 0.4567, 1.0, 1.5, 2.0)):
+        im = fxm.MidSideImager()
+        im.parameters.bal.value = bal
+        fx[f"imager_{i}"] = im.process(xs.copy())
+    fx["imager_bals"] = np.array((0.0, 0.4567, 1.0, 1.5, 2.0))
+    for i, (g, inv) in enumerate(((3.0, False), (-6.0, True))):
+        gp = fxm.Gain()
+        gp.parameters.gain.value = g
+        gp.parameters.invert.value = inv
+        fx[f"gain_{i}"] = gp.process(xs.copy())
+    fx["haas_left"] = fxm.haas_process(xs.copy(), 37, 0.35, "left")
+    fx["haas_right"] = fxm.haas_process(xs.copy(), -12, 0.5, "right")
+    for i, (pan, law) in enumerate(((0.3, "-4.5dB"), (0.8, "linear"), (0.5, "constant_power"))):
+        pn = fxm.Panner()
+        pn.parameters.pan.value = pan
+        pn.parameters.pan_law.value = law
+        pn.update()
+        fx[f"pan_gains_{i}"] = np.array(pn.gains)
+    chain = fxm.AugmentationChain()
+    gp = fxm.Gain()
+    gp.parameters.gain.value = 5.0
+    fx["rms_norm"] = chain.apply_processor(xs.copy(), gp, True)
+    np.savez_compressed(os.path.join(HERE, "fx.npz"), **fx)
+    for f in ("nets_tiny.npz", "nets_full.npz", "bookkeeping.npz", "fx.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()
