@@ -68,7 +68,7 @@ def fxencoder_state_dict(cfg, seed=0, gain=1.0):
 
 
 def tcn_state_dict(nblocks=14, ninputs=2, noutputs=2, channel_width=128, kernel_size=15,
-                   cond_dim=2048, seed=0, gain=0.85, film_gain=0.2, out_gain=0.25):
+                   cond_dim=2048, seed=0, gain=0.85, film_gain=0.2, out_gain=0.3):
     sd = OrderedDict()
     for n in range(nblocks):
         cin = ninputs if n == 0 else channel_width
