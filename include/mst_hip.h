@@ -1,0 +1,166 @@
+/* mst_hip.h - C ABI of libmst_hip.so: the MI355X (gfx950) hot path of the music-mixing-style-transfer
+ * inference pipeline (FXencoder -> mean FX embedding -> FiLM-conditioned TCN "MixFXcloner", plus the
+ * FX-manipulator processors).
+ *
+ * The reference (jhtonyKoo/music_mixing_style_transfer) is pure Python and has no native boundary; its
+ * boundary for this path is the torch module API `from networks import FXencoder, TCNModel`
+ * (inference/style_transfer.py:22,47-57,149,161).  The entry points below are what sits directly under
+ * those modules' forward() in this build - each one names the reference code it replaces.  A binding
+ * only needs raw pointers, sizes and a hipStream_t: there are no torch types in any signature.
+ *
+ * Conventions
+ *   - every function returns MST_OK (0) or a negative MstStatus; nothing throws or exits;
+ *     mst_last_error() returns a thread-local human readable message for the last failure.
+ *   - "host" pointers are CPU memory in the REFERENCE's own tensor layouts (state_dict layouts);
+ *     "dev" pointers are device memory owned by the caller.  The library owns only the opaque handle,
+ *     its packed/folded weights and the FiLM factor table; forward() allocates nothing - the caller
+ *     passes a workspace of mst_*_workspace_bytes().
+ *   - all kernels are enqueued on the caller's stream and return immediately.
+ *   - a handle belongs to one device and is not thread-safe (one stream at a time).
+ */
+#ifndef MST_HIP_H
+#define MST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    MST_OK = 0,
+    MST_ERR_ARG = -1,          /* bad argument (null pointer, non-positive size, ...) */
+    MST_ERR_UNSUPPORTED = -2,  /* configuration outside what the gfx950 kernels implement */
+    MST_ERR_HIP = -3,          /* HIP runtime error (see mst_last_error) */
+    MST_ERR_STATE = -4,        /* weights / condition not loaded before forward */
+    MST_ERR_WORKSPACE = -5     /* workspace pointer null or too small */
+} MstStatus;
+
+/* arithmetic mode of the TCN's dense 128x128x15 dilated convolutions (blocks 1..n-1) */
+typedef enum {
+    MST_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32, fp32 activations in HBM: the parity mode */
+    MST_PREC_BF16 = 1   /* v_mfma_f32_32x32x16_bf16, bf16 activations in HBM, fp32 accumulate */
+} MstPrecision;
+
+#define MST_MAX_BLOCKS 32
+
+int mst_version(void);
+const char *mst_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * MixFXcloner: TCNModel (networks/architectures.py:76-174) / TCNBlock (:177-234) / FiLM
+ * (networks/network_utils.py:156-182).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct MstTcn MstTcn;
+
+typedef struct {
+    int nblocks;                   /* TCNModel(nblocks)                      default cfg: 14  */
+    int ninputs;                   /* input channels of block 0              default cfg: 2   */
+    int noutputs;                  /* channels of the 1x1 output conv        default cfg: 2   */
+    int channels;                  /* channel_width                          default cfg: 128 */
+    int kernel_size;               /*                                        default cfg: 15  */
+    int cond_dim;                  /* FiLM condition length                  default cfg: 2048 */
+    int dilations[MST_MAX_BLOCKS]; /* dilation_growth ** (n % stack_size), architectures.py:122 */
+} MstTcnDesc;
+
+/* replaces TCNModel.__init__ (architectures.py:93-133).  Non-causal, ungrouped, conditional blocks only
+ * (what inference/style_transfer.py:48-57 constructs); anything else -> MST_ERR_UNSUPPORTED. */
+int mst_tcn_create(const MstTcnDesc *desc, MstTcn **out);
+int mst_tcn_destroy(MstTcn *tcn);
+
+/* replaces load_state_dict for blocks.{n}.* (style_transfer.py:94-108).  Host fp32, reference layouts:
+ *   conv_w  [channels, cin, k]      blocks.n.conv1.weight (bias=False, architectures.py:201-207)
+ *   bn_*    [channels]              blocks.n.bn.{weight,bias,running_mean,running_var}; eval-mode BN is
+ *                                   folded into the conv weight + a per-channel shift
+ *   film_w  [2*channels, cond_dim]  blocks.n.film.film_fc.weight ; film_b [2*channels]
+ *   res_w   [channels]              blocks.n.res.weight ([channels,1,1]: grouped 1x1, groups=cin,
+ *                                   architectures.py:216-220; block 0: out-channel o reads in-channel
+ *                                   o / (channels/ninputs)) */
+int mst_tcn_load_block(MstTcn *tcn, int n, const float *conv_w, const float *bn_weight, const float *bn_bias,
+                       const float *bn_mean, const float *bn_var, float bn_eps, const float *film_w,
+                       const float *film_b, const float *res_w, void *stream);
+/* output.weight [noutputs, channels(,1)] , output.bias [noutputs]  (architectures.py:133) */
+int mst_tcn_load_output(MstTcn *tcn, const float *w, const float *b, void *stream);
+
+/* replaces FiLM.forward's film_fc(condition) for all blocks at once (network_utils.py:180-181): computes
+ * the (r, b) factor table.  cond_dev: device fp32; n_rows = 1 (one embedding broadcast over the batch,
+ * what style_transfer.py:161 passes) or B (one row per batch item).  block_stride (in floats) = 0 when
+ * every block sees the same condition, else block n reads cond_dev + n*block_stride (the reference's
+ * list-of-conditions branch, architectures.py:139-140). */
+int mst_tcn_set_cond(MstTcn *tcn, const float *cond_dev, int n_rows, long block_stride, void *stream);
+
+size_t mst_tcn_workspace_bytes(const MstTcn *tcn, int B, int L, int precision);
+
+/* replaces TCNModel.forward (architectures.py:135-147): x_dev fp32 [B, ninputs, L] (NCL, contiguous) ->
+ * y_dev fp32 [B, noutputs, L], clamped to [-1, 1].  Zero padding ((k-1)*d)//2 both sides per block. */
+int mst_tcn_forward(MstTcn *tcn, const float *x_dev, float *y_dev, int B, int L, int precision,
+                    void *workspace, size_t workspace_bytes, void *stream);
+/* parity probe: run only the first n_run blocks and return that block's output activations as fp32
+ * [B, channels, L] (NCL, the reference's layout) - the per-block hook the parity tests compare. */
+int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int B, int L, int precision, int n_run,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * FXencoder (networks/architectures.py:26-70) = Res_ConvBlock x N (network_utils.py:96-119), each two
+ * Conv1d_layer (network_utils.py:15-89: ReflectionPad1d -> Conv1d -> BatchNorm1d(eval) -> ReLU), then
+ * AdaptiveAvgPool1d(1).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct MstEnc MstEnc;
+
+typedef struct {
+    int nblocks;                       /* len(config["kernels"])                                   */
+    int channels[MST_MAX_BLOCKS + 1];  /* [2] + config["channels"]  (architectures.py:30)           */
+    int kernels[MST_MAX_BLOCKS];
+    int strides[MST_MAX_BLOCKS];
+    int dilations[MST_MAX_BLOCKS];
+} MstEncDesc;
+
+int mst_enc_create(const MstEncDesc *desc, MstEnc **out);
+int mst_enc_destroy(MstEnc *enc);
+/* which = 0: encoder.{block}.conv1 (cin->cin, stride 1), 1: encoder.{block}.conv2 (cin->cout, stride s).
+ * w [cout, cin, k]; bias [cout] or NULL; BN arrays [cout]. */
+int mst_enc_load_conv(MstEnc *enc, int block, int which, const float *w, const float *bias,
+                      const float *bn_weight, const float *bn_bias, const float *bn_mean, const float *bn_var,
+                      float bn_eps, void *stream);
+size_t mst_enc_workspace_bytes(const MstEnc *enc, int B, int L);
+/* replaces FXencoder.forward (architectures.py:65-70): x_dev fp32 [B, 2, L] -> emb_dev fp32 [B, C_last]. */
+int mst_enc_forward(MstEnc *enc, const float *x_dev, float *emb_dev, int B, int L, void *workspace,
+                    size_t workspace_bytes, void *stream);
+/* parity probe: run only the first n_run Res_ConvBlocks; out_dev fp32 [B, channels[n_run], L_out(n_run)] */
+int mst_enc_forward_blocks(MstEnc *enc, const float *x_dev, float *out_dev, int B, int L, int n_run, void *workspace,
+                           size_t workspace_bytes, void *stream);
+/* output length of Res_ConvBlock `block` for input length L ("SAME" padding ignores the stride:
+ * L_out = floor((L-1)/s)+1, network_utils.py:30-34,48-51) */
+int mst_enc_block_length(const MstEnc *enc, int block, int L);
+
+/* replaces torch.stack/reshape/mean(axis=0) over segment embeddings (style_transfer.py:152-153):
+ * out[d] = mean over rows of emb[n_rows, dim], summed in row order (so the result does not depend on
+ * how rows were sharded across GPUs before the all-gather). */
+int mst_embedding_mean(const float *emb_dev, int n_rows, int dim, float *out_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * FX-manipulator processors (mixing_manipulator/common_audioeffects.py).  Audio layout as in the
+ * reference processors: [n_items][L][C] time-major, interleaved channels, fp32.  One (item, channel)
+ * sequence per lane for the serial recursions; float64 internal arithmetic like the reference.
+ * ---------------------------------------------------------------------------------------------- */
+/* Equaliser.process (:500-525): cascade of n_bands biquads, zero initial state per band; coef host
+ * float64 [n_bands][6] = (b0,b1,b2,a0=1,a1,a2) shared by all items. */
+int mst_fx_biquad_cascade(const float *x_dev, float *y_dev, int n_items, long L, int C, const double *coef_host,
+                          int n_bands, void *stream);
+/* Compressor.process / compressor_process (:529-587, :637-649), makeup gain 0 */
+int mst_fx_compressor(const float *x_dev, float *y_dev, int n_items, long L, int C, double threshold_db,
+                      double attack_ms, double release_ms, double ratio, double sample_rate, void *stream);
+/* MidSideImager.process (:964-1007), stereo only; scratch_dev: >= n_items*2 doubles */
+int mst_fx_midside_imager(const float *x_dev, float *y_dev, int n_items, long L, double bal, double *scratch_dev,
+                          void *stream);
+/* Gain.process (:1041-1051) */
+int mst_fx_gain(const float *x_dev, float *y_dev, int n_items, long L, int C, double gain_db, int invert, void *stream);
+/* AugmentationChain.apply_processor rms_normalize branch (:143-146): y *= sqrt(mean(x^2)/max(1e-7, mean(y^2)))
+ * per item; scratch_dev: >= n_items*4 doubles */
+int mst_fx_rms_normalize(const float *x_dev, float *y_dev, int n_items, long L, int C, double *scratch_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MST_HIP_H */

@@ -1,0 +1,114 @@
+"""ctypes binding of libmst_hip.so (the C ABI declared in include/mst_hip.h).
+
+The product path has NO fallback: if the HIP library is missing, import of anything that needs it raises.
+(tests/ may bind the CPU emulator build of the same sources through `bind(path)`; the product never does.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmst_hip.so")
+
+MST_OK = 0
+MST_PREC_F32 = 0
+MST_PREC_BF16 = 1
+MST_MAX_BLOCKS = 32
+PRECISIONS = {"fp32": MST_PREC_F32, "f32": MST_PREC_F32, "bf16": MST_PREC_BF16}
+
+STATUS_NAMES = {0: "MST_OK", -1: "MST_ERR_ARG", -2: "MST_ERR_UNSUPPORTED", -3: "MST_ERR_HIP", -4: "MST_ERR_STATE",
+                -5: "MST_ERR_WORKSPACE"}
+
+
+class MstTcnDesc(C.Structure):
+    _fields_ = [("nblocks", C.c_int), ("ninputs", C.c_int), ("noutputs", C.c_int), ("channels", C.c_int),
+                ("kernel_size", C.c_int), ("cond_dim", C.c_int), ("dilations", C.c_int * MST_MAX_BLOCKS)]
+
+
+class MstEncDesc(C.Structure):
+    _fields_ = [("nblocks", C.c_int), ("channels", C.c_int * (MST_MAX_BLOCKS + 1)), ("kernels", C.c_int * MST_MAX_BLOCKS),
+                ("strides", C.c_int * MST_MAX_BLOCKS), ("dilations", C.c_int * MST_MAX_BLOCKS)]
+
+
+_P = C.c_void_p
+_F = C.c_void_p   # float* passed as integer addresses (tensor.data_ptr())
+
+# name -> (restype, argtypes); kept in sync with include/mst_hip.h (tests/test_abi.py checks the export list)
+SIGNATURES = {
+    "mst_version": (C.c_int, []),
+    "mst_last_error": (C.c_char_p, []),
+    "mst_tcn_create": (C.c_int, [C.POINTER(MstTcnDesc), C.POINTER(_P)]),
+    "mst_tcn_destroy": (C.c_int, [_P]),
+    "mst_tcn_load_block": (C.c_int, [_P, C.c_int, _F, _F, _F, _F, _F, C.c_float, _F, _F, _F, _P]),
+    "mst_tcn_load_output": (C.c_int, [_P, _F, _F, _P]),
+    "mst_tcn_set_cond": (C.c_int, [_P, _F, C.c_int, C.c_long, _P]),
+    "mst_tcn_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int]),
+    "mst_tcn_forward": (C.c_int, [_P, _F, _F, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "mst_tcn_forward_blocks": (C.c_int, [_P, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "mst_enc_create": (C.c_int, [C.POINTER(MstEncDesc), C.POINTER(_P)]),
+    "mst_enc_destroy": (C.c_int, [_P]),
+    "mst_enc_load_conv": (C.c_int, [_P, C.c_int, C.c_int, _F, _F, _F, _F, _F, _F, C.c_float, _P]),
+    "mst_enc_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int]),
+    "mst_enc_forward": (C.c_int, [_P, _F, _F, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "mst_enc_forward_blocks": (C.c_int, [_P, _F, _F, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "mst_enc_block_length": (C.c_int, [_P, C.c_int, C.c_int]),
+    "mst_embedding_mean": (C.c_int, [_F, C.c_int, C.c_int, _F, _P]),
+    "mst_fx_biquad_cascade": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.POINTER(C.c_double), C.c_int, _P]),
+    "mst_fx_compressor": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                    C.c_double, _P]),
+    "mst_fx_midside_imager": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_double, _P, _P]),
+    "mst_fx_gain": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_double, C.c_int, _P]),
+    "mst_fx_rms_normalize": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, _P, _P]),
+}
+
+
+class MstError(RuntimeError):
+    pass
+
+
+class Binding:
+    """A loaded library with typed entry points and status checking."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} not found: the HIP extension has not been built (python -c 'import __graft_entry__ as g; "
+                f"g.build()' or make -C music_mixing_style_transfer_amd/csrc).  There is no CPU fallback.")
+        self.path = path
+        self.cdll = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.cdll, name)   # AttributeError if the symbol is missing: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+
+    def check(self, status, what=""):
+        if status != MST_OK:
+            msg = self.mst_last_error()
+            msg = msg.decode() if msg else ""
+            code = STATUS_NAMES.get(status, str(status))
+            if status == -2:
+                raise NotImplementedError(f"{what}: {code}: {msg}")
+            if status == -1:
+                raise ValueError(f"{what}: {code}: {msg}")
+            raise MstError(f"{what}: {code}: {msg}")
+
+
+def bind(path):
+    return Binding(path)
+
+
+_default = None
+
+
+def lib():
+    """The product binding (libmst_hip.so), loaded on first use."""
+    global _default
+    if _default is None:
+        _default = Binding(LIB_PATH)
+    return _default
+
+
+def set_default_binding(binding):
+    """TEST HOOK: route the module API through another build of the same C ABI (the CPU SIMT emulator)."""
+    global _default
+    _default = binding

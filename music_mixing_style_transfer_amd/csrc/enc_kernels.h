@@ -1,0 +1,153 @@
+// gfx950 kernels of the FXencoder (reference networks/architectures.py:26-70; one Conv1d_layer =
+// ReflectionPad1d -> Conv1d(stride) -> BatchNorm1d(eval) -> ReLU, networks/network_utils.py:28-34,47-51,74-83;
+// Res_ConvBlock = conv2(conv1(x) + x), network_utils.py:116-119).
+//
+// One generic implicit-GEMM convolution in exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32):
+//     D[co][n] = sum_k W'[co][k] * X[k][n],   k = ci*ksz + j,  n = b*Lout + to,
+//     X[k][n] = x[b][ci][reflect(to*stride + j*dil - pad_l)]
+// Layout: activations NCL fp32 (time contiguous) like the reference, so the MFMA B fragment (32 consecutive
+// output times per half-wave) and the epilogue stores (32 consecutive times per accumulator register)
+// are both coalesced.  BatchNorm is folded into W' and a per-channel shift on the host; weights are
+// pre-packed per (co-tile, k-chunk) in the exact [16][MT] image the LDS wants, so staging A is a straight
+// 16-byte copy.  The im2col gather (reflection + stride) happens while staging B; the (ci, tap offset) of
+// every k comes from a small per-layer table instead of integer divisions.
+// Workgroup = 4 waves; wave = 32 output channels x 128 columns (4 accumulator tiles).  MW waves along
+// channels: tile = (32*MW) x (128 * 4/MW); MW is picked from Cout (1 for <=32, 2 for 64, 4 otherwise).
+#pragma once
+#include "mst_dev.h"
+
+struct EncConvArgs {
+    const float *x;      // [B][Cin][Lin]
+    float *y;            // [B][Cout][Lout]
+    const float *wpk;    // [co_tiles][nchunks][16][MT]
+    const float *shift;  // [co_tiles*MT] folded bias/BN shift (zero padded)
+    const int *ktab;     // [nchunks*16][2]: (ci, j*dil - pad_l), ci = -1 for the zero padding of K
+    int B, Cin, Lin, Cout, Lout, stride;
+    int nchunks;
+    int residual;        // conv1 of a Res block: add x[b][co][to] after the ReLU
+    long Ntot;           // B * Lout
+};
+
+template <int MW>
+__global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
+    constexpr int NW = 4 / MW, MT = 32 * MW, NT = 128 * NW;
+    constexpr int NB = NT / 16;                       // B elements gathered per thread per chunk
+    constexpr int NA = (16 * MT / 4 + 255) / 256;     // A float4 per thread per chunk
+    __shared__ __attribute__((aligned(16))) float As[16 * MT];
+    __shared__ float Bs[16 * NT];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ln = lane & 31, h = lane >> 5;
+    const int mi = w % MW, ni = w / MW;
+    const long n0 = (long)blockIdx.x * NT;
+    const int cot = blockIdx.y;
+
+    // the <= 2 columns this thread gathers for (fixed for the whole K loop)
+    constexpr int NCOL = (NT + 255) / 256;
+    long colbase[NCOL];
+    int colt[NCOL];
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+        const long n = n0 + (tid + c * 256) % NT;
+        if (n < a.Ntot) {
+            const int b = (int)(n / a.Lout), to = (int)(n % a.Lout);
+            colbase[c] = (long)b * a.Cin * a.Lin;
+            colt[c] = to * a.stride;
+        } else {
+            colbase[c] = -1;
+            colt[c] = 0;
+        }
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
+
+    f32x4 areg[NA];
+    float breg[NB];
+    const f32x4 *wtile = (const f32x4 *)(a.wpk + (size_t)cot * a.nchunks * 16 * MT);
+
+    auto fetch = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < 16 * MT / 4) areg[i] = wtile[(size_t)kc * (16 * MT / 4) + idx];
+        }
+#pragma unroll
+        for (int e = 0; e < NB; ++e) {
+            const int idx = tid + e * 256;
+            const int krow = idx / NT;
+            const int c = (NT > 256) ? (e & 1) : 0;
+            const int ci = a.ktab[(kc * 16 + krow) * 2], joff = a.ktab[(kc * 16 + krow) * 2 + 1];
+            float v = 0.0f;
+            if (ci >= 0 && colbase[c] >= 0) {
+                int ti = colt[c] + joff;
+                if (ti < 0) ti = -ti;
+                if (ti >= a.Lin) ti = 2 * (a.Lin - 1) - ti;
+                v = a.x[colbase[c] + (long)ci * a.Lin + ti];
+            }
+            breg[e] = v;
+        }
+    };
+
+    fetch(0);
+    for (int kc = 0; kc < a.nchunks; ++kc) {
+        if (kc) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < 16 * MT / 4) ((f32x4 *)As)[idx] = areg[i];
+        }
+#pragma unroll
+        for (int e = 0; e < NB; ++e) Bs[tid + e * 256] = breg[e];
+        __syncthreads();
+        if (kc + 1 < a.nchunks) fetch(kc + 1);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const float av = As[(2 * ks + h) * MT + 32 * mi + ln];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float bv = Bs[(2 * ks + h) * NT + 128 * ni + 32 * q + ln];
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[q], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long n = n0 + 128 * ni + 32 * q + ln;
+        if (n < a.Ntot) {
+            const int b = (int)(n / a.Lout), to = (int)(n % a.Lout);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cot * MT + 32 * mi + mfma32_row(r, lane);
+                if (co < a.Cout) {
+                    float v = fmaxf(acc[q][r] + a.shift[co], 0.0f);
+                    if (a.residual) v += a.x[((long)b * a.Cin + co) * a.Lin + to];
+                    a.y[((long)b * a.Cout + co) * a.Lout + to] = v;
+                }
+            }
+        }
+    }
+}
+
+// AdaptiveAvgPool1d(1) + squeeze (architectures.py:62,67): one wave per (b, c) row.
+__global__ __launch_bounds__(256) void enc_avgpool_kernel(const float *x, float *y, long rows, int Lf) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.0f;
+    for (int t = lane; t < Lf; t += 64) s += x[row * Lf + t];
+    s = wave_sum(s);
+    if (lane == 0) y[row] = s / (float)Lf;
+}
+
+// mean over segment embeddings in canonical row order (style_transfer.py:152-153)
+__global__ void embedding_mean_kernel(const float *emb, int n_rows, int dim, float *out) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= dim) return;
+    float s = 0.0f;
+    for (int r = 0; r < n_rows; ++r) s += emb[(size_t)r * dim + d];
+    out[d] = s / (float)n_rows;
+}

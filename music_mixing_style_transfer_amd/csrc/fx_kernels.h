@@ -1,0 +1,177 @@
+// gfx950 kernels of the FX-manipulator processors (reference mixing_manipulator/common_audioeffects.py).
+// Audio layout as the reference's processors: x[item][n][c], time-major with interleaved channels, fp32;
+// float64 internal arithmetic for the recursions like the reference.  These are latency / HBM bound:
+// no matrix work here.
+#pragma once
+#include "mst_dev.h"
+
+#define MST_MAX_BANDS 8
+
+// ------------------------------------------------------------------------------------------------
+// Equaliser.process (:500-525): cascade of biquads, each over the whole signal with zero initial state
+// (transposed direct form II, the scipy.signal.lfilter recursion).  Running the bands sample-by-sample in
+// one pass is the same arithmetic as the reference's band-by-band passes (band k's output sequence only
+// depends on band k-1's output sequence).  One lane per (item, channel) sequence; samples are fetched 16 at
+// a time so the global loads are off the recursion's dependency chain.
+// ------------------------------------------------------------------------------------------------
+struct BiquadArgs {
+    const float *x;
+    float *y;
+    int n_seq;      // n_items * C
+    int C;
+    long L;
+    int n_bands;
+    double coef[MST_MAX_BANDS][5];   // b0 b1 b2 a1 a2
+};
+
+__global__ __launch_bounds__(64) void fx_biquad_kernel(BiquadArgs a) {
+    const int seq = blockIdx.x * 64 + threadIdx.x;
+    if (seq >= a.n_seq) return;
+    const int item = seq / a.C, c = seq % a.C;
+    const float *xp = a.x + (size_t)item * a.L * a.C + c;
+    float *yp = a.y + (size_t)item * a.L * a.C + c;
+    double z1[MST_MAX_BANDS], z2[MST_MAX_BANDS];
+#pragma unroll
+    for (int k = 0; k < MST_MAX_BANDS; ++k) z1[k] = z2[k] = 0.0;
+    for (long n0 = 0; n0 < a.L; n0 += 16) {
+        float xin[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xin[i] = (n0 + i < a.L) ? xp[(n0 + i) * a.C] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double v = (double)xin[i];
+#pragma unroll
+            for (int k = 0; k < MST_MAX_BANDS; ++k) {
+                if (k < a.n_bands) {
+                    const double yn = a.coef[k][0] * v + z1[k];
+                    z1[k] = a.coef[k][1] * v - a.coef[k][3] * yn + z2[k];
+                    z2[k] = a.coef[k][2] * v - a.coef[k][4] * yn;
+                    v = yn;
+                }
+            }
+            if (n0 + i < a.L) yp[(n0 + i) * a.C] = (float)v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// compressor_process (:529-587) as called by Compressor.process (:637-649, makeup 0).  One WAVE per
+// (item, channel) sequence, 64 samples per step: the log-domain gain computer (log10) and the gain
+// application (pow) run lane-parallel; only the branchy one-pole attack/release smoother is serial, walked
+// in sample order by broadcasting x_l lane by lane (every lane carries the same recurrence state).
+// ------------------------------------------------------------------------------------------------
+struct CompArgs {
+    const float *x;
+    float *y;
+    int n_seq, C;
+    long L;
+    double threshold, ratio, alpha_att, alpha_rel, makeup;
+};
+
+__global__ __launch_bounds__(256) void fx_compressor_kernel(CompArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seq >= a.n_seq) return;   // wave-uniform
+    const int item = seq / a.C, c = seq % a.C;
+    const float *xp = a.x + (size_t)item * a.L * a.C + c;
+    float *yp = a.y + (size_t)item * a.L * a.C + c;
+    double prev = 0.0;            // yL_prev is forced to 0 on entry (:553)
+    for (long n0 = 0; n0 < a.L; n0 += 64) {
+        const long n = n0 + lane;
+        const double xv = (n < a.L) ? (double)xp[n * a.C] : 0.0;
+        const double ax = fabs(xv);
+        const double xg = (ax < 0.000001) ? -120.0 : 20.0 * log10(ax);
+        double yg = 0.0;          // ratio == 1: neither branch assigns y_g (:564-573)
+        if (a.ratio > 1.0)
+            yg = (xg >= a.threshold) ? a.threshold + (xg - a.threshold) / a.ratio : xg;
+        else if (a.ratio < 1.0)
+            yg = (xg <= a.threshold) ? a.threshold + (xg - a.threshold) / (1.0 / a.ratio) : xg;
+        const double xl = xg - yg;
+        double yl = 0.0;
+        const int cnt = (a.L - n0) < 64 ? (int)(a.L - n0) : 64;
+        for (int i = 0; i < cnt; ++i) {
+            const double v = __shfl(xl, i);
+            if (v > prev)
+                prev = a.alpha_att * prev + (1.0 - a.alpha_att) * v;
+            else
+                prev = a.alpha_rel * prev + (1.0 - a.alpha_rel) * v;
+            if (lane == i) yl = prev;
+        }
+        if (n < a.L) yp[n * a.C] = (float)(xv * pow(10.0, (a.makeup - yl) / 20.0));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// energy reductions (float64 accumulation; the reference sums in the input dtype, i.e. float32 pairwise
+// for float32 audio - a 1e-6-relative difference documented in DESIGN.md).
+//   mode 0: acc[item][0] += sum x^2                       (rms normalise, over all L*C samples)
+//   mode 1: acc[item][0] += sum (l+r)^2 ; [1] += sum (l-r)^2   (mid / side energies, stereo frames)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fx_energy_kernel(const float *x, double *acc, long per_item, int mode,
+                                                        int chunks) {
+    __shared__ double red[2][4];
+    const int item = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const long frames = (mode == 1) ? per_item / 2 : per_item;
+    const long per_chunk = (frames + chunks - 1) / chunks;
+    const long lo = chunk * per_chunk, hi = (lo + per_chunk < frames) ? lo + per_chunk : frames;
+    const float *xp = x + (size_t)item * per_item;
+    double s0 = 0.0, s1 = 0.0;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        if (mode == 1) {
+            const float l = xp[2 * i], r = xp[2 * i + 1];
+            const float m = l + r, s = l - r;
+            s0 += (double)(m * m);
+            s1 += (double)(s * s);
+        } else {
+            const float v = xp[i];
+            s0 += (double)(v * v);
+        }
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s0;
+        red[1][threadIdx.x >> 6] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&acc[item * 2 + 0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        if (mode == 1) atomicAdd(&acc[item * 2 + 1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+// MidSideImager.process (:964-1007): gains from the two energies, applied in float32 like the reference
+__global__ __launch_bounds__(256) void fx_imager_apply_kernel(const float *x, float *y, const double *acc, long L,
+                                                              double bal_rounded) {
+    const int item = blockIdx.y;
+    const double mid_e = acc[item * 2], side_e = acc[item * 2 + 1];
+    const double total_e = mid_e + side_e;
+    const double max_side = sqrt(total_e / (side_e + 1e-3));
+    const double side_gain = (bal_rounded <= 1.0) ? bal_rounded : max_side * (bal_rounded - 1.0);
+    const double mid_gain = sqrt((total_e - side_e * side_gain * side_gain) / (mid_e + 1e-3));
+    const float sg = (float)side_gain, mg = (float)mid_gain;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= L) return;
+    const float *xp = x + ((size_t)item * L + i) * 2;
+    float *yp = y + ((size_t)item * L + i) * 2;
+    const float l = xp[0], r = xp[1];
+    const float nm = (l + r) * mg, ns = (l - r) * sg;
+    yp[0] = (nm + ns) / 2.0f;
+    yp[1] = (nm - ns) / 2.0f;
+}
+
+// Gain.process (:1041-1051) and the final multiply of the rms normalise (:145-146)
+// mode 0: y = g * x ; mode 1: y *= sqrt(ex / max(1e-7, ey)) with ex = acc_x/per_item, ey = acc_y/per_item
+__global__ __launch_bounds__(256) void fx_scale_kernel(const float *x, float *y, long per_item, float g,
+                                                       const double *acc_x, const double *acc_y, int mode) {
+    const int item = blockIdx.y;
+    float scale = g;
+    if (mode == 1) {
+        const double ex = acc_x[item * 2] / (double)per_item, ey = acc_y[item * 2] / (double)per_item;
+        scale = (float)sqrt(ex / fmax(1e-7, ey));
+    }
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_item) return;
+    const size_t off = (size_t)item * per_item + i;
+    y[off] = (mode == 1 ? y[off] : x[off]) * scale;
+}

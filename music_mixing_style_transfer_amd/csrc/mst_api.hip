@@ -1,0 +1,636 @@
+// libmst_hip.so - C ABI implementation (host side): opaque handles, BatchNorm folding + weight packing into
+// MFMA fragment order, tile geometry and kernel launches.  See include/mst_hip.h for the contract.
+#include "../../include/mst_hip.h"
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "enc_kernels.h"
+#include "fx_kernels.h"
+#include "tcn_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define MST_HIP_TRY(expr)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(MST_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+#define MST_CHECK_LAUNCH(name)                                                                     \
+    do {                                                                                           \
+        hipError_t e_ = hipGetLastError();                                                         \
+        if (e_ != hipSuccess) return fail(MST_ERR_HIP, std::string(name) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <typename T> int upload(T **dev, const std::vector<T> &host) {
+    if (*dev == nullptr) MST_HIP_TRY(hipMalloc((void **)dev, host.size() * sizeof(T)));
+    MST_HIP_TRY(hipMemcpy(*dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MST_OK;
+}
+
+// eval-mode BatchNorm as y = x*scale + shift
+void bn_fold(const float *w, const float *b, const float *mean, const float *var, float eps, int c,
+             std::vector<float> &scale, std::vector<float> &shift) {
+    scale.resize(c);
+    shift.resize(c);
+    for (int i = 0; i < c; ++i) {
+        scale[i] = w[i] / std::sqrt(var[i] + eps);
+        shift[i] = b[i] - mean[i] * scale[i];
+    }
+}
+
+}  // namespace
+
+// =================================================================================================
+// TCN
+// =================================================================================================
+struct MstTcnBlock {
+    void *w_bf16 = nullptr;   // blocks >= 1: [120][4][64][8] bf16
+    float *w_f32 = nullptr;   // blocks >= 1: [15][4][4][4][64][4] fp32 ; block 0: [2][15][128]
+    float *shift = nullptr;   // [128]
+    float *res = nullptr;     // [128]
+    bool loaded = false;
+};
+
+struct MstTcn {
+    MstTcnDesc d;
+    std::vector<MstTcnBlock> blk;
+    float *film_w = nullptr;  // [nblocks][2C][D]
+    float *film_b = nullptr;  // [nblocks][2C]
+    float *film = nullptr;    // [nblocks][rows][2C]
+    int film_rows = 0, film_cap = 0;
+    float *out_w = nullptr, *out_b = nullptr;
+    bool out_loaded = false;
+};
+
+extern "C" int mst_version(void) { return 100; }
+extern "C" const char *mst_last_error(void) { return g_err.c_str(); }
+
+extern "C" int mst_tcn_create(const MstTcnDesc *desc, MstTcn **out) {
+    if (!desc || !out) return fail(MST_ERR_ARG, "mst_tcn_create: null argument");
+    const MstTcnDesc &d = *desc;
+    if (d.nblocks < 1 || d.nblocks > MST_MAX_BLOCKS) return fail(MST_ERR_ARG, "mst_tcn_create: nblocks out of range");
+    if (d.channels != 128 || d.kernel_size != 15 || d.ninputs != 2 || d.noutputs < 1 || d.noutputs > 2 ||
+        d.cond_dim < 1 || d.dilations[0] != 1)
+        return fail(MST_ERR_UNSUPPORTED,
+                    "mst_tcn_create: the gfx950 kernels implement channel_width=128, kernel_size=15, ninputs=2, "
+                    "noutputs<=2, dilation(block 0)=1 (the configs.yaml TCN.default shape)");
+    for (int n = 0; n < d.nblocks; ++n)
+        if (d.dilations[n] < 1) return fail(MST_ERR_ARG, "mst_tcn_create: dilation < 1");
+    MstTcn *t = new MstTcn();
+    t->d = d;
+    t->blk.resize(d.nblocks);
+    const size_t fw = (size_t)d.nblocks * 2 * d.channels * d.cond_dim;
+    if (hipMalloc((void **)&t->film_w, fw * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&t->film_b, (size_t)d.nblocks * 2 * d.channels * sizeof(float)) != hipSuccess) {
+        delete t;
+        return fail(MST_ERR_HIP, "mst_tcn_create: hipMalloc failed");
+    }
+    *out = t;
+    return MST_OK;
+}
+
+extern "C" int mst_tcn_destroy(MstTcn *t) {
+    if (!t) return MST_OK;
+    for (auto &b : t->blk) {
+        (void)hipFree(b.w_bf16);
+        (void)hipFree(b.w_f32);
+        (void)hipFree(b.shift);
+        (void)hipFree(b.res);
+    }
+    (void)hipFree(t->film_w);
+    (void)hipFree(t->film_b);
+    (void)hipFree(t->film);
+    (void)hipFree(t->out_w);
+    (void)hipFree(t->out_b);
+    delete t;
+    return MST_OK;
+}
+
+extern "C" int mst_tcn_load_block(MstTcn *t, int n, const float *conv_w, const float *bn_weight, const float *bn_bias,
+                                  const float *bn_mean, const float *bn_var, float bn_eps, const float *film_w,
+                                  const float *film_b, const float *res_w, void *) {
+    if (!t || !conv_w || !bn_weight || !bn_bias || !bn_mean || !bn_var || !film_w || !film_b || !res_w)
+        return fail(MST_ERR_ARG, "mst_tcn_load_block: null argument");
+    if (n < 0 || n >= t->d.nblocks) return fail(MST_ERR_ARG, "mst_tcn_load_block: block index out of range");
+    const int C = 128, K = 15;
+    const int cin = n == 0 ? t->d.ninputs : C;
+    std::vector<float> scale, shift;
+    bn_fold(bn_weight, bn_bias, bn_mean, bn_var, bn_eps, C, scale, shift);
+    MstTcnBlock &b = t->blk[n];
+    auto W = [&](int co, int ci, int j) { return conv_w[((size_t)co * cin + ci) * K + j] * scale[co]; };
+    int rc;
+    if (n == 0) {
+        std::vector<float> w0((size_t)cin * K * C);
+        for (int ci = 0; ci < cin; ++ci)
+            for (int j = 0; j < K; ++j)
+                for (int co = 0; co < C; ++co) w0[((size_t)ci * K + j) * C + co] = W(co, ci, j);
+        if ((rc = upload(&b.w_f32, w0))) return rc;
+    } else {
+        // bf16 A fragments of v_mfma_f32_32x32x16_bf16: [ks = j*8 + kc][wave][lane][e]
+        std::vector<__bf16> wb((size_t)120 * 4 * 64 * 8);
+        for (int j = 0; j < K; ++j)
+            for (int kc = 0; kc < 8; ++kc)
+                for (int w = 0; w < 4; ++w)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 8; ++e)
+                            wb[((((size_t)(j * 8 + kc) * 4 + w) * 64 + l) * 8) + e] =
+                                (__bf16)W(32 * w + (l & 31), 16 * kc + 8 * (l >> 5) + e, j);
+        if ((rc = upload((__bf16 **)&b.w_bf16, wb))) return rc;
+        // fp32 A fragments of v_mfma_f32_32x32x2_f32: [j][chunk c][ksg][wave][lane][i]
+        std::vector<float> wf((size_t)K * 4 * 4 * 4 * 64 * 4);
+        for (int j = 0; j < K; ++j)
+            for (int c = 0; c < 4; ++c)
+                for (int ksg = 0; ksg < 4; ++ksg)
+                    for (int w = 0; w < 4; ++w)
+                        for (int l = 0; l < 64; ++l)
+                            for (int i = 0; i < 4; ++i)
+                                wf[(((((size_t)(j * 4 + c) * 4 + ksg) * 4 + w) * 64 + l) * 4) + i] =
+                                    W(32 * w + (l & 31), 32 * c + 2 * (4 * ksg + i) + (l >> 5), j);
+        if ((rc = upload(&b.w_f32, wf))) return rc;
+    }
+    if ((rc = upload(&b.shift, shift))) return rc;
+    std::vector<float> res(res_w, res_w + C);
+    if ((rc = upload(&b.res, res))) return rc;
+    const size_t fwn = (size_t)2 * C * t->d.cond_dim;
+    MST_HIP_TRY(hipMemcpy(t->film_w + (size_t)n * fwn, film_w, fwn * sizeof(float), hipMemcpyHostToDevice));
+    MST_HIP_TRY(hipMemcpy(t->film_b + (size_t)n * 2 * C, film_b, 2 * C * sizeof(float), hipMemcpyHostToDevice));
+    b.loaded = true;
+    return MST_OK;
+}
+
+extern "C" int mst_tcn_load_output(MstTcn *t, const float *w, const float *b, void *) {
+    if (!t || !w || !b) return fail(MST_ERR_ARG, "mst_tcn_load_output: null argument");
+    std::vector<float> wv(w, w + (size_t)t->d.noutputs * 128), bv(b, b + t->d.noutputs);
+    int rc;
+    if ((rc = upload(&t->out_w, wv))) return rc;
+    if ((rc = upload(&t->out_b, bv))) return rc;
+    t->out_loaded = true;
+    return MST_OK;
+}
+
+extern "C" int mst_tcn_set_cond(MstTcn *t, const float *cond_dev, int n_rows, long block_stride, void *stream) {
+    if (!t || !cond_dev || n_rows < 1 || block_stride < 0) return fail(MST_ERR_ARG, "mst_tcn_set_cond: bad argument");
+    for (auto &b : t->blk)
+        if (!b.loaded) return fail(MST_ERR_STATE, "mst_tcn_set_cond: block weights not loaded");
+    if (n_rows > t->film_cap) {
+        (void)hipFree(t->film);
+        t->film = nullptr;
+        t->film_cap = 0;
+        MST_HIP_TRY(hipMalloc((void **)&t->film, (size_t)t->d.nblocks * n_rows * 256 * sizeof(float)));
+        t->film_cap = n_rows;
+    }
+    FilmArgs a;
+    a.fw = t->film_w;
+    a.fb = t->film_b;
+    a.cond = cond_dev;
+    a.film = t->film;
+    a.nblocks = t->d.nblocks;
+    a.two_c = 256;
+    a.D = t->d.cond_dim;
+    a.rows = n_rows;
+    a.block_stride = block_stride;
+    const int outs = t->d.nblocks * 256;
+    MST_LAUNCH(tcn_film_kernel, dim3((outs + 3) / 4), dim3(256), stream, a);
+    MST_CHECK_LAUNCH("tcn_film_kernel");
+    t->film_rows = n_rows;
+    return MST_OK;
+}
+
+namespace {
+
+size_t tcn_elem(int precision) { return precision == MST_PREC_BF16 ? 2 : 4; }
+
+// phases per tile: P | d, P*Mt = 256.  4 keeps the bf16 tile at 78 KB of LDS (2 workgroups per CU);
+// grow P while a tile would span more steps than the segment has (large dilation on a short segment).
+int choose_phases(int d, int L) {
+    int P = (d % 4 == 0) ? 4 : (d % 2 == 0 ? 2 : 1);
+    const long nsteps = ((long)L + d - 1) / d;
+    while (P < 16 && d % (2 * P) == 0 && 256 / P > nsteps) P *= 2;
+    return P;
+}
+
+template <int P> int launch_block(int precision, const TcnBlockArgs &a, int grid, void *stream) {
+    if (precision == MST_PREC_BF16)
+        MST_LAUNCH((tcn_block_bf16_kernel<P>), dim3(grid), dim3(256), stream, a);
+    else
+        MST_LAUNCH((tcn_block_f32_kernel<P>), dim3(grid), dim3(256), stream, a);
+    MST_CHECK_LAUNCH("tcn_block_kernel");
+    return MST_OK;
+}
+
+int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, int precision, int n_run, void *ws,
+            size_t ws_bytes, void *stream) {
+    if (!t || !x || B < 1 || L < 1) return fail(MST_ERR_ARG, "mst_tcn_forward: bad argument");
+    if (precision != MST_PREC_F32 && precision != MST_PREC_BF16) return fail(MST_ERR_ARG, "mst_tcn_forward: bad precision");
+    for (auto &b : t->blk)
+        if (!b.loaded) return fail(MST_ERR_STATE, "mst_tcn_forward: block weights not loaded");
+    if (!t->out_loaded) return fail(MST_ERR_STATE, "mst_tcn_forward: output conv not loaded");
+    if (t->film_rows == 0) return fail(MST_ERR_STATE, "mst_tcn_forward: mst_tcn_set_cond has not been called");
+    if (t->film_rows != 1 && t->film_rows != B)
+        return fail(MST_ERR_ARG, "mst_tcn_forward: condition rows must be 1 or equal the batch size");
+    const size_t need = mst_tcn_workspace_bytes(t, B, L, precision);
+    if (!ws || ws_bytes < need) return fail(MST_ERR_WORKSPACE, "mst_tcn_forward: workspace too small");
+    const size_t es = tcn_elem(precision);
+    const size_t buf_bytes = align_up((size_t)B * L * 128 * es, 256);
+    unsigned char *buf[2] = {(unsigned char *)ws, (unsigned char *)ws + buf_bytes};
+    const int Lp = L;
+
+    {
+        TcnBlock0Args a;
+        a.x = x;
+        a.y = buf[0];
+        a.w = t->blk[0].w_f32;
+        a.shift = t->blk[0].shift;
+        a.film = t->film;
+        a.res = t->blk[0].res;
+        a.film_rows = t->film_rows;
+        a.B = B;
+        a.L = L;
+        a.Lp = Lp;
+        const int grid = B * ((L + 63) / 64);
+        if (precision == MST_PREC_BF16)
+            MST_LAUNCH((tcn_block0_kernel<__bf16>), dim3(grid), dim3(256), stream, a);
+        else
+            MST_LAUNCH((tcn_block0_kernel<float>), dim3(grid), dim3(256), stream, a);
+        MST_CHECK_LAUNCH("tcn_block0_kernel");
+    }
+    int cur = 0;
+    for (int n = 1; n < n_run; ++n) {
+        const int d = t->d.dilations[n];
+        const int P = choose_phases(d, L);
+        TcnBlockArgs a;
+        a.x = buf[cur];
+        a.y = buf[cur ^ 1];
+        a.wpk = precision == MST_PREC_BF16 ? t->blk[n].w_bf16 : (void *)t->blk[n].w_f32;
+        a.shift = t->blk[n].shift;
+        a.film = t->film + (size_t)n * t->film_rows * 256;
+        a.res = t->blk[n].res;
+        a.film_rows = t->film_rows;
+        a.B = B;
+        a.L = L;
+        a.Lp = Lp;
+        a.d = d;
+        a.tiles_phase = d / P;
+        const long nsteps = ((long)L + d - 1) / d;
+        a.tiles_step = (int)((nsteps + 256 / P - 1) / (256 / P));
+        const long grid = (long)B * a.tiles_phase * a.tiles_step;
+        if (grid > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_tcn_forward: grid too large");
+        int rc;
+        switch (P) {
+            case 1: rc = launch_block<1>(precision, a, (int)grid, stream); break;
+            case 2: rc = launch_block<2>(precision, a, (int)grid, stream); break;
+            case 4: rc = launch_block<4>(precision, a, (int)grid, stream); break;
+            case 8: rc = launch_block<8>(precision, a, (int)grid, stream); break;
+            default: rc = launch_block<16>(precision, a, (int)grid, stream); break;
+        }
+        if (rc) return rc;
+        cur ^= 1;
+    }
+    if (act_out) {
+        const size_t total = (size_t)B * L * 128;
+        const unsigned grid = (unsigned)((total + 255) / 256);
+        if (precision == MST_PREC_BF16)
+            MST_LAUNCH((tcn_unpack_kernel<__bf16>), dim3(grid), dim3(256), stream, (const void *)buf[cur], act_out, B, L, Lp);
+        else
+            MST_LAUNCH((tcn_unpack_kernel<float>), dim3(grid), dim3(256), stream, (const void *)buf[cur], act_out, B, L, Lp);
+        MST_CHECK_LAUNCH("tcn_unpack_kernel");
+        return MST_OK;
+    }
+    TcnOutArgs o;
+    o.x = buf[cur];
+    o.y = y;
+    o.w = t->out_w;
+    o.bias = t->out_b;
+    o.nout = t->d.noutputs;
+    o.B = B;
+    o.L = L;
+    o.Lp = Lp;
+    const int grid = B * ((L + 63) / 64);
+    if (precision == MST_PREC_BF16)
+        MST_LAUNCH((tcn_output_kernel<__bf16>), dim3(grid), dim3(256), stream, o);
+    else
+        MST_LAUNCH((tcn_output_kernel<float>), dim3(grid), dim3(256), stream, o);
+    MST_CHECK_LAUNCH("tcn_output_kernel");
+    return MST_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mst_tcn_workspace_bytes(const MstTcn *, int B, int L, int precision) {
+    if (B < 1 || L < 1) return 0;
+    return 2 * align_up((size_t)B * L * 128 * tcn_elem(precision), 256);
+}
+
+extern "C" int mst_tcn_forward(MstTcn *t, const float *x, float *y, int B, int L, int precision, void *ws,
+                               size_t ws_bytes, void *stream) {
+    if (!y) return fail(MST_ERR_ARG, "mst_tcn_forward: null output");
+    return tcn_run(t, x, y, nullptr, B, L, precision, t ? t->d.nblocks : 0, ws, ws_bytes, stream);
+}
+
+extern "C" int mst_tcn_forward_blocks(MstTcn *t, const float *x, float *act, int B, int L, int precision, int n_run,
+                                      void *ws, size_t ws_bytes, void *stream) {
+    if (!t || !act || n_run < 1 || n_run > t->d.nblocks) return fail(MST_ERR_ARG, "mst_tcn_forward_blocks: bad argument");
+    return tcn_run(t, x, nullptr, act, B, L, precision, n_run, ws, ws_bytes, stream);
+}
+
+// =================================================================================================
+// FXencoder
+// =================================================================================================
+struct MstEncConv {
+    float *wpk = nullptr, *shift = nullptr;
+    int *ktab = nullptr;
+    int cin = 0, cout = 0, ksz = 0, stride = 1, dil = 1, pad_l = 0, pad_r = 0, nchunks = 0, mw = 4;
+    bool loaded = false;
+};
+
+struct MstEnc {
+    MstEncDesc d;
+    std::vector<MstEncConv> conv;   // 2 per block
+};
+
+extern "C" int mst_enc_create(const MstEncDesc *desc, MstEnc **out) {
+    if (!desc || !out) return fail(MST_ERR_ARG, "mst_enc_create: null argument");
+    if (desc->nblocks < 1 || desc->nblocks > MST_MAX_BLOCKS) return fail(MST_ERR_ARG, "mst_enc_create: nblocks out of range");
+    for (int i = 0; i < desc->nblocks; ++i)
+        if (desc->kernels[i] < 1 || desc->strides[i] < 1 || desc->dilations[i] < 1 || desc->channels[i] < 1 ||
+            desc->channels[i + 1] < 1)
+            return fail(MST_ERR_ARG, "mst_enc_create: bad layer description");
+    MstEnc *e = new MstEnc();
+    e->d = *desc;
+    e->conv.resize(2 * desc->nblocks);
+    for (int i = 0; i < desc->nblocks; ++i)
+        for (int which = 0; which < 2; ++which) {
+            MstEncConv &c = e->conv[2 * i + which];
+            c.cin = desc->channels[i];
+            c.cout = which ? desc->channels[i + 1] : desc->channels[i];
+            c.ksz = desc->kernels[i];
+            c.stride = which ? desc->strides[i] : 1;
+            c.dil = desc->dilations[i];
+            const int pad = (c.ksz - 1) * c.dil;   // "SAME": total (k-1)*d, left = total//2 (network_utils.py:30-34)
+            c.pad_l = pad / 2;
+            c.pad_r = pad - c.pad_l;
+            c.nchunks = (c.cin * c.ksz + 15) / 16;
+            c.mw = c.cout <= 32 ? 1 : (c.cout <= 64 ? 2 : 4);
+        }
+    *out = e;
+    return MST_OK;
+}
+
+extern "C" int mst_enc_destroy(MstEnc *e) {
+    if (!e) return MST_OK;
+    for (auto &c : e->conv) {
+        (void)hipFree(c.wpk);
+        (void)hipFree(c.shift);
+        (void)hipFree(c.ktab);
+    }
+    delete e;
+    return MST_OK;
+}
+
+extern "C" int mst_enc_load_conv(MstEnc *e, int block, int which, const float *w, const float *bias,
+                                 const float *bn_weight, const float *bn_bias, const float *bn_mean,
+                                 const float *bn_var, float bn_eps, void *) {
+    if (!e || !w || !bn_weight || !bn_bias || !bn_mean || !bn_var) return fail(MST_ERR_ARG, "mst_enc_load_conv: null argument");
+    if (block < 0 || block >= e->d.nblocks || which < 0 || which > 1) return fail(MST_ERR_ARG, "mst_enc_load_conv: index out of range");
+    MstEncConv &c = e->conv[2 * block + which];
+    std::vector<float> scale, shift;
+    bn_fold(bn_weight, bn_bias, bn_mean, bn_var, bn_eps, c.cout, scale, shift);
+    const int MT = 32 * c.mw, K = c.cin * c.ksz;
+    const int co_tiles = (c.cout + MT - 1) / MT;
+    std::vector<float> wp((size_t)co_tiles * c.nchunks * 16 * MT, 0.0f);
+    for (int cot = 0; cot < co_tiles; ++cot)
+        for (int kc = 0; kc < c.nchunks; ++kc)
+            for (int kr = 0; kr < 16; ++kr) {
+                const int k = kc * 16 + kr;
+                if (k >= K) continue;
+                for (int m = 0; m < MT; ++m) {
+                    const int co = cot * MT + m;
+                    if (co < c.cout) wp[(((size_t)cot * c.nchunks + kc) * 16 + kr) * MT + m] = w[(size_t)co * K + k] * scale[co];
+                }
+            }
+    std::vector<float> sh((size_t)co_tiles * MT, 0.0f);
+    for (int co = 0; co < c.cout; ++co) sh[co] = shift[co] + (bias ? bias[co] * scale[co] : 0.0f);
+    std::vector<int> kt((size_t)c.nchunks * 16 * 2);
+    for (int k = 0; k < c.nchunks * 16; ++k) {
+        kt[2 * k] = k < K ? k / c.ksz : -1;
+        kt[2 * k + 1] = k < K ? (k % c.ksz) * c.dil - c.pad_l : 0;
+    }
+    int rc;
+    if ((rc = upload(&c.wpk, wp))) return rc;
+    if ((rc = upload(&c.shift, sh))) return rc;
+    if ((rc = upload(&c.ktab, kt))) return rc;
+    c.loaded = true;
+    return MST_OK;
+}
+
+extern "C" int mst_enc_block_length(const MstEnc *e, int block, int L) {
+    if (!e || block < 0 || block >= e->d.nblocks) return -1;
+    for (int i = 0; i <= block; ++i) L = (L - 1) / e->d.strides[i] + 1;
+    return L;
+}
+
+namespace {
+
+size_t enc_buf_floats(const MstEnc *e, int B, int L) {
+    size_t mx = 0;
+    int len = L;
+    for (int i = 0; i < e->d.nblocks; ++i) {
+        mx = std::max(mx, (size_t)B * e->d.channels[i] * len);
+        len = (len - 1) / e->d.strides[i] + 1;
+        mx = std::max(mx, (size_t)B * e->d.channels[i + 1] * len);
+    }
+    return mx;
+}
+
+int enc_launch(const MstEncConv &c, const float *x, float *y, int B, int Lin, int Lout, int residual, void *stream) {
+    if (Lin <= c.pad_l || Lin <= c.pad_r)
+        return fail(MST_ERR_ARG, "mst_enc_forward: reflection padding needs the input to be longer than the padding");
+    EncConvArgs a;
+    a.x = x;
+    a.y = y;
+    a.wpk = c.wpk;
+    a.shift = c.shift;
+    a.ktab = c.ktab;
+    a.B = B;
+    a.Cin = c.cin;
+    a.Lin = Lin;
+    a.Cout = c.cout;
+    a.Lout = Lout;
+    a.stride = c.stride;
+    a.nchunks = c.nchunks;
+    a.residual = residual;
+    a.Ntot = (long)B * Lout;
+    const int MT = 32 * c.mw, NT = 128 * (4 / c.mw);
+    const dim3 grid((unsigned)((a.Ntot + NT - 1) / NT), (unsigned)((c.cout + MT - 1) / MT));
+    switch (c.mw) {
+        case 1: MST_LAUNCH((enc_conv_kernel<1>), grid, dim3(256), stream, a); break;
+        case 2: MST_LAUNCH((enc_conv_kernel<2>), grid, dim3(256), stream, a); break;
+        default: MST_LAUNCH((enc_conv_kernel<4>), grid, dim3(256), stream, a); break;
+    }
+    MST_CHECK_LAUNCH("enc_conv_kernel");
+    return MST_OK;
+}
+
+int enc_run(MstEnc *e, const float *x, float *emb, float *blk_out, int B, int L, int n_run, void *ws, size_t ws_bytes,
+            void *stream) {
+    if (!e || !x || B < 1 || L < 1) return fail(MST_ERR_ARG, "mst_enc_forward: bad argument");
+    for (auto &c : e->conv)
+        if (!c.loaded) return fail(MST_ERR_STATE, "mst_enc_forward: conv weights not loaded");
+    if (!ws || ws_bytes < mst_enc_workspace_bytes(e, B, L)) return fail(MST_ERR_WORKSPACE, "mst_enc_forward: workspace too small");
+    const size_t nb = align_up(enc_buf_floats(e, B, L) * sizeof(float), 256);
+    float *t1 = (float *)ws;
+    float *o[2] = {(float *)((unsigned char *)ws + nb), (float *)((unsigned char *)ws + 2 * nb)};
+    const float *cur = x;
+    int len = L, rc, pp = 0;
+    for (int i = 0; i < n_run; ++i) {
+        const int lout = (len - 1) / e->d.strides[i] + 1;
+        if ((rc = enc_launch(e->conv[2 * i], cur, t1, B, len, len, 1, stream))) return rc;
+        float *dst = (blk_out && i == n_run - 1) ? blk_out : o[pp];
+        if ((rc = enc_launch(e->conv[2 * i + 1], t1, dst, B, len, lout, 0, stream))) return rc;
+        cur = dst;
+        pp ^= 1;
+        len = lout;
+    }
+    if (emb) {
+        const long rows = (long)B * e->d.channels[e->d.nblocks];
+        MST_LAUNCH(enc_avgpool_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), stream, cur, emb, rows, len);
+        MST_CHECK_LAUNCH("enc_avgpool_kernel");
+    }
+    return MST_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mst_enc_workspace_bytes(const MstEnc *e, int B, int L) {
+    if (!e || B < 1 || L < 1) return 0;
+    return 3 * align_up(enc_buf_floats(e, B, L) * sizeof(float), 256);
+}
+
+extern "C" int mst_enc_forward(MstEnc *e, const float *x, float *emb, int B, int L, void *ws, size_t ws_bytes, void *stream) {
+    if (!emb) return fail(MST_ERR_ARG, "mst_enc_forward: null output");
+    return enc_run(e, x, emb, nullptr, B, L, e ? e->d.nblocks : 0, ws, ws_bytes, stream);
+}
+
+extern "C" int mst_enc_forward_blocks(MstEnc *e, const float *x, float *out, int B, int L, int n_run, void *ws,
+                                      size_t ws_bytes, void *stream) {
+    if (!e || !out || n_run < 1 || n_run > e->d.nblocks) return fail(MST_ERR_ARG, "mst_enc_forward_blocks: bad argument");
+    return enc_run(e, x, nullptr, out, B, L, n_run, ws, ws_bytes, stream);
+}
+
+extern "C" int mst_embedding_mean(const float *emb, int n_rows, int dim, float *out, void *stream) {
+    if (!emb || !out || n_rows < 1 || dim < 1) return fail(MST_ERR_ARG, "mst_embedding_mean: bad argument");
+    MST_LAUNCH(embedding_mean_kernel, dim3((dim + 255) / 256), dim3(256), stream, emb, n_rows, dim, out);
+    MST_CHECK_LAUNCH("embedding_mean_kernel");
+    return MST_OK;
+}
+
+// =================================================================================================
+// FX processors
+// =================================================================================================
+extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long L, int C, const double *coef, int n_bands,
+                                     void *stream) {
+    if (!x || !y || !coef || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_biquad_cascade: bad argument");
+    if (n_bands < 0 || n_bands > MST_MAX_BANDS) return fail(MST_ERR_UNSUPPORTED, "mst_fx_biquad_cascade: at most 8 bands");
+    BiquadArgs a;
+    a.x = x;
+    a.y = y;
+    a.n_seq = n_items * C;
+    a.C = C;
+    a.L = L;
+    a.n_bands = n_bands;
+    for (int k = 0; k < MST_MAX_BANDS; ++k)
+        for (int i = 0; i < 5; ++i) a.coef[k][i] = 0.0;
+    for (int k = 0; k < n_bands; ++k) {
+        const double a0 = coef[6 * k + 3];
+        a.coef[k][0] = coef[6 * k + 0] / a0;
+        a.coef[k][1] = coef[6 * k + 1] / a0;
+        a.coef[k][2] = coef[6 * k + 2] / a0;
+        a.coef[k][3] = coef[6 * k + 4] / a0;
+        a.coef[k][4] = coef[6 * k + 5] / a0;
+    }
+    MST_LAUNCH(fx_biquad_kernel, dim3((a.n_seq + 63) / 64), dim3(64), stream, a);
+    MST_CHECK_LAUNCH("fx_biquad_kernel");
+    return MST_OK;
+}
+
+extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, int C, double threshold_db,
+                                 double attack_ms, double release_ms, double ratio, double sample_rate, void *stream) {
+    if (!x || !y || n_items < 1 || L < 1 || C < 1 || attack_ms <= 0 || release_ms <= 0 || ratio <= 0 || sample_rate <= 0)
+        return fail(MST_ERR_ARG, "mst_fx_compressor: bad argument");
+    if (threshold_db == 0.0 && ratio == 1.0) {   // bypass (common_audioeffects.py:637)
+        if (x != y) MST_HIP_TRY(hipMemcpyAsync(y, x, (size_t)n_items * L * C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return MST_OK;
+    }
+    CompArgs a;
+    a.x = x;
+    a.y = y;
+    a.n_seq = n_items * C;
+    a.C = C;
+    a.L = L;
+    a.threshold = threshold_db;
+    a.ratio = ratio;
+    a.alpha_att = std::exp(-1.0 / (0.001 * sample_rate * attack_ms));
+    a.alpha_rel = std::exp(-1.0 / (0.001 * sample_rate * release_ms));
+    a.makeup = 0.0;
+    MST_LAUNCH(fx_compressor_kernel, dim3((a.n_seq + 3) / 4), dim3(256), stream, a);
+    MST_CHECK_LAUNCH("fx_compressor_kernel");
+    return MST_OK;
+}
+
+namespace {
+int energy(const float *x, double *acc, int n_items, long per_item, int mode, void *stream) {
+    MST_HIP_TRY(hipMemsetAsync(acc, 0, (size_t)n_items * 2 * sizeof(double), (hipStream_t)stream));
+    const long frames = mode == 1 ? per_item / 2 : per_item;
+    int chunks = (int)std::min<long>(64, (frames + 8191) / 8192);
+    if (chunks < 1) chunks = 1;
+    MST_LAUNCH(fx_energy_kernel, dim3(n_items * chunks), dim3(256), stream, x, acc, per_item, mode, chunks);
+    MST_CHECK_LAUNCH("fx_energy_kernel");
+    return MST_OK;
+}
+}  // namespace
+
+extern "C" int mst_fx_midside_imager(const float *x, float *y, int n_items, long L, double bal, double *scratch, void *stream) {
+    if (!x || !y || !scratch || n_items < 1 || L < 1) return fail(MST_ERR_ARG, "mst_fx_midside_imager: bad argument");
+    int rc;
+    if ((rc = energy(x, scratch, n_items, 2 * L, 1, stream))) return rc;
+    const double bal_r = std::round(bal * 1000.0) / 1000.0;   // round(bal, 3) (:980)
+    MST_LAUNCH(fx_imager_apply_kernel, dim3((unsigned)((L + 255) / 256), n_items), dim3(256), stream, x, y,
+               (const double *)scratch, L, bal_r);
+    MST_CHECK_LAUNCH("fx_imager_apply_kernel");
+    return MST_OK;
+}
+
+extern "C" int mst_fx_gain(const float *x, float *y, int n_items, long L, int C, double gain_db, int invert, void *stream) {
+    if (!x || !y || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_gain: bad argument");
+    double g = std::pow(10.0, gain_db / 20.0);
+    if (invert) g = -g;
+    const long per = L * C;
+    MST_LAUNCH(fx_scale_kernel, dim3((unsigned)((per + 255) / 256), n_items), dim3(256), stream, x, y, per, (float)g,
+               (const double *)nullptr, (const double *)nullptr, 0);
+    MST_CHECK_LAUNCH("fx_scale_kernel");
+    return MST_OK;
+}
+
+extern "C" int mst_fx_rms_normalize(const float *x, float *y, int n_items, long L, int C, double *scratch, void *stream) {
+    if (!x || !y || !scratch || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_rms_normalize: bad argument");
+    const long per = L * C;
+    int rc;
+    if ((rc = energy(x, scratch, n_items, per, 0, stream))) return rc;
+    if ((rc = energy(y, scratch + 2 * n_items, n_items, per, 0, stream))) return rc;
+    MST_LAUNCH(fx_scale_kernel, dim3((unsigned)((per + 255) / 256), n_items), dim3(256), stream, x, y, per, 1.0f,
+               (const double *)scratch, (const double *)(scratch + 2 * n_items), 1);
+    MST_CHECK_LAUNCH("fx_scale_kernel");
+    return MST_OK;
+}

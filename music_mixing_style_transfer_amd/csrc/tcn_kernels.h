@@ -1,0 +1,428 @@
+// gfx950 kernels of the MixFXcloner TCN (reference networks/architectures.py:177-234 TCNBlock.forward,
+// :135-147 TCNModel.forward, networks/network_utils.py:180-182 FiLM).
+//
+// Data layout in HBM: activations between blocks are TIME-MAJOR / CHANNEL-MINOR ("NLC"):
+//     act[b][t][c]   c = 0..127 contiguous (256 B per time step in bf16, 512 B in fp32), row pitch Lp.
+// so that (a) one time step is one contiguous row: any set of time steps - in particular the dilated
+// taps t + (j-7)*d - is gathered at full cache-line efficiency whatever d is, and (b) the 8 consecutive
+// input channels a bf16 MFMA lane needs are one 16-byte LDS read.
+//
+// Tiling ("polyphase rows"): a dilated conv with dilation d is d independent dense convs over the
+// phases t = m*d + phi.  A workgroup owns P consecutive phases x Mt consecutive steps (P*Mt = 256 output
+// time steps, P | d) and all 128 output channels.  Its input rows are staged ONCE into LDS as a flat list
+//     row r  <->  step (m0 + r/P - 7), phase (phi0 + r%P)         r in [0, 256 + 14*P)
+// so output o = (m - m0)*P + (phi - phi0) reads row o + j*P for tap j: inside LDS the dilated conv is a
+// conv with stride-P taps, and the input is read from HBM (256+14P)/256 = 1.1-1.9x instead of 15x.
+// The main loop then has NO barrier: B operands (activations) come from LDS, A operands (BN-folded
+// weights, pre-packed in fragment order) stream from L2 straight into registers.
+//
+// MFMA orientation: D[co][t] = sum_k W'[co][k] * X[k][t]; wave w owns output channels 32w..32w+31 and all
+// 256 time steps of the tile (8 accumulator tiles of 32x32).  A lane's 4 consecutive accumulator rows are
+// 4 consecutive channels -> one 8-byte (bf16) / 16-byte (fp32) store per time step.
+//
+// Epilogue (fused): + BN shift -> LeakyReLU(0.01) -> FiLM r*y+b -> + res_scale * x_in  -> store.
+#pragma once
+#include "mst_dev.h"
+
+struct TcnBlockArgs {
+    const void *x;        // act in  [B][Lp][128]
+    void *y;              // act out [B][Lp][128]
+    const void *wpk;      // packed BN-folded conv weights (fragment order, see pack_* in mst_api)
+    const float *shift;   // [128] BN shift  beta - mean*gamma/sqrt(var+eps)
+    const float *film;    // [film_rows][256]  r = [0,128), b = [128,256)
+    const float *res;     // [128] grouped 1x1 residual scale
+    int film_rows;        // 1 (broadcast) or B
+    int B, L, Lp, d;
+    int tiles_phase;      // d / P
+    int tiles_step;       // ceil(ceil(L/d) / (256/P))
+};
+
+// ------------------------------------------------------------------------------------------------
+// blocks 1..n-1, bf16 MFMA (v_mfma_f32_32x32x16_bf16), bf16 activations.  MFMA-bound:
+// 2*128*1920 = 491 520 FLOP per output time step against 512 B of HBM traffic.
+// ------------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(256) void tcn_block_bf16_kernel(TcnBlockArgs a) {
+    constexpr int T = 256, R = T + 14 * P, MT = T / P;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ln = lane & 31, h = lane >> 5;
+
+    int tile = blockIdx.x;
+    const int mg = tile % a.tiles_step;
+    tile /= a.tiles_step;
+    const int pg = tile % a.tiles_phase;
+    const int b = tile / a.tiles_phase;
+    const int m0 = mg * MT, phi0 = pg * P;
+    const __bf16 *xb = (const __bf16 *)a.x + (size_t)b * a.Lp * 128;
+    __bf16 *yb = (__bf16 *)a.y + (size_t)b * a.Lp * 128;
+
+    // ---- stage the (256 + 14P) input rows: 16 lanes x 16 B per row, XOR-swizzled 16-B slots so that the
+    //      32 consecutive rows of one B-fragment read hit 16 distinct slots per ds_read_b128 lane group
+    {
+        const int slot = tid & 15;
+#pragma unroll 4
+        for (int r = tid >> 4; r < R; r += 16) {
+            const long t = (long)(m0 + r / P - 7) * a.d + phi0 + (r % P);
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (t >= 0 && t < a.L) v = *(const bf16x8 *)(xb + t * 128 + slot * 8);
+            *(bf16x8 *)(smem + r * 256 + ((slot ^ (r & 15)) << 4)) = v;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
+
+    // A fragments: wpk[ks = j*8 + kc][wave][lane] = 8 bf16 = W'[32w + ln][16kc + 8h + e][j]
+    const bf16x8 *wp = (const bf16x8 *)a.wpk + (w * 64 + lane);
+    bf16x8 acur[8], anxt[8];
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) anxt[kc] = acur[kc] = wp[kc * 256];
+
+    for (int j = 0; j < 15; ++j) {
+        if (j < 14) {
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) anxt[kc] = wp[((j + 1) * 8 + kc) * 256];
+        }
+        const int rowbase = j * P + ln;
+        const int sw = rowbase & 15;
+        const unsigned char *rp = smem + rowbase * 256;
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            const int off = ((2 * kc + h) ^ sw) << 4;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const bf16x8 bfr = *(const bf16x8 *)(rp + q * 8192 + off);
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[kc], bfr, acc[q], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) acur[kc] = anxt[kc];
+    }
+
+    // ---- fused epilogue
+    const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int co0 = 32 * w + 8 * g + 4 * h;
+        const f32x4 sh = *(const f32x4 *)(a.shift + co0);
+        const f32x4 fr = *(const f32x4 *)(frow + co0);
+        const f32x4 fb = *(const f32x4 *)(frow + 128 + co0);
+        const f32x4 rs = *(const f32x4 *)(a.res + co0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int o = 32 * q + ln;
+            const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
+            if (t < a.L) {
+                const int row = o + 7 * P;
+                const bf16x4 xin = *(const bf16x4 *)(smem + row * 256 + (((co0 >> 3) ^ (row & 15)) << 4) + 8 * h);
+                bf16x4 out;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = leaky_relu(acc[q][4 * g + i] + sh[i]);
+                    v = fr[i] * v + fb[i];
+                    v += rs[i] * (float)xin[i];
+                    out[i] = (__bf16)v;
+                }
+                *(bf16x4 *)(yb + t * 128 + co0) = out;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// blocks 1..n-1, exact fp32 (v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain), fp32 activations.
+// The parity mode.  Input channels are staged in 4 chunks of 32 (128 B per row) to keep LDS small.
+// ------------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(256) void tcn_block_f32_kernel(TcnBlockArgs a) {
+    constexpr int T = 256, R = T + 14 * P, MT = T / P;
+    __shared__ __attribute__((aligned(16))) float smem[R * 32];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ln = lane & 31, h = lane >> 5;
+
+    int tile = blockIdx.x;
+    const int mg = tile % a.tiles_step;
+    tile /= a.tiles_step;
+    const int pg = tile % a.tiles_phase;
+    const int b = tile / a.tiles_phase;
+    const int m0 = mg * MT, phi0 = pg * P;
+    const float *xb = (const float *)a.x + (size_t)b * a.Lp * 128;
+    float *yb = (float *)a.y + (size_t)b * a.Lp * 128;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
+
+    // A fragments: wpk[((j*4 + c)*4 + ksg)*256 + w*64 + lane] = 4 floats, element i = W'[32w+ln][32c + 2(4ksg+i) + h][j]
+    const f32x4 *wp = (const f32x4 *)a.wpk + (w * 64 + lane);
+
+    for (int c = 0; c < 4; ++c) {
+        if (c) __syncthreads();   // every wave is done reading the previous chunk
+        {
+            // 8 lanes x 16 B per row; dword-granular XOR swizzle (dword i of row r lives at i ^ (r & 31)) so the
+            // 32 rows read by one half-wave ds_read_b32 land in 32 distinct banks
+            const int s = tid & 7;
+#pragma unroll 2
+            for (int r = tid >> 3; r < R; r += 32) {
+                const long t = (long)(m0 + r / P - 7) * a.d + phi0 + (r % P);
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (t >= 0 && t < a.L) v = *(const f32x4 *)(xb + t * 128 + c * 32 + s * 4);
+                const int rs = r & 31;
+                f32x4 o1, o2;   // o2[i ^ (rs & 3)] = v[i] as two conditional swaps (no runtime vector indexing)
+                o1[0] = (rs & 1) ? v[1] : v[0];
+                o1[1] = (rs & 1) ? v[0] : v[1];
+                o1[2] = (rs & 1) ? v[3] : v[2];
+                o1[3] = (rs & 1) ? v[2] : v[3];
+                o2[0] = (rs & 2) ? o1[2] : o1[0];
+                o2[1] = (rs & 2) ? o1[3] : o1[1];
+                o2[2] = (rs & 2) ? o1[0] : o1[2];
+                o2[3] = (rs & 2) ? o1[1] : o1[3];
+                *(f32x4 *)(smem + r * 32 + ((s ^ (rs >> 2)) << 2)) = o2;
+            }
+        }
+        __syncthreads();
+
+        for (int j = 0; j < 15; ++j) {
+            const int rowbase = j * P + ln;
+            const int sw = rowbase & 31;
+            const float *rp = smem + rowbase * 32;
+            f32x4 af[4];
+#pragma unroll
+            for (int ksg = 0; ksg < 4; ++ksg) af[ksg] = wp[((j * 4 + c) * 4 + ksg) * 256];
+#pragma unroll
+            for (int ksg = 0; ksg < 4; ++ksg) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int off = (2 * (4 * ksg + i) + h) ^ sw;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float bv = rp[q * 1024 + off];
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ksg][i], bv, acc[q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int co0 = 32 * w + 8 * g + 4 * h;
+        const f32x4 sh = *(const f32x4 *)(a.shift + co0);
+        const f32x4 fr = *(const f32x4 *)(frow + co0);
+        const f32x4 fb = *(const f32x4 *)(frow + 128 + co0);
+        const f32x4 rs = *(const f32x4 *)(a.res + co0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int o = 32 * q + ln;
+            const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
+            if (t < a.L) {
+                const f32x4 xin = *(const f32x4 *)(xb + t * 128 + co0);
+                f32x4 out;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = leaky_relu(acc[q][4 * g + i] + sh[i]);
+                    v = fr[i] * v + fb[i];
+                    out[i] = v + rs[i] * xin[i];
+                }
+                *(f32x4 *)(yb + t * 128 + co0) = out;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// block 0: 2 -> 128 channels, k = 15, dilation 1, input fp32 NCL [B][2][L] (the caller's tensor),
+// output NLC.  30 MAC per output element: fp32 VALU (exact), register-tiled 8 channels x 4 time steps.
+// res is the grouped 1x1 with groups = 2: out-channel co reads in-channel co / 64.
+// ------------------------------------------------------------------------------------------------
+struct TcnBlock0Args {
+    const float *x;       // [B][2][L]
+    void *y;              // [B][Lp][128]
+    const float *w;       // [2][15][128] BN-folded
+    const float *shift, *film, *res;
+    int film_rows, B, L, Lp;
+};
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void tcn_block0_kernel(TcnBlock0Args a) {
+    constexpr int TT = 64, XW = TT + 14;
+    __shared__ __attribute__((aligned(16))) float ws[2 * 15 * 128];
+    __shared__ float xs[2 * XW];
+    const int tid = threadIdx.x;
+    const int tiles_t = (a.L + TT - 1) / TT;
+    const int b = blockIdx.x / tiles_t;
+    const int t0 = (blockIdx.x % tiles_t) * TT;
+    for (int i = tid; i < 2 * 15 * 128 / 4; i += 256) ((f32x4 *)ws)[i] = ((const f32x4 *)a.w)[i];
+    if (tid < 2 * XW) {
+        const int ci = tid / XW, k = tid % XW;
+        const long t = (long)t0 - 7 + k;
+        xs[tid] = (t >= 0 && t < a.L) ? a.x[((size_t)b * 2 + ci) * a.L + t] : 0.0f;
+    }
+    __syncthreads();
+    const int cg = tid & 15, tg = tid >> 4;
+    const int co0 = cg * 8;
+    float xw[2][18];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int k = 0; k < 18; ++k) xw[ci][k] = xs[ci * XW + 4 * tg + k];
+    float acc[4][8];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[tt][c] = 0.0f;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+#pragma unroll
+        for (int j = 0; j < 15; ++j) {
+            const f32x4 w0 = *(const f32x4 *)(ws + (ci * 15 + j) * 128 + co0);
+            const f32x4 w1 = *(const f32x4 *)(ws + (ci * 15 + j) * 128 + co0 + 4);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const float xv = xw[ci][tt + j];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[tt][c] = fmaf(w0[c], xv, acc[tt][c]);
+                    acc[tt][c + 4] = fmaf(w1[c], xv, acc[tt][c + 4]);
+                }
+            }
+        }
+    }
+    const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+    float sh[8], fr[8], fb[8], rs[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        sh[c] = a.shift[co0 + c];
+        fr[c] = frow[co0 + c];
+        fb[c] = frow[128 + co0 + c];
+        rs[c] = a.res[co0 + c];
+    }
+    const int cin = co0 >> 6;
+    OutT *yb = (OutT *)a.y + (size_t)b * a.Lp * 128;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        const int t = t0 + 4 * tg + tt;
+        if (t < a.L) {
+            const float xin = xw[cin][tt + 7];
+            float o8[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float v = leaky_relu(acc[tt][c] + sh[c]);
+                v = fr[c] * v + fb[c];
+                o8[c] = v + rs[c] * xin;
+            }
+            store8(yb + (size_t)t * 128 + co0, o8);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// output 1x1 conv (128 -> noutputs <= 2) + bias + clamp(-1, 1)  (architectures.py:133,145); NLC in,
+// fp32 NCL [B][nout][L] out (the caller's tensor).  HBM-bound: one read of the last activation.
+// ------------------------------------------------------------------------------------------------
+struct TcnOutArgs {
+    const void *x;     // [B][Lp][128]
+    float *y;          // [B][nout][L]
+    const float *w;    // [nout][128]
+    const float *bias; // [nout]
+    int nout, B, L, Lp;
+};
+
+template <typename InT>
+__global__ __launch_bounds__(256) void tcn_output_kernel(TcnOutArgs a) {
+    constexpr int TT = 64;
+    __shared__ float outs[2][TT];
+    const int tid = threadIdx.x, sl = tid & 15, rr = tid >> 4;
+    const int tiles_t = (a.L + TT - 1) / TT;
+    const int b = blockIdx.x / tiles_t;
+    const int t0 = (blockIdx.x % tiles_t) * TT;
+    float w0[8], w1[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        w0[c] = a.w[8 * sl + c];
+        w1[c] = a.nout > 1 ? a.w[128 + 8 * sl + c] : 0.0f;
+    }
+    const InT *xb = (const InT *)a.x + (size_t)b * a.Lp * 128;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int i = pass * 16 + rr;
+        const int t = t0 + i;
+        float s0 = 0.0f, s1 = 0.0f;
+        if (t < a.L) {
+            float v8[8];
+            load8(xb + (size_t)t * 128 + 8 * sl, v8);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                s0 = fmaf(w0[c], v8[c], s0);
+                s1 = fmaf(w1[c], v8[c], s1);
+            }
+        }
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+            s0 += __shfl_xor(s0, m);
+            s1 += __shfl_xor(s1, m);
+        }
+        if (sl == 0) {
+            outs[0][i] = s0;
+            outs[1][i] = s1;
+        }
+    }
+    __syncthreads();
+    if (tid < a.nout * TT) {
+        const int o = tid / TT, i = tid % TT;
+        const int t = t0 + i;
+        if (t < a.L) {
+            float v = outs[o][i] + a.bias[o];
+            v = fminf(1.0f, fmaxf(-1.0f, v));
+            a.y[((size_t)b * a.nout + o) * a.L + t] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FiLM factor table: film[n][row][0..2C) = film_fc_n(cond[row])   (network_utils.py:180-181).
+// One wave per output feature; 14 GEMVs of 256 x 2048 - once per embedding, not per segment.
+// ------------------------------------------------------------------------------------------------
+struct FilmArgs {
+    const float *fw;     // [nblocks][2C][D]
+    const float *fb;     // [nblocks][2C]
+    const float *cond;   // [rows][D] (+ n*block_stride)
+    float *film;         // [nblocks][rows][2C]
+    int nblocks, two_c, D, rows;
+    long block_stride;
+};
+
+__global__ __launch_bounds__(256) void tcn_film_kernel(FilmArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int out = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (out >= a.nblocks * a.two_c) return;   // wave-uniform
+    const int n = out / a.two_c, oc = out % a.two_c;
+    const float *wrow = a.fw + ((size_t)n * a.two_c + oc) * a.D;
+    for (int row = 0; row < a.rows; ++row) {
+        const float *cv = a.cond + (size_t)n * a.block_stride + (size_t)row * a.D;
+        float s = 0.0f;
+        for (int i = lane; i < a.D; i += 64) s = fmaf(wrow[i], cv[i], s);
+        s = wave_sum(s);
+        if (lane == 0) a.film[((size_t)n * a.rows + row) * a.two_c + oc] = s + a.fb[n * a.two_c + oc];
+    }
+}
+
+// NLC -> NCL fp32 copy of an intermediate activation (parity probe only, not on the hot path)
+template <typename InT>
+__global__ void tcn_unpack_kernel(const void *x, float *y, int B, int L, int Lp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * L * 128) return;
+    const int c = i % 128;
+    const size_t bt = i / 128;
+    const int t = bt % L;
+    const int b = bt / L;
+    y[((size_t)b * 128 + c) * L + t] = (float)((const InT *)x)[((size_t)b * Lp + t) * 128 + c];
+}

@@ -1,0 +1,335 @@
+"""FXencoder and the TCN "MixFXcloner" behind the reference's module API
+(networks/architectures.py of the reference: FXencoder :26-70, TCNModel :76-174, TCNBlock :177-234).
+
+Same constructor signatures, attribute names and state_dict keys, so
+    enc = FXencoder(cfg); enc.load_state_dict(ckpt)            # strict
+    tcn = TCNModel(nparams=2048, ninputs=2, ...); tcn(x, emb)
+work unchanged (inference/style_transfer.py:47-57,94-108,149,161).  forward() hands raw device pointers and
+the current HIP stream to libmst_hip.so (include/mst_hip.h); weights are BN-folded and packed into MFMA
+fragment order by the library when the module first runs (and again whenever parameters change).
+pytorch_lightning is not a dependency: TCNModel is a plain nn.Module carrying `hparams`.
+"""
+import ctypes as C
+import inspect
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .network_utils import Conv1d_layer, ConvBlock, FiLM, Res_ConvBlock  # noqa: F401  (star-export parity)
+
+
+class _HParams(dict):
+    """Attribute-style access like Lightning's save_hyperparameters() namespace."""
+    __getattr__ = dict.__getitem__
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _stream_ptr(t):
+    if t.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return C.c_void_p(0)
+
+
+def _check_device(t, what):
+    b = _lib.lib()
+    if not t.is_cuda and not getattr(b, "emulated", False):
+        raise RuntimeError(f"{what}: input must live on the MI355X (a CUDA/HIP tensor); there is no CPU path")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{what}: float32 input expected, got {t.dtype}")
+    return b
+
+
+def _signature(module):
+    return tuple((p.data_ptr(), p._version, p.device) for p in list(module.parameters()) + list(module.buffers()))
+
+
+class _Workspace:
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = None
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self.buf
+
+
+# ------------------------------------------------------------------------------------------------ encoder
+class _EncoderRunner:
+    """Owns one MstEnc handle for a list of Res_ConvBlocks."""
+
+    def __init__(self, blocks):
+        self.blocks = blocks
+        self.handle = None
+        self.sig = None
+        self.ws = _Workspace()
+        self.lib = None
+
+    def _module_sig(self):
+        return tuple(s for blk in self.blocks for s in _signature(blk))
+
+    def _ensure(self, b):
+        sig = self._module_sig()
+        if self.handle is not None and sig == self.sig and self.lib is b:
+            return
+        self.close()
+        for blk in self.blocks:
+            if not (blk.conv1.hip_supported() and blk.conv2.hip_supported()):
+                raise NotImplementedError("FXencoder: only norm='batch', activation='relu', padding='SAME' blocks "
+                                          "are implemented on gfx950")
+        d = _lib.MstEncDesc()
+        d.nblocks = len(self.blocks)
+        d.channels[0] = self.blocks[0].conv1.in_channels
+        for i, blk in enumerate(self.blocks):
+            d.channels[i + 1] = blk.conv2.out_channels
+            d.kernels[i] = blk.conv2.kernel_size
+            d.strides[i] = blk.conv2.stride
+            d.dilations[i] = blk.conv2.dilation
+        h = C.c_void_p()
+        b.check(b.mst_enc_create(C.byref(d), C.byref(h)), "mst_enc_create")
+        self.handle, self.lib = h, b
+        for i, blk in enumerate(self.blocks):
+            for which, conv in enumerate((blk.conv1, blk.conv2)):
+                a = conv.export_arrays()
+                ptr = lambda t: None if t is None else t.data_ptr()
+                b.check(b.mst_enc_load_conv(h, i, which, ptr(a["w"]), ptr(a["bias"]), ptr(a["bn_w"]), ptr(a["bn_b"]),
+                                            ptr(a["bn_mean"]), ptr(a["bn_var"]), a["eps"], None), "mst_enc_load_conv")
+        self.sig = sig
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.mst_enc_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, x, pooled=True, n_run=None):
+        b = _check_device(x, "FXencoder.forward")
+        if x.dim() != 3 or x.shape[1] != self.blocks[0].conv1.in_channels:
+            raise ValueError(f"FXencoder.forward: expected [B, {self.blocks[0].conv1.in_channels}, L], got {tuple(x.shape)}")
+        self._ensure(b)
+        x = x.contiguous()
+        B, _, L = x.shape
+        nbytes = b.mst_enc_workspace_bytes(self.handle, B, L)
+        ws = self.ws.get(nbytes, x.device)
+        st = _stream_ptr(x)
+        if pooled:
+            out = torch.empty(B, self.blocks[-1].conv2.out_channels, dtype=torch.float32, device=x.device)
+            b.check(b.mst_enc_forward(self.handle, x.data_ptr(), out.data_ptr(), B, L, ws.data_ptr(), nbytes, st),
+                    "mst_enc_forward")
+            return out
+        n_run = len(self.blocks) if n_run is None else n_run
+        lout = b.mst_enc_block_length(self.handle, n_run - 1, L)
+        out = torch.empty(B, self.blocks[n_run - 1].conv2.out_channels, lout, dtype=torch.float32, device=x.device)
+        b.check(b.mst_enc_forward_blocks(self.handle, x.data_ptr(), out.data_ptr(), B, L, n_run, ws.data_ptr(), nbytes, st),
+                "mst_enc_forward_blocks")
+        return out
+
+
+class FXencoder(nn.Module):
+    """Audio-effects encoder: stereo waveform [B, 2, L] -> FX embedding [B, channels[-1]]."""
+
+    def __init__(self, config):
+        super().__init__()
+        # the reference prepends the stereo input to the caller's list in place (architectures.py:30);
+        # the observable side effect on `config` is kept.
+        config["channels"].insert(0, 2)
+        ch = config["channels"]
+        encoder = []
+        for i in range(len(config["kernels"])):
+            if config["conv_block"] == "res":
+                encoder.append(Res_ConvBlock(dimension=1, in_channels=ch[i], out_channels=ch[i + 1],
+                                             kernel_size=config["kernels"][i], stride=config["strides"][i],
+                                             padding="SAME", dilation=config["dilation"][i], norm=config["norm"],
+                                             activation=config["activation"], last_activation=config["activation"]))
+            elif config["conv_block"] == "conv":
+                encoder.append(ConvBlock(dimension=1, layer_num=1, in_channels=ch[i], out_channels=ch[i + 1],
+                                         kernel_size=config["kernels"][i], stride=config["strides"][i], padding="VALID",
+                                         dilation=config["dilation"][i], norm=config["norm"],
+                                         activation=config["activation"], last_activation=config["activation"],
+                                         mode="conv"))
+        self.encoder = nn.Sequential(*encoder)
+        self.glob_pool = nn.AdaptiveAvgPool1d(1)
+        self._runner = None
+
+    def _get_runner(self):
+        if self._runner is None:
+            blocks = list(self.encoder)
+            if not all(isinstance(b, Res_ConvBlock) for b in blocks):
+                raise NotImplementedError("FXencoder: conv_block='conv' is not implemented on gfx950 (the shipped "
+                                          "configs.yaml uses 'res')")
+            self._runner = _EncoderRunner(blocks)
+        return self._runner
+
+    def forward(self, input):
+        return self._get_runner().run(input, pooled=True)
+
+    def forward_blocks(self, input, n_run):
+        """Parity probe: output of the n_run-th Res_ConvBlock, [B, C, L_out]."""
+        return self._get_runner().run(input, pooled=False, n_run=n_run)
+
+
+# ------------------------------------------------------------------------------------------------ TCN
+class TCNBlock(nn.Module):
+    """dilated conv -> BatchNorm -> LeakyReLU -> FiLM -> + grouped 1x1 residual.  Parameter container: the block
+    runs fused inside TCNModel.forward (one gfx950 kernel per block)."""
+
+    def __init__(self, in_ch, out_ch, kernel_size=3, dilation=1, cond_dim=2048, grouped=False, causal=False,
+                 conditional=False, **kwargs):
+        super().__init__()
+        self.in_ch, self.out_ch = in_ch, out_ch
+        self.kernel_size, self.dilation = kernel_size, dilation
+        self.grouped, self.causal, self.conditional = grouped, causal, conditional
+        groups = out_ch if grouped and (in_ch % out_ch == 0) else 1
+        span = (kernel_size - 1) * dilation
+        self.pad_length = span if causal else span // 2
+        self.conv1 = nn.Conv1d(in_ch, out_ch, kernel_size=kernel_size, padding=self.pad_length, dilation=dilation,
+                               groups=groups, bias=False)
+        if grouped:
+            self.conv1b = nn.Conv1d(out_ch, out_ch, kernel_size=1)
+        if conditional:
+            self.film = FiLM(cond_dim, out_ch)
+        self.bn = nn.BatchNorm1d(out_ch)
+        self.relu = nn.LeakyReLU()
+        self.res = nn.Conv1d(in_ch, out_ch, kernel_size=1, groups=in_ch, bias=False)
+
+    def forward(self, x, p):  # pragma: no cover - guard
+        raise NotImplementedError("TCNBlock runs fused inside TCNModel.forward on MI355X; there is no torch fallback")
+
+
+class TCNModel(nn.Module):
+    """Temporal convolutional network with FiLM conditioning (the MixFXcloner).
+
+    forward(x [B, ninputs, L], cond [1|B, cond_dim] or list of nblocks such tensors) -> [B, noutputs, L] in [-1, 1].
+    `precision` selects the arithmetic of the dense dilated convolutions: "fp32" (exact fp32 on the matrix
+    cores, the parity mode, default) or "bf16" (bf16 operands / fp32 accumulate, the throughput mode).
+    """
+
+    def __init__(self, nparams, ninputs=1, noutputs=1, nblocks=10, kernel_size=3, dilation_growth=1, channel_growth=1,
+                 channel_width=32, stack_size=10, cond_dim=2048, grouped=False, causal=False, skip_connections=False,
+                 num_examples=4, save_dir=None, **kwargs):
+        super().__init__()
+        frame = inspect.currentframe()
+        names, _, _, values = inspect.getargvalues(frame)
+        self.hparams = _HParams({n: values[n] for n in names if n not in ("self", "frame")})
+        self.blocks = nn.ModuleList()
+        out_ch = None
+        for n in range(nblocks):
+            in_ch = out_ch if n > 0 else ninputs
+            out_ch = in_ch * channel_growth if channel_growth > 1 else channel_width
+            dilation = dilation_growth ** (n % stack_size)
+            self.blocks.append(TCNBlock(in_ch, out_ch, kernel_size=kernel_size, dilation=dilation,
+                                        padding="same" if causal else "valid", causal=causal, cond_dim=cond_dim,
+                                        grouped=grouped, conditional=True if nparams > 0 else False))
+        self.output = nn.Conv1d(out_ch, noutputs, kernel_size=1)
+        self.precision = os.environ.get("MST_TCN_PRECISION", "fp32")
+        self._handle = None
+        self._lib = None
+        self._sig = None
+        self._ws = _Workspace()
+
+    # ---- reference API -------------------------------------------------------------------------
+    def compute_receptive_field(self):
+        """Receptive field in samples."""
+        hp = self.hparams
+        rf = hp.kernel_size
+        for n in range(1, hp.nblocks):
+            rf += (hp.kernel_size - 1) * hp.dilation_growth ** (n % hp.stack_size)
+        return rf
+
+    # ---- gfx950 plumbing -----------------------------------------------------------------------
+    def _ensure(self, b):
+        sig = _signature(self)
+        if self._handle is not None and sig == self._sig and self._lib is b:
+            return
+        self._close()
+        hp = self.hparams
+        if hp.causal or hp.grouped or hp.channel_growth > 1 or not hp.nparams > 0:
+            raise NotImplementedError("TCNModel: only the non-causal, ungrouped, conditional configuration of "
+                                      "inference/style_transfer.py is implemented on gfx950")
+        d = _lib.MstTcnDesc()
+        d.nblocks, d.ninputs, d.noutputs = hp.nblocks, hp.ninputs, hp.noutputs
+        d.channels, d.kernel_size, d.cond_dim = hp.channel_width, hp.kernel_size, hp.cond_dim
+        for n, blk in enumerate(self.blocks):
+            d.dilations[n] = blk.dilation
+        h = C.c_void_p()
+        b.check(b.mst_tcn_create(C.byref(d), C.byref(h)), "mst_tcn_create")
+        self._handle, self._lib = h, b
+        f = lambda t: t.detach().to("cpu", torch.float32).contiguous()
+        for n, blk in enumerate(self.blocks):
+            arrs = [f(blk.conv1.weight), f(blk.bn.weight), f(blk.bn.bias), f(blk.bn.running_mean), f(blk.bn.running_var),
+                    f(blk.film.film_fc.weight), f(blk.film.film_fc.bias), f(blk.res.weight)]
+            b.check(b.mst_tcn_load_block(h, n, arrs[0].data_ptr(), arrs[1].data_ptr(), arrs[2].data_ptr(),
+                                         arrs[3].data_ptr(), arrs[4].data_ptr(), float(blk.bn.eps), arrs[5].data_ptr(),
+                                         arrs[6].data_ptr(), arrs[7].data_ptr(), None), "mst_tcn_load_block")
+        ow, ob = f(self.output.weight), f(self.output.bias)
+        b.check(b.mst_tcn_load_output(h, ow.data_ptr(), ob.data_ptr(), None), "mst_tcn_load_output")
+        self._sig = sig
+
+    def _close(self):
+        if self._handle is not None:
+            self._lib.mst_tcn_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._close()
+        except Exception:
+            pass
+
+    def _set_cond(self, b, x, cond):
+        hp = self.hparams
+        if isinstance(cond, (list, tuple)):     # one condition per block (reference's SeFa branch, :139-140)
+            if len(cond) != hp.nblocks:
+                raise ValueError("TCNModel.forward: a condition list needs one entry per block")
+            c = torch.stack([ci.to(x.device, torch.float32) for ci in cond], 0).contiguous()   # [nblocks, rows, D]
+            rows, stride = c.shape[1], c.shape[1] * c.shape[2]
+        else:
+            c = cond.to(x.device, torch.float32).contiguous()
+            rows, stride = c.shape[0], 0
+        if c.shape[-1] != hp.cond_dim:
+            raise ValueError(f"TCNModel.forward: condition length {c.shape[-1]} != cond_dim {hp.cond_dim}")
+        if rows not in (1, x.shape[0]):
+            raise RuntimeError(f"The size of tensor a ({rows}) must match the size of tensor b ({x.shape[0]}) at "
+                               f"non-singleton dimension 0")
+        b.check(b.mst_tcn_set_cond(self._handle, c.data_ptr(), rows, stride, _stream_ptr(x)), "mst_tcn_set_cond")
+        return c   # keep alive until the kernels are enqueued
+
+    def forward(self, x, cond):
+        return self._run(x, cond, None)
+
+    def forward_blocks(self, x, cond, n_run):
+        """Parity probe: activations after the n_run-th block, fp32 [B, channel_width, L]."""
+        return self._run(x, cond, n_run)
+
+    def _run(self, x, cond, n_run):
+        b = _check_device(x, "TCNModel.forward")
+        hp = self.hparams
+        if x.dim() != 3 or x.shape[1] != hp.ninputs:
+            raise ValueError(f"TCNModel.forward: expected [B, {hp.ninputs}, L], got {tuple(x.shape)}")
+        self._ensure(b)
+        prec = _lib.PRECISIONS[self.precision]
+        x = x.contiguous()
+        B, _, L = x.shape
+        keep = self._set_cond(b, x, cond)
+        nbytes = b.mst_tcn_workspace_bytes(self._handle, B, L, prec)
+        ws = self._ws.get(nbytes, x.device)
+        st = _stream_ptr(x)
+        if n_run is None:
+            y = torch.empty(B, hp.noutputs, L, dtype=torch.float32, device=x.device)
+            b.check(b.mst_tcn_forward(self._handle, x.data_ptr(), y.data_ptr(), B, L, prec, ws.data_ptr(), nbytes, st),
+                    "mst_tcn_forward")
+        else:
+            y = torch.empty(B, hp.channel_width, L, dtype=torch.float32, device=x.device)
+            b.check(b.mst_tcn_forward_blocks(self._handle, x.data_ptr(), y.data_ptr(), B, L, prec, n_run, ws.data_ptr(),
+                                             nbytes, st), "mst_tcn_forward_blocks")
+        del keep
+        return y

@@ -1,0 +1,43 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    config.addinivalue_line("markers", "slow: long CPU test")
+
+
+@pytest.fixture(scope="session")
+def emu():
+    """The C ABI compiled for the host against the SIMT emulator (tests/emu) - same sources as libmst_hip.so."""
+    from music_mixing_style_transfer_amd import _lib
+    d = os.path.join(REPO, "tests", "emu")
+    subprocess.run(["make", "-C", d], check=True, capture_output=True)
+    b = _lib.bind(os.path.join(d, "libmst_emu.so"))
+    b.emulated = True
+    return b
+
+
+@pytest.fixture()
+def emu_default(emu):
+    """Route the module API (networks.*, mixing_manipulator.*) through the emulator for one test."""
+    from music_mixing_style_transfer_amd import _lib
+    prev = _lib._default
+    _lib.set_default_binding(emu)
+    yield emu
+    _lib.set_default_binding(prev)
+
+
+@pytest.fixture(scope="session")
+def oracle_fx_lib():
+    import ctypes
+    d = os.path.join(REPO, "oracle")
+    subprocess.run(["make", "-C", d], check=True, capture_output=True)
+    return ctypes.CDLL(os.path.join(d, "libfx_ref.so"))

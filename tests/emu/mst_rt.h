@@ -1,0 +1,150 @@
+// TEST INFRASTRUCTURE ONLY - a CPU SIMT emulator standing in for <hip/hip_runtime.h>.
+//
+// The product sources under music_mixing_style_transfer_amd/csrc include "mst_rt.h"; the product build
+// (hipcc, gfx950) finds csrc/mst_rt.h, the emulator build (host clang++) puts THIS directory first on
+// the include path.  Kernels then run unmodified on the host: every HIP thread is a fiber, 64 fibers
+// form a wavefront, __syncthreads / MFMA / shuffles are fiber rendezvous points.  This exists because
+// the build container has no GPU and GPU box minutes are scarce: index math, MFMA fragment layouts,
+// LDS swizzles and the C-ABI host logic are all checked here first (tests/test_emu_*.py).
+// It is never loaded by the product (music_mixing_style_transfer_amd/_lib.py loads libmst_hip.so only).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define MST_EMULATED 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static thread_local
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct emu_uint3 { unsigned x, y, z; };
+extern thread_local emu_uint3 threadIdx, blockIdx;
+extern thread_local dim3 blockDim, gridDim;
+
+typedef int hipError_t;
+typedef void *hipStream_t;
+#define hipSuccess 0
+#define hipMemcpyHostToDevice 1
+#define hipMemcpyDeviceToHost 2
+#define hipMemcpyDeviceToDevice 3
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? 0 : 2; }
+static inline hipError_t hipFree(void *p) { free(p); return 0; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { memcpy(d, s, n); return 0; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static inline hipError_t hipDeviceSynchronize() { return 0; }
+static inline hipError_t hipGetLastError() { return 0; }
+static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
+
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return {x, y}; }
+
+namespace emu {
+void launch(dim3 grid, dim3 block, const std::function<void()> &body);
+void block_barrier();
+// wave rendezvous with a 64 x 64-byte exchange area (double buffered internally)
+unsigned char *wave_publish(const void *src, size_t bytes);   // returns pointer to slot[lane 0]; stride 64 B
+int lane_id();
+}  // namespace emu
+
+#define MST_LAUNCH(kern, grid, block, stream, ...) \
+    emu::launch((grid), (block), [&]() { kern(__VA_ARGS__); })
+
+static inline void __syncthreads() { emu::block_barrier(); }
+
+// ---- wave collectives ------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float emu_f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 emu_bf16x8;
+
+// v_mfma_f32_32x32x2_f32: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31];
+// D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5); exact k-ordered fmaf chain (guide section 3).
+static inline emu_f32x16 emu_mfma_f32_32x32x2f32(float a, float b, emu_f32x16 c) {
+    struct AB { float a, b; } me = {a, b};
+    const unsigned char *base = emu::wave_publish(&me, sizeof(me));
+    const int l = emu::lane_id(), col = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            const AB *pa = (const AB *)(base + 64 * (row + 32 * k));
+            const AB *pb = (const AB *)(base + 64 * (col + 32 * k));
+            acc = fmaf(pa->a, pb->b, acc);
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+
+// v_mfma_f32_32x32x16_bf16: lane l holds 8 consecutive k of A row (l&31) / B column (l&31),
+// k group = l>>5; fp32 accumulate.
+static inline emu_f32x16 emu_mfma_f32_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c) {
+    struct AB { emu_bf16x8 a, b; } me = {a, b};
+    const unsigned char *base = emu::wave_publish(&me, sizeof(me));
+    const int l = emu::lane_id(), col = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        double acc = 0.0;
+        for (int g = 0; g < 2; ++g) {
+            const AB *pa = (const AB *)(base + 64 * (row + 32 * g));
+            const AB *pb = (const AB *)(base + 64 * (col + 32 * g));
+            for (int e = 0; e < 8; ++e) acc += (double)(float)pa->a[e] * (double)(float)pb->b[e];
+        }
+        c[r] = (float)((double)c[r] + acc);
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_f32_32x32x2f32((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_f32_32x32x16_bf16((a), (b), (c))
+
+template <typename T> static inline T emu_shfl(T v, int src) {
+    const unsigned char *base = emu::wave_publish(&v, sizeof(T));
+    T out;
+    memcpy(&out, base + 64 * (src & 63), sizeof(T));
+    return out;
+}
+template <typename T> static inline T __shfl_xor(T v, int mask, int = 64) { return emu_shfl(v, emu::lane_id() ^ mask); }
+template <typename T> static inline T __shfl_down(T v, int d, int = 64) {
+    const int l = emu::lane_id();
+    return emu_shfl(v, l + d < 64 ? l + d : l);
+}
+template <typename T> static inline T __shfl(T v, int src, int = 64) { return emu_shfl(v, src); }
+#define __builtin_amdgcn_readfirstlane(v) emu_shfl((v), 0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+
+static inline float atomicAdd(float *p, float v) {
+    uint32_t o = __atomic_load_n((uint32_t *)p, __ATOMIC_RELAXED), n;
+    float old, neu;
+    do {
+        memcpy(&old, &o, 4);
+        neu = old + v;
+        memcpy(&n, &neu, 4);
+    } while (!__atomic_compare_exchange_n((uint32_t *)p, &o, n, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    return old;
+}
+static inline double atomicAdd(double *p, double v) {
+    uint64_t o = __atomic_load_n((uint64_t *)p, __ATOMIC_RELAXED), n;
+    double old, neu;
+    do {
+        memcpy(&old, &o, 8);
+        neu = old + v;
+        memcpy(&n, &neu, 8);
+    } while (!__atomic_compare_exchange_n((uint64_t *)p, &o, n, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    return old;
+}
+static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
