@@ -101,6 +101,13 @@ int mst_tcn_forward(MstTcn *tcn, const float *x_dev, float *y_dev, int B, int L,
 int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int B, int L, int precision, int n_run,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* measurement hook (bench.py's roofline leg): between _begin and _end every mst_tcn_forward records HIP events
+ * on its stream around each kernel; _end synchronises, writes the AVERAGE milliseconds per forward of
+ * block kernels 0..nblocks-1 followed by the output kernel into ms_out[nblocks+1], and the number of
+ * forwards seen into *n_forwards. */
+int mst_tcn_timing_begin(MstTcn *tcn, int max_forwards);
+int mst_tcn_timing_end(MstTcn *tcn, float *ms_out, int *n_forwards);
+
 /* ------------------------------------------------------------------------------------------------
  * FXencoder (networks/architectures.py:26-70) = Res_ConvBlock x N (network_utils.py:96-119), each two
  * Conv1d_layer (network_utils.py:15-89: ReflectionPad1d -> Conv1d -> BatchNorm1d(eval) -> ReLU), then

@@ -72,6 +72,8 @@ struct MstTcn {
     int film_rows = 0, film_cap = 0;
     float *out_w = nullptr, *out_b = nullptr;
     bool out_loaded = false;
+    std::vector<hipEvent_t> ev;   // timing hook: (nblocks + 2) events per recorded forward
+    int ev_max = 0, ev_used = 0;
 };
 
 extern "C" int mst_version(void) { return 100; }
@@ -114,6 +116,7 @@ extern "C" int mst_tcn_destroy(MstTcn *t) {
     (void)hipFree(t->film);
     (void)hipFree(t->out_w);
     (void)hipFree(t->out_b);
+    for (auto e : t->ev) (void)hipEventDestroy(e);
     delete t;
     return MST_OK;
 }
@@ -246,6 +249,12 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
     const size_t buf_bytes = align_up((size_t)B * L * 128 * es, 256);
     unsigned char *buf[2] = {(unsigned char *)ws, (unsigned char *)ws + buf_bytes};
     const int Lp = L;
+    hipEvent_t *ev = nullptr;
+    if (!act_out && t->ev_used < t->ev_max) {
+        ev = t->ev.data() + (size_t)t->ev_used * (t->d.nblocks + 2);
+        t->ev_used++;
+        MST_HIP_TRY(hipEventRecord(ev[0], (hipStream_t)stream));
+    }
 
     {
         TcnBlock0Args a;
@@ -265,6 +274,7 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         else
             MST_LAUNCH((tcn_block0_kernel<float>), dim3(grid), dim3(256), stream, a);
         MST_CHECK_LAUNCH("tcn_block0_kernel");
+        if (ev) MST_HIP_TRY(hipEventRecord(ev[1], (hipStream_t)stream));
     }
     int cur = 0;
     for (int n = 1; n < n_run; ++n) {
@@ -296,6 +306,7 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
             default: rc = launch_block<16>(precision, a, (int)grid, stream); break;
         }
         if (rc) return rc;
+        if (ev) MST_HIP_TRY(hipEventRecord(ev[n + 1], (hipStream_t)stream));
         cur ^= 1;
     }
     if (act_out) {
@@ -323,10 +334,42 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
     else
         MST_LAUNCH((tcn_output_kernel<float>), dim3(grid), dim3(256), stream, o);
     MST_CHECK_LAUNCH("tcn_output_kernel");
+    if (ev) MST_HIP_TRY(hipEventRecord(ev[t->d.nblocks + 1], (hipStream_t)stream));
     return MST_OK;
 }
 
 }  // namespace
+
+extern "C" int mst_tcn_timing_begin(MstTcn *t, int max_forwards) {
+    if (!t || max_forwards < 1) return fail(MST_ERR_ARG, "mst_tcn_timing_begin: bad argument");
+    for (auto e : t->ev) (void)hipEventDestroy(e);
+    t->ev.assign((size_t)max_forwards * (t->d.nblocks + 2), nullptr);
+    for (auto &e : t->ev) MST_HIP_TRY(hipEventCreate(&e));
+    t->ev_max = max_forwards;
+    t->ev_used = 0;
+    return MST_OK;
+}
+
+extern "C" int mst_tcn_timing_end(MstTcn *t, float *ms_out, int *n_forwards) {
+    if (!t || !ms_out || !n_forwards) return fail(MST_ERR_ARG, "mst_tcn_timing_end: bad argument");
+    const int per = t->d.nblocks + 2;
+    for (int k = 0; k <= t->d.nblocks; ++k) ms_out[k] = 0.0f;
+    for (int f = 0; f < t->ev_used; ++f) {
+        MST_HIP_TRY(hipEventSynchronize(t->ev[(size_t)f * per + per - 1]));
+        for (int k = 0; k <= t->d.nblocks; ++k) {
+            float ms = 0.0f;
+            MST_HIP_TRY(hipEventElapsedTime(&ms, t->ev[(size_t)f * per + k], t->ev[(size_t)f * per + k + 1]));
+            ms_out[k] += ms;
+        }
+    }
+    if (t->ev_used > 0)
+        for (int k = 0; k <= t->d.nblocks; ++k) ms_out[k] /= (float)t->ev_used;
+    *n_forwards = t->ev_used;
+    for (auto e : t->ev) (void)hipEventDestroy(e);
+    t->ev.clear();
+    t->ev_max = t->ev_used = 0;
+    return MST_OK;
+}
 
 extern "C" size_t mst_tcn_workspace_bytes(const MstTcn *, int B, int L, int precision) {
     if (B < 1 || L < 1) return 0;

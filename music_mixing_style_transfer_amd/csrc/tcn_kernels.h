@@ -42,7 +42,7 @@ struct TcnBlockArgs {
 // 2*128*1920 = 491 520 FLOP per output time step against 512 B of HBM traffic.
 // ------------------------------------------------------------------------------------------------
 template <int P>
-__global__ __launch_bounds__(256) void tcn_block_bf16_kernel(TcnBlockArgs a) {
+__global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(TcnBlockArgs a) {
     constexpr int T = 256, R = T + 14 * P, MT = T / P;
     __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void tcn_block_bf16_kernel(TcnBlockArgs a) {
 // The parity mode.  Input channels are staged in 4 chunks of 32 (128 B per row) to keep LDS small.
 // ------------------------------------------------------------------------------------------------
 template <int P>
-__global__ __launch_bounds__(256) void tcn_block_f32_kernel(TcnBlockArgs a) {
+__global__ __launch_bounds__(256, 2) void tcn_block_f32_kernel(TcnBlockArgs a) {
     constexpr int T = 256, R = T + 14 * P, MT = T / P;
     __shared__ __attribute__((aligned(16))) float smem[R * 32];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -269,25 +269,20 @@ __global__ __launch_bounds__(256) void tcn_block0_kernel(TcnBlock0Args a) {
     __syncthreads();
     const int cg = tid & 15, tg = tid >> 4;
     const int co0 = cg * 8;
-    float xw[2][18];
-#pragma unroll
-    for (int ci = 0; ci < 2; ++ci)
-#pragma unroll
-        for (int k = 0; k < 18; ++k) xw[ci][k] = xs[ci * XW + 4 * tg + k];
     float acc[4][8];
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[tt][c] = 0.0f;
-#pragma unroll
     for (int ci = 0; ci < 2; ++ci) {
-#pragma unroll
+        const float *xrow = xs + ci * XW + 4 * tg;
+#pragma unroll 3
         for (int j = 0; j < 15; ++j) {
             const f32x4 w0 = *(const f32x4 *)(ws + (ci * 15 + j) * 128 + co0);
             const f32x4 w1 = *(const f32x4 *)(ws + (ci * 15 + j) * 128 + co0 + 4);
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
-                const float xv = xw[ci][tt + j];
+                const float xv = xrow[tt + j];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     acc[tt][c] = fmaf(w0[c], xv, acc[tt][c]);
@@ -311,7 +306,7 @@ __global__ __launch_bounds__(256) void tcn_block0_kernel(TcnBlock0Args a) {
     for (int tt = 0; tt < 4; ++tt) {
         const int t = t0 + 4 * tg + tt;
         if (t < a.L) {
-            const float xin = xw[cin][tt + 7];
+            const float xin = xs[cin * XW + 4 * tg + tt + 7];
             float o8[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {

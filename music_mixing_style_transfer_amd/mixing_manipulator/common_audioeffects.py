@@ -1,0 +1,298 @@
+"""FX-manipulator processors on MI355X, behind the reference's processor API
+(mixing_manipulator/common_audioeffects.py of the reference: AugmentationChain :91-201, Equaliser :370-525,
+Compressor :590-661, MidSideImager :956-1007, Gain :1011-1051).
+
+Same vocabulary as the reference: `Processor.process(x)`, `processor.parameters.<name>.value`, `update()`,
+`randomize()`, `AugmentationChain(fxs=[(processor, probability, rms_normalize), ...])(x_list)`.
+pymixconsole is not a dependency: Parameter / ParameterList / Processor are minimal local equivalents.
+
+Audio layout: [L, C] (time-major, interleaved) like the reference, or a batch [n_items, L, C]; float32.
+numpy in -> numpy out (drop-in); a CUDA torch tensor in -> a CUDA tensor out (stays on the device).
+All arithmetic runs in libmst_hip.so (csrc/fx_kernels.h); there is no numpy fallback.
+"""
+import ctypes as C
+import math
+import random
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+class Parameter:
+    def __init__(self, name, value, kind, units=None, minimum=None, maximum=None, options=None, processor=None, **kw):
+        self.name, self.value, self.kind, self.units = name, value, kind, units
+        self.min, self.max, self.options, self.default = minimum, maximum, options, value
+
+    def randomize(self):
+        if self.kind == "float":
+            self.value = random.uniform(self.min, self.max)
+        elif self.kind == "int":
+            self.value = random.randint(self.min, self.max)
+        elif self.kind == "bool":
+            self.value = random.random() < 0.5
+        elif self.kind == "string":
+            self.value = random.choice(self.options)
+
+    def __repr__(self):
+        return f"Parameter({self.name!r}={self.value!r})"
+
+
+class ParameterList:
+    def __init__(self):
+        self._names = []
+
+    def add(self, p):
+        self._names.append(p.name)
+        setattr(self, p.name, p)
+
+    def __iter__(self):
+        return (getattr(self, n) for n in self._names)
+
+    def __repr__(self):
+        return "ParameterList(" + ", ".join(repr(p) for p in self) + ")"
+
+
+class Processor:
+    def __init__(self, name, parameters, block_size, sample_rate, dtype="float32"):
+        self.name, self.parameters = name, parameters
+        self.block_size, self.sample_rate, self.dtype = block_size, sample_rate, dtype
+
+    def randomize(self):
+        for p in self.parameters:
+            p.randomize()
+        self.update(None)
+
+    def update(self, parameter_name=None):
+        pass
+
+    def __repr__(self):
+        return f"Processor(name={self.name!r}, parameters={self.parameters!r}"
+
+
+# ---------------------------------------------------------------------------------------------- device glue
+class _Dev:
+    """Moves one processor call onto the device and back in the caller's container type."""
+
+    def __init__(self, x):
+        self.lib = _lib.lib()
+        self.numpy = isinstance(x, np.ndarray)
+        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)) if self.numpy else x
+        if t.dtype != torch.float32:
+            t = t.float()
+        self.batched = t.dim() == 3
+        if t.dim() == 1:
+            t = t[:, None]
+        if not self.batched:
+            t = t[None]
+        if not t.is_cuda and not getattr(self.lib, "emulated", False):
+            if not torch.cuda.is_available():
+                raise RuntimeError("FX processors run on the MI355X only; no GPU is visible and there is no CPU path")
+            t = t.cuda()
+        self.x = t.contiguous()
+        self.n, self.L, self.C = self.x.shape
+        self.stream = C.c_void_p(torch.cuda.current_stream(self.x.device).cuda_stream) if self.x.is_cuda else C.c_void_p(0)
+
+    def scratch(self, n_doubles):
+        return torch.empty(n_doubles, dtype=torch.float64, device=self.x.device)
+
+    def out(self, y):
+        if not self.batched:
+            y = y[0]
+        return y.cpu().numpy() if self.numpy else y
+
+
+def rms_normalize_(x, y):
+    """In-place on y: y *= sqrt(mean(x^2) / max(1e-7, mean(y^2))) per item (reference apply_processor :143-146)."""
+    d = _Dev(x)
+    yt = y if isinstance(y, torch.Tensor) else torch.from_numpy(y)
+    yy = yt.reshape(d.n, d.L, d.C).contiguous()
+    if yy.device != d.x.device:
+        yy = yy.to(d.x.device)
+    sc = d.scratch(4 * d.n)
+    d.lib.check(d.lib.mst_fx_rms_normalize(d.x.data_ptr(), yy.data_ptr(), d.n, d.L, d.C, sc.data_ptr(), d.stream),
+                "mst_fx_rms_normalize")
+    return d.out(yy)
+
+
+# ---------------------------------------------------------------------------------------------- processors
+def rbj_coefficients(filter_type, gain_db, q, fc, rate):
+    """RBJ audio-EQ-cookbook biquad (b0,b1,b2,a0,a1,a2), un-normalised, float64 - the published algorithm of
+    pymixconsole==0.0.1 components/iirfilter.py (not vendored by the reference; see DESIGN.md, parity unpinned)."""
+    A = 10.0 ** (gain_db / 40.0)
+    w0 = 2.0 * math.pi * (fc / rate)
+    alpha = math.sin(w0) / (2.0 * q)
+    cw, sA = math.cos(w0), math.sqrt(A)
+    if filter_type == "high_shelf":
+        return (A * ((A + 1) + (A - 1) * cw + 2 * sA * alpha), -2 * A * ((A - 1) + (A + 1) * cw),
+                A * ((A + 1) + (A - 1) * cw - 2 * sA * alpha), (A + 1) - (A - 1) * cw + 2 * sA * alpha,
+                2 * ((A - 1) - (A + 1) * cw), (A + 1) - (A - 1) * cw - 2 * sA * alpha)
+    if filter_type == "low_shelf":
+        return (A * ((A + 1) - (A - 1) * cw + 2 * sA * alpha), 2 * A * ((A - 1) - (A + 1) * cw),
+                A * ((A + 1) - (A - 1) * cw - 2 * sA * alpha), (A + 1) + (A - 1) * cw + 2 * sA * alpha,
+                -2 * ((A - 1) + (A + 1) * cw), (A + 1) + (A - 1) * cw - 2 * sA * alpha)
+    if filter_type == "peaking":
+        return (1 + alpha * A, -2 * cw, 1 - alpha * A, 1 + alpha / A, -2 * cw, 1 - alpha / A)
+    raise ValueError(f"unknown filter type {filter_type}")
+
+
+class Equaliser(Processor):
+    """Five-band parametric EQ: low shelf, three peaking bands, high shelf (shelves at Q = 0.707), a cascade of
+    RBJ biquads each applied to the whole signal from zero state."""
+
+    def __init__(self, n_channels, sample_rate, gain_range=(-15.0, 15.0), q_range=(0.1, 2.0),
+                 bands=("low_shelf", "first_band", "second_band", "third_band", "high_shelf"), hard_clip=False,
+                 name="Equaliser", parameters=None):
+        super().__init__(name, parameters=parameters, block_size=None, sample_rate=sample_rate)
+        self.n_channels = n_channels
+        lo, hi = gain_range
+        qlo, qhi = q_range
+        if not parameters:
+            self.parameters = ParameterList()
+            spec = [("low_shelf", 80.0, 30.0, 200.0, None), ("first_band", 400.0, 200.0, 1000.0, 0.7),
+                    ("second_band", 2000.0, 1000.0, 3000.0, 0.7), ("third_band", 4000.0, 3000.0, 8000.0, 0.7),
+                    ("high_shelf", 8000.0, 5000.0, 10000.0, None)]
+            for band, f0, fmin, fmax, q0 in spec:
+                self.parameters.add(Parameter(band + "_gain", 0.0, "float", minimum=lo, maximum=hi))
+                self.parameters.add(Parameter(band + "_freq", f0, "float", minimum=fmin, maximum=fmax))
+                if q0 is not None:
+                    self.parameters.add(Parameter(band + "_q", q0, "float", minimum=qlo, maximum=qhi))
+        self.bands = list(bands)
+        self.hard_clip = hard_clip
+
+    def coefficients(self):
+        rows = []
+        for band in self.bands:
+            g = getattr(self.parameters, band + "_gain").value
+            fc = getattr(self.parameters, band + "_freq").value
+            if band in ("low_shelf", "high_shelf"):
+                rows.append(rbj_coefficients(band, g, 0.707, fc, self.sample_rate))
+            else:
+                rows.append(rbj_coefficients("peaking", g, getattr(self.parameters, band + "_q").value, fc, self.sample_rate))
+        return np.asarray(rows, dtype=np.float64)
+
+    def reset_state(self):
+        pass   # every process() call starts each band from zero state, like the reference (:511-513)
+
+    def process(self, x):
+        d = _Dev(x)
+        coef = np.ascontiguousarray(self.coefficients())
+        y = torch.empty_like(d.x)
+        d.lib.check(d.lib.mst_fx_biquad_cascade(d.x.data_ptr(), y.data_ptr(), d.n, d.L, d.C,
+                                                coef.ctypes.data_as(C.POINTER(C.c_double)), coef.shape[0], d.stream),
+                    "mst_fx_biquad_cascade")
+        if self.hard_clip:
+            y = y.clamp_(-1.0, 1.0)
+        return d.out(y)
+
+
+class Compressor(Processor):
+    """Single-band dynamic range compressor: log-domain gain computer + branchy one-pole attack/release
+    smoother per channel (makeup gain 0)."""
+
+    def __init__(self, sample_rate, name="Compressor", parameters=None):
+        super().__init__(name=name, parameters=parameters, block_size=None, sample_rate=sample_rate)
+        if not parameters:
+            self.parameters = ParameterList()
+            self.parameters.add(Parameter("threshold", -20.0, "float", units="dB", minimum=-80.0, maximum=-5.0))
+            self.parameters.add(Parameter("attack_time", 2.0, "float", units="ms", minimum=1.0, maximum=20.0))
+            self.parameters.add(Parameter("release_time", 100.0, "float", units="ms", minimum=50.0, maximum=500.0))
+            self.parameters.add(Parameter("ratio", 4.0, "float", minimum=4.0, maximum=40.0))
+        self.yL_prev = None
+
+    def process(self, x):
+        p = self.parameters
+        if p.threshold.value == 0.0 and p.ratio.value == 1.0:
+            return x
+        d = _Dev(x)
+        y = torch.empty_like(d.x)
+        d.lib.check(d.lib.mst_fx_compressor(d.x.data_ptr(), y.data_ptr(), d.n, d.L, d.C, float(p.threshold.value),
+                                            float(p.attack_time.value), float(p.release_time.value), float(p.ratio.value),
+                                            float(self.sample_rate), d.stream), "mst_fx_compressor")
+        return d.out(y)
+
+    def update(self, parameter_name=None):
+        self.yL_prev = None
+
+
+class MidSideImager(Processor):
+    """Mid/side energy re-balancing; bal in [0, 1] narrows, (1, 2] widens.  Stereo input only."""
+
+    def __init__(self, name="IMAGER", parameters=None):
+        super().__init__(name, parameters=parameters, block_size=None, sample_rate=None)
+        if not parameters:
+            self.parameters = ParameterList()
+            self.parameters.add(Parameter("bal", 0.0, "float", processor=self, minimum=0.0, maximum=2.0))
+
+    def process(self, data):
+        d = _Dev(data)
+        if d.C != 2:
+            raise ValueError("MidSideImager needs stereo audio [L, 2]")
+        y = torch.empty_like(d.x)
+        sc = d.scratch(2 * d.n)
+        d.lib.check(d.lib.mst_fx_midside_imager(d.x.data_ptr(), y.data_ptr(), d.n, d.L, float(self.parameters.bal.value),
+                                                sc.data_ptr(), d.stream), "mst_fx_midside_imager")
+        return d.out(y)
+
+
+class Gain(Processor):
+    """Gain in dB, optional polarity inversion."""
+
+    def __init__(self, name="Gain", parameters=None):
+        super().__init__(name, parameters=parameters, block_size=None, sample_rate=None)
+        if not parameters:
+            self.parameters = ParameterList()
+            self.parameters.add(Parameter("gain", 1.0, "float", units="dB", minimum=-6.0, maximum=9.0))
+            self.parameters.add(Parameter("invert", False, "bool"))
+
+    def process(self, x):
+        d = _Dev(x)
+        y = torch.empty_like(d.x)
+        d.lib.check(d.lib.mst_fx_gain(d.x.data_ptr(), y.data_ptr(), d.n, d.L, d.C, float(self.parameters.gain.value),
+                                      int(bool(self.parameters.invert.value)), d.stream), "mst_fx_gain")
+        return d.out(y)
+
+
+class AugmentationChain:
+    """Apply (processor, probability, rms_normalize) entries in order to every array of a list; optional shuffle
+    and parallel dry/wet mix - the reference's chain semantics (:156-192)."""
+
+    def __init__(self, fxs=None, shuffle=False, parallel=False, parallel_weight_factor=None, randomize_param_value=True):
+        self.fxs = fxs if fxs is not None else []
+        self.shuffle, self.parallel = shuffle, parallel
+        self.parallel_weight_factor = parallel_weight_factor
+        self.randomize_param_value = randomize_param_value
+
+    def apply_processor(self, x, processor, rms_normalize):
+        if processor.block_size is not None:
+            raise NotImplementedError("block-wise processors are not on the gfx950 path")
+        y = processor.process(x)
+        if rms_normalize:
+            y = rms_normalize_(x, y)
+        return y
+
+    def apply_same_processor(self, x_list, processor, rms_normalize):
+        return [self.apply_processor(x, processor, rms_normalize) for x in x_list]
+
+    def __call__(self, x_list):
+        if self.shuffle:
+            random.shuffle(self.fxs)
+        y_list = list(x_list)
+        for fx, p, rms in self.fxs:
+            if np.random.rand() < p:
+                if isinstance(fx, Processor):
+                    if self.randomize_param_value:
+                        fx.randomize()
+                    else:
+                        fx.update(None)
+                    y_list = self.apply_same_processor(y_list, fx, rms)
+                else:
+                    y_list = fx(y_list)
+        if self.parallel:
+            w = self.parallel_weight_factor if self.parallel_weight_factor else np.random.rand() / 2.0
+            y_list = [w * x + (1 - w) * y for x, y in zip(x_list, y_list)]
+        return y_list
+
+    def __repr__(self):
+        return f"AugmentationChain(fxs={self.fxs!r}, shuffle={self.shuffle!r})"

@@ -5,6 +5,7 @@
 #include "mst_rt.h"
 
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -34,6 +35,10 @@ emu_ctx_switch:
     ret
 .size emu_ctx_switch, .-emu_ctx_switch
 )");
+
+double emu_now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 namespace emu {
 

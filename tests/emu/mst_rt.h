@@ -47,6 +47,13 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline hipError_t hipDeviceSynchronize() { return 0; }
 static inline hipError_t hipGetLastError() { return 0; }
 static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
+typedef struct emu_event { double t; } *hipEvent_t;
+double emu_now_ms();
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emu_event{0.0}; return 0; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu_now_ms(); return 0; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return 0; }
 
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
