@@ -6,6 +6,10 @@ The product path has NO fallback: if the HIP library is missing, import of anyth
 import ctypes as C
 import os
 
+import torch  # noqa: F401  - MUST precede loading libmst_hip.so: the library has to share torch's HIP runtime
+#                            (same libamdhip64 instance => same streams / device pointers); loading it first binds
+#                            /opt/rocm's copy and every hipMalloc then fails with "no ROCm-capable device".
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmst_hip.so")
 

@@ -1,0 +1,123 @@
+"""The gfx950 kernel sources + C-ABI host code, compiled for the host against the SIMT emulator (tests/emu),
+checked against the oracle.  Catches index math / MFMA fragment layout / LDS swizzle / packing bugs without a
+GPU.  Same sources as libmst_hip.so, same C ABI, driven through the same module API."""
+import numpy as np
+import pytest
+import torch
+
+from music_mixing_style_transfer_amd.utils import synth
+from oracle import fx_ref as F
+from oracle import networks_ref as R
+
+
+def _tcn(nblocks, cond_dim=64, growth=2, seed=0):
+    from music_mixing_style_transfer_amd.networks import TCNModel
+    sd = synth.tcn_state_dict(nblocks=nblocks, cond_dim=cond_dim, seed=seed)
+    m = TCNModel(nparams=cond_dim, ninputs=2, noutputs=2, nblocks=nblocks, dilation_growth=growth, kernel_size=15,
+                 channel_width=128, stack_size=15, cond_dim=cond_dim, causal=False)
+    m.load_state_dict(sd)
+    return m, sd
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 4e-2)])
+def test_tcn_blocks_emulated(emu_default, prec, tol):
+    m, sd = _tcn(4)
+    m.precision = prec
+    x = synth.synth_audio((2, 2, 777), seed=1)
+    cond = synth.synth_audio((1, 64), seed=2)
+    col = []
+    y_ref = R.tcn_forward(sd, x, cond, nblocks=4, collect=col)
+    for n in (1, 2, 4):
+        a = m.forward_blocks(x, cond, n)
+        assert float((a - col[n - 1]).abs().max()) <= tol * float(col[n - 1].abs().max())
+    y = m(x, cond)
+    assert float((y - y_ref).abs().max()) <= tol
+    assert float(y.abs().max()) <= 1.0
+
+
+def test_tcn_large_dilation_and_odd_growth_emulated(emu_default):
+    """dilation 3**n exercises P = 1 tiles with non power-of-two d; a short segment exercises growing P."""
+    m, sd = _tcn(4, growth=3)
+    x = synth.synth_audio((1, 2, 300), seed=4)
+    cond = synth.synth_audio((1, 64), seed=5)
+    y_ref = R.tcn_forward(sd, x, cond, nblocks=4, dilation_growth=3)
+    assert float((m(x, cond) - y_ref).abs().max()) <= 2e-5
+    m2, sd2 = _tcn(6)          # d up to 32 on L = 200: tiles with P = 8 and 16
+    x = synth.synth_audio((1, 2, 200), seed=6)
+    y_ref = R.tcn_forward(sd2, x, cond, nblocks=6)
+    assert float((m2(x, cond) - y_ref).abs().max()) <= 2e-5
+    m2.precision = "bf16"
+    assert float((m2(x, cond) - y_ref).abs().max()) <= 4e-2
+
+
+def test_tcn_condition_forms_emulated(emu_default):
+    m, sd = _tcn(2)
+    x = synth.synth_audio((2, 2, 260), seed=7)
+    condB = synth.synth_audio((2, 64), seed=8)
+    condL = [synth.synth_audio((1, 64), seed=9 + i) for i in range(2)]
+    for cond in (condB, condL):
+        assert float((m(x, cond) - R.tcn_forward(sd, x, cond, nblocks=2)).abs().max()) <= 2e-5
+    with pytest.raises(RuntimeError):
+        m(x, synth.synth_audio((3, 64), seed=1))          # rows must be 1 or B, as in torch broadcasting
+
+
+def test_encoder_emulated(emu_default):
+    from music_mixing_style_transfer_amd.networks import FXencoder
+    cfg = {"channels": [4, 40, 72, 136], "kernels": [5, 4, 3, 10], "strides": [2, 2, 1, 2], "dilation": [1, 1, 1, 1],
+           "bias": True, "norm": "batch", "conv_block": "res", "activation": "relu"}
+    sd = synth.fxencoder_state_dict(cfg, seed=3)
+    user_cfg = {k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()}
+    enc = FXencoder(user_cfg)
+    assert user_cfg["channels"][0] == 2        # the reference mutates the caller's list (architectures.py:30)
+    enc.load_state_dict(sd)
+    x = synth.synth_audio((3, 2, 333), seed=11)
+    col = []
+    R.fxencoder_blocks(x, sd, cfg, collect=col)
+    for n in range(1, 5):
+        a = enc.forward_blocks(x, n)
+        assert a.shape == col[n - 1].shape
+        assert float((a - col[n - 1]).abs().max()) <= 2e-5
+    assert float((enc(x) - R.fxencoder_forward(sd, cfg, x)).abs().max()) <= 2e-5
+    blk = enc.encoder[0]                      # a Res_ConvBlock runs stand-alone too
+    assert float((blk(x) - col[0]).abs().max()) <= 2e-5
+    with pytest.raises(ValueError):
+        enc(synth.synth_audio((1, 2, 3), seed=1))          # reflection padding longer than the input
+
+
+def test_embedding_mean_and_engine_emulated(emu_default):
+    from music_mixing_style_transfer_amd.inference import embedding_mean
+    e = synth.synth_audio((7, 40), seed=2)
+    assert float((embedding_mean(e) - e.mean(0)).abs().max()) <= 1e-6
+
+
+def test_fx_emulated(emu_default):
+    from music_mixing_style_transfer_amd.mixing_manipulator import (AugmentationChain, Compressor, Equaliser, Gain,
+                                                                     MidSideImager)
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "fx.npz"))
+    x = g["x"][:1500]
+    c = Compressor(44100)
+    for th, at, rt, ra in g["comp_cases"]:
+        c.parameters.threshold.value, c.parameters.attack_time.value = th, at
+        c.parameters.release_time.value, c.parameters.ratio.value = rt, ra
+        assert np.abs(c.process(x.copy()) - F.compressor(x.copy(), th, at, rt, ra)).max() <= 2e-7
+    eq = Equaliser(2, 44100)
+    for band, (gg, fc, q) in F.CONFIG4["eq"].items():
+        getattr(eq.parameters, band + "_gain").value = gg
+    assert np.abs(eq.process(x.copy()) - F.equaliser(x.copy(), F.CONFIG4["eq"])).max() <= 1e-7
+    im = MidSideImager()
+    for bal in (0.0, 0.4567, 1.5, 2.0):
+        im.parameters.bal.value = bal
+        assert np.abs(im.process(x.copy()) - F.midside_imager(x.copy(), bal)).max() <= 2e-6
+    # the config-4 chain through AugmentationChain (probability 1, fixed parameters) vs the oracle chain
+    comp = Compressor(44100)
+    im.parameters.bal.value = F.CONFIG4["imager_bal"]
+    gn = Gain()
+    gn.parameters.gain.value = F.CONFIG4["gain_db"]
+    chain = AugmentationChain([(eq, 1.0, True), (comp, 1.0, True), (im, 1.0, True), (gn, 1.0, False)],
+                              randomize_param_value=False)
+    y = chain([x.copy()])[0]
+    assert np.abs(y - F.fx_chain(x.copy())).max() <= 5e-6
+    # batched [n_items, L, C] input
+    xb = np.stack([x, 0.5 * x[::-1].copy()])
+    yb = comp.process(xb)
+    assert np.abs(yb[1] - F.compressor(xb[1].copy(), -20.0, 2.0, 100.0, 4.0)).max() <= 2e-7

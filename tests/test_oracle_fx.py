@@ -1,0 +1,62 @@
+"""FX oracle (oracle/fx_ref.py, oracle/fx_ref.c) against golden vectors produced by the real reference's
+common_audioeffects.py (third-party imports stubbed; see tests/golden/make_golden.py)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from oracle import fx_ref as F
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_compressor_matches_reference():
+    g = np.load(os.path.join(GOLD, "fx.npz"))
+    x = g["x"]
+    for i, (th, at, rt, ra) in enumerate(g["comp_cases"]):
+        # float64 input: pure float64 arithmetic in the reference -> bit exact
+        assert np.array_equal(F.compressor(x.astype(np.float64), th, at, rt, ra), g[f"comp_f64in_{i}"])
+        # float32 input: the reference evaluates log10 in float32 (numpy scalar promotion) -> 1e-7 class
+        y = F.compressor(x.copy(), th, at, rt, ra)
+        assert y.dtype == np.float32
+        assert np.abs(y - g[f"comp_f32in_{i}"]).max() <= 2e-7
+
+
+def test_imager_gain_haas_panner_rms_match_reference():
+    g = np.load(os.path.join(GOLD, "fx.npz"))
+    x = g["x"]
+    for i, bal in enumerate(g["imager_bals"]):
+        assert np.array_equal(F.midside_imager(x.copy(), float(bal)), g[f"imager_{i}"])
+    assert np.array_equal(F.gain(x.copy(), 3.0, False), g["gain_0"])
+    assert np.array_equal(F.gain(x.copy(), -6.0, True), g["gain_1"])
+    assert np.array_equal(F.haas(x.copy(), 37, 0.35, "left"), g["haas_left"])
+    assert np.array_equal(F.haas(x.copy(), -12, 0.5, "right"), g["haas_right"])
+    for i, (pan, law) in enumerate(((0.3, "-4.5dB"), (0.8, "linear"), (0.5, "constant_power"))):
+        assert np.array_equal(F.panner_gains(pan, law), g[f"pan_gains_{i}"])
+    assert np.array_equal(F.rms_normalize(x.copy(), F.gain(x.copy(), 5.0)), g["rms_norm"])
+
+
+def test_c_oracle_matches_numpy_oracle(oracle_fx_lib):
+    g = np.load(os.path.join(GOLD, "fx.npz"))
+    x = np.ascontiguousarray(g["x"])
+    fp = C.POINTER(C.c_float)
+    for th, at, rt, ra in g["comp_cases"]:
+        y = np.empty_like(x)
+        oracle_fx_lib.ref_compressor(x.ctypes.data_as(fp), y.ctypes.data_as(fp), C.c_long(x.shape[0]), 2, C.c_double(th),
+                                     C.c_double(at), C.c_double(rt), C.c_double(ra), C.c_double(0.0), C.c_double(44100.0))
+        assert np.abs(y - F.compressor(x.copy(), th, at, rt, ra)).max() <= 2e-7
+    coef = np.ascontiguousarray(F.equaliser_coeffs(F.CONFIG4["eq"]))
+    y = np.empty_like(x)
+    oracle_fx_lib.ref_biquad_cascade(x.ctypes.data_as(fp), y.ctypes.data_as(fp), C.c_long(x.shape[0]), 2,
+                                     coef.ctypes.data_as(C.POINTER(C.c_double)), 5)
+    assert np.abs(y - F.equaliser(x, F.CONFIG4["eq"])).max() <= 1e-7
+    # explicit TDF-II loop == scipy.signal.lfilter (the restated recursion is the published one)
+    assert np.abs(F.equaliser(x, F.CONFIG4["eq"], use_scipy=False) - F.equaliser(x, F.CONFIG4["eq"])).max() <= 1e-7
+
+
+def test_eq_flat_is_identity_and_chain_runs():
+    g = np.load(os.path.join(GOLD, "fx.npz"))
+    x = g["x"]
+    assert np.abs(F.equaliser(x, {}) - x).max() <= 1e-6      # 0 dB on every band
+    y = F.fx_chain(x)
+    assert y.shape == x.shape and y.dtype == np.float32 and np.isfinite(y).all()
