@@ -224,10 +224,24 @@ int choose_phases(int d, int L) {
     return P;
 }
 
+// experiment switch for the bf16 main-loop schedule (0 = compiler-scheduled, 1 = software-pipelined ring,
+// 2 = ring + sched_group_barrier pinning); the default is the measured best.
+int bf16_variant() {
+    static const int v = [] {
+        const char *e = getenv("MST_TCN_BF16_VARIANT");
+        return e ? atoi(e) : 2;
+    }();
+    return v;
+}
+
 template <int P> int launch_block(int precision, const TcnBlockArgs &a, int grid, void *stream) {
-    if (precision == MST_PREC_BF16)
-        MST_LAUNCH((tcn_block_bf16_kernel<P>), dim3(grid), dim3(256), stream, a);
-    else
+    if (precision == MST_PREC_BF16) {
+        switch (bf16_variant()) {
+            case 0: MST_LAUNCH((tcn_block_bf16_kernel<P, 0>), dim3(grid), dim3(256), stream, a); break;
+            case 2: MST_LAUNCH((tcn_block_bf16_kernel<P, 2>), dim3(grid), dim3(256), stream, a); break;
+            default: MST_LAUNCH((tcn_block_bf16_kernel<P, 1>), dim3(grid), dim3(256), stream, a); break;
+        }
+    } else
         MST_LAUNCH((tcn_block_f32_kernel<P>), dim3(grid), dim3(256), stream, a);
     MST_CHECK_LAUNCH("tcn_block_kernel");
     return MST_OK;
@@ -296,6 +310,15 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         const long nsteps = ((long)L + d - 1) / d;
         a.tiles_step = (int)((nsteps + 256 / P - 1) / (256 / P));
         const long grid = (long)B * a.tiles_phase * a.tiles_step;
+        a.prof = nullptr;
+        // developer hook: MST_TCN_PROF_BLOCK=n MST_TCN_PROF_FILE=path dumps per-workgroup phase clock stamps of block n
+        static const char *prof_file = getenv("MST_TCN_PROF_FILE");
+        static const int prof_block = getenv("MST_TCN_PROF_BLOCK") ? atoi(getenv("MST_TCN_PROF_BLOCK")) : -1;
+        long long *prof_dev = nullptr;
+        if (prof_file && prof_block == n && precision == MST_PREC_BF16) {
+            MST_HIP_TRY(hipMalloc((void **)&prof_dev, (size_t)grid * 4 * sizeof(long long)));
+            a.prof = prof_dev;
+        }
         if (grid > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_tcn_forward: grid too large");
         int rc;
         switch (P) {
@@ -306,6 +329,16 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
             default: rc = launch_block<16>(precision, a, (int)grid, stream); break;
         }
         if (rc) return rc;
+        if (prof_dev) {
+            std::vector<long long> hp((size_t)grid * 4);
+            MST_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            MST_HIP_TRY(hipMemcpy(hp.data(), prof_dev, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            (void)hipFree(prof_dev);
+            if (FILE *f = fopen(prof_file, "wb")) {
+                fwrite(hp.data(), sizeof(long long), hp.size(), f);
+                fclose(f);
+            }
+        }
         if (ev) MST_HIP_TRY(hipEventRecord(ev[n + 1], (hipStream_t)stream));
         cur ^= 1;
     }

@@ -16,6 +16,8 @@ __device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) 
 
 __device__ __forceinline__ float leaky_relu(float v) { return v > 0.0f ? v : MST_LEAKY * v; }
 
+__device__ __forceinline__ long long mst_clock() { return (long long)__builtin_readcyclecounter(); }
+
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);

@@ -35,13 +35,14 @@ struct TcnBlockArgs {
     int B, L, Lp, d;
     int tiles_phase;      // d / P
     int tiles_step;       // ceil(ceil(L/d) / (256/P))
+    long long *prof;      // developer hook: per-workgroup shader-clock stamps at phase boundaries (null = off)
 };
 
 // ------------------------------------------------------------------------------------------------
 // blocks 1..n-1, bf16 MFMA (v_mfma_f32_32x32x16_bf16), bf16 activations.  MFMA-bound:
 // 2*128*1920 = 491 520 FLOP per output time step against 512 B of HBM traffic.
 // ------------------------------------------------------------------------------------------------
-template <int P>
+template <int P, int PIPE>
 __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(TcnBlockArgs a) {
     constexpr int T = 256, R = T + 14 * P, MT = T / P;
     __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
@@ -56,20 +57,31 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
     const int m0 = mg * MT, phi0 = pg * P;
     const __bf16 *xb = (const __bf16 *)a.x + (size_t)b * a.Lp * 128;
     __bf16 *yb = (__bf16 *)a.y + (size_t)b * a.Lp * 128;
+    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 4 + 0] = mst_clock();
 
     // ---- stage the (256 + 14P) input rows: 16 lanes x 16 B per row, XOR-swizzled 16-B slots so that the
     //      32 consecutive rows of one B-fragment read hit 16 distinct slots per ds_read_b128 lane group
     {
+        // all (R+15)/16 row loads of a thread are issued back to back (one exposed memory latency per tile;
+        // the accumulators are not live yet, so the registers are free), then written to LDS
         const int slot = tid & 15;
-#pragma unroll 4
-        for (int r = tid >> 4; r < R; r += 16) {
+        constexpr int NPASS = (R + 15) / 16;
+        bf16x8 v[NPASS];
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int r = (tid >> 4) + 16 * i;
             const long t = (long)(m0 + r / P - 7) * a.d + phi0 + (r % P);
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (t >= 0 && t < a.L) v = *(const bf16x8 *)(xb + t * 128 + slot * 8);
-            *(bf16x8 *)(smem + r * 256 + ((slot ^ (r & 15)) << 4)) = v;
+            v[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (r < R && t >= 0 && t < a.L) v[i] = *(const bf16x8 *)(xb + t * 128 + slot * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int r = (tid >> 4) + 16 * i;
+            if (r < R) *(bf16x8 *)(smem + r * 256 + ((slot ^ (r & 15)) << 4)) = v[i];
         }
     }
     __syncthreads();
+    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 4 + 1] = mst_clock();
 
     f32x16 acc[8];
 #pragma unroll
@@ -79,33 +91,80 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
 
     // A fragments: wpk[ks = j*8 + kc][wave][lane] = 8 bf16 = W'[32w + ln][16kc + 8h + e][j]
     const bf16x8 *wp = (const bf16x8 *)a.wpk + (w * 64 + lane);
-    bf16x8 acur[8], anxt[8];
+    if constexpr (PIPE == 0) {
+        bf16x8 acur[8], anxt[8];
 #pragma unroll
-    for (int kc = 0; kc < 8; ++kc) anxt[kc] = acur[kc] = wp[kc * 256];
-
-    for (int j = 0; j < 15; ++j) {
-        if (j < 14) {
+        for (int kc = 0; kc < 8; ++kc) anxt[kc] = acur[kc] = wp[kc * 256];
+        for (int j = 0; j < 15; ++j) {
+            if (j < 14) {
 #pragma unroll
-            for (int kc = 0; kc < 8; ++kc) anxt[kc] = wp[((j + 1) * 8 + kc) * 256];
+                for (int kc = 0; kc < 8; ++kc) anxt[kc] = wp[((j + 1) * 8 + kc) * 256];
+            }
+            const int rowbase = j * P + ln;
+            const int sw = rowbase & 15;
+            const unsigned char *rp = smem + rowbase * 256;
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                const int off = ((2 * kc + h) ^ sw) << 4;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const bf16x8 bfr = *(const bf16x8 *)(rp + q * 8192 + off);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[kc], bfr, acc[q], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) acur[kc] = anxt[kc];
         }
-        const int rowbase = j * P + ln;
-        const int sw = rowbase & 15;
-        const unsigned char *rp = smem + rowbase * 256;
+    } else {
+        // software pipeline: the B fragments of k-step ks+1 are requested from LDS right behind the MFMAs of
+        // k-step ks that free their registers (ring of 8 fragments, one full k-step = 8 MFMAs of latency cover);
+        // the A fragment of (j+1, kc) is requested from L2 as soon as (j, kc) has been consumed.
+        bf16x8 af[8], bf[8];
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc) {
-            const int off = ((2 * kc + h) ^ sw) << 4;
+        for (int kc = 0; kc < 8; ++kc) af[kc] = wp[kc * 256];
+        {
+            const unsigned char *rp0 = smem + ln * 256 + ((h ^ (ln & 15)) << 4);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const bf16x8 bfr = *(const bf16x8 *)(rp + q * 8192 + off);
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[kc], bfr, acc[q], 0, 0, 0);
+            for (int q = 0; q < 8; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 8192);
+        }
+        for (int j = 0; j < 15; ++j) {
+            const int jn = j < 14 ? j + 1 : 14;
+            const int rb0 = j * P + ln, rb1 = jn * P + ln;
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                const int rbn = (kc == 7) ? rb1 : rb0;
+                const int kcn = (kc + 1) & 7;
+                const unsigned char *np = smem + rbn * 256 + (((2 * kcn + h) ^ (rbn & 15)) << 4);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kc], bf[q], acc[q], 0, 0, 0);
+                    bf[q] = *(const bf16x8 *)(np + q * 8192);
+                    if constexpr (PIPE == 2) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                af[kc] = wp[(jn * 8 + kc) * 256];
             }
         }
-#pragma unroll
-        for (int kc = 0; kc < 8; ++kc) acur[kc] = anxt[kc];
     }
 
     // ---- fused epilogue
+    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 4 + 2] = mst_clock();
     const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+    // residual inputs (centre tap rows) -> registers, then the input tile is dead and LDS is reused to transpose
+    // the output tile so that global stores are whole 256-byte rows, 16 B per lane
+    bf16x4 xin[4][8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int co0 = 32 * w + 8 * g + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = 32 * q + ln + 7 * P;
+            xin[g][q] = *(const bf16x4 *)(smem + row * 256 + (((co0 >> 3) ^ (row & 15)) << 4) + 8 * h);
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int co0 = 32 * w + 8 * g + 4 * h;
@@ -116,22 +175,28 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int o = 32 * q + ln;
-            const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
-            if (t < a.L) {
-                const int row = o + 7 * P;
-                const bf16x4 xin = *(const bf16x4 *)(smem + row * 256 + (((co0 >> 3) ^ (row & 15)) << 4) + 8 * h);
-                bf16x4 out;
+            bf16x4 out;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = leaky_relu(acc[q][4 * g + i] + sh[i]);
-                    v = fr[i] * v + fb[i];
-                    v += rs[i] * (float)xin[i];
-                    out[i] = (__bf16)v;
-                }
-                *(bf16x4 *)(yb + t * 128 + co0) = out;
+            for (int i = 0; i < 4; ++i) {
+                float v = leaky_relu(acc[q][4 * g + i] + sh[i]);
+                v = fr[i] * v + fb[i];
+                v += rs[i] * (float)xin[g][q][i];
+                out[i] = (__bf16)v;
             }
+            *(bf16x4 *)(smem + o * 256 + (((co0 >> 3) ^ (o & 15)) << 4) + 8 * h) = out;
         }
     }
+    __syncthreads();
+    {
+        const int slot = tid & 15;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = (tid >> 4) + 16 * i;
+            const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
+            if (t < a.L) *(bf16x8 *)(yb + t * 128 + slot * 8) = *(const bf16x8 *)(smem + o * 256 + ((slot ^ (o & 15)) << 4));
+        }
+    }
+    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 4 + 3] = mst_clock();
 }
 
 // ------------------------------------------------------------------------------------------------

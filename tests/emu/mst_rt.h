@@ -132,6 +132,7 @@ template <typename T> static inline T __shfl(T v, int src, int = 64) { return em
 #define __builtin_amdgcn_readfirstlane(v) emu_shfl((v), 0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 
 static inline float atomicAdd(float *p, float v) {
     uint32_t o = __atomic_load_n((uint32_t *)p, __ATOMIC_RELAXED), n;
