@@ -37,7 +37,7 @@ typedef enum {
     MST_ERR_WORKSPACE = -5     /* workspace pointer null or too small */
 } MstStatus;
 
-/* arithmetic mode of the TCN's dense 128x128x15 dilated convolutions (blocks 1..n-1) */
+/* arithmetic mode of the dense convolutions (TCN blocks 1..n-1, all FXencoder convs) */
 typedef enum {
     MST_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32, fp32 activations in HBM: the parity mode */
     MST_PREC_BF16 = 1   /* v_mfma_f32_32x32x16_bf16, bf16 activations in HBM, fp32 accumulate */
@@ -131,12 +131,14 @@ int mst_enc_load_conv(MstEnc *enc, int block, int which, const float *w, const f
                       const float *bn_weight, const float *bn_bias, const float *bn_mean, const float *bn_var,
                       float bn_eps, void *stream);
 size_t mst_enc_workspace_bytes(const MstEnc *enc, int B, int L);
-/* replaces FXencoder.forward (architectures.py:65-70): x_dev fp32 [B, 2, L] -> emb_dev fp32 [B, C_last]. */
-int mst_enc_forward(MstEnc *enc, const float *x_dev, float *emb_dev, int B, int L, void *workspace,
+/* replaces FXencoder.forward (architectures.py:65-70): x_dev fp32 [B, 2, L] -> emb_dev fp32 [B, C_last].
+ * precision: MST_PREC_F32 (exact fp32 MFMA, parity mode) or MST_PREC_BF16 (bf16 operands, fp32 accumulate;
+ * activations stay fp32 in HBM). */
+int mst_enc_forward(MstEnc *enc, const float *x_dev, float *emb_dev, int B, int L, int precision, void *workspace,
                     size_t workspace_bytes, void *stream);
 /* parity probe: run only the first n_run Res_ConvBlocks; out_dev fp32 [B, channels[n_run], L_out(n_run)] */
-int mst_enc_forward_blocks(MstEnc *enc, const float *x_dev, float *out_dev, int B, int L, int n_run, void *workspace,
-                           size_t workspace_bytes, void *stream);
+int mst_enc_forward_blocks(MstEnc *enc, const float *x_dev, float *out_dev, int B, int L, int precision, int n_run,
+                           void *workspace, size_t workspace_bytes, void *stream);
 /* output length of Res_ConvBlock `block` for input length L ("SAME" padding ignores the stride:
  * L_out = floor((L-1)/s)+1, network_utils.py:30-34,48-51) */
 int mst_enc_block_length(const MstEnc *enc, int block, int L);

@@ -21,7 +21,9 @@ struct EncConvArgs {
     float *y;            // [B][Cout][Lout]
     const float *wpk;    // [co_tiles][nchunks][16][MT]
     const float *shift;  // [co_tiles*MT] folded bias/BN shift (zero padded)
-    const int *ktab;     // [nchunks*16][2]: (ci, j*dil - pad_l), ci = -1 for the zero padding of K
+    const int *ktab;     // [nchunks32*32][2]: (ci, j*dil - pad_l), ci = -1 for the zero padding of K
+    const void *wpk16;   // bf16 A fragments [co_tiles][nchunks32][2][MW][64][8]
+    int nchunks32;       // ceil(K / 32)
     int B, Cin, Lin, Cout, Lout, stride;
     int nchunks;
     int residual;        // conv1 of a Res block: add x[b][co][to] after the ReLU
@@ -110,6 +112,121 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
             for (int q = 0; q < 4; ++q) {
                 const float bv = Bs[(2 * ks + h) * NT + 128 * ni + 32 * q + ln];
                 acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[q], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long n = n0 + 128 * ni + 32 * q + ln;
+        if (n < a.Ntot) {
+            const int b = (int)(n / a.Lout), to = (int)(n % a.Lout);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cot * MT + 32 * mi + mfma32_row(r, lane);
+                if (co < a.Cout) {
+                    float v = fmaxf(acc[q][r] + a.shift[co], 0.0f);
+                    if (a.residual) v += a.x[((long)b * a.Cin + co) * a.Lin + to];
+                    a.y[((long)b * a.Cout + co) * a.Lout + to] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Same convolution with bf16 MFMA operands (v_mfma_f32_32x32x16_bf16, fp32 accumulate): the throughput mode.
+// Activations stay fp32 NCL in HBM; operands are rounded to bf16 while staging.  K-chunk = 32.
+//   A: BN-folded weights pre-packed in fragment order, streamed from L2 straight into registers.
+//   B: im2col tile in LDS as Bs[n][32 k] (k contiguous, 64 B per column) so a lane's 8 consecutive k are one
+//      ds_read_b128; each staging thread gathers the 8 k of one (n, 16-byte slot) - consecutive lanes take
+//      consecutive n, so every one of the 8 gathers is coalesced along time - and writes one ds_write_b128.
+//      16-B slot index is XORed with (n >> 2) & 3 so reads and writes are bank-conflict free.
+// ------------------------------------------------------------------------------------------------
+template <int MW>
+__global__ __launch_bounds__(256) void enc_conv_bf16_kernel(EncConvArgs a) {
+    constexpr int NW = 4 / MW, MT = 32 * MW, NT = 128 * NW;
+    constexpr int NE = NT / 64;                       // 16-byte slots gathered per thread per chunk
+    constexpr int NCOL = (NT + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[NT * 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ln = lane & 31, h = lane >> 5;
+    const int mi = w % MW, ni = w / MW;
+    const long n0 = (long)blockIdx.x * NT;
+    const int cot = blockIdx.y;
+
+    long colbase[NCOL];
+    int colt[NCOL];
+#pragma unroll
+    for (int c = 0; c < NCOL; ++c) {
+        const long n = n0 + (tid + c * 256) % NT;
+        if (n < a.Ntot) {
+            const int b = (int)(n / a.Lout), to = (int)(n % a.Lout);
+            colbase[c] = (long)b * a.Cin * a.Lin;
+            colt[c] = to * a.stride;
+        } else {
+            colbase[c] = -1;
+            colt[c] = 0;
+        }
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
+
+    const bf16x8 *wtile = (const bf16x8 *)a.wpk16 + (size_t)cot * a.nchunks32 * 2 * MW * 64;
+    bf16x8 anxt[2], acur[2];
+    float breg[NE][8];
+
+    auto fetch = [&](int kc) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) anxt[ks] = wtile[((size_t)(kc * 2 + ks) * MW + mi) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = tid + e * 256;
+            const int slot = idx / NT;
+            const int c = (NT > 256) ? (e & 1) : 0;
+            const int *kt = a.ktab + (size_t)(kc * 32 + slot * 8) * 2;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ci = kt[2 * i], joff = kt[2 * i + 1];
+                float v = 0.0f;
+                if (ci >= 0 && colbase[c] >= 0) {
+                    int ti = colt[c] + joff;
+                    if (ti < 0) ti = -ti;
+                    if (ti >= a.Lin) ti = 2 * (a.Lin - 1) - ti;
+                    v = a.x[colbase[c] + (long)ci * a.Lin + ti];
+                }
+                breg[e][i] = v;
+            }
+        }
+    };
+
+    fetch(0);
+    for (int kc = 0; kc < a.nchunks32; ++kc) {
+        if (kc) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = tid + e * 256;
+            const int n = idx % NT, slot = idx / NT;
+            bf16x8 v;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (__bf16)breg[e][i];
+            *(bf16x8 *)(Bs + n * 64 + ((slot ^ ((n >> 2) & 3)) << 4)) = v;
+        }
+        acur[0] = anxt[0];
+        acur[1] = anxt[1];
+        __syncthreads();
+        if (kc + 1 < a.nchunks32) fetch(kc + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = 128 * ni + 32 * q + ln;
+                const bf16x8 bv = *(const bf16x8 *)(Bs + nl * 64 + (((2 * ks + h) ^ ((nl >> 2) & 3)) << 4));
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[ks], bv, acc[q], 0, 0, 0);
             }
         }
     }

@@ -426,8 +426,9 @@ extern "C" int mst_tcn_forward_blocks(MstTcn *t, const float *x, float *act, int
 // =================================================================================================
 struct MstEncConv {
     float *wpk = nullptr, *shift = nullptr;
+    __bf16 *wpk16 = nullptr;
     int *ktab = nullptr;
-    int cin = 0, cout = 0, ksz = 0, stride = 1, dil = 1, pad_l = 0, pad_r = 0, nchunks = 0, mw = 4;
+    int cin = 0, cout = 0, ksz = 0, stride = 1, dil = 1, pad_l = 0, pad_r = 0, nchunks = 0, nchunks32 = 0, mw = 4;
     bool loaded = false;
 };
 
@@ -458,6 +459,7 @@ extern "C" int mst_enc_create(const MstEncDesc *desc, MstEnc **out) {
             c.pad_l = pad / 2;
             c.pad_r = pad - c.pad_l;
             c.nchunks = (c.cin * c.ksz + 15) / 16;
+            c.nchunks32 = (c.cin * c.ksz + 31) / 32;
             c.mw = c.cout <= 32 ? 1 : (c.cout <= 64 ? 2 : 4);
         }
     *out = e;
@@ -468,6 +470,7 @@ extern "C" int mst_enc_destroy(MstEnc *e) {
     if (!e) return MST_OK;
     for (auto &c : e->conv) {
         (void)hipFree(c.wpk);
+        (void)hipFree(c.wpk16);
         (void)hipFree(c.shift);
         (void)hipFree(c.ktab);
     }
@@ -498,13 +501,27 @@ extern "C" int mst_enc_load_conv(MstEnc *e, int block, int which, const float *w
             }
     std::vector<float> sh((size_t)co_tiles * MT, 0.0f);
     for (int co = 0; co < c.cout; ++co) sh[co] = shift[co] + (bias ? bias[co] * scale[co] : 0.0f);
-    std::vector<int> kt((size_t)c.nchunks * 16 * 2);
-    for (int k = 0; k < c.nchunks * 16; ++k) {
+    // bf16 A fragments of v_mfma_f32_32x32x16_bf16: [cot][kc32][ks][mi][lane][e]
+    std::vector<__bf16> wp16((size_t)co_tiles * c.nchunks32 * 2 * c.mw * 64 * 8);
+    for (int cot = 0; cot < co_tiles; ++cot)
+        for (int kc = 0; kc < c.nchunks32; ++kc)
+            for (int ks = 0; ks < 2; ++ks)
+                for (int mi = 0; mi < c.mw; ++mi)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = cot * MT + 32 * mi + (l & 31);
+                            const int k = kc * 32 + ks * 16 + 8 * (l >> 5) + e;
+                            const float v = (co < c.cout && k < K) ? w[(size_t)co * K + k] * scale[co] : 0.0f;
+                            wp16[((((((size_t)cot * c.nchunks32 + kc) * 2 + ks) * c.mw + mi) * 64 + l) * 8) + e] = (__bf16)v;
+                        }
+    std::vector<int> kt((size_t)c.nchunks32 * 32 * 2);
+    for (int k = 0; k < c.nchunks32 * 32; ++k) {
         kt[2 * k] = k < K ? k / c.ksz : -1;
         kt[2 * k + 1] = k < K ? (k % c.ksz) * c.dil - c.pad_l : 0;
     }
     int rc;
     if ((rc = upload(&c.wpk, wp))) return rc;
+    if ((rc = upload(&c.wpk16, wp16))) return rc;
     if ((rc = upload(&c.shift, sh))) return rc;
     if ((rc = upload(&c.ktab, kt))) return rc;
     c.loaded = true;
@@ -530,7 +547,8 @@ size_t enc_buf_floats(const MstEnc *e, int B, int L) {
     return mx;
 }
 
-int enc_launch(const MstEncConv &c, const float *x, float *y, int B, int Lin, int Lout, int residual, void *stream) {
+int enc_launch(const MstEncConv &c, const float *x, float *y, int B, int Lin, int Lout, int residual, int precision,
+               void *stream) {
     if (Lin <= c.pad_l || Lin <= c.pad_r)
         return fail(MST_ERR_ARG, "mst_enc_forward: reflection padding needs the input to be longer than the padding");
     EncConvArgs a;
@@ -539,6 +557,8 @@ int enc_launch(const MstEncConv &c, const float *x, float *y, int B, int Lin, in
     a.wpk = c.wpk;
     a.shift = c.shift;
     a.ktab = c.ktab;
+    a.wpk16 = c.wpk16;
+    a.nchunks32 = c.nchunks32;
     a.B = B;
     a.Cin = c.cin;
     a.Lin = Lin;
@@ -550,18 +570,27 @@ int enc_launch(const MstEncConv &c, const float *x, float *y, int B, int Lin, in
     a.Ntot = (long)B * Lout;
     const int MT = 32 * c.mw, NT = 128 * (4 / c.mw);
     const dim3 grid((unsigned)((a.Ntot + NT - 1) / NT), (unsigned)((c.cout + MT - 1) / MT));
-    switch (c.mw) {
-        case 1: MST_LAUNCH((enc_conv_kernel<1>), grid, dim3(256), stream, a); break;
-        case 2: MST_LAUNCH((enc_conv_kernel<2>), grid, dim3(256), stream, a); break;
-        default: MST_LAUNCH((enc_conv_kernel<4>), grid, dim3(256), stream, a); break;
+    if (precision == MST_PREC_BF16) {
+        switch (c.mw) {
+            case 1: MST_LAUNCH((enc_conv_bf16_kernel<1>), grid, dim3(256), stream, a); break;
+            case 2: MST_LAUNCH((enc_conv_bf16_kernel<2>), grid, dim3(256), stream, a); break;
+            default: MST_LAUNCH((enc_conv_bf16_kernel<4>), grid, dim3(256), stream, a); break;
+        }
+    } else {
+        switch (c.mw) {
+            case 1: MST_LAUNCH((enc_conv_kernel<1>), grid, dim3(256), stream, a); break;
+            case 2: MST_LAUNCH((enc_conv_kernel<2>), grid, dim3(256), stream, a); break;
+            default: MST_LAUNCH((enc_conv_kernel<4>), grid, dim3(256), stream, a); break;
+        }
     }
     MST_CHECK_LAUNCH("enc_conv_kernel");
     return MST_OK;
 }
 
-int enc_run(MstEnc *e, const float *x, float *emb, float *blk_out, int B, int L, int n_run, void *ws, size_t ws_bytes,
-            void *stream) {
+int enc_run(MstEnc *e, const float *x, float *emb, float *blk_out, int B, int L, int precision, int n_run, void *ws,
+            size_t ws_bytes, void *stream) {
     if (!e || !x || B < 1 || L < 1) return fail(MST_ERR_ARG, "mst_enc_forward: bad argument");
+    if (precision != MST_PREC_F32 && precision != MST_PREC_BF16) return fail(MST_ERR_ARG, "mst_enc_forward: bad precision");
     for (auto &c : e->conv)
         if (!c.loaded) return fail(MST_ERR_STATE, "mst_enc_forward: conv weights not loaded");
     if (!ws || ws_bytes < mst_enc_workspace_bytes(e, B, L)) return fail(MST_ERR_WORKSPACE, "mst_enc_forward: workspace too small");
@@ -572,9 +601,9 @@ int enc_run(MstEnc *e, const float *x, float *emb, float *blk_out, int B, int L,
     int len = L, rc, pp = 0;
     for (int i = 0; i < n_run; ++i) {
         const int lout = (len - 1) / e->d.strides[i] + 1;
-        if ((rc = enc_launch(e->conv[2 * i], cur, t1, B, len, len, 1, stream))) return rc;
+        if ((rc = enc_launch(e->conv[2 * i], cur, t1, B, len, len, 1, precision, stream))) return rc;
         float *dst = (blk_out && i == n_run - 1) ? blk_out : o[pp];
-        if ((rc = enc_launch(e->conv[2 * i + 1], t1, dst, B, len, lout, 0, stream))) return rc;
+        if ((rc = enc_launch(e->conv[2 * i + 1], t1, dst, B, len, lout, 0, precision, stream))) return rc;
         cur = dst;
         pp ^= 1;
         len = lout;
@@ -594,15 +623,16 @@ extern "C" size_t mst_enc_workspace_bytes(const MstEnc *e, int B, int L) {
     return 3 * align_up(enc_buf_floats(e, B, L) * sizeof(float), 256);
 }
 
-extern "C" int mst_enc_forward(MstEnc *e, const float *x, float *emb, int B, int L, void *ws, size_t ws_bytes, void *stream) {
+extern "C" int mst_enc_forward(MstEnc *e, const float *x, float *emb, int B, int L, int precision, void *ws,
+                               size_t ws_bytes, void *stream) {
     if (!emb) return fail(MST_ERR_ARG, "mst_enc_forward: null output");
-    return enc_run(e, x, emb, nullptr, B, L, e ? e->d.nblocks : 0, ws, ws_bytes, stream);
+    return enc_run(e, x, emb, nullptr, B, L, precision, e ? e->d.nblocks : 0, ws, ws_bytes, stream);
 }
 
-extern "C" int mst_enc_forward_blocks(MstEnc *e, const float *x, float *out, int B, int L, int n_run, void *ws,
-                                      size_t ws_bytes, void *stream) {
+extern "C" int mst_enc_forward_blocks(MstEnc *e, const float *x, float *out, int B, int L, int precision, int n_run,
+                                      void *ws, size_t ws_bytes, void *stream) {
     if (!e || !out || n_run < 1 || n_run > e->d.nblocks) return fail(MST_ERR_ARG, "mst_enc_forward_blocks: bad argument");
-    return enc_run(e, x, nullptr, out, B, L, n_run, ws, ws_bytes, stream);
+    return enc_run(e, x, nullptr, out, B, L, precision, n_run, ws, ws_bytes, stream);
 }
 
 extern "C" int mst_embedding_mean(const float *emb, int n_rows, int dim, float *out, void *stream) {

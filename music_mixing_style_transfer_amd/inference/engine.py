@@ -23,6 +23,7 @@ def build_models(cfg_encoder, cfg_converter, device, precision="fp32"):
                    stack_size=cfg_converter["stack_size"], cond_dim=cfg_converter["condition_dimension"],
                    causal=cfg_converter["causal"]).to(device)
     tcn.precision = precision
+    enc.precision = precision
     enc.eval()
     tcn.eval()
     return enc, tcn

@@ -111,8 +111,9 @@ class _EncoderRunner:
         except Exception:
             pass
 
-    def run(self, x, pooled=True, n_run=None):
+    def run(self, x, pooled=True, n_run=None, precision="fp32"):
         b = _check_device(x, "FXencoder.forward")
+        prec = _lib.PRECISIONS[precision]
         if x.dim() != 3 or x.shape[1] != self.blocks[0].conv1.in_channels:
             raise ValueError(f"FXencoder.forward: expected [B, {self.blocks[0].conv1.in_channels}, L], got {tuple(x.shape)}")
         self._ensure(b)
@@ -123,14 +124,14 @@ class _EncoderRunner:
         st = _stream_ptr(x)
         if pooled:
             out = torch.empty(B, self.blocks[-1].conv2.out_channels, dtype=torch.float32, device=x.device)
-            b.check(b.mst_enc_forward(self.handle, x.data_ptr(), out.data_ptr(), B, L, ws.data_ptr(), nbytes, st),
+            b.check(b.mst_enc_forward(self.handle, x.data_ptr(), out.data_ptr(), B, L, prec, ws.data_ptr(), nbytes, st),
                     "mst_enc_forward")
             return out
         n_run = len(self.blocks) if n_run is None else n_run
         lout = b.mst_enc_block_length(self.handle, n_run - 1, L)
         out = torch.empty(B, self.blocks[n_run - 1].conv2.out_channels, lout, dtype=torch.float32, device=x.device)
-        b.check(b.mst_enc_forward_blocks(self.handle, x.data_ptr(), out.data_ptr(), B, L, n_run, ws.data_ptr(), nbytes, st),
-                "mst_enc_forward_blocks")
+        b.check(b.mst_enc_forward_blocks(self.handle, x.data_ptr(), out.data_ptr(), B, L, prec, n_run, ws.data_ptr(),
+                                         nbytes, st), "mst_enc_forward_blocks")
         return out
 
 
@@ -158,6 +159,7 @@ class FXencoder(nn.Module):
                                          mode="conv"))
         self.encoder = nn.Sequential(*encoder)
         self.glob_pool = nn.AdaptiveAvgPool1d(1)
+        self.precision = os.environ.get("MST_ENC_PRECISION", "fp32")   # "fp32" (parity) | "bf16" (throughput)
         self._runner = None
 
     def _get_runner(self):
@@ -170,11 +172,11 @@ class FXencoder(nn.Module):
         return self._runner
 
     def forward(self, input):
-        return self._get_runner().run(input, pooled=True)
+        return self._get_runner().run(input, pooled=True, precision=self.precision)
 
     def forward_blocks(self, input, n_run):
         """Parity probe: output of the n_run-th Res_ConvBlock, [B, C, L_out]."""
-        return self._get_runner().run(input, pooled=False, n_run=n_run)
+        return self._get_runner().run(input, pooled=False, n_run=n_run, precision=self.precision)
 
 
 # ------------------------------------------------------------------------------------------------ TCN

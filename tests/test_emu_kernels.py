@@ -78,6 +78,12 @@ def test_encoder_emulated(emu_default):
         assert a.shape == col[n - 1].shape
         assert float((a - col[n - 1]).abs().max()) <= 2e-5
     assert float((enc(x) - R.fxencoder_forward(sd, cfg, x)).abs().max()) <= 2e-5
+    enc.precision = "bf16"                    # bf16 MFMA operands, fp32 accumulate, fp32 activations
+    for n in (1, 2, 4):
+        a = enc.forward_blocks(x, n)
+        assert float((a - col[n - 1]).abs().max()) <= 3e-2 * float(col[n - 1].abs().max())
+    assert float((enc(x) - R.fxencoder_forward(sd, cfg, x)).abs().max()) <= 3e-2
+    enc.precision = "fp32"
     blk = enc.encoder[0]                      # a Res_ConvBlock runs stand-alone too
     assert float((blk(x) - col[0]).abs().max()) <= 2e-5
     with pytest.raises(ValueError):

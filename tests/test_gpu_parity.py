@@ -113,6 +113,26 @@ def test_encoder_vs_oracle(nets, B, L):
     assert float((e - e_ref).abs().max()) <= 1e-4 * max(1.0, float(e_ref.abs().max()))
 
 
+def test_encoder_bf16_vs_oracle(nets):
+    from music_mixing_style_transfer_amd.utils import synth
+    from oracle import networks_ref as R
+    enc = nets["enc"]
+    x = synth.synth_audio((2, 2, 32768), seed=77)
+    col = []
+    R.fxencoder_blocks(x, nets["enc_sd"], nets["enc_cfg"], collect=col)
+    e_ref = R.fxencoder_forward(nets["enc_sd"], nets["enc_cfg"], x)
+    enc.precision = "bf16"
+    try:
+        for n in (1, 3, 6, 12):
+            a = enc.forward_blocks(x.cuda(), n).cpu()
+            err = float((a - col[n - 1]).abs().max())
+            assert err <= 5e-2 * max(1.0, float(col[n - 1].abs().max())), f"block {n}: {err}"
+        e = enc(x.cuda()).cpu()
+        assert float((e - e_ref).abs().max()) <= 2e-2 * max(1.0, float(e_ref.abs().max()))
+    finally:
+        enc.precision = "fp32"
+
+
 def test_full_size_against_reference_golden(nets):
     """BASELINE full segment size (2 x 131072): compare with vectors produced by the real reference."""
     from music_mixing_style_transfer_amd.utils import synth
