@@ -249,6 +249,234 @@ __global__ __launch_bounds__(256) void enc_conv_bf16_kernel(EncConvArgs a) {
     }
 }
 
+// ================================================================================================
+// bf16 throughput pipeline, channel-minor ("NLC") activations:  act[b][t][C] bf16.
+// With the contraction index ordered k = j*Cin + ci, the 8 consecutive k an MFMA lane needs are 8 consecutive
+// channels of ONE input row, i.e. one aligned 16-byte load - the im2col gather costs one load per 8 operands
+// (reflection and stride only move whole rows).  Layers whose Cin < 8 (the stereo input block) run on the
+// small direct kernel below, which also converts NCL fp32 -> NLC bf16.
+// ================================================================================================
+struct EncDirectArgs {
+    const float *x;      // [B][Cin][Lin] fp32
+    void *y;             // OUT_NLC ? bf16 [B][Lout][Cout] : fp32 [B][Cout][Lout]
+    const float *w;      // [Cout][Cin][ksz] BN-folded
+    const float *shift;  // [Cout]
+    int B, Cin, Lin, Cout, Lout, ksz, stride, dil, pad_l, residual;
+};
+
+// direct VALU convolution for tiny channel counts (Cin <= 4, Cout <= 32): one thread per output time step
+template <bool OUT_NLC>
+__global__ __launch_bounds__(256) void enc_direct_kernel(EncDirectArgs a) {
+    constexpr int XS_MAX = 4 * (256 * 8 + 64);
+    __shared__ float xs[XS_MAX];
+    __shared__ float ws[32 * 4 * 64];
+    const int tid = threadIdx.x;
+    const int tiles = (a.Lout + 255) / 256;
+    const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * 256;
+    const int span = 255 * a.stride + (a.ksz - 1) * a.dil + 1;
+    for (int i = tid; i < a.Cin * span; i += 256) {
+        const int ci = i / span, k = i % span;
+        int ti = t0 * a.stride - a.pad_l + k;
+        if (ti < 0) ti = -ti;
+        if (ti >= a.Lin) ti = 2 * (a.Lin - 1) - ti;
+        xs[i] = (ti >= 0 && ti < a.Lin) ? a.x[((size_t)b * a.Cin + ci) * a.Lin + ti] : 0.0f;
+    }
+    for (int i = tid; i < a.Cout * a.Cin * a.ksz; i += 256) ws[i] = a.w[i];
+    __syncthreads();
+    const int to = t0 + tid;
+    float acc[32];
+#pragma unroll
+    for (int co = 0; co < 32; ++co) acc[co] = 0.0f;
+    for (int ci = 0; ci < a.Cin; ++ci)
+        for (int j = 0; j < a.ksz; ++j) {
+            const float xv = xs[ci * span + tid * a.stride + j * a.dil];
+#pragma unroll
+            for (int co = 0; co < 32; ++co)
+                if (co < a.Cout) acc[co] = fmaf(ws[(co * a.Cin + ci) * a.ksz + j], xv, acc[co]);
+        }
+    if (to >= a.Lout) return;
+#pragma unroll
+    for (int co = 0; co < 32; ++co) {
+        if (co < a.Cout) {
+            float v = fmaxf(acc[co] + a.shift[co], 0.0f);
+            if (a.residual) v += xs[co * span + tid + a.pad_l];
+            acc[co] = v;
+        }
+    }
+    if (OUT_NLC) {
+        __bf16 *yp = (__bf16 *)a.y + ((size_t)b * a.Lout + to) * a.Cout;
+#pragma unroll
+        for (int c8 = 0; c8 < 4; ++c8) {
+            if (c8 * 8 < a.Cout) {
+                bf16x8 o;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = (__bf16)acc[c8 * 8 + i];
+                *(bf16x8 *)(yp + c8 * 8) = o;
+            }
+        }
+    } else {
+        float *yp = (float *)a.y + (size_t)b * a.Cout * a.Lout + to;
+#pragma unroll
+        for (int co = 0; co < 32; ++co)
+            if (co < a.Cout) yp[(size_t)co * a.Lout] = acc[co];
+    }
+}
+
+struct EncNlcArgs {
+    const __bf16 *x;     // [B][Lin][Cin]
+    __bf16 *y;           // [B][Lout][Cout]
+    float *part;         // split-K partial sums [S][Ntot][Cout] fp32 (null when S == 1)
+    const void *wpk;     // bf16 A fragments [co_tiles][nchunks][4][MW][64][8], k = j*Cin + ci
+    const float *shift;  // [co_tiles*MT]
+    const int *stab;     // [nchunks*8][2]: 16-byte slot -> (j*dil - pad_l, ci0); ci0 = -1 beyond K
+    int B, Cin, Lin, Cout, Lout, stride, nchunks, residual, S;
+    long Ntot;
+};
+
+// implicit-GEMM convolution on NLC bf16 activations, v_mfma_f32_32x32x16_bf16, K-chunk = 64 (8 slots per row).
+// Tile (32*MW) channels x (128*4/MW) columns; optional split-K over blockIdx.z for the short, wide late layers.
+template <int MW>
+__global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
+    constexpr int NW = 4 / MW, MT = 32 * MW, NT = 128 * NW;
+    constexpr int NL = NT / 32;                        // 16-byte loads per thread per chunk
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[NT * 128];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ln = lane & 31, h = lane >> 5;
+    const int mi = w % MW, ni = w / MW;
+    const long n0 = (long)blockIdx.x * NT;
+    const int cot = blockIdx.y, z = blockIdx.z;
+    const int kc_lo = (int)((long)z * a.nchunks / a.S), kc_hi = (int)((long)(z + 1) * a.nchunks / a.S);
+    const int slot = tid & 7;
+
+    int rowb[NL], rowt[NL];                           // batch item / first input time of the rows this thread stages
+#pragma unroll
+    for (int e = 0; e < NL; ++e) {
+        const long n = n0 + (tid >> 3) + 32 * e;
+        if (n < a.Ntot) {
+            rowb[e] = (int)(n / a.Lout);
+            rowt[e] = (int)(n % a.Lout) * a.stride;
+        } else {
+            rowb[e] = -1;
+            rowt[e] = 0;
+        }
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
+
+    const bf16x8 *wtile = (const bf16x8 *)a.wpk + (size_t)cot * a.nchunks * 4 * MW * 64;
+    bf16x8 anxt[4], acur[4], breg[NL];
+
+    auto fetch = [&](int kc) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) anxt[ks] = wtile[((size_t)(kc * 4 + ks) * MW + mi) * 64 + lane];
+        const int joff = a.stab[(kc * 8 + slot) * 2], ci0 = a.stab[(kc * 8 + slot) * 2 + 1];
+#pragma unroll
+        for (int e = 0; e < NL; ++e) {
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ci0 >= 0 && rowb[e] >= 0) {
+                int ti = rowt[e] + joff;
+                if (ti < 0) ti = -ti;
+                if (ti >= a.Lin) ti = 2 * (a.Lin - 1) - ti;
+                v = *(const bf16x8 *)(a.x + ((size_t)rowb[e] * a.Lin + ti) * a.Cin + ci0);
+            }
+            breg[e] = v;
+        }
+    };
+
+    if (kc_lo < kc_hi) fetch(kc_lo);
+    for (int kc = kc_lo; kc < kc_hi; ++kc) {
+        if (kc > kc_lo) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NL; ++e) {
+            const int n = (tid >> 3) + 32 * e;
+            *(bf16x8 *)(Bs + n * 128 + ((slot ^ ((n >> 1) & 7)) << 4)) = breg[e];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acur[ks] = anxt[ks];
+        __syncthreads();
+        if (kc + 1 < kc_hi) fetch(kc + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = 128 * ni + 32 * q + ln;
+                const bf16x8 bv = *(const bf16x8 *)(Bs + nl * 128 + (((2 * ks + h) ^ ((nl >> 1) & 7)) << 4));
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[ks], bv, acc[q], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long n = n0 + 128 * ni + 32 * q + ln;
+        if (n < a.Ntot) {
+            const int b = (int)(n / a.Lout), to = (int)(n % a.Lout);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co0 = cot * MT + 32 * mi + 8 * g + 4 * h;
+                if (co0 < a.Cout) {
+                    if (a.part) {
+                        f32x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = acc[q][4 * g + i];
+                        *(f32x4 *)(a.part + ((size_t)z * a.Ntot + n) * a.Cout + co0) = o;
+                    } else {
+                        const f32x4 sh = *(const f32x4 *)(a.shift + co0);
+                        bf16x4 o, r = {0, 0, 0, 0};
+                        if (a.residual) r = *(const bf16x4 *)(a.x + ((size_t)b * a.Lin + to) * a.Cin + co0);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = (__bf16)(fmaxf(acc[q][4 * g + i] + sh[i], 0.0f) + (float)r[i]);
+                        *(bf16x4 *)(a.y + ((size_t)b * a.Lout + to) * a.Cout + co0) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// split-K epilogue: sum the S partial tiles, + shift, ReLU, + residual, -> bf16 NLC
+__global__ __launch_bounds__(256) void enc_splitk_finalize_kernel(const float *part, int S, long Ntot, int Cout,
+                                                                  const float *shift, const __bf16 *xres, __bf16 *y) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;       // one thread per 4 channels
+    const long total = Ntot * (Cout / 4);
+    if (i >= total) return;
+    const long n = i / (Cout / 4);
+    const int co0 = (int)(i % (Cout / 4)) * 4;
+    f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int zz = 0; zz < S; ++zz) s += *(const f32x4 *)(part + ((size_t)zz * Ntot + n) * Cout + co0);
+    const f32x4 sh = *(const f32x4 *)(shift + co0);
+    bf16x4 r = {0, 0, 0, 0}, o;
+    if (xres) r = *(const bf16x4 *)(xres + (size_t)n * Cout + co0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (__bf16)(fmaxf(s[k] + sh[k], 0.0f) + (float)r[k]);
+    *(bf16x4 *)(y + (size_t)n * Cout + co0) = o;
+}
+
+// global average pool over time of an NLC bf16 activation -> fp32 [B][C]
+__global__ __launch_bounds__(256) void enc_avgpool_nlc_kernel(const __bf16 *x, float *y, int B, int Lf, int C) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * C) return;
+    const int b = (int)(i / C), c = (int)(i % C);
+    float s = 0.0f;
+    for (int t = 0; t < Lf; ++t) s += (float)x[((size_t)b * Lf + t) * C + c];
+    y[i] = s / (float)Lf;
+}
+
+// NLC bf16 -> NCL fp32 (parity probe only)
+__global__ void enc_unpack_nlc_kernel(const __bf16 *x, float *y, int B, int L, int C) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)B * L * C) return;
+    const int c = i % C;
+    const size_t bt = i / C;
+    const int t = bt % L;
+    const int b = bt / L;
+    y[((size_t)b * C + c) * L + t] = (float)x[i];
+}
+
 // AdaptiveAvgPool1d(1) + squeeze (architectures.py:62,67): one wave per (b, c) row.
 __global__ __launch_bounds__(256) void enc_avgpool_kernel(const float *x, float *y, long rows, int Lf) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);

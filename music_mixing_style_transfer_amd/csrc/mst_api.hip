@@ -428,6 +428,10 @@ struct MstEncConv {
     float *wpk = nullptr, *shift = nullptr;
     __bf16 *wpk16 = nullptr;
     int *ktab = nullptr;
+    float *w_direct = nullptr;   // [Cout][Cin][ksz] folded fp32 (layers with Cin < 8: direct kernel)
+    __bf16 *wpk_nlc = nullptr;   // NLC pipeline A fragments, k = j*Cin + ci, K-chunk 64
+    int *stab = nullptr;         // NLC pipeline slot table
+    int nchunks64 = 0;
     int cin = 0, cout = 0, ksz = 0, stride = 1, dil = 1, pad_l = 0, pad_r = 0, nchunks = 0, nchunks32 = 0, mw = 4;
     bool loaded = false;
 };
@@ -471,6 +475,9 @@ extern "C" int mst_enc_destroy(MstEnc *e) {
     for (auto &c : e->conv) {
         (void)hipFree(c.wpk);
         (void)hipFree(c.wpk16);
+        (void)hipFree(c.w_direct);
+        (void)hipFree(c.wpk_nlc);
+        (void)hipFree(c.stab);
         (void)hipFree(c.shift);
         (void)hipFree(c.ktab);
     }
@@ -520,6 +527,36 @@ extern "C" int mst_enc_load_conv(MstEnc *e, int block, int which, const float *w
         kt[2 * k + 1] = k < K ? (k % c.ksz) * c.dil - c.pad_l : 0;
     }
     int rc;
+    if (c.cin < 8) {
+        std::vector<float> wd((size_t)c.cout * K);
+        for (int co = 0; co < c.cout; ++co)
+            for (int k = 0; k < K; ++k) wd[(size_t)co * K + k] = w[(size_t)co * K + k] * scale[co];
+        if ((rc = upload(&c.w_direct, wd))) return rc;
+    } else if (c.cin % 8 == 0) {
+        // NLC pipeline: contraction index k = j*Cin + ci; fragments [cot][kc64][ks 0..3][mi][lane][e]
+        c.nchunks64 = (K + 63) / 64;
+        std::vector<__bf16> wn((size_t)co_tiles * c.nchunks64 * 4 * c.mw * 64 * 8);
+        for (int cot = 0; cot < co_tiles; ++cot)
+            for (int kc = 0; kc < c.nchunks64; ++kc)
+                for (int ks = 0; ks < 4; ++ks)
+                    for (int mi = 0; mi < c.mw; ++mi)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 8; ++e) {
+                                const int co = cot * MT + 32 * mi + (l & 31);
+                                const int k = kc * 64 + ks * 16 + 8 * (l >> 5) + e;
+                                float v = 0.0f;
+                                if (co < c.cout && k < K) v = w[((size_t)co * c.cin + (k % c.cin)) * c.ksz + k / c.cin] * scale[co];
+                                wn[((((((size_t)cot * c.nchunks64 + kc) * 4 + ks) * c.mw + mi) * 64 + l) * 8) + e] = (__bf16)v;
+                            }
+        std::vector<int> st((size_t)c.nchunks64 * 8 * 2);
+        for (int sidx = 0; sidx < c.nchunks64 * 8; ++sidx) {
+            const int k0 = sidx * 8;
+            st[2 * sidx] = k0 < K ? (k0 / c.cin) * c.dil - c.pad_l : 0;
+            st[2 * sidx + 1] = k0 < K ? k0 % c.cin : -1;
+        }
+        if ((rc = upload(&c.wpk_nlc, wn))) return rc;
+        if ((rc = upload(&c.stab, st))) return rc;
+    }
     if ((rc = upload(&c.wpk, wp))) return rc;
     if ((rc = upload(&c.wpk16, wp16))) return rc;
     if ((rc = upload(&c.shift, sh))) return rc;
@@ -587,6 +624,146 @@ int enc_launch(const MstEncConv &c, const float *x, float *y, int B, int Lin, in
     return MST_OK;
 }
 
+// the channel-minor bf16 pipeline needs a stereo-like first block for the direct kernel and channel counts that are
+// multiples of 8 afterwards (true for configs.yaml); otherwise bf16 mode uses the NCL gather kernel
+bool enc_nlc_eligible(const MstEnc *e) {
+    const MstEncDesc &d = e->d;
+    if (d.channels[0] > 4 || d.channels[1] > 32 || d.channels[1] % 8 != 0 || d.kernels[0] > 64) return false;
+    if (255 * d.strides[0] + (d.kernels[0] - 1) * d.dilations[0] + 1 > 256 * 8 + 64) return false;
+    for (int i = 1; i <= d.nblocks; ++i)
+        if (d.channels[i] % 8 != 0) return false;
+    const char *env = getenv("MST_ENC_NLC");
+    return !(env && atoi(env) == 0);
+}
+
+int enc_splitk(long tiles, int nchunks) {
+    if (tiles >= 512) return 1;
+    int S = (int)((768 + tiles - 1) / tiles);
+    if (S > 8) S = 8;
+    if (S > nchunks / 4) S = nchunks / 4;
+    return S < 1 ? 1 : S;
+}
+
+size_t enc_scratch_floats(const MstEnc *e, int B, int L) {
+    size_t mx = 0;
+    int len = L;
+    for (int i = 0; i < e->d.nblocks; ++i) {
+        const int lout = (len - 1) / e->d.strides[i] + 1;
+        for (int which = 0; which < 2; ++which) {
+            const MstEncConv &c = e->conv[2 * i + which];
+            const long ntot = (long)B * (which ? lout : len);
+            const int MT = 32 * c.mw, NT = 128 * (4 / c.mw);
+            const long tiles = ((ntot + NT - 1) / NT) * ((c.cout + MT - 1) / MT);
+            const int nch = (c.cin * c.ksz + 63) / 64;
+            const int S = enc_splitk(tiles, nch);
+            if (S > 1) mx = std::max(mx, (size_t)S * ntot * c.cout);
+        }
+        len = lout;
+    }
+    return mx;
+}
+
+int enc_launch_direct(const MstEncConv &c, const float *x, void *y, bool out_nlc, int B, int Lin, int Lout, int residual,
+                      void *stream) {
+    if (Lin <= c.pad_l || Lin <= c.pad_r)
+        return fail(MST_ERR_ARG, "mst_enc_forward: reflection padding needs the input to be longer than the padding");
+    EncDirectArgs a;
+    a.x = x;
+    a.y = y;
+    a.w = c.w_direct;
+    a.shift = c.shift;
+    a.B = B;
+    a.Cin = c.cin;
+    a.Lin = Lin;
+    a.Cout = c.cout;
+    a.Lout = Lout;
+    a.ksz = c.ksz;
+    a.stride = c.stride;
+    a.dil = c.dil;
+    a.pad_l = c.pad_l;
+    a.residual = residual;
+    const dim3 grid((unsigned)(B * ((Lout + 255) / 256)));
+    if (out_nlc)
+        MST_LAUNCH((enc_direct_kernel<true>), grid, dim3(256), stream, a);
+    else
+        MST_LAUNCH((enc_direct_kernel<false>), grid, dim3(256), stream, a);
+    MST_CHECK_LAUNCH("enc_direct_kernel");
+    return MST_OK;
+}
+
+int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scratch, int B, int Lin, int Lout, int residual,
+                   void *stream) {
+    if (Lin <= c.pad_l || Lin <= c.pad_r)
+        return fail(MST_ERR_ARG, "mst_enc_forward: reflection padding needs the input to be longer than the padding");
+    EncNlcArgs a;
+    a.x = x;
+    a.y = y;
+    a.wpk = c.wpk_nlc;
+    a.shift = c.shift;
+    a.stab = c.stab;
+    a.B = B;
+    a.Cin = c.cin;
+    a.Lin = Lin;
+    a.Cout = c.cout;
+    a.Lout = Lout;
+    a.stride = c.stride;
+    a.nchunks = c.nchunks64;
+    a.residual = residual;
+    a.Ntot = (long)B * Lout;
+    const int MT = 32 * c.mw, NT = 128 * (4 / c.mw);
+    const long ntiles = (a.Ntot + NT - 1) / NT, cotiles = (c.cout + MT - 1) / MT;
+    a.S = enc_splitk(ntiles * cotiles, c.nchunks64);
+    a.part = a.S > 1 ? scratch : nullptr;
+    const dim3 grid((unsigned)ntiles, (unsigned)cotiles, (unsigned)a.S);
+    switch (c.mw) {
+        case 1: MST_LAUNCH((enc_conv_nlc_kernel<1>), grid, dim3(256), stream, a); break;
+        case 2: MST_LAUNCH((enc_conv_nlc_kernel<2>), grid, dim3(256), stream, a); break;
+        default: MST_LAUNCH((enc_conv_nlc_kernel<4>), grid, dim3(256), stream, a); break;
+    }
+    MST_CHECK_LAUNCH("enc_conv_nlc_kernel");
+    if (a.S > 1) {
+        const long total = a.Ntot * (c.cout / 4);
+        MST_LAUNCH(enc_splitk_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, (const float *)scratch,
+                   a.S, a.Ntot, c.cout, (const float *)c.shift, residual ? x : (const __bf16 *)nullptr, y);
+        MST_CHECK_LAUNCH("enc_splitk_finalize_kernel");
+    }
+    return MST_OK;
+}
+
+int enc_run_nlc(MstEnc *e, const float *x, float *emb, float *blk_out, int B, int L, int n_run, void *ws, void *stream) {
+    const size_t nb = align_up(enc_buf_floats(e, B, L) * sizeof(float), 256);
+    unsigned char *base = (unsigned char *)ws;
+    void *t1 = base;
+    void *o[2] = {base + nb, base + 2 * nb};
+    float *scratch = (float *)(base + 3 * nb);
+    int len = L, rc, pp = 0;
+    const void *cur = x;
+    for (int i = 0; i < n_run; ++i) {
+        const int lout = (len - 1) / e->d.strides[i] + 1;
+        if (i == 0) {
+            if ((rc = enc_launch_direct(e->conv[0], (const float *)cur, t1, false, B, len, len, 1, stream))) return rc;
+            if ((rc = enc_launch_direct(e->conv[1], (const float *)t1, o[pp], true, B, len, lout, 0, stream))) return rc;
+        } else {
+            if ((rc = enc_launch_nlc(e->conv[2 * i], (const __bf16 *)cur, (__bf16 *)t1, scratch, B, len, len, 1, stream))) return rc;
+            if ((rc = enc_launch_nlc(e->conv[2 * i + 1], (const __bf16 *)t1, (__bf16 *)o[pp], scratch, B, len, lout, 0, stream))) return rc;
+        }
+        cur = o[pp];
+        pp ^= 1;
+        len = lout;
+    }
+    const int C = e->d.channels[n_run];
+    if (blk_out) {
+        const size_t total = (size_t)B * len * C;
+        MST_LAUNCH(enc_unpack_nlc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, (const __bf16 *)cur, blk_out, B, len, C);
+        MST_CHECK_LAUNCH("enc_unpack_nlc_kernel");
+    }
+    if (emb) {
+        MST_LAUNCH(enc_avgpool_nlc_kernel, dim3((unsigned)(((long)B * C + 255) / 256)), dim3(256), stream, (const __bf16 *)cur, emb, B, len, C);
+        MST_CHECK_LAUNCH("enc_avgpool_nlc_kernel");
+    }
+    return MST_OK;
+}
+
 int enc_run(MstEnc *e, const float *x, float *emb, float *blk_out, int B, int L, int precision, int n_run, void *ws,
             size_t ws_bytes, void *stream) {
     if (!e || !x || B < 1 || L < 1) return fail(MST_ERR_ARG, "mst_enc_forward: bad argument");
@@ -594,6 +771,7 @@ int enc_run(MstEnc *e, const float *x, float *emb, float *blk_out, int B, int L,
     for (auto &c : e->conv)
         if (!c.loaded) return fail(MST_ERR_STATE, "mst_enc_forward: conv weights not loaded");
     if (!ws || ws_bytes < mst_enc_workspace_bytes(e, B, L)) return fail(MST_ERR_WORKSPACE, "mst_enc_forward: workspace too small");
+    if (precision == MST_PREC_BF16 && enc_nlc_eligible(e)) return enc_run_nlc(e, x, emb, blk_out, B, L, n_run, ws, stream);
     const size_t nb = align_up(enc_buf_floats(e, B, L) * sizeof(float), 256);
     float *t1 = (float *)ws;
     float *o[2] = {(float *)((unsigned char *)ws + nb), (float *)((unsigned char *)ws + 2 * nb)};
@@ -620,7 +798,7 @@ int enc_run(MstEnc *e, const float *x, float *emb, float *blk_out, int B, int L,
 
 extern "C" size_t mst_enc_workspace_bytes(const MstEnc *e, int B, int L) {
     if (!e || B < 1 || L < 1) return 0;
-    return 3 * align_up(enc_buf_floats(e, B, L) * sizeof(float), 256);
+    return 3 * align_up(enc_buf_floats(e, B, L) * sizeof(float), 256) + align_up(enc_scratch_floats(e, B, L) * sizeof(float), 256);
 }
 
 extern "C" int mst_enc_forward(MstEnc *e, const float *x, float *emb, int B, int L, int precision, void *ws,

@@ -90,6 +90,26 @@ def test_encoder_emulated(emu_default):
         enc(synth.synth_audio((1, 2, 3), seed=1))          # reflection padding longer than the input
 
 
+def test_encoder_nlc_bf16_pipeline_emulated(emu_default):
+    """bf16 mode on a configs.yaml-like net (channels % 8 == 0): direct kernel for the stereo block, channel-minor
+    bf16 activations afterwards, split-K + finalize on the short late layers."""
+    from music_mixing_style_transfer_amd.networks import FXencoder
+    cfg = {"channels": [16, 40, 72, 136, 264], "kernels": [25, 5, 4, 3, 10], "strides": [4, 2, 2, 1, 2],
+           "dilation": [1, 1, 1, 1, 1], "bias": True, "norm": "batch", "conv_block": "res", "activation": "relu"}
+    sd = synth.fxencoder_state_dict(cfg, seed=3)
+    enc = FXencoder({k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()})
+    enc.load_state_dict(sd)
+    x = synth.synth_audio((3, 2, 1333), seed=11)
+    col = []
+    R.fxencoder_blocks(x, sd, cfg, collect=col)
+    enc.precision = "bf16"
+    for n in range(1, 6):
+        a = enc.forward_blocks(x, n)
+        assert a.shape == col[n - 1].shape
+        assert float((a - col[n - 1]).abs().max()) <= 2e-2 * float(col[n - 1].abs().max())
+    assert float((enc(x) - R.fxencoder_forward(sd, cfg, x)).abs().max()) <= 2e-2
+
+
 def test_embedding_mean_and_engine_emulated(emu_default):
     from music_mixing_style_transfer_amd.inference import embedding_mean
     e = synth.synth_audio((7, 40), seed=2)
