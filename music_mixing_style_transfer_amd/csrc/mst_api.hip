@@ -316,7 +316,7 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         static const int prof_block = getenv("MST_TCN_PROF_BLOCK") ? atoi(getenv("MST_TCN_PROF_BLOCK")) : -1;
         long long *prof_dev = nullptr;
         if (prof_file && prof_block == n && precision == MST_PREC_BF16) {
-            MST_HIP_TRY(hipMalloc((void **)&prof_dev, (size_t)grid * 4 * sizeof(long long)));
+            MST_HIP_TRY(hipMalloc((void **)&prof_dev, (size_t)grid * 10 * sizeof(long long)));
             a.prof = prof_dev;
         }
         if (grid > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_tcn_forward: grid too large");
@@ -330,7 +330,7 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         }
         if (rc) return rc;
         if (prof_dev) {
-            std::vector<long long> hp((size_t)grid * 4);
+            std::vector<long long> hp((size_t)grid * 10);
             MST_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
             MST_HIP_TRY(hipMemcpy(hp.data(), prof_dev, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
             (void)hipFree(prof_dev);

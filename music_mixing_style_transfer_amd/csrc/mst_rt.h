@@ -11,3 +11,8 @@
 
 #define MST_LAUNCH(kern, grid, block, stream, ...) \
     hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__)
+
+// hardware wave slot of the calling wave (s_getreg_b32 hwreg(HW_REG_HW_ID, 0, 4)) and a 127*64-clock sleep
+__device__ __forceinline__ unsigned mst_wave_slot() { return __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)); }
+__device__ __forceinline__ unsigned mst_hw_id() { return __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); }
+__device__ __forceinline__ unsigned mst_xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); }

@@ -57,8 +57,7 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
     const int m0 = mg * MT, phi0 = pg * P;
     const __bf16 *xb = (const __bf16 *)a.x + (size_t)b * a.Lp * 128;
     __bf16 *yb = (__bf16 *)a.y + (size_t)b * a.Lp * 128;
-    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 4 + 0] = mst_clock();
-
+    if (a.prof && tid == 0) { a.prof[(size_t)blockIdx.x * 10 + 0] = mst_clock(); a.prof[(size_t)blockIdx.x * 10 + 4] = mst_hw_id(); a.prof[(size_t)blockIdx.x * 10 + 5] = mst_xcc_id(); }
     // ---- stage the (256 + 14P) input rows: 16 lanes x 16 B per row, XOR-swizzled 16-B slots so that the
     //      32 consecutive rows of one B-fragment read hit 16 distinct slots per ds_read_b128 lane group
     {
@@ -81,7 +80,7 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
         }
     }
     __syncthreads();
-    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 4 + 1] = mst_clock();
+    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 1] = mst_clock();
 
     f32x16 acc[8];
 #pragma unroll
@@ -150,7 +149,7 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
     }
 
     // ---- fused epilogue
-    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 4 + 2] = mst_clock();
+    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 2] = mst_clock();
     const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
     // residual inputs (centre tap rows) -> registers, then the input tile is dead and LDS is reused to transpose
     // the output tile so that global stores are whole 256-byte rows, 16 B per lane
@@ -165,6 +164,7 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
         }
     }
     __syncthreads();
+    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 6] = mst_clock();
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int co0 = 32 * w + 8 * g + 4 * h;
@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
         }
     }
     __syncthreads();
+    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 7] = mst_clock();
     {
         const int slot = tid & 15;
 #pragma unroll
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
             if (t < a.L) *(bf16x8 *)(yb + t * 128 + slot * 8) = *(const bf16x8 *)(smem + o * 256 + ((slot ^ (o & 15)) << 4));
         }
     }
-    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 4 + 3] = mst_clock();
+    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 3] = mst_clock();
 }
 
 // ------------------------------------------------------------------------------------------------

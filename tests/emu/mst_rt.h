@@ -156,3 +156,7 @@ static inline double atomicAdd(double *p, double v) {
 }
 static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+
+static inline unsigned mst_wave_slot() { return 0; }
+static inline unsigned mst_hw_id() { return 0; }
+static inline unsigned mst_xcc_id() { return 0; }
