@@ -126,6 +126,11 @@ def main():
     dt = float(tmax.item())
 
     if rank == 0:
+        traffic = None      # HBM bytes per launch of the dominant kernel: offline rocprofv3 --pmc passes (tools/pmc_traffic.py)
+        tpath = os.path.join(REPO, "profiles", "r01_tcn_block_bf16_traffic.json")
+        if args.precision == "bf16" and B == BATCH and os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get("traffic_bytes")
         block_ms = [float(v) for v in ms]
         dense = block_ms[1:nb]                                   # the 13 dilated 128->128 blocks
         avg_ms = sum(dense) / len(dense)
@@ -152,7 +157,7 @@ def main():
             "roofline": {"kernel": "tcn_block_%s_kernel (dilated 128x128x15 conv + fused BN/LeakyReLU/FiLM/residual)" %
                                    ("bf16" if args.precision == "bf16" else "f32"),
                          "bound": "mfma", "achieved": achieved, "peak": PEAK[args.precision], "unit": "TFLOP/s",
-                         "frac": achieved / PEAK[args.precision], "traffic": None,
+                         "frac": achieved / PEAK[args.precision], "traffic": traffic,
                          "avg_launch_ms": avg_ms, "launches_per_step": nb - 1, "timed_forwards": int(nf.value),
                          "flop_per_launch": flop_per_launch, "per_block_ms": block_ms},
         }

@@ -263,7 +263,32 @@ def main():
     gp.parameters.gain.value = 5.0
     fx["rms_norm"] = chain.apply_processor(xs.copy(), gp, True)
     np.savez_compressed(os.path.join(HERE, "fx.npz"), **fx)
-    for f in ("nets_tiny.npz", "nets_full.npz", "bookkeeping.npz", "fx.npz"):
+    # ---------------------------------------------------------------- wav reader (loader_utils.load_wav_segment)
+    import tempfile
+    import wave
+    sys.modules["soundfile"] = types.ModuleType("soundfile")
+    spec = importlib.util.spec_from_file_location(
+        "ref_loader_utils", os.path.join(REF, "mixing_style_transfer", "data_loader", "loader_utils.py"))
+    lu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lu)
+    wv = {}
+    rng = np.random.default_rng(0)
+    pcm16 = rng.integers(-32768, 32767, size=(777, 2), dtype=np.int16)
+    pcm32 = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(333, 2), dtype=np.int32)
+    with tempfile.TemporaryDirectory() as td:
+        for name, pcm, width in (("pcm16", pcm16, 2), ("pcm32", pcm32, 4)):
+            path = os.path.join(td, name + ".wav")
+            with wave.open(path, "w") as w:
+                w.setnchannels(2)
+                w.setsampwidth(width)
+                w.setframerate(44100)
+                w.writeframes(pcm.tobytes())
+            wv[name] = pcm
+            wv[name + "_axis0"] = lu.load_wav_segment(path, axis=0)
+            wv[name + "_axis1_seg"] = lu.load_wav_segment(path, start_point=10, duration=100, axis=1)
+            wv[name + "_len"] = np.int64(lu.load_wav_length(path))
+    np.savez_compressed(os.path.join(HERE, "wav.npz"), **wv)
+    for f in ("nets_tiny.npz", "nets_full.npz", "bookkeeping.npz", "fx.npz", "wav.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
 

@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""BASELINE.json configs[3]: the FX-manipulator chain (biquad EQ -> rms-norm -> compressor -> rms-norm -> mid/side
+imager -> rms-norm -> gain) on a batch of 64 stereo segments of 131072 samples on one MI355X, with fixed
+parameters (oracle/fx_ref.py CONFIG4).  Prints one JSON line: segments/s, algorithmic GB/s, per-processor ms,
+max deviation from the oracle on a checked sample, and the oracle's C restatement timed on one host core."""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    from music_mixing_style_transfer_amd.mixing_manipulator import Compressor, Equaliser, Gain, MidSideImager, rms_normalize_
+    from oracle import fx_ref as F
+    n, L = 64, 131072
+    g = torch.Generator().manual_seed(0)
+    x = (0.1 * torch.randn(n, L, 2, generator=g)).clamp_(-1, 1).cuda()
+    eq = Equaliser(2, 44100)
+    for band, (gg, fc, q) in F.CONFIG4["eq"].items():
+        getattr(eq.parameters, band + "_gain").value = gg
+    comp, im, gn = Compressor(44100), MidSideImager(), Gain()
+    im.parameters.bal.value = F.CONFIG4["imager_bal"]
+    gn.parameters.gain.value = F.CONFIG4["gain_db"]
+
+    def chain(x, times=None):
+        def timed(name, fn):
+            if times is None:
+                return fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            r = fn()
+            b.record()
+            torch.cuda.synchronize()
+            times[name] = times.get(name, 0.0) + a.elapsed_time(b)
+            return r
+        y = timed("equaliser", lambda: eq.process(x))
+        y = timed("rms_norm", lambda: rms_normalize_(x, y))
+        z = timed("compressor", lambda: comp.process(y))
+        z = timed("rms_norm", lambda: rms_normalize_(y, z))
+        w = timed("imager", lambda: im.process(z))
+        w = timed("rms_norm", lambda: rms_normalize_(z, w))
+        return timed("gain", lambda: gn.process(w))
+
+    out = chain(x)
+    torch.cuda.synchronize()
+    steps = 5
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = chain(x)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    times = {}
+    chain(x, times)
+    # parity on two items against the oracle chain (compressor via the oracle's C restatement for speed)
+    import subprocess
+    subprocess.run(["make", "-C", os.path.join(REPO, "oracle")], check=True, capture_output=True)
+    lib = C.CDLL(os.path.join(REPO, "oracle", "libfx_ref.so"))
+    fp = C.POINTER(C.c_float)
+
+    def c_comp(xx, threshold, attack_time, release_time, ratio, sample_rate):
+        xx = np.ascontiguousarray(xx, dtype=np.float32)
+        yy = np.empty_like(xx)
+        lib.ref_compressor(xx.ctypes.data_as(fp), yy.ctypes.data_as(fp), C.c_long(xx.shape[0]), xx.shape[1], C.c_double(threshold),
+                           C.c_double(attack_time), C.c_double(release_time), C.c_double(ratio), C.c_double(0.0), C.c_double(sample_rate))
+        return yy
+    dev = 0.0
+    t1 = time.perf_counter()
+    for i in (0, 17):
+        ref = F.fx_chain(x[i].cpu().numpy(), compressor_fn=c_comp)
+        dev = max(dev, float(np.abs(out[i].cpu().numpy() - ref).max()))
+    cpu_dt = (time.perf_counter() - t1) / 2
+    alg_bytes = 144 * L * n           # unfused per-processor read+write bytes of the chain
+    print(json.dumps({"metric": "FX chain segments/sec (EQ+compressor+imager+gain, rms-normalised)", "value": n / dt,
+                      "unit": "segments/s", "n_items": n, "segment": [L, 2], "ms_per_chain": dt * 1e3,
+                      "algorithmic_GBps": alg_bytes / dt / 1e9, "per_processor_ms": times,
+                      "max_abs_dev_vs_oracle": dev,
+                      "cpu_baseline": {"value": 1.0 / cpu_dt, "unit": "segments/s", "cores": 1, "kind": "port",
+                                       "sample": "2 segments, oracle/fx_ref.py chain (scipy lfilter EQ + oracle/fx_ref.c compressor)"}}))
+
+
+if __name__ == "__main__":
+    main()
