@@ -234,7 +234,28 @@ int bf16_variant() {
     return v;
 }
 
-template <int P> int launch_block(int precision, const TcnBlockArgs &a, int grid, void *stream) {
+int bf16_persist() {
+    static const int v = [] {
+        const char *e = getenv("MST_TCN_PERSIST");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
+template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream) {
+    TcnBlockArgs a = a0;
+    if constexpr (P <= 4) {
+        if (precision == MST_PREC_BF16 && bf16_persist() > 0) {
+            // the persistent kernel tiles 128 output times per workgroup pass
+            const long nsteps = ((long)a.L + a.d - 1) / a.d;
+            a.tiles_step = (int)((nsteps + 128 / P - 1) / (128 / P));
+            const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
+            const int pg = (int)(ntiles < bf16_persist() ? ntiles : bf16_persist());
+            MST_LAUNCH((tcn_block_bf16_persist_kernel<P>), dim3(pg), dim3(256), stream, a);
+            MST_CHECK_LAUNCH("tcn_block_bf16_persist_kernel");
+            return MST_OK;
+        }
+    }
     if (precision == MST_PREC_BF16) {
         switch (bf16_variant()) {
             case 0: MST_LAUNCH((tcn_block_bf16_kernel<P, 0>), dim3(grid), dim3(256), stream, a); break;

@@ -14,7 +14,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 // C/D fragment row of accumulator register `reg` for the 32x32 MFMA shapes (col = lane & 31).
 __device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-__device__ __forceinline__ float leaky_relu(float v) { return v > 0.0f ? v : MST_LEAKY * v; }
+// slope < 1: max(v, slope*v) == (v > 0 ? v : slope*v), one multiply + one max (packs into v_pk_mul / v_pk_max)
+__device__ __forceinline__ float leaky_relu(float v) { return fmaxf(v, MST_LEAKY * v); }
 
 __device__ __forceinline__ long long mst_clock() { return (long long)__builtin_readcyclecounter(); }
 

@@ -22,6 +22,8 @@
 //
 // Epilogue (fused): + BN shift -> LeakyReLU(0.01) -> FiLM r*y+b -> + res_scale * x_in  -> store.
 #pragma once
+#include <type_traits>
+
 #include "mst_dev.h"
 
 struct TcnBlockArgs {
@@ -198,6 +200,280 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
         }
     }
     if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 3] = mst_clock();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent form of the bf16 block kernel: ONE workgroup per CU (4 waves, one per SIMD) walks the tiles.
+// Measured on the non-persistent kernel: two co-resident workgroups run their phases in lock-step, and epilogue
+// VALU work starves (5x slower) beside the other workgroup's back-to-back MFMA stream.  Here everything that is
+// not MFMA rides in the MFMA issue gaps of the SAME wave:
+//   * two LDS tile buffers: while tile i is computed from buffer A, the results of tile i-1 are transposed
+//     through buffer B and stored, then tile i+1 is staged into buffer B;
+//   * two accumulator sets: `accp` holds tile i-1 while `acc` accumulates tile i; the epilogue math of tile i-1
+//     is spread one (channel-group, column-tile) unit per k-step over the first taps.
+// Tile = 128 output times (4 accumulator tiles per wave) so that both accumulator sets, the A/B fragment rings
+// and the staging registers fit the 256 architectural VGPRs without spilling.
+// Same arithmetic, tiling rule and weight packing as tcn_block_bf16_kernel<P, 2>.
+// ------------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(256, 1) void tcn_block_bf16_persist_kernel(TcnBlockArgs a) {
+    constexpr int NQ = 4, T = 32 * NQ, R = T + 14 * P, MT = T / P, NPASS = (R + 15) / 16;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * R * 256];
+    __shared__ __attribute__((aligned(16))) float par[4 * 128];     // shift | res | FiLM r | FiLM b of the block
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ln = lane & 31, h = lane >> 5;
+    const int slot = tid & 15, prow = tid >> 4;
+    const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
+    long tile = blockIdx.x;
+    if (tile >= ntiles) return;
+
+    struct Coord { int b, m0, phi0; };
+    auto decode = [&](long t) {
+        Coord c;
+        const int mg = (int)(t % a.tiles_step);
+        t /= a.tiles_step;
+        c.phi0 = (int)(t % a.tiles_phase) * P;
+        c.b = (int)(t / a.tiles_phase);
+        c.m0 = mg * MT;
+        return c;
+    };
+    // row i*16 + prow of a tile: 16 bytes (slot) of the input row, zeros outside the segment
+    auto stage_load = [&](int i, const Coord &c, bool live) {
+        const int r = prow + 16 * i;
+        const long t = (long)(c.m0 + r / P - 7) * a.d + c.phi0 + (r % P);
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (live && r < R && t >= 0 && t < a.L)
+            v = *(const bf16x8 *)((const __bf16 *)a.x + ((size_t)c.b * a.Lp + t) * 128 + slot * 8);
+        return v;
+    };
+    auto stage_store = [&](unsigned char *buf, int i, bf16x8 v) {
+        const int r = prow + 16 * i;
+        if (r < R) *(bf16x8 *)(buf + r * 256 + ((slot ^ (r & 15)) << 4)) = v;
+    };
+
+    // per-channel epilogue parameters live in LDS: one ds_read_b128 each instead of an L2 round trip inside the MFMA loop
+    int par_b = -1;
+    auto load_params = [&](int b) {
+        const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+        if (tid < 128) {
+            par[tid] = a.shift[tid];
+            par[128 + tid] = a.res[tid];
+            par[256 + tid] = frow[tid];
+            par[384 + tid] = frow[128 + tid];
+        }
+        par_b = b;
+    };
+    Coord cc = decode(tile);
+    load_params(cc.b);
+    {
+        bf16x8 v[NPASS];
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) v[i] = stage_load(i, cc, true);
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) stage_store(smem, i, v[i]);
+    }
+    __syncthreads();
+
+    f32x16 acc[NQ], accp[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accp[q][i] = 0.0f;
+    Coord pc = {0, 1 << 28, 0};          // "previous tile" of the first iteration: every time >= L, nothing is stored
+    int cur = 0;
+    const bf16x8 *wp = (const bf16x8 *)a.wpk + (w * 64 + lane);
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        cc = decode(tile);
+        const bool stamp = a.prof && tid == 0 && tile == (long)blockIdx.x + 2 * (long)gridDim.x;   // third tile of this workgroup
+        if (stamp) a.prof[(size_t)blockIdx.x * 10 + 0] = mst_clock();
+        const bool has_next = tile + gridDim.x < ntiles;
+        const Coord nc = decode(has_next ? tile + gridDim.x : tile);
+        unsigned char *bufc = smem + cur * (R * 256), *bufo = smem + (cur ^ 1) * (R * 256);
+        if (a.film_rows > 1 && pc.m0 < (1 << 28) && pc.b != par_b) {     // per-item FiLM rows: refresh when the batch item changes
+            __syncthreads();
+            load_params(pc.b);
+            __syncthreads();
+        }
+        __bf16 *ybp = (__bf16 *)a.y + (size_t)pc.b * a.Lp * 128;
+
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
+        // With one wave per SIMD nothing else hides latency, so the operand rings run deep: A fragments are requested
+        // two taps (16 k-steps) ahead of their use, B fragments two k-steps (8 MFMAs) ahead.
+        bf16x8 af[2][8], bf[2][NQ];
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            af[0][kc] = wp[kc * 256];
+            af[1][kc] = wp[(8 + kc) * 256];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const unsigned char *rp0 = bufc + ln * 256 + (((2 * s2 + h) ^ (ln & 15)) << 4);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) bf[s2][q] = *(const bf16x8 *)(rp0 + q * 8192);
+        }
+
+        // one k-step (NQ MFMAs) of tap j, input-channel chunk kc; refills the B ring for k-step +2 and the A ring for
+        // tap j+2.  j's parity and kc must be compile-time constants at every call site (static register indices).
+        auto kstep = [&](auto PAR, int j, int kc) {
+            constexpr int par = decltype(PAR)::value;                   // j & 1
+            const int jb = (kc >= 6) ? (j < 14 ? j + 1 : 14) : j;      // tap of k-step +2
+            const int kcn = (kc + 2) & 7;
+            const int rbn = jb * P + ln;
+            const unsigned char *np = bufc + rbn * 256 + (((2 * kcn + h) ^ (rbn & 15)) << 4);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[par][kc], bf[kc & 1][q], acc[q], 0, 0, 0);
+                bf[kc & 1][q] = *(const bf16x8 *)(np + q * 8192);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // keep "MFMA, then its ring refill" in program
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // order (the scheduler otherwise sinks the reads)
+            }
+            const int ja = j + 2 < 15 ? j + 2 : 14;
+            af[par][kc] = wp[(ja * 8 + kc) * 256];
+        };
+        auto kstep_even = [&](int j, int kc) { kstep(std::integral_constant<int, 0>{}, j, kc); };
+        auto kstep_odd = [&](int j, int kc) { kstep(std::integral_constant<int, 1>{}, j, kc); };
+
+        // ---- taps 0..1: epilogue math of the previous tile, one unit (g, q) per k-step -> buffer B.
+        // Buffer B still holds the previous tile's input: its centre-tap rows are the residual input.  Each wave only
+        // touches its own 4 channel slots of a row (same row swizzle for the input and the output image), and a unit
+        // reads rows [32q+7P, +32) before writing rows [32q, +32): no cross-unit hazard (the lanes of a wave execute
+        // each LDS instruction together, and consecutive units are separated by MFMAs).
+        auto e_phase = [&](auto PAR, int j) {
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                const int g = 2 * j + (kc >> 2), q = kc & 3;
+                const int co0 = 32 * w + 8 * g + 4 * h;
+                const int o = 32 * q + ln, row = o + 7 * P;
+                const bf16x4 xr = *(const bf16x4 *)(bufo + row * 256 + (((co0 >> 3) ^ (row & 15)) << 4) + 8 * h);
+                const f32x4 sh = *(const f32x4 *)(par + co0);
+                const f32x4 rs = *(const f32x4 *)(par + 128 + co0);
+                const f32x4 fr = *(const f32x4 *)(par + 256 + co0);
+                const f32x4 fb = *(const f32x4 *)(par + 384 + co0);
+                kstep(PAR, j, kc);     // the residual / parameter loads above complete under these MFMAs
+                bf16x4 out;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = leaky_relu(accp[q][4 * g + i] + sh[i]);
+                    v = fr[i] * v + fb[i];
+                    v += rs[i] * (float)xr[i];
+                    out[i] = (__bf16)v;
+                }
+                *(bf16x4 *)(bufo + o * 256 + (((co0 >> 3) ^ (o & 15)) << 4) + 8 * h) = out;
+            }
+        };
+        e_phase(std::integral_constant<int, 0>{}, 0);
+        e_phase(std::integral_constant<int, 1>{}, 1);
+        if (stamp) a.prof[(size_t)blockIdx.x * 10 + 1] = mst_clock();
+        __syncthreads();
+        if (stamp) a.prof[(size_t)blockIdx.x * 10 + 2] = mst_clock();
+        // ---- tap 2: whole-row stores of the previous tile from buffer B (T*16/256 = 8 pieces per thread)
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            kstep_even(2, kc);
+            const int o = prow + 16 * kc;
+            const long t = (long)(pc.m0 + o / P) * a.d + pc.phi0 + (o % P);
+            if (t < a.L) *(bf16x8 *)(ybp + t * 128 + slot * 8) = *(const bf16x8 *)(bufo + o * 256 + ((slot ^ (o & 15)) << 4));
+        }
+        if (stamp) a.prof[(size_t)blockIdx.x * 10 + 3] = mst_clock();
+        __syncthreads();
+        if (stamp) a.prof[(size_t)blockIdx.x * 10 + 4] = mst_clock();
+        // ---- staging of the next tile into buffer B: 6 row loads in tap jA, their LDS writes in tap jA+2 (a longer
+        // hold needs more registers than the wave has: holding all rows for 8 taps spilled and ran slower)
+        if (stamp) a.prof[(size_t)blockIdx.x * 10 + 5] = mst_clock();
+        {
+            bf16x8 s0[6], s1[6];
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                kstep_odd(3, kc);
+                if (kc < 6) s0[kc] = stage_load(kc, nc, has_next && kc < NPASS);
+            }
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                kstep_even(4, kc);
+                if (kc < 6) s1[kc] = stage_load(6 + kc, nc, has_next && 6 + kc < NPASS);
+            }
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                kstep_odd(5, kc);
+                if (kc < 6 && kc < NPASS) stage_store(bufo, kc, s0[kc]);
+            }
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                kstep_even(6, kc);
+                if (kc < 6 && 6 + kc < NPASS) stage_store(bufo, 6 + kc, s1[kc]);
+            }
+            if (NPASS > 12) {
+#pragma unroll
+                for (int i = 12; i < NPASS; ++i) stage_store(bufo, i, stage_load(i, nc, has_next));
+            }
+        }
+#pragma unroll 1
+        for (int jp = 7; jp < 15; jp += 2) {                  // (odd, even) tap pairs keep the A-ring index static
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) kstep_odd(jp, kc);
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) kstep_even(jp + 1, kc);
+        }
+
+        // ---- hand the tile over to the next iteration (its input rows stay in this buffer for the residual)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) accp[q] = acc[q];
+        pc = cc;
+        if (stamp) a.prof[(size_t)blockIdx.x * 10 + 6] = mst_clock();
+        __syncthreads();
+        if (stamp) a.prof[(size_t)blockIdx.x * 10 + 7] = mst_clock();
+        cur ^= 1;
+    }
+
+    // ---- drain: epilogue of the last tile of this workgroup; its input tile sits in buffer cur^1
+    {
+        unsigned char *bufo = smem + (cur ^ 1) * (R * 256);
+        const float *frow = a.film + (a.film_rows > 1 ? (size_t)pc.b * 256 : 0);
+        __bf16 *ybp = (__bf16 *)a.y + (size_t)pc.b * a.Lp * 128;
+        bf16x4 xin[4][NQ];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co0 = 32 * w + 8 * g + 4 * h;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int row = 32 * q + ln + 7 * P;
+                xin[g][q] = *(const bf16x4 *)(bufo + row * 256 + (((co0 >> 3) ^ (row & 15)) << 4) + 8 * h);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co0 = 32 * w + 8 * g + 4 * h;
+            const f32x4 sh = *(const f32x4 *)(a.shift + co0);
+            const f32x4 fr = *(const f32x4 *)(frow + co0);
+            const f32x4 fb = *(const f32x4 *)(frow + 128 + co0);
+            const f32x4 rs = *(const f32x4 *)(a.res + co0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int o = 32 * q + ln;
+                bf16x4 out;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = leaky_relu(accp[q][4 * g + i] + sh[i]);
+                    v = fr[i] * v + fb[i];
+                    v += rs[i] * (float)xin[g][q][i];
+                    out[i] = (__bf16)v;
+                }
+                *(bf16x4 *)(bufo + o * 256 + (((co0 >> 3) ^ (o & 15)) << 4) + 8 * h) = out;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < T / 16; ++i) {
+            const int o = prow + 16 * i;
+            const long t = (long)(pc.m0 + o / P) * a.d + pc.phi0 + (o % P);
+            if (t < a.L) *(bf16x8 *)(ybp + t * 128 + slot * 8) = *(const bf16x8 *)(bufo + o * 256 + ((slot ^ (o & 15)) << 4));
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
