@@ -265,11 +265,11 @@ struct EncDirectArgs {
 };
 
 // direct VALU convolution for tiny channel counts (Cin <= 4, Cout <= 32): one thread per output time step
-template <bool OUT_NLC>
+template <bool OUT_NLC, int CM>
 __global__ __launch_bounds__(256) void enc_direct_kernel(EncDirectArgs a) {
     constexpr int XS_MAX = 4 * (256 * 8 + 64);
     __shared__ float xs[XS_MAX];
-    __shared__ float ws[32 * 4 * 64];
+    __shared__ float ws[CM * 4 * 64];
     const int tid = threadIdx.x;
     const int tiles = (a.Lout + 255) / 256;
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * 256;
@@ -284,19 +284,19 @@ __global__ __launch_bounds__(256) void enc_direct_kernel(EncDirectArgs a) {
     for (int i = tid; i < a.Cout * a.Cin * a.ksz; i += 256) ws[i] = a.w[i];
     __syncthreads();
     const int to = t0 + tid;
-    float acc[32];
+    float acc[CM];
 #pragma unroll
-    for (int co = 0; co < 32; ++co) acc[co] = 0.0f;
+    for (int co = 0; co < CM; ++co) acc[co] = 0.0f;
     for (int ci = 0; ci < a.Cin; ++ci)
         for (int j = 0; j < a.ksz; ++j) {
             const float xv = xs[ci * span + tid * a.stride + j * a.dil];
 #pragma unroll
-            for (int co = 0; co < 32; ++co)
+            for (int co = 0; co < CM; ++co)
                 if (co < a.Cout) acc[co] = fmaf(ws[(co * a.Cin + ci) * a.ksz + j], xv, acc[co]);
         }
     if (to >= a.Lout) return;
 #pragma unroll
-    for (int co = 0; co < 32; ++co) {
+    for (int co = 0; co < CM; ++co) {
         if (co < a.Cout) {
             float v = fmaxf(acc[co] + a.shift[co], 0.0f);
             if (a.residual) v += xs[co * span + tid + a.pad_l];
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void enc_direct_kernel(EncDirectArgs a) {
     if (OUT_NLC) {
         __bf16 *yp = (__bf16 *)a.y + ((size_t)b * a.Lout + to) * a.Cout;
 #pragma unroll
-        for (int c8 = 0; c8 < 4; ++c8) {
+        for (int c8 = 0; c8 < CM / 8; ++c8) {
             if (c8 * 8 < a.Cout) {
                 bf16x8 o;
 #pragma unroll
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void enc_direct_kernel(EncDirectArgs a) {
     } else {
         float *yp = (float *)a.y + (size_t)b * a.Cout * a.Lout + to;
 #pragma unroll
-        for (int co = 0; co < 32; ++co)
+        for (int co = 0; co < CM; ++co)
             if (co < a.Cout) yp[(size_t)co * a.Lout] = acc[co];
     }
 }

@@ -224,16 +224,6 @@ int choose_phases(int d, int L) {
     return P;
 }
 
-// experiment switch for the bf16 main-loop schedule (0 = compiler-scheduled, 1 = software-pipelined ring,
-// 2 = ring + sched_group_barrier pinning); the default is the measured best.
-int bf16_variant() {
-    static const int v = [] {
-        const char *e = getenv("MST_TCN_BF16_VARIANT");
-        return e ? atoi(e) : 2;
-    }();
-    return v;
-}
-
 int bf16_persist() {
     static const int v = [] {
         const char *e = getenv("MST_TCN_PERSIST");
@@ -245,7 +235,7 @@ int bf16_persist() {
 template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream) {
     TcnBlockArgs a = a0;
     if constexpr (P <= 4) {
-        if (precision == MST_PREC_BF16 && bf16_persist() > 0) {
+        if (precision == MST_PREC_BF16 && bf16_persist() > 0 && a.y_out == nullptr) {
             // the persistent kernel tiles 128 output times per workgroup pass
             const long nsteps = ((long)a.L + a.d - 1) / a.d;
             a.tiles_step = (int)((nsteps + 128 / P - 1) / (128 / P));
@@ -257,11 +247,10 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
         }
     }
     if (precision == MST_PREC_BF16) {
-        switch (bf16_variant()) {
-            case 0: MST_LAUNCH((tcn_block_bf16_kernel<P, 0>), dim3(grid), dim3(256), stream, a); break;
-            case 2: MST_LAUNCH((tcn_block_bf16_kernel<P, 2>), dim3(grid), dim3(256), stream, a); break;
-            default: MST_LAUNCH((tcn_block_bf16_kernel<P, 1>), dim3(grid), dim3(256), stream, a); break;
-        }
+        if (a.y_out)
+            MST_LAUNCH((tcn_block_bf16_kernel<P, 2, true>), dim3(grid), dim3(256), stream, a);
+        else
+            MST_LAUNCH((tcn_block_bf16_kernel<P, 2, false>), dim3(grid), dim3(256), stream, a);
     } else
         MST_LAUNCH((tcn_block_f32_kernel<P>), dim3(grid), dim3(256), stream, a);
     MST_CHECK_LAUNCH("tcn_block_kernel");
@@ -331,6 +320,12 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         const long nsteps = ((long)L + d - 1) / d;
         a.tiles_step = (int)((nsteps + 256 / P - 1) / (256 / P));
         const long grid = (long)B * a.tiles_phase * a.tiles_step;
+        // bf16 mode: the last block applies the output head in its epilogue (no separate output kernel)
+        const bool fuse_out = precision == MST_PREC_BF16 && !act_out && n == t->d.nblocks - 1;
+        a.out_w = t->out_w;
+        a.out_b = t->out_b;
+        a.y_out = fuse_out ? y : nullptr;
+        a.nout = t->d.noutputs;
         a.prof = nullptr;
         // developer hook: MST_TCN_PROF_BLOCK=n MST_TCN_PROF_FILE=path dumps per-workgroup phase clock stamps of block n
         static const char *prof_file = getenv("MST_TCN_PROF_FILE");
@@ -371,6 +366,12 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         else
             MST_LAUNCH((tcn_unpack_kernel<float>), dim3(grid), dim3(256), stream, (const void *)buf[cur], act_out, B, L, Lp);
         MST_CHECK_LAUNCH("tcn_unpack_kernel");
+        return MST_OK;
+    }
+    if (precision == MST_PREC_BF16 && n_run == t->d.nblocks && t->d.nblocks > 1) {
+        if (ev) {      // the output head ran inside the last block kernel
+            MST_HIP_TRY(hipEventRecord(ev[t->d.nblocks + 1], (hipStream_t)stream));
+        }
         return MST_OK;
     }
     TcnOutArgs o;
@@ -704,10 +705,23 @@ int enc_launch_direct(const MstEncConv &c, const float *x, void *y, bool out_nlc
     a.pad_l = c.pad_l;
     a.residual = residual;
     const dim3 grid((unsigned)(B * ((Lout + 255) / 256)));
-    if (out_nlc)
-        MST_LAUNCH((enc_direct_kernel<true>), grid, dim3(256), stream, a);
-    else
-        MST_LAUNCH((enc_direct_kernel<false>), grid, dim3(256), stream, a);
+    // accumulator capacity of the instantiation: next power of two >= Cout (NLC output packs 8 channels per store)
+    const int cm = c.cout <= 2 ? 2 : c.cout <= 4 ? 4 : c.cout <= 8 ? 8 : c.cout <= 16 ? 16 : 32;
+    if (out_nlc) {
+        switch (cm) {
+            case 8: MST_LAUNCH((enc_direct_kernel<true, 8>), grid, dim3(256), stream, a); break;
+            case 16: MST_LAUNCH((enc_direct_kernel<true, 16>), grid, dim3(256), stream, a); break;
+            default: MST_LAUNCH((enc_direct_kernel<true, 32>), grid, dim3(256), stream, a); break;
+        }
+    } else {
+        switch (cm) {
+            case 2: MST_LAUNCH((enc_direct_kernel<false, 2>), grid, dim3(256), stream, a); break;
+            case 4: MST_LAUNCH((enc_direct_kernel<false, 4>), grid, dim3(256), stream, a); break;
+            case 8: MST_LAUNCH((enc_direct_kernel<false, 8>), grid, dim3(256), stream, a); break;
+            case 16: MST_LAUNCH((enc_direct_kernel<false, 16>), grid, dim3(256), stream, a); break;
+            default: MST_LAUNCH((enc_direct_kernel<false, 32>), grid, dim3(256), stream, a); break;
+        }
+    }
     MST_CHECK_LAUNCH("enc_direct_kernel");
     return MST_OK;
 }

@@ -37,6 +37,10 @@ struct TcnBlockArgs {
     int B, L, Lp, d;
     int tiles_phase;      // d / P
     int tiles_step;       // ceil(ceil(L/d) / (256/P))
+    const float *out_w;   // fused output head (last block only): 1x1 conv [nout][128], bias [nout], y [B][nout][L] fp32
+    const float *out_b;
+    float *y_out;
+    int nout;
     long long *prof;      // developer hook: per-workgroup shader-clock stamps at phase boundaries (null = off)
 };
 
@@ -44,7 +48,7 @@ struct TcnBlockArgs {
 // blocks 1..n-1, bf16 MFMA (v_mfma_f32_32x32x16_bf16), bf16 activations.  MFMA-bound:
 // 2*128*1920 = 491 520 FLOP per output time step against 512 B of HBM traffic.
 // ------------------------------------------------------------------------------------------------
-template <int P, int PIPE>
+template <int P, int PIPE, bool FUSE_OUT>
 __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(TcnBlockArgs a) {
     constexpr int T = 256, R = T + 14 * P, MT = T / P;
     __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
@@ -190,13 +194,56 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
     }
     __syncthreads();
     if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 7] = mst_clock();
-    {
+    if constexpr (!FUSE_OUT) {
         const int slot = tid & 15;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int o = (tid >> 4) + 16 * i;
             const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
             if (t < a.L) *(bf16x8 *)(yb + t * 128 + slot * 8) = *(const bf16x8 *)(smem + o * 256 + ((slot ^ (o & 15)) << 4));
+        }
+    } else {
+        // last block: the 1x1 output conv + bias + clamp(-1, 1) (reference architectures.py:133,145) is applied to the
+        // transposed bf16 rows right here, so the last activation never travels to HBM.  Same arithmetic and summation
+        // order as tcn_output_kernel (8 channels per lane, xor-reduce over the 16 lanes of a row).
+        const int slot = tid & 15;
+        float w0[8], w1[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            w0[c] = a.out_w[8 * slot + c];
+            w1[c] = a.nout > 1 ? a.out_w[128 + 8 * slot + c] : 0.0f;
+        }
+        float *outs = (float *)(smem + 256 * 256);          // the 14P halo rows behind the 256 output rows are free
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = (tid >> 4) + 16 * i;
+            float v8[8];
+            load8((const __bf16 *)(smem + o * 256 + ((slot ^ (o & 15)) << 4)), v8);
+            float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                s0 = fmaf(w0[c], v8[c], s0);
+                s1 = fmaf(w1[c], v8[c], s1);
+            }
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) {
+                s0 += __shfl_xor(s0, m);
+                s1 += __shfl_xor(s1, m);
+            }
+            if (slot == 0) {
+                outs[o] = s0;
+                outs[256 + o] = s1;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i, c = idx >> 8, o = idx & 255;
+            const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
+            if (c < a.nout && t < a.L) {
+                const float v = outs[idx] + a.out_b[c];
+                a.y_out[((size_t)b * a.nout + c) * a.L + t] = fminf(1.0f, fmaxf(-1.0f, v));
+            }
         }
     }
     if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 3] = mst_clock();
