@@ -154,9 +154,12 @@ int mst_embedding_mean(const float *emb_dev, int n_rows, int dim, float *out_dev
  * sequence per lane for the serial recursions; float64 internal arithmetic like the reference.
  * ---------------------------------------------------------------------------------------------- */
 /* Equaliser.process (:500-525): cascade of n_bands biquads, zero initial state per band; coef host
- * float64 [n_bands][6] = (b0,b1,b2,a0=1,a1,a2) shared by all items. */
+ * float64 [n_bands][6] = (b0,b1,b2,a0,a1,a2) shared by all items.  With a scratch buffer of
+ * mst_fx_biquad_scratch_bytes() the cascade runs parallel in time (chunked state-space scan, same float64
+ * per-sample recursion); with scratch_dev = NULL it runs one lane per (item, channel) sequence. */
+size_t mst_fx_biquad_scratch_bytes(int n_items, long L, int C, int n_bands);
 int mst_fx_biquad_cascade(const float *x_dev, float *y_dev, int n_items, long L, int C, const double *coef_host,
-                          int n_bands, void *stream);
+                          int n_bands, double *scratch_dev, size_t scratch_bytes, void *stream);
 /* Compressor.process / compressor_process (:529-587, :637-649), makeup gain 0 */
 int mst_fx_compressor(const float *x_dev, float *y_dev, int n_items, long L, int C, double threshold_db,
                       double attack_ms, double release_ms, double ratio, double sample_rate, void *stream);

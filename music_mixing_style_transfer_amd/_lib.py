@@ -58,7 +58,8 @@ SIGNATURES = {
     "mst_enc_forward_blocks": (C.c_int, [_P, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "mst_enc_block_length": (C.c_int, [_P, C.c_int, C.c_int]),
     "mst_embedding_mean": (C.c_int, [_F, C.c_int, C.c_int, _F, _P]),
-    "mst_fx_biquad_cascade": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.POINTER(C.c_double), C.c_int, _P]),
+    "mst_fx_biquad_scratch_bytes": (C.c_size_t, [C.c_int, C.c_long, C.c_int, C.c_int]),
+    "mst_fx_biquad_cascade": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.POINTER(C.c_double), C.c_int, _P, C.c_size_t, _P]),
     "mst_fx_compressor": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                     C.c_double, _P]),
     "mst_fx_midside_imager": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_double, _P, _P]),

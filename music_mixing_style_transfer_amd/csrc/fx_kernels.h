@@ -55,6 +55,102 @@ __global__ __launch_bounds__(64) void fx_biquad_kernel(BiquadArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same cascade, parallel in time.  A biquad cascade is a linear time-invariant system with state s (2 per
+// band): s[n+1] = A s[n] + B x[n].  Cutting every sequence into chunks of M samples,
+//   pass 1 (fx_biquad_chunk_state_kernel): each chunk runs the cascade from ZERO state -> its end state e_k;
+//   scan   (fx_biquad_scan_kernel): true chunk-start states  s_k = A^M s_{k-1} + e_{k-1}  (A^M from the host);
+//   pass 2 (fx_biquad_chunk_apply_kernel): each chunk re-runs the cascade from s_k and writes the output.
+// Same float64 recursion per sample as the serial kernel; only the chunk-start states come through the scan
+// (float64, rounding-level differences).  One lane per (sequence, chunk): 16 384 lanes instead of 128.
+// ------------------------------------------------------------------------------------------------
+struct BiquadChunkArgs {
+    const float *x;
+    float *y;             // pass 2 only
+    double *ends;         // [n_seq][nchunks][2*MST_MAX_BANDS]  zero-state end states (pass 1 out)
+    const double *starts; // [n_seq][nchunks][2*MST_MAX_BANDS]  true start states (pass 2 in)
+    int n_seq, C, nchunks, M;
+    long L;
+    int n_bands;
+    double coef[MST_MAX_BANDS][5];
+};
+
+template <bool APPLY>
+__global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) {
+    const long gid = (long)blockIdx.x * 64 + threadIdx.x;
+    if (gid >= (long)a.n_seq * a.nchunks) return;
+    // lanes: channel fastest, then chunk, then item - neighbouring lanes read neighbouring samples of a frame
+    const int c = (int)(gid % a.C);
+    const int k = (int)((gid / a.C) % a.nchunks);
+    const int item = (int)(gid / ((long)a.C * a.nchunks));
+    const int seq = item * a.C + c;
+    const long n_lo = (long)k * a.M, n_hi = (n_lo + a.M < a.L) ? n_lo + a.M : a.L;
+    const float *xp = a.x + (size_t)item * a.L * a.C + c;
+    double z1[MST_MAX_BANDS], z2[MST_MAX_BANDS];
+#pragma unroll
+    for (int b = 0; b < MST_MAX_BANDS; ++b) {
+        z1[b] = APPLY ? a.starts[((size_t)seq * a.nchunks + k) * (2 * MST_MAX_BANDS) + 2 * b] : 0.0;
+        z2[b] = APPLY ? a.starts[((size_t)seq * a.nchunks + k) * (2 * MST_MAX_BANDS) + 2 * b + 1] : 0.0;
+    }
+    for (long n0 = n_lo; n0 < n_hi; n0 += 16) {
+        float xin[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xin[i] = (n0 + i < n_hi) ? xp[(n0 + i) * a.C] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (n0 + i < n_hi) {
+                double v = (double)xin[i];
+#pragma unroll
+                for (int b = 0; b < MST_MAX_BANDS; ++b) {
+                    if (b < a.n_bands) {
+                        const double yn = a.coef[b][0] * v + z1[b];
+                        z1[b] = a.coef[b][1] * v - a.coef[b][3] * yn + z2[b];
+                        z2[b] = a.coef[b][2] * v - a.coef[b][4] * yn;
+                        v = yn;
+                    }
+                }
+                if (APPLY) a.y[((size_t)item * a.L + n0 + i) * a.C + c] = (float)v;
+            }
+        }
+    }
+    if (!APPLY) {
+#pragma unroll
+        for (int b = 0; b < MST_MAX_BANDS; ++b) {
+            a.ends[((size_t)seq * a.nchunks + k) * (2 * MST_MAX_BANDS) + 2 * b] = z1[b];
+            a.ends[((size_t)seq * a.nchunks + k) * (2 * MST_MAX_BANDS) + 2 * b + 1] = z2[b];
+        }
+    }
+}
+
+// s_0 = 0 ; s_k = A^M s_{k-1} + e_{k-1}.  One lane per sequence; AM is [S][S] row-major with S = 2*n_bands,
+// state order (z1, z2) per band.
+__global__ __launch_bounds__(64) void fx_biquad_scan_kernel(const double *ends, double *starts, const double *AM,
+                                                           int n_seq, int nchunks, int n_bands) {
+    const int seq = blockIdx.x * 64 + threadIdx.x;
+    if (seq >= n_seq) return;
+    constexpr int SM = 2 * MST_MAX_BANDS;
+    const int S = 2 * n_bands;
+    double s[SM];
+#pragma unroll
+    for (int i = 0; i < SM; ++i) s[i] = 0.0;
+    for (int k = 0; k < nchunks; ++k) {
+#pragma unroll
+        for (int i = 0; i < SM; ++i) starts[((size_t)seq * nchunks + k) * SM + i] = s[i];
+        if (k + 1 == nchunks) break;
+        double nx[SM];
+#pragma unroll
+        for (int i = 0; i < SM; ++i) {
+            double acc = ends[((size_t)seq * nchunks + k) * SM + i];
+#pragma unroll
+            for (int j = 0; j < SM; ++j)
+                if (i < S && j < S) acc += AM[i * S + j] * s[j];
+            nx[i] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < SM; ++i) s[i] = nx[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // compressor_process (:529-587) as called by Compressor.process (:637-649, makeup 0).  One WAVE per
 // (item, channel) sequence, 64 samples per step: the log-domain gain computer (log10) and the gain
 // application (pow) run lane-parallel; only the branchy one-pole attack/release smoother is serial, walked

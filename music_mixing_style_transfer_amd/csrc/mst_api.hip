@@ -858,10 +858,80 @@ extern "C" int mst_embedding_mean(const float *emb, int n_rows, int dim, float *
 // =================================================================================================
 // FX processors
 // =================================================================================================
+namespace {
+constexpr int BIQUAD_CHUNK = 1024;
+void biquad_coefs(const double *coef, int n_bands, double (*out)[5]) {
+    for (int k = 0; k < MST_MAX_BANDS; ++k)
+        for (int i = 0; i < 5; ++i) out[k][i] = 0.0;
+    for (int k = 0; k < n_bands; ++k) {
+        const double a0 = coef[6 * k + 3];
+        out[k][0] = coef[6 * k + 0] / a0;
+        out[k][1] = coef[6 * k + 1] / a0;
+        out[k][2] = coef[6 * k + 2] / a0;
+        out[k][3] = coef[6 * k + 4] / a0;
+        out[k][4] = coef[6 * k + 5] / a0;
+    }
+}
+}  // namespace
+
+extern "C" size_t mst_fx_biquad_scratch_bytes(int n_items, long L, int C, int n_bands) {
+    if (n_items < 1 || L < 1 || C < 1 || n_bands < 1) return 0;
+    const long nchunks = (L + BIQUAD_CHUNK - 1) / BIQUAD_CHUNK;
+    const size_t states = (size_t)n_items * C * nchunks * 2 * MST_MAX_BANDS;
+    return (2 * states + (size_t)4 * MST_MAX_BANDS * MST_MAX_BANDS) * sizeof(double);
+}
+
 extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long L, int C, const double *coef, int n_bands,
-                                     void *stream) {
+                                     double *scratch, size_t scratch_bytes, void *stream) {
     if (!x || !y || !coef || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_biquad_cascade: bad argument");
     if (n_bands < 0 || n_bands > MST_MAX_BANDS) return fail(MST_ERR_UNSUPPORTED, "mst_fx_biquad_cascade: at most 8 bands");
+    const long nchunks = (L + BIQUAD_CHUNK - 1) / BIQUAD_CHUNK;
+    if (scratch && nchunks > 1 && n_bands > 0) {
+        if (scratch_bytes < mst_fx_biquad_scratch_bytes(n_items, L, C, n_bands))
+            return fail(MST_ERR_WORKSPACE, "mst_fx_biquad_cascade: scratch too small");
+        BiquadChunkArgs a;
+        a.x = x;
+        a.y = y;
+        a.n_seq = n_items * C;
+        a.C = C;
+        a.nchunks = (int)nchunks;
+        a.M = BIQUAD_CHUNK;
+        a.L = L;
+        a.n_bands = n_bands;
+        biquad_coefs(coef, n_bands, a.coef);
+        const size_t states = (size_t)a.n_seq * nchunks * 2 * MST_MAX_BANDS;
+        double *ends = scratch, *starts = scratch + states, *am_dev = scratch + 2 * states;
+        a.ends = ends;
+        a.starts = starts;
+        // A^M column by column: run the cascade M steps on zero input from each unit state (host, float64)
+        const int S = 2 * n_bands;
+        std::vector<double> am((size_t)S * S);
+        for (int col = 0; col < S; ++col) {
+            std::vector<double> z(S, 0.0);
+            z[col] = 1.0;
+            for (int n = 0; n < BIQUAD_CHUNK; ++n) {
+                double v = 0.0;
+                for (int b = 0; b < n_bands; ++b) {
+                    const double yn = a.coef[b][0] * v + z[2 * b];
+                    z[2 * b] = a.coef[b][1] * v - a.coef[b][3] * yn + z[2 * b + 1];
+                    z[2 * b + 1] = a.coef[b][2] * v - a.coef[b][4] * yn;
+                    v = yn;
+                }
+            }
+            for (int row = 0; row < S; ++row) am[(size_t)row * S + col] = z[row];
+        }
+        MST_HIP_TRY(hipMemcpyAsync(am_dev, am.data(), am.size() * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)stream));
+        MST_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));      // `am` is a stack-lifetime host buffer
+        const long lanes = (long)a.n_seq * nchunks;
+        MST_LAUNCH((fx_biquad_chunk_kernel<false>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), stream, a);
+        MST_CHECK_LAUNCH("fx_biquad_chunk_kernel<state>");
+        MST_LAUNCH(fx_biquad_scan_kernel, dim3((a.n_seq + 63) / 64), dim3(64), stream, (const double *)ends, starts,
+                   (const double *)am_dev, a.n_seq, (int)nchunks, n_bands);
+        MST_CHECK_LAUNCH("fx_biquad_scan_kernel");
+        MST_LAUNCH((fx_biquad_chunk_kernel<true>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), stream, a);
+        MST_CHECK_LAUNCH("fx_biquad_chunk_kernel<apply>");
+        return MST_OK;
+    }
     BiquadArgs a;
     a.x = x;
     a.y = y;
@@ -869,16 +939,7 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
     a.C = C;
     a.L = L;
     a.n_bands = n_bands;
-    for (int k = 0; k < MST_MAX_BANDS; ++k)
-        for (int i = 0; i < 5; ++i) a.coef[k][i] = 0.0;
-    for (int k = 0; k < n_bands; ++k) {
-        const double a0 = coef[6 * k + 3];
-        a.coef[k][0] = coef[6 * k + 0] / a0;
-        a.coef[k][1] = coef[6 * k + 1] / a0;
-        a.coef[k][2] = coef[6 * k + 2] / a0;
-        a.coef[k][3] = coef[6 * k + 4] / a0;
-        a.coef[k][4] = coef[6 * k + 5] / a0;
-    }
+    biquad_coefs(coef, n_bands, a.coef);
     MST_LAUNCH(fx_biquad_kernel, dim3((a.n_seq + 63) / 64), dim3(64), stream, a);
     MST_CHECK_LAUNCH("fx_biquad_kernel");
     return MST_OK;

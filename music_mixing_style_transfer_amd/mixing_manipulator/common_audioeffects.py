@@ -179,9 +179,11 @@ class Equaliser(Processor):
         d = _Dev(x)
         coef = np.ascontiguousarray(self.coefficients())
         y = torch.empty_like(d.x)
+        nbytes = d.lib.mst_fx_biquad_scratch_bytes(d.n, d.L, d.C, coef.shape[0])      # time-parallel (chunked scan) path
+        sc = d.scratch((nbytes + 7) // 8)
         d.lib.check(d.lib.mst_fx_biquad_cascade(d.x.data_ptr(), y.data_ptr(), d.n, d.L, d.C,
-                                                coef.ctypes.data_as(C.POINTER(C.c_double)), coef.shape[0], d.stream),
-                    "mst_fx_biquad_cascade")
+                                                coef.ctypes.data_as(C.POINTER(C.c_double)), coef.shape[0],
+                                                sc.data_ptr(), nbytes, d.stream), "mst_fx_biquad_cascade")
         if self.hard_clip:
             y = y.clamp_(-1.0, 1.0)
         return d.out(y)

@@ -57,8 +57,13 @@ def _worker(rank, world, port, out_path):
 
 def test_two_ranks_equal_one(tmp_path, emu):
     from music_mixing_style_transfer_amd.inference import segmentation as S
+    from music_mixing_style_transfer_amd import _lib
     one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
-    _worker(0, 1, 0, one)
+    prev = _lib._default
+    try:
+        _worker(0, 1, 0, one)          # single-process reference run (binds the emulator in this process)
+    finally:
+        _lib.set_default_binding(prev)
     mp.spawn(_worker, args=(2, 29641, two), nprocs=2, join=True)
     full = torch.load(one)["full"]
     parts = sorted(torch.load(two, weights_only=False)["parts"], key=lambda p: p[0])
