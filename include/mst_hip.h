@@ -160,9 +160,13 @@ int mst_embedding_mean(const float *emb_dev, int n_rows, int dim, float *out_dev
 size_t mst_fx_biquad_scratch_bytes(int n_items, long L, int C, int n_bands);
 int mst_fx_biquad_cascade(const float *x_dev, float *y_dev, int n_items, long L, int C, const double *coef_host,
                           int n_bands, double *scratch_dev, size_t scratch_bytes, void *stream);
-/* Compressor.process / compressor_process (:529-587, :637-649), makeup gain 0 */
+/* Compressor.process / compressor_process (:529-587, :637-649), makeup gain 0.  With a scratch buffer of
+ * mst_fx_compressor_scratch_bytes() the gain computer and the gain application run over all samples in parallel
+ * and only the one-pole smoother is serial (one lane per sequence); scratch_dev = NULL runs one wave per sequence. */
+size_t mst_fx_compressor_scratch_bytes(int n_items, long L, int C);
 int mst_fx_compressor(const float *x_dev, float *y_dev, int n_items, long L, int C, double threshold_db,
-                      double attack_ms, double release_ms, double ratio, double sample_rate, void *stream);
+                      double attack_ms, double release_ms, double ratio, double sample_rate, double *scratch_dev,
+                      size_t scratch_bytes, void *stream);
 /* MidSideImager.process (:964-1007), stereo only; scratch_dev: >= n_items*2 doubles */
 int mst_fx_midside_imager(const float *x_dev, float *y_dev, int n_items, long L, double bal, double *scratch_dev,
                           void *stream);

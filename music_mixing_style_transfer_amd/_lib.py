@@ -60,8 +60,9 @@ SIGNATURES = {
     "mst_embedding_mean": (C.c_int, [_F, C.c_int, C.c_int, _F, _P]),
     "mst_fx_biquad_scratch_bytes": (C.c_size_t, [C.c_int, C.c_long, C.c_int, C.c_int]),
     "mst_fx_biquad_cascade": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.POINTER(C.c_double), C.c_int, _P, C.c_size_t, _P]),
+    "mst_fx_compressor_scratch_bytes": (C.c_size_t, [C.c_int, C.c_long, C.c_int]),
     "mst_fx_compressor": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
-                                    C.c_double, _P]),
+                                    C.c_double, _P, C.c_size_t, _P]),
     "mst_fx_midside_imager": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_double, _P, _P]),
     "mst_fx_gain": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_double, C.c_int, _P]),
     "mst_fx_rms_normalize": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, _P, _P]),

@@ -198,6 +198,84 @@ __global__ __launch_bounds__(256) void fx_compressor_kernel(CompArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same compressor split by dependency structure (needs 8 bytes of scratch per sample):
+//   fx_comp_gain_kernel    every sample in parallel: x_l = x_g - y_g (log10 + static curve), float64
+//   fx_comp_smooth_kernel  one lane per sequence: ONLY the branchy one-pole recursion (2 FMAs + compare + select per
+//                          sample, loads batched 16 ahead), y_l written over x_l
+//   fx_comp_apply_kernel   every sample in parallel: y = x * 10^((makeup - y_l) / 20)
+// Same float64 arithmetic per sample; the serial part shrinks to the recursion itself.
+// ------------------------------------------------------------------------------------------------
+// scratch layout: xl[seq][n] (sequence-major) so that the serial kernel streams whole cache lines per lane
+__global__ __launch_bounds__(256) void fx_comp_gain_kernel(CompArgs a, double *xl) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // index into x[item][n][c]
+    if (i >= (size_t)a.n_seq * a.L) return;
+    const int c = (int)(i % a.C);
+    const size_t fr = i / a.C;
+    const long n = (long)(fr % a.L);
+    const int item = (int)(fr / a.L);
+    const double ax = fabs((double)a.x[i]);
+    const double xg = (ax < 0.000001) ? -120.0 : 20.0 * log10(ax);
+    double yg = 0.0;
+    if (a.ratio > 1.0)
+        yg = (xg >= a.threshold) ? a.threshold + (xg - a.threshold) / a.ratio : xg;
+    else if (a.ratio < 1.0)
+        yg = (xg <= a.threshold) ? a.threshold + (xg - a.threshold) / (1.0 / a.ratio) : xg;
+    xl[((size_t)item * a.C + c) * a.L + n] = xg - yg;
+}
+
+__global__ __launch_bounds__(64) void fx_comp_smooth_kernel(CompArgs a, double *xl) {
+    const int seq = blockIdx.x * 64 + threadIdx.x;
+    if (seq >= a.n_seq) return;
+    double *p = xl + (size_t)seq * a.L;
+    const double ca = 1.0 - a.alpha_att, cr = 1.0 - a.alpha_rel;
+    double prev = 0.0;
+    // full batches of 16 samples without per-element predicates, the next batch's loads in flight behind the current
+    // recursion.  (Predicated loads made hipcc drain vmcnt(0) every batch: 14.3 ms; this form: 7.6 ms; a 4-deep ring of
+    // batches: 9.0 ms - with 2 active waves the chip sits in a low clock state and the recursion itself dominates.)
+    constexpr int NB = 16;
+    const long nfull = a.L / NB;
+    double nx[NB];
+    if (nfull > 0) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) nx[i] = p[i];
+    }
+    for (long bt = 0; bt < nfull; ++bt) {
+        double v[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) v[i] = nx[i];
+        const long nn = (bt + 1 < nfull) ? (bt + 1) * NB : bt * NB;      // last batch: harmless reload
+#pragma unroll
+        for (int i = 0; i < NB; ++i) nx[i] = p[nn + i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const double ya = a.alpha_att * prev + ca * v[i];
+            const double yr = a.alpha_rel * prev + cr * v[i];
+            prev = (v[i] > prev) ? ya : yr;
+            v[i] = prev;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) p[bt * NB + i] = v[i];
+    }
+    for (long n = nfull * NB; n < a.L; ++n) {
+        const double v = p[n];
+        const double ya = a.alpha_att * prev + ca * v;
+        const double yr = a.alpha_rel * prev + cr * v;
+        prev = (v > prev) ? ya : yr;
+        p[n] = prev;
+    }
+}
+
+__global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const double *yl) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)a.n_seq * a.L) return;
+    const int c = (int)(i % a.C);
+    const size_t fr = i / a.C;
+    const long n = (long)(fr % a.L);
+    const int item = (int)(fr / a.L);
+    a.y[i] = (float)((double)a.x[i] * pow(10.0, (a.makeup - yl[((size_t)item * a.C + c) * a.L + n]) / 20.0));
+}
+
+// ------------------------------------------------------------------------------------------------
 // energy reductions (float64 accumulation; the reference sums in the input dtype, i.e. float32 pairwise
 // for float32 audio - a 1e-6-relative difference documented in DESIGN.md).
 //   mode 0: acc[item][0] += sum x^2                       (rms normalise, over all L*C samples)

@@ -945,8 +945,14 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
     return MST_OK;
 }
 
+extern "C" size_t mst_fx_compressor_scratch_bytes(int n_items, long L, int C) {
+    if (n_items < 1 || L < 1 || C < 1) return 0;
+    return (size_t)n_items * L * C * sizeof(double);
+}
+
 extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, int C, double threshold_db,
-                                 double attack_ms, double release_ms, double ratio, double sample_rate, void *stream) {
+                                 double attack_ms, double release_ms, double ratio, double sample_rate, double *scratch,
+                                 size_t scratch_bytes, void *stream) {
     if (!x || !y || n_items < 1 || L < 1 || C < 1 || attack_ms <= 0 || release_ms <= 0 || ratio <= 0 || sample_rate <= 0)
         return fail(MST_ERR_ARG, "mst_fx_compressor: bad argument");
     if (threshold_db == 0.0 && ratio == 1.0) {   // bypass (common_audioeffects.py:637)
@@ -964,6 +970,18 @@ extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, 
     a.alpha_att = std::exp(-1.0 / (0.001 * sample_rate * attack_ms));
     a.alpha_rel = std::exp(-1.0 / (0.001 * sample_rate * release_ms));
     a.makeup = 0.0;
+    if (scratch) {
+        if (scratch_bytes < mst_fx_compressor_scratch_bytes(n_items, L, C))
+            return fail(MST_ERR_WORKSPACE, "mst_fx_compressor: scratch too small");
+        const size_t total = (size_t)a.n_seq * L;
+        MST_LAUNCH(fx_comp_gain_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, a, scratch);
+        MST_CHECK_LAUNCH("fx_comp_gain_kernel");
+        MST_LAUNCH(fx_comp_smooth_kernel, dim3((a.n_seq + 63) / 64), dim3(64), stream, a, scratch);
+        MST_CHECK_LAUNCH("fx_comp_smooth_kernel");
+        MST_LAUNCH(fx_comp_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, a, (const double *)scratch);
+        MST_CHECK_LAUNCH("fx_comp_apply_kernel");
+        return MST_OK;
+    }
     MST_LAUNCH(fx_compressor_kernel, dim3((a.n_seq + 3) / 4), dim3(256), stream, a);
     MST_CHECK_LAUNCH("fx_compressor_kernel");
     return MST_OK;

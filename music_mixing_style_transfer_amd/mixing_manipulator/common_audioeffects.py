@@ -209,9 +209,11 @@ class Compressor(Processor):
             return x
         d = _Dev(x)
         y = torch.empty_like(d.x)
+        nbytes = d.lib.mst_fx_compressor_scratch_bytes(d.n, d.L, d.C)
+        sc = d.scratch((nbytes + 7) // 8)
         d.lib.check(d.lib.mst_fx_compressor(d.x.data_ptr(), y.data_ptr(), d.n, d.L, d.C, float(p.threshold.value),
                                             float(p.attack_time.value), float(p.release_time.value), float(p.ratio.value),
-                                            float(self.sample_rate), d.stream), "mst_fx_compressor")
+                                            float(self.sample_rate), sc.data_ptr(), nbytes, d.stream), "mst_fx_compressor")
         return d.out(y)
 
     def update(self, parameter_name=None):
