@@ -64,8 +64,10 @@ typedef struct {
     int dilations[MST_MAX_BLOCKS]; /* dilation_growth ** (n % stack_size), architectures.py:122 */
 } MstTcnDesc;
 
-/* replaces TCNModel.__init__ (architectures.py:93-133).  Non-causal, ungrouped, conditional blocks only
- * (what inference/style_transfer.py:48-57 constructs); anything else -> MST_ERR_UNSUPPORTED. */
+/* replaces TCNModel.__init__ (architectures.py:93-133).  Non-causal, ungrouped, conditional blocks (what
+ * inference/style_transfer.py:48-57 constructs).  The configs.yaml shape (channel_width 128, kernel_size 15,
+ * ninputs 2, noutputs <= 2) runs on the specialised kernels in both precisions; any other channel width / kernel
+ * size / dilation runs on a generic exact-fp32 implicit-GEMM path (the precision argument is then ignored). */
 int mst_tcn_create(const MstTcnDesc *desc, MstTcn **out);
 int mst_tcn_destroy(MstTcn *tcn);
 

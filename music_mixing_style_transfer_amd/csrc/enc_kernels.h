@@ -28,6 +28,12 @@ struct EncConvArgs {
     int nchunks;
     int residual;        // conv1 of a Res block: add x[b][co][to] after the ReLU
     long Ntot;           // B * Lout
+    // generic-TCN use of the same kernel (fp32 only): zero instead of reflection padding and other epilogues
+    int pad_zero;        // 1: taps outside [0, Lin) read 0 (TCNBlock conv1 padding), 0: reflection (encoder)
+    int epi;             // 0: ReLU (+ same-channel skip); 1: TCN block LeakyReLU -> FiLM -> + grouped 1x1 residual; 2: clamp(-1, 1)
+    const float *film;   // epi 1: [film_rows][2*Cout]  (r | b)
+    const float *res;    // epi 1: [Cout] grouped 1x1 residual scale; out-channel co reads in-channel co / res_div
+    int film_rows, res_div;
 };
 
 template <int MW>
@@ -85,9 +91,13 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
             float v = 0.0f;
             if (ci >= 0 && colbase[c] >= 0) {
                 int ti = colt[c] + joff;
-                if (ti < 0) ti = -ti;
-                if (ti >= a.Lin) ti = 2 * (a.Lin - 1) - ti;
-                v = a.x[colbase[c] + (long)ci * a.Lin + ti];
+                if (a.pad_zero) {
+                    if (ti >= 0 && ti < a.Lin) v = a.x[colbase[c] + (long)ci * a.Lin + ti];
+                } else {
+                    if (ti < 0) ti = -ti;
+                    if (ti >= a.Lin) ti = 2 * (a.Lin - 1) - ti;
+                    v = a.x[colbase[c] + (long)ci * a.Lin + ti];
+                }
             }
             breg[e] = v;
         }
@@ -125,8 +135,17 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int co = cot * MT + 32 * mi + mfma32_row(r, lane);
                 if (co < a.Cout) {
-                    float v = fmaxf(acc[q][r] + a.shift[co], 0.0f);
-                    if (a.residual) v += a.x[((long)b * a.Cin + co) * a.Lin + to];
+                    float v = acc[q][r] + a.shift[co];
+                    if (a.epi == 0) {
+                        v = fmaxf(v, 0.0f);
+                        if (a.residual) v += a.x[((long)b * a.Cin + co) * a.Lin + to];
+                    } else if (a.epi == 1) {
+                        const float *fr = a.film + (a.film_rows > 1 ? (size_t)b * 2 * a.Cout : 0);
+                        v = fr[co] * leaky_relu(v) + fr[a.Cout + co];
+                        v += a.res[co] * a.x[((long)b * a.Cin + co / a.res_div) * a.Lin + to];
+                    } else {
+                        v = fminf(1.0f, fmaxf(-1.0f, v));
+                    }
                     a.y[((long)b * a.Cout + co) * a.Lout + to] = v;
                 }
             }

@@ -52,6 +52,60 @@ void bn_fold(const float *w, const float *b, const float *mean, const float *var
 
 }  // namespace
 
+// one convolution layer as packed for enc_conv_kernel / enc_conv_bf16_kernel / the NLC pipeline
+struct MstEncConv {
+    float *wpk = nullptr, *shift = nullptr;
+    __bf16 *wpk16 = nullptr;
+    int *ktab = nullptr;
+    float *w_direct = nullptr;   // [Cout][Cin][ksz] folded fp32 (layers with Cin < 8: direct kernel)
+    __bf16 *wpk_nlc = nullptr;   // NLC pipeline A fragments, k = j*Cin + ci, K-chunk 64
+    int *stab = nullptr;         // NLC pipeline slot table
+    int nchunks64 = 0;
+    int cin = 0, cout = 0, ksz = 0, stride = 1, dil = 1, pad_l = 0, pad_r = 0, nchunks = 0, nchunks32 = 0, mw = 4;
+    bool loaded = false;
+};
+
+
+namespace {
+// fp32 image for enc_conv_kernel: wpk[cot][kc][kr][m] = W[cot*MT+m][kc*16+kr] * scale[co], zero padded
+int pack_conv_f32(MstEncConv &c, const float *w, const std::vector<float> &scale) {
+    const int MT = 32 * c.mw, K = c.cin * c.ksz;
+    const int co_tiles = (c.cout + MT - 1) / MT;
+    std::vector<float> wp((size_t)co_tiles * c.nchunks * 16 * MT, 0.0f);
+    for (int cot = 0; cot < co_tiles; ++cot)
+        for (int kc = 0; kc < c.nchunks; ++kc)
+            for (int kr = 0; kr < 16; ++kr) {
+                const int k = kc * 16 + kr;
+                if (k >= K) continue;
+                for (int m = 0; m < MT; ++m) {
+                    const int co = cot * MT + m;
+                    if (co < c.cout) wp[(((size_t)cot * c.nchunks + kc) * 16 + kr) * MT + m] = w[(size_t)co * K + k] * scale[co];
+                }
+            }
+    std::vector<int> kt((size_t)c.nchunks32 * 32 * 2);
+    for (int k = 0; k < c.nchunks32 * 32; ++k) {
+        kt[2 * k] = k < K ? k / c.ksz : -1;
+        kt[2 * k + 1] = k < K ? (k % c.ksz) * c.dil - c.pad_l : 0;
+    }
+    int rc;
+    if ((rc = upload(&c.wpk, wp))) return rc;
+    if ((rc = upload(&c.ktab, kt))) return rc;
+    return MST_OK;
+}
+void conv_geometry(MstEncConv &c, int cin, int cout, int ksz, int stride, int dil, int pad_l, int pad_r) {
+    c.cin = cin;
+    c.cout = cout;
+    c.ksz = ksz;
+    c.stride = stride;
+    c.dil = dil;
+    c.pad_l = pad_l;
+    c.pad_r = pad_r;
+    c.nchunks = (cin * ksz + 15) / 16;
+    c.nchunks32 = (cin * ksz + 31) / 32;
+    c.mw = cout <= 32 ? 1 : (cout <= 64 ? 2 : 4);
+}
+}  // namespace
+
 // =================================================================================================
 // TCN
 // =================================================================================================
@@ -65,6 +119,8 @@ struct MstTcnBlock {
 
 struct MstTcn {
     MstTcnDesc d;
+    bool generic = false;              // configuration outside the specialised 128-channel / k=15 kernels
+    std::vector<MstEncConv> gconv;     // generic path: one packed conv per block + the output head (fp32 implicit GEMM)
     std::vector<MstTcnBlock> blk;
     float *film_w = nullptr;  // [nblocks][2C][D]
     float *film_b = nullptr;  // [nblocks][2C]
@@ -83,16 +139,26 @@ extern "C" int mst_tcn_create(const MstTcnDesc *desc, MstTcn **out) {
     if (!desc || !out) return fail(MST_ERR_ARG, "mst_tcn_create: null argument");
     const MstTcnDesc &d = *desc;
     if (d.nblocks < 1 || d.nblocks > MST_MAX_BLOCKS) return fail(MST_ERR_ARG, "mst_tcn_create: nblocks out of range");
-    if (d.channels != 128 || d.kernel_size != 15 || d.ninputs != 2 || d.noutputs < 1 || d.noutputs > 2 ||
-        d.cond_dim < 1 || d.dilations[0] != 1)
-        return fail(MST_ERR_UNSUPPORTED,
-                    "mst_tcn_create: the gfx950 kernels implement channel_width=128, kernel_size=15, ninputs=2, "
-                    "noutputs<=2, dilation(block 0)=1 (the configs.yaml TCN.default shape)");
+    if (d.channels < 1 || d.kernel_size < 1 || d.ninputs < 1 || d.noutputs < 1 || d.cond_dim < 1)
+        return fail(MST_ERR_ARG, "mst_tcn_create: bad layer description");
+    if (d.channels % d.ninputs != 0)
+        return fail(MST_ERR_UNSUPPORTED, "mst_tcn_create: channel_width must be a multiple of ninputs (grouped 1x1 residual)");
+    const bool fast = d.channels == 128 && d.kernel_size == 15 && d.ninputs == 2 && d.noutputs <= 2 && d.dilations[0] == 1 &&
+                      !(getenv("MST_TCN_GENERIC") && atoi(getenv("MST_TCN_GENERIC")));
     for (int n = 0; n < d.nblocks; ++n)
         if (d.dilations[n] < 1) return fail(MST_ERR_ARG, "mst_tcn_create: dilation < 1");
     MstTcn *t = new MstTcn();
     t->d = d;
+    t->generic = !fast;
     t->blk.resize(d.nblocks);
+    if (t->generic) {
+        t->gconv.resize(d.nblocks + 1);
+        for (int n = 0; n < d.nblocks; ++n) {
+            const int pad = ((d.kernel_size - 1) * d.dilations[n]) / 2;     // architectures.py:199 (non-causal)
+            conv_geometry(t->gconv[n], n == 0 ? d.ninputs : d.channels, d.channels, d.kernel_size, 1, d.dilations[n], pad, pad);
+        }
+        conv_geometry(t->gconv[d.nblocks], d.channels, d.noutputs, 1, 1, 1, 0, 0);
+    }
     const size_t fw = (size_t)d.nblocks * 2 * d.channels * d.cond_dim;
     if (hipMalloc((void **)&t->film_w, fw * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&t->film_b, (size_t)d.nblocks * 2 * d.channels * sizeof(float)) != hipSuccess) {
@@ -116,6 +182,11 @@ extern "C" int mst_tcn_destroy(MstTcn *t) {
     (void)hipFree(t->film);
     (void)hipFree(t->out_w);
     (void)hipFree(t->out_b);
+    for (auto &c : t->gconv) {
+        (void)hipFree(c.wpk);
+        (void)hipFree(c.ktab);
+        (void)hipFree(c.shift);
+    }
     for (auto e : t->ev) (void)hipEventDestroy(e);
     delete t;
     return MST_OK;
@@ -127,11 +198,26 @@ extern "C" int mst_tcn_load_block(MstTcn *t, int n, const float *conv_w, const f
     if (!t || !conv_w || !bn_weight || !bn_bias || !bn_mean || !bn_var || !film_w || !film_b || !res_w)
         return fail(MST_ERR_ARG, "mst_tcn_load_block: null argument");
     if (n < 0 || n >= t->d.nblocks) return fail(MST_ERR_ARG, "mst_tcn_load_block: block index out of range");
-    const int C = 128, K = 15;
+    const int C = t->d.channels, K = t->d.kernel_size;
     const int cin = n == 0 ? t->d.ninputs : C;
     std::vector<float> scale, shift;
     bn_fold(bn_weight, bn_bias, bn_mean, bn_var, bn_eps, C, scale, shift);
     MstTcnBlock &b = t->blk[n];
+    if (t->generic) {
+        int rc;
+        MstEncConv &c = t->gconv[n];
+        if ((rc = pack_conv_f32(c, conv_w, scale))) return rc;
+        std::vector<float> sh((size_t)((C + 32 * c.mw - 1) / (32 * c.mw)) * 32 * c.mw, 0.0f);
+        for (int co = 0; co < C; ++co) sh[co] = shift[co];
+        if ((rc = upload(&c.shift, sh))) return rc;
+        std::vector<float> res(res_w, res_w + C);
+        if ((rc = upload(&b.res, res))) return rc;
+        const size_t fwn = (size_t)2 * C * t->d.cond_dim;
+        MST_HIP_TRY(hipMemcpy(t->film_w + (size_t)n * fwn, film_w, fwn * sizeof(float), hipMemcpyHostToDevice));
+        MST_HIP_TRY(hipMemcpy(t->film_b + (size_t)n * 2 * C, film_b, 2 * C * sizeof(float), hipMemcpyHostToDevice));
+        c.loaded = b.loaded = true;
+        return MST_OK;
+    }
     auto W = [&](int co, int ci, int j) { return conv_w[((size_t)co * cin + ci) * K + j] * scale[co]; };
     int rc;
     if (n == 0) {
@@ -175,8 +261,18 @@ extern "C" int mst_tcn_load_block(MstTcn *t, int n, const float *conv_w, const f
 
 extern "C" int mst_tcn_load_output(MstTcn *t, const float *w, const float *b, void *) {
     if (!t || !w || !b) return fail(MST_ERR_ARG, "mst_tcn_load_output: null argument");
-    std::vector<float> wv(w, w + (size_t)t->d.noutputs * 128), bv(b, b + t->d.noutputs);
     int rc;
+    if (t->generic) {
+        MstEncConv &c = t->gconv[t->d.nblocks];
+        std::vector<float> ones(t->d.noutputs, 1.0f);
+        if ((rc = pack_conv_f32(c, w, ones))) return rc;
+        std::vector<float> sh((size_t)32 * c.mw * ((t->d.noutputs + 32 * c.mw - 1) / (32 * c.mw)), 0.0f);
+        for (int o = 0; o < t->d.noutputs; ++o) sh[o] = b[o];
+        if ((rc = upload(&c.shift, sh))) return rc;
+        c.loaded = t->out_loaded = true;
+        return MST_OK;
+    }
+    std::vector<float> wv(w, w + (size_t)t->d.noutputs * 128), bv(b, b + t->d.noutputs);
     if ((rc = upload(&t->out_w, wv))) return rc;
     if ((rc = upload(&t->out_b, bv))) return rc;
     t->out_loaded = true;
@@ -191,7 +287,7 @@ extern "C" int mst_tcn_set_cond(MstTcn *t, const float *cond_dev, int n_rows, lo
         (void)hipFree(t->film);
         t->film = nullptr;
         t->film_cap = 0;
-        MST_HIP_TRY(hipMalloc((void **)&t->film, (size_t)t->d.nblocks * n_rows * 256 * sizeof(float)));
+        MST_HIP_TRY(hipMalloc((void **)&t->film, (size_t)t->d.nblocks * n_rows * 2 * t->d.channels * sizeof(float)));
         t->film_cap = n_rows;
     }
     FilmArgs a;
@@ -200,11 +296,11 @@ extern "C" int mst_tcn_set_cond(MstTcn *t, const float *cond_dev, int n_rows, lo
     a.cond = cond_dev;
     a.film = t->film;
     a.nblocks = t->d.nblocks;
-    a.two_c = 256;
+    a.two_c = 2 * t->d.channels;
     a.D = t->d.cond_dim;
     a.rows = n_rows;
     a.block_stride = block_stride;
-    const int outs = t->d.nblocks * 256;
+    const int outs = t->d.nblocks * 2 * t->d.channels;
     MST_LAUNCH(tcn_film_kernel, dim3((outs + 3) / 4), dim3(256), stream, a);
     MST_CHECK_LAUNCH("tcn_film_kernel");
     t->film_rows = n_rows;
@@ -257,6 +353,63 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
     return MST_OK;
 }
 
+// generic configuration: every block is one launch of the fp32 implicit-GEMM conv kernel (NCL activations, zero
+// padding) with the TCN epilogue; the output head is the same kernel with k = 1 and the clamp epilogue
+int tcn_launch_generic(const MstEncConv &c, const float *x, float *y, int B, int L, int epi, const float *film, int film_rows,
+                       const float *res, int res_div, void *stream) {
+    EncConvArgs a;
+    a.x = x;
+    a.y = y;
+    a.wpk = c.wpk;
+    a.shift = c.shift;
+    a.ktab = c.ktab;
+    a.wpk16 = nullptr;
+    a.nchunks32 = c.nchunks32;
+    a.B = B;
+    a.Cin = c.cin;
+    a.Lin = L;
+    a.Cout = c.cout;
+    a.Lout = L;
+    a.stride = 1;
+    a.nchunks = c.nchunks;
+    a.residual = 0;
+    a.Ntot = (long)B * L;
+    a.pad_zero = 1;
+    a.epi = epi;
+    a.film = film;
+    a.res = res;
+    a.film_rows = film_rows;
+    a.res_div = res_div;
+    const int MT = 32 * c.mw, NT = 128 * (4 / c.mw);
+    const dim3 grid((unsigned)((a.Ntot + NT - 1) / NT), (unsigned)((c.cout + MT - 1) / MT));
+    switch (c.mw) {
+        case 1: MST_LAUNCH((enc_conv_kernel<1>), grid, dim3(256), stream, a); break;
+        case 2: MST_LAUNCH((enc_conv_kernel<2>), grid, dim3(256), stream, a); break;
+        default: MST_LAUNCH((enc_conv_kernel<4>), grid, dim3(256), stream, a); break;
+    }
+    MST_CHECK_LAUNCH("enc_conv_kernel (generic TCN)");
+    return MST_OK;
+}
+
+int tcn_run_generic(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, int n_run, void *ws, void *stream) {
+    const int C = t->d.channels;
+    const size_t buf_bytes = align_up((size_t)B * L * C * sizeof(float), 256);
+    float *buf[2] = {(float *)ws, (float *)((unsigned char *)ws + buf_bytes)};
+    const float *cur = x;
+    int rc, pp = 0;
+    for (int n = 0; n < n_run; ++n) {
+        float *dst = (act_out && n == n_run - 1) ? act_out : buf[pp];
+        const int cin = n == 0 ? t->d.ninputs : C;
+        if ((rc = tcn_launch_generic(t->gconv[n], cur, dst, B, L, 1, t->film + (size_t)n * t->film_rows * 2 * C, t->film_rows,
+                                     t->blk[n].res, C / cin, stream)))
+            return rc;
+        cur = dst;
+        pp ^= 1;
+    }
+    if (act_out) return MST_OK;
+    return tcn_launch_generic(t->gconv[t->d.nblocks], cur, y, B, L, 2, nullptr, 1, nullptr, 1, stream);
+}
+
 int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, int precision, int n_run, void *ws,
             size_t ws_bytes, void *stream) {
     if (!t || !x || B < 1 || L < 1) return fail(MST_ERR_ARG, "mst_tcn_forward: bad argument");
@@ -269,6 +422,7 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         return fail(MST_ERR_ARG, "mst_tcn_forward: condition rows must be 1 or equal the batch size");
     const size_t need = mst_tcn_workspace_bytes(t, B, L, precision);
     if (!ws || ws_bytes < need) return fail(MST_ERR_WORKSPACE, "mst_tcn_forward: workspace too small");
+    if (t->generic) return tcn_run_generic(t, x, y, act_out, B, L, n_run, ws, stream);
     const size_t es = tcn_elem(precision);
     const size_t buf_bytes = align_up((size_t)B * L * 128 * es, 256);
     unsigned char *buf[2] = {(unsigned char *)ws, (unsigned char *)ws + buf_bytes};
@@ -426,8 +580,9 @@ extern "C" int mst_tcn_timing_end(MstTcn *t, float *ms_out, int *n_forwards) {
     return MST_OK;
 }
 
-extern "C" size_t mst_tcn_workspace_bytes(const MstTcn *, int B, int L, int precision) {
+extern "C" size_t mst_tcn_workspace_bytes(const MstTcn *t, int B, int L, int precision) {
     if (B < 1 || L < 1) return 0;
+    if (t && t->generic) return 2 * align_up((size_t)B * L * t->d.channels * sizeof(float), 256);
     return 2 * align_up((size_t)B * L * 128 * tcn_elem(precision), 256);
 }
 
@@ -446,18 +601,6 @@ extern "C" int mst_tcn_forward_blocks(MstTcn *t, const float *x, float *act, int
 // =================================================================================================
 // FXencoder
 // =================================================================================================
-struct MstEncConv {
-    float *wpk = nullptr, *shift = nullptr;
-    __bf16 *wpk16 = nullptr;
-    int *ktab = nullptr;
-    float *w_direct = nullptr;   // [Cout][Cin][ksz] folded fp32 (layers with Cin < 8: direct kernel)
-    __bf16 *wpk_nlc = nullptr;   // NLC pipeline A fragments, k = j*Cin + ci, K-chunk 64
-    int *stab = nullptr;         // NLC pipeline slot table
-    int nchunks64 = 0;
-    int cin = 0, cout = 0, ksz = 0, stride = 1, dil = 1, pad_l = 0, pad_r = 0, nchunks = 0, nchunks32 = 0, mw = 4;
-    bool loaded = false;
-};
-
 struct MstEnc {
     MstEncDesc d;
     std::vector<MstEncConv> conv;   // 2 per block
@@ -627,6 +770,12 @@ int enc_launch(const MstEncConv &c, const float *x, float *y, int B, int Lin, in
     a.nchunks = c.nchunks;
     a.residual = residual;
     a.Ntot = (long)B * Lout;
+    a.pad_zero = 0;
+    a.epi = 0;
+    a.film = nullptr;
+    a.res = nullptr;
+    a.film_rows = 1;
+    a.res_div = 1;
     const int MT = 32 * c.mw, NT = 128 * (4 / c.mw);
     const dim3 grid((unsigned)((a.Ntot + NT - 1) / NT), (unsigned)((c.cout + MT - 1) / MT));
     if (precision == MST_PREC_BF16) {

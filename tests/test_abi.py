@@ -37,10 +37,11 @@ def test_argument_errors_without_gpu(hip_lib):
     h = C.c_void_p()
     assert hip_lib.mst_tcn_create(None, C.byref(h)) == -1
     d = _lib.MstTcnDesc()
-    d.nblocks, d.ninputs, d.noutputs, d.channels, d.kernel_size, d.cond_dim = 4, 2, 2, 32, 3, 16
-    d.dilations[0] = 1
+    d.nblocks, d.ninputs, d.noutputs, d.channels, d.kernel_size, d.cond_dim = 4, 4, 2, 30, 3, 16
+    for n in range(4):
+        d.dilations[n] = 1
     assert hip_lib.mst_tcn_create(C.byref(d), C.byref(h)) == -2       # MST_ERR_UNSUPPORTED, with a message
-    assert b"channel_width=128" in hip_lib.mst_last_error()
+    assert b"multiple of ninputs" in hip_lib.mst_last_error()
     with pytest.raises(NotImplementedError):
         hip_lib.check(-2, "x")
     assert hip_lib.mst_fx_gain(None, None, 1, 10, 2, 0.0, 0, None) == -1

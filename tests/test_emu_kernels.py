@@ -110,6 +110,33 @@ def test_encoder_nlc_bf16_pipeline_emulated(emu_default):
     assert float((enc(x) - R.fxencoder_forward(sd, cfg, x)).abs().max()) <= 2e-2
 
 
+def test_tiny_reference_goldens_through_the_product(emu_default):
+    """The tiny FXencoder / TCNModel configurations whose outputs were recorded from the REAL reference run through the
+    product's generic exact-fp32 path (any channel width / kernel size): product vs reference directly."""
+    import os
+    from music_mixing_style_transfer_amd.networks import FXencoder, TCNModel
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "nets_tiny.npz"))
+    cfg = {"channels": [4, 8, 8], "kernels": [5, 4, 3], "strides": [2, 2, 1], "dilation": [1, 1, 1], "bias": True,
+           "norm": "batch", "conv_block": "res", "activation": "relu"}
+    enc = FXencoder({k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()})
+    enc.load_state_dict(synth.fxencoder_state_dict(cfg, seed=3))
+    assert float((enc(torch.from_numpy(g["tiny_enc_x"])) - torch.from_numpy(g["tiny_enc_out"])).abs().max()) <= 2e-6
+    tcn = TCNModel(nparams=16, ninputs=2, noutputs=2, nblocks=4, dilation_growth=2, kernel_size=5, channel_width=8,
+                   stack_size=15, cond_dim=16, causal=False)
+    tcn.load_state_dict(synth.tcn_state_dict(nblocks=4, kernel_size=5, channel_width=8, cond_dim=16, seed=5))
+    x = torch.from_numpy(g["tiny_tcn_x"])
+    for name, cond in (("", torch.from_numpy(g["tiny_tcn_cond"])), ("_condB", torch.from_numpy(g["tiny_tcn_condB"])),
+                       ("_condL", [torch.from_numpy(c) for c in g["tiny_tcn_condL"]])):
+        assert float((tcn(x, cond) - torch.from_numpy(g["tiny_tcn_out" + name])).abs().max()) <= 2e-6
+    # mono, 48 channels, k = 3, dilation 3**n
+    sd = synth.tcn_state_dict(nblocks=3, ninputs=1, noutputs=1, kernel_size=3, channel_width=48, cond_dim=32, seed=7)
+    m = TCNModel(nparams=32, ninputs=1, noutputs=1, nblocks=3, dilation_growth=3, kernel_size=3, channel_width=48,
+                 stack_size=15, cond_dim=32, causal=False)
+    m.load_state_dict(sd)
+    xm, cm = synth.synth_audio((2, 1, 333), seed=1), synth.synth_audio((1, 32), seed=2)
+    assert float((m(xm, cm) - R.tcn_forward(sd, xm, cm, nblocks=3, kernel_size=3, dilation_growth=3)).abs().max()) <= 2e-6
+
+
 def test_embedding_mean_and_engine_emulated(emu_default):
     from music_mixing_style_transfer_amd.inference import embedding_mean
     e = synth.synth_audio((7, 40), seed=2)

@@ -321,3 +321,23 @@ def test_feature_extraction_cli(tmp_path):
     assert [b.shape[0] for b in batches] == [3, 1]             # ragged last batch is fine here (torch.cat)
     ref = np.concatenate([R.fxencoder_forward(enc_sd, enc_cfg, torch.from_numpy(b)).numpy() for b in batches], 0).mean(0)
     assert emb.shape == (2048,) and np.abs(emb - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+def test_tiny_reference_goldens_on_gpu():
+    """Tiny nets recorded from the real reference, through the product's generic exact-fp32 path on the GPU."""
+    from music_mixing_style_transfer_amd.networks import FXencoder, TCNModel
+    from music_mixing_style_transfer_amd.utils import synth
+    g = np.load(os.path.join(GOLD, "nets_tiny.npz"))
+    cfg = {"channels": [4, 8, 8], "kernels": [5, 4, 3], "strides": [2, 2, 1], "dilation": [1, 1, 1], "bias": True,
+           "norm": "batch", "conv_block": "res", "activation": "relu"}
+    enc = FXencoder({k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()}).cuda()
+    enc.load_state_dict(synth.fxencoder_state_dict(cfg, seed=3))
+    e = enc(torch.from_numpy(g["tiny_enc_x"]).cuda()).cpu()
+    assert float((e - torch.from_numpy(g["tiny_enc_out"])).abs().max()) <= 2e-6
+    tcn = TCNModel(nparams=16, ninputs=2, noutputs=2, nblocks=4, dilation_growth=2, kernel_size=5, channel_width=8,
+                   stack_size=15, cond_dim=16, causal=False).cuda()
+    tcn.load_state_dict(synth.tcn_state_dict(nblocks=4, kernel_size=5, channel_width=8, cond_dim=16, seed=5))
+    x = torch.from_numpy(g["tiny_tcn_x"]).cuda()
+    for name, cond in (("", torch.from_numpy(g["tiny_tcn_cond"]).cuda()), ("_condB", torch.from_numpy(g["tiny_tcn_condB"]).cuda()),
+                       ("_condL", [torch.from_numpy(c).cuda() for c in g["tiny_tcn_condL"]])):
+        assert float((tcn(x, cond).cpu() - torch.from_numpy(g["tiny_tcn_out" + name])).abs().max()) <= 2e-6
