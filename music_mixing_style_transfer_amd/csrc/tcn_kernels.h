@@ -132,9 +132,22 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
 #pragma unroll
             for (int q = 0; q < 8; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 8192);
         }
+        // P = 16 tiles (largest dilation on a short segment) cover steps far outside the segment: a (column tile q, tap j)
+        // pair whose 32 input rows are all zero padding contributes nothing and its MFMAs are skipped (wave-uniform;
+        // 20 % of the MFMAs at d = 8192, L = 131072.  At P = 8 only 7 % are skippable and the branches cost more).
+        const int nsteps = (int)(((long)a.L + a.d - 1) / a.d);
         for (int j = 0; j < 15; ++j) {
             const int jn = j < 14 ? j + 1 : 14;
             const int rb0 = j * P + ln, rb1 = jn * P + ln;
+            unsigned live = 0xffu;
+            if constexpr (P >= 16) {
+                live = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int s_lo = m0 + (32 * q) / P + j - 7, s_hi = m0 + (32 * q + 31) / P + j - 7;
+                    if (!(s_hi < 0 || s_lo >= nsteps)) live |= 1u << q;
+                }
+            }
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) {
                 const int rbn = (kc == 7) ? rb1 : rb0;
@@ -142,7 +155,8 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
                 const unsigned char *np = smem + rbn * 256 + (((2 * kcn + h) ^ (rbn & 15)) << 4);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kc], bf[q], acc[q], 0, 0, 0);
+                    if (P < 16 || ((live >> q) & 1u))
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kc], bf[q], acc[q], 0, 0, 0);
                     bf[q] = *(const bf16x8 *)(np + q * 8192);
                     if constexpr (PIPE == 2) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -171,6 +185,9 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
     }
     __syncthreads();
     if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 6] = mst_clock();
+    float hs0[8], hs1[8];            // FUSE_OUT: this lane's partial sums of the 1x1 output head, per column tile
+#pragma unroll
+    for (int q = 0; q < 8; ++q) hs0[q] = hs1[q] = 0.0f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int co0 = 32 * w + 8 * g + 4 * h;
@@ -178,6 +195,11 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
         const f32x4 fr = *(const f32x4 *)(frow + co0);
         const f32x4 fb = *(const f32x4 *)(frow + 128 + co0);
         const f32x4 rs = *(const f32x4 *)(a.res + co0);
+        f32x4 ow0 = {0.0f, 0.0f, 0.0f, 0.0f}, ow1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (FUSE_OUT) {
+            ow0 = *(const f32x4 *)(a.out_w + co0);
+            if (a.nout > 1) ow1 = *(const f32x4 *)(a.out_w + 128 + co0);
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int o = 32 * q + ln;
@@ -188,51 +210,26 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
                 v = fr[i] * v + fb[i];
                 v += rs[i] * (float)xin[g][q][i];
                 out[i] = (__bf16)v;
+                if constexpr (FUSE_OUT) {      // the head reads the bf16-rounded activation, like the separate output kernel
+                    hs0[q] = fmaf(ow0[i], (float)out[i], hs0[q]);
+                    hs1[q] = fmaf(ow1[i], (float)out[i], hs1[q]);
+                }
             }
-            *(bf16x4 *)(smem + o * 256 + (((co0 >> 3) ^ (o & 15)) << 4) + 8 * h) = out;
+            if constexpr (!FUSE_OUT) *(bf16x4 *)(smem + o * 256 + (((co0 >> 3) ^ (o & 15)) << 4) + 8 * h) = out;
         }
     }
-    __syncthreads();
-    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 7] = mst_clock();
-    if constexpr (!FUSE_OUT) {
-        const int slot = tid & 15;
+    if constexpr (FUSE_OUT) {
+        // last block: 1x1 output conv + bias + clamp(-1, 1) (reference architectures.py:133,145) straight from the
+        // registers - the last activation never travels to HBM.  Lane pairs (l, l+32) hold the two channel halves of a
+        // column, the four waves the four channel quarters: one shuffle, then a 4-way sum through LDS.
+        float *part = (float *)smem;                 // [4 waves][2 outputs][256 columns]
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int o = (tid >> 4) + 16 * i;
-            const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
-            if (t < a.L) *(bf16x8 *)(yb + t * 128 + slot * 8) = *(const bf16x8 *)(smem + o * 256 + ((slot ^ (o & 15)) << 4));
-        }
-    } else {
-        // last block: the 1x1 output conv + bias + clamp(-1, 1) (reference architectures.py:133,145) is applied to the
-        // transposed bf16 rows right here, so the last activation never travels to HBM.  Same arithmetic and summation
-        // order as tcn_output_kernel (8 channels per lane, xor-reduce over the 16 lanes of a row).
-        const int slot = tid & 15;
-        float w0[8], w1[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            w0[c] = a.out_w[8 * slot + c];
-            w1[c] = a.nout > 1 ? a.out_w[128 + 8 * slot + c] : 0.0f;
-        }
-        float *outs = (float *)(smem + 256 * 256);          // the 14P halo rows behind the 256 output rows are free
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int o = (tid >> 4) + 16 * i;
-            float v8[8];
-            load8((const __bf16 *)(smem + o * 256 + ((slot ^ (o & 15)) << 4)), v8);
-            float s0 = 0.0f, s1 = 0.0f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                s0 = fmaf(w0[c], v8[c], s0);
-                s1 = fmaf(w1[c], v8[c], s1);
-            }
-#pragma unroll
-            for (int m = 8; m >= 1; m >>= 1) {
-                s0 += __shfl_xor(s0, m);
-                s1 += __shfl_xor(s1, m);
-            }
-            if (slot == 0) {
-                outs[o] = s0;
-                outs[256 + o] = s1;
+        for (int q = 0; q < 8; ++q) {
+            hs0[q] += __shfl_xor(hs0[q], 32);
+            hs1[q] += __shfl_xor(hs1[q], 32);
+            if (h == 0) {
+                part[(w * 2 + 0) * 256 + 32 * q + ln] = hs0[q];
+                part[(w * 2 + 1) * 256 + 32 * q + ln] = hs1[q];
             }
         }
         __syncthreads();
@@ -241,9 +238,20 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
             const int idx = tid + 256 * i, c = idx >> 8, o = idx & 255;
             const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
             if (c < a.nout && t < a.L) {
-                const float v = outs[idx] + a.out_b[c];
+                const float v = part[(0 * 2 + c) * 256 + o] + part[(1 * 2 + c) * 256 + o] + part[(2 * 2 + c) * 256 + o] +
+                                part[(3 * 2 + c) * 256 + o] + a.out_b[c];
                 a.y_out[((size_t)b * a.nout + c) * a.L + t] = fminf(1.0f, fmaxf(-1.0f, v));
             }
+        }
+    } else {
+        __syncthreads();
+        if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 7] = mst_clock();
+        const int slot = tid & 15;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int o = (tid >> 4) + 16 * i;
+            const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
+            if (t < a.L) *(bf16x8 *)(yb + t * 128 + slot * 8) = *(const bf16x8 *)(smem + o * 256 + ((slot ^ (o & 15)) << 4));
         }
     }
     if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 3] = mst_clock();

@@ -9,7 +9,16 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 
+def _ensure_hip_library():
+    """Test infrastructure: (re)build libmst_hip.so when the sources are newer or it is missing.  The product itself
+    never builds implicitly - it fails loudly without the library."""
+    csrc = os.path.join(REPO, "music_mixing_style_transfer_amd", "csrc")
+    if os.path.exists("/opt/rocm/bin/hipcc"):
+        subprocess.run(["make", "-C", csrc], check=False, capture_output=True)
+
+
 def pytest_configure(config):
+    _ensure_hip_library()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
     config.addinivalue_line("markers", "slow: long CPU test")
 
