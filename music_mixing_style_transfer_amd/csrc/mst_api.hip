@@ -311,16 +311,18 @@ namespace {
 
 size_t tcn_elem(int precision) { return precision == MST_PREC_BF16 ? 2 : 4; }
 
-// phases per tile: P | d, P*Mt = 256.  4 keeps the bf16 tile at 78 KB of LDS (2 workgroups per CU);
-// grow P while a tile would span more steps than the segment has (large dilation on a short segment).
+// phases per tile: P | d.  P = 4 with 256-time tiles (78 KB of LDS, 2 workgroups per CU) whenever a tile's 64 steps
+// fit the segment; for larger dilations P = 8 with 128-time tiles (16 steps per tile, 61 KB, still 2 per CU); P = 16
+// (256-time tiles, 16 steps per tile) only for segments with fewer than 16 steps per phase.
 int choose_phases(int d, int L) {
     int P = (d % 4 == 0) ? 4 : (d % 2 == 0 ? 2 : 1);
     const long nsteps = ((long)L + d - 1) / d;
-    while (P < 16 && d % (2 * P) == 0 && 256 / P > nsteps) P *= 2;
+    while (P < 8 && d % (2 * P) == 0 && 256 / P > nsteps) P *= 2;
+    if (P == 8 && d % 16 == 0 && nsteps < 16) P = 16;     // very short segments: 16-step tiles of 16 phases
     return P;
 }
 
-int bf16_persist() {
+int bf16_persist() {      // experimental persistent kernel (MST_TCN_PERSIST=<workgroups>), off by default
     static const int v = [] {
         const char *e = getenv("MST_TCN_PERSIST");
         return e ? atoi(e) : 0;
@@ -343,10 +345,22 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
         }
     }
     if (precision == MST_PREC_BF16) {
-        if (a.y_out)
-            MST_LAUNCH((tcn_block_bf16_kernel<P, 2, true>), dim3(grid), dim3(256), stream, a);
-        else
-            MST_LAUNCH((tcn_block_bf16_kernel<P, 2, false>), dim3(grid), dim3(256), stream, a);
+        if constexpr (P == 8) {
+            // P = 8 tiles of 256 times need 94 KB of LDS (one workgroup per CU); 128-time tiles (61 KB) keep two resident:
+            // measured 1.98 -> 1.70 ms for the d = 4096 block at L = 131072
+            const long nsteps = ((long)a.L + a.d - 1) / a.d;
+            a.tiles_step = (int)((nsteps + 128 / P - 1) / (128 / P));
+            const long g2 = (long)a.B * a.tiles_phase * a.tiles_step;
+            if (a.y_out)
+                MST_LAUNCH((tcn_block_bf16_kernel<P, 2, true, 4>), dim3((unsigned)g2), dim3(256), stream, a);
+            else
+                MST_LAUNCH((tcn_block_bf16_kernel<P, 2, false, 4>), dim3((unsigned)g2), dim3(256), stream, a);
+        } else {
+            if (a.y_out)
+                MST_LAUNCH((tcn_block_bf16_kernel<P, 2, true, 8>), dim3(grid), dim3(256), stream, a);
+            else
+                MST_LAUNCH((tcn_block_bf16_kernel<P, 2, false, 8>), dim3(grid), dim3(256), stream, a);
+        }
     } else
         MST_LAUNCH((tcn_block_f32_kernel<P>), dim3(grid), dim3(256), stream, a);
     MST_CHECK_LAUNCH("tcn_block_kernel");

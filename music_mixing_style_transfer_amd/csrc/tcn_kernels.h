@@ -48,9 +48,11 @@ struct TcnBlockArgs {
 // blocks 1..n-1, bf16 MFMA (v_mfma_f32_32x32x16_bf16), bf16 activations.  MFMA-bound:
 // 2*128*1920 = 491 520 FLOP per output time step against 512 B of HBM traffic.
 // ------------------------------------------------------------------------------------------------
-template <int P, int PIPE, bool FUSE_OUT>
-__global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(TcnBlockArgs a) {
-    constexpr int T = 256, R = T + 14 * P, MT = T / P;
+// NQ = column tiles (of 32 output times) per wave: 8 -> 256-time tiles (2 workgroups per CU at P <= 4), 4 -> 128-time tiles
+// (half the accumulators and LDS: 3 workgroups per CU, A fragments re-streamed twice as often).
+template <int P, int PIPE, bool FUSE_OUT, int NQ>
+__global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1))) void tcn_block_bf16_kernel(TcnBlockArgs a) {
+    constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P;
     __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ln = lane & 31, h = lane >> 5;
@@ -88,9 +90,9 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
     __syncthreads();
     if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 1] = mst_clock();
 
-    f32x16 acc[8];
+    f32x16 acc[NQ];
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
 
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
             for (int kc = 0; kc < 8; ++kc) {
                 const int off = ((2 * kc + h) ^ sw) << 4;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     const bf16x8 bfr = *(const bf16x8 *)(rp + q * 8192 + off);
                     acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[kc], bfr, acc[q], 0, 0, 0);
                 }
@@ -124,13 +126,13 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
         // software pipeline: the B fragments of k-step ks+1 are requested from LDS right behind the MFMAs of
         // k-step ks that free their registers (ring of 8 fragments, one full k-step = 8 MFMAs of latency cover);
         // the A fragment of (j+1, kc) is requested from L2 as soon as (j, kc) has been consumed.
-        bf16x8 af[8], bf[8];
+        bf16x8 af[8], bf[NQ];
 #pragma unroll
         for (int kc = 0; kc < 8; ++kc) af[kc] = wp[kc * 256];
         {
             const unsigned char *rp0 = smem + ln * 256 + ((h ^ (ln & 15)) << 4);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 8192);
+            for (int q = 0; q < NQ; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 8192);
         }
         // P = 16 tiles (largest dilation on a short segment) cover steps far outside the segment: a (column tile q, tap j)
         // pair whose 32 input rows are all zero padding contributes nothing and its MFMAs are skipped (wave-uniform;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
             if constexpr (P >= 16) {
                 live = 0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     const int s_lo = m0 + (32 * q) / P + j - 7, s_hi = m0 + (32 * q + 31) / P + j - 7;
                     if (!(s_hi < 0 || s_lo >= nsteps)) live |= 1u << q;
                 }
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
                 const int kcn = (kc + 1) & 7;
                 const unsigned char *np = smem + rbn * 256 + (((2 * kcn + h) ^ (rbn & 15)) << 4);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     if (P < 16 || ((live >> q) & 1u))
                         acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kc], bf[q], acc[q], 0, 0, 0);
                     bf[q] = *(const bf16x8 *)(np + q * 8192);
@@ -173,21 +175,21 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
     const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
     // residual inputs (centre tap rows) -> registers, then the input tile is dead and LDS is reused to transpose
     // the output tile so that global stores are whole 256-byte rows, 16 B per lane
-    bf16x4 xin[4][8];
+    bf16x4 xin[4][NQ];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int co0 = 32 * w + 8 * g + 4 * h;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int row = 32 * q + ln + 7 * P;
             xin[g][q] = *(const bf16x4 *)(smem + row * 256 + (((co0 >> 3) ^ (row & 15)) << 4) + 8 * h);
         }
     }
     __syncthreads();
     if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 6] = mst_clock();
-    float hs0[8], hs1[8];            // FUSE_OUT: this lane's partial sums of the 1x1 output head, per column tile
+    float hs0[NQ], hs1[NQ];            // FUSE_OUT: this lane's partial sums of the 1x1 output head, per column tile
 #pragma unroll
-    for (int q = 0; q < 8; ++q) hs0[q] = hs1[q] = 0.0f;
+    for (int q = 0; q < NQ; ++q) hs0[q] = hs1[q] = 0.0f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int co0 = 32 * w + 8 * g + 4 * h;
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
             if (a.nout > 1) ow1 = *(const f32x4 *)(a.out_w + 128 + co0);
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int o = 32 * q + ln;
             bf16x4 out;
 #pragma unroll
@@ -222,24 +224,24 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
         // last block: 1x1 output conv + bias + clamp(-1, 1) (reference architectures.py:133,145) straight from the
         // registers - the last activation never travels to HBM.  Lane pairs (l, l+32) hold the two channel halves of a
         // column, the four waves the four channel quarters: one shuffle, then a 4-way sum through LDS.
-        float *part = (float *)smem;                 // [4 waves][2 outputs][256 columns]
+        float *part = (float *)smem;                 // [4 waves][2 outputs][T columns]
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             hs0[q] += __shfl_xor(hs0[q], 32);
             hs1[q] += __shfl_xor(hs1[q], 32);
             if (h == 0) {
-                part[(w * 2 + 0) * 256 + 32 * q + ln] = hs0[q];
-                part[(w * 2 + 1) * 256 + 32 * q + ln] = hs1[q];
+                part[(w * 2 + 0) * T + 32 * q + ln] = hs0[q];
+                part[(w * 2 + 1) * T + 32 * q + ln] = hs1[q];
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i, c = idx >> 8, o = idx & 255;
+        for (int i = 0; i < 2 * T / 256; ++i) {
+            const int idx = tid + 256 * i, c = idx / T, o = idx % T;
             const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
             if (c < a.nout && t < a.L) {
-                const float v = part[(0 * 2 + c) * 256 + o] + part[(1 * 2 + c) * 256 + o] + part[(2 * 2 + c) * 256 + o] +
-                                part[(3 * 2 + c) * 256 + o] + a.out_b[c];
+                const float v = part[(0 * 2 + c) * T + o] + part[(1 * 2 + c) * T + o] + part[(2 * 2 + c) * T + o] +
+                                part[(3 * 2 + c) * T + o] + a.out_b[c];
                 a.y_out[((size_t)b * a.nout + c) * a.L + t] = fminf(1.0f, fmaxf(-1.0f, v));
             }
         }
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256, (P <= 4 ? 2 : 1)) void tcn_block_bf16_kernel(T
         if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 7] = mst_clock();
         const int slot = tid & 15;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < T / 16; ++i) {
             const int o = (tid >> 4) + 16 * i;
             const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
             if (t < a.L) *(bf16x8 *)(yb + t * 128 + slot * 8) = *(const bf16x8 *)(smem + o * 256 + ((slot ^ (o & 15)) << 4));
