@@ -314,9 +314,13 @@ size_t tcn_elem(int precision) { return precision == MST_PREC_BF16 ? 2 : 4; }
 // phases per tile: P | d.  P = 4 with 256-time tiles (78 KB of LDS, 2 workgroups per CU) whenever a tile's 64 steps
 // fit the segment; for larger dilations P = 8 with 128-time tiles (16 steps per tile, 61 KB, still 2 per CU); P = 16
 // (256-time tiles, 16 steps per tile) only for segments with fewer than 16 steps per phase.
-int choose_phases(int d, int L) {
+int choose_phases(int d, int L, int precision) {
     int P = (d % 4 == 0) ? 4 : (d % 2 == 0 ? 2 : 1);
     const long nsteps = ((long)L + d - 1) / d;
+    if (precision != MST_PREC_BF16) {      // fp32 kernel: 256-time tiles only (its LDS tile is a 32-channel chunk)
+        while (P < 16 && d % (2 * P) == 0 && 256 / P > nsteps) P *= 2;
+        return P;
+    }
     while (P < 8 && d % (2 * P) == 0 && 256 / P > nsteps) P *= 2;
     if (P == 8 && d % 16 == 0 && nsteps < 16) P = 16;     // very short segments: 16-step tiles of 16 phases
     return P;
@@ -471,7 +475,7 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
     int cur = 0;
     for (int n = 1; n < n_run; ++n) {
         const int d = t->d.dilations[n];
-        const int P = choose_phases(d, L);
+        const int P = choose_phases(d, L, precision);
         TcnBlockArgs a;
         a.x = buf[cur];
         a.y = buf[cur ^ 1];
