@@ -172,6 +172,15 @@ int mst_fx_compressor(const float *x_dev, float *y_dev, int n_items, long L, int
 /* MidSideImager.process (:964-1007), stereo only; scratch_dev: >= n_items*2 doubles */
 int mst_fx_midside_imager(const float *x_dev, float *y_dev, int n_items, long L, double bal, double *scratch_dev,
                           void *stream);
+/* Haas.process / haas_process (:768-786, :826-843): y = x, y[:, wet] += feedback * np.roll(x[:, wet], delay) - the roll is
+ * circular, delay may be negative; wet_channel 0 = 'left', 1 = 'right'.  c_in = 1 (mono, repeated to stereo) or 2;
+ * y is always [n_items, L, 2]. */
+int mst_fx_haas(const float *x_dev, float *y_dev, int n_items, long L, int c_in, long delay, double feedback,
+                int wet_channel, void *stream);
+/* Panner.process (:927-943): x * gains with the two gains of Panner._calculate_pan_coefficents (:882-912) computed by
+ * the caller (float32, like the reference's self.gains); c_in = 1 or 2, y is [n_items, L, 2]. */
+int mst_fx_panner(const float *x_dev, float *y_dev, int n_items, long L, int c_in, float gain_left, float gain_right,
+                  void *stream);
 /* Gain.process (:1041-1051) */
 int mst_fx_gain(const float *x_dev, float *y_dev, int n_items, long L, int C, double gain_db, int invert, void *stream);
 /* AugmentationChain.apply_processor rms_normalize branch (:143-146): y *= sqrt(mean(x^2)/max(1e-7, mean(y^2)))

@@ -65,6 +65,8 @@ SIGNATURES = {
                                     C.c_double, _P, C.c_size_t, _P]),
     "mst_fx_midside_imager": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_double, _P, _P]),
     "mst_fx_gain": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_double, C.c_int, _P]),
+    "mst_fx_haas": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_long, C.c_double, C.c_int, _P]),
+    "mst_fx_panner": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_float, C.c_float, _P]),
     "mst_fx_rms_normalize": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, _P, _P]),
 }
 

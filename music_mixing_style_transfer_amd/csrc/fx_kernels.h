@@ -349,3 +349,33 @@ __global__ __launch_bounds__(256) void fx_scale_kernel(const float *x, float *y,
     const size_t off = (size_t)item * per_item + i;
     y[off] = (mode == 1 ? y[off] : x[off]) * scale;
 }
+
+// Haas effect, haas_process (:768-786): y = x; y[:, ch] += feedback * np.roll(x[:, ch], delay).  np.roll is circular:
+// roll(x, d)[i] = x[(i - d) mod L]; `shift` = delay mod L in [0, L).  float32 like numpy on a float32 array: one
+// rounded multiply, one rounded add (no fused multiply-add).  A mono input [L, 1] is repeated to stereo first (:838-839).
+__global__ __launch_bounds__(256) void fx_haas_kernel(const float *x, float *y, long L, int c_in, long shift, float fb, int ch) {
+    const int item = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= L) return;
+    const float *xp = x + (size_t)item * L * c_in;
+    float *yp = y + ((size_t)item * L + i) * 2;
+    float l = xp[i * c_in], r = xp[i * c_in + (c_in - 1)];
+    long k = i - shift;
+    if (k < 0) k += L;
+    const float wet = __fmul_rn(fb, xp[k * c_in + (c_in == 2 ? ch : 0)]);
+    if (ch == 0) l = __fadd_rn(l, wet);
+    else r = __fadd_rn(r, wet);
+    yp[0] = l;
+    yp[1] = r;
+}
+
+// Panner.process (:927-943): x * gains, mono repeated to stereo first; the gains come from the pan law on the host
+__global__ __launch_bounds__(256) void fx_panner_kernel(const float *x, float *y, long L, int c_in, float g0, float g1) {
+    const int item = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= L) return;
+    const float *xp = x + ((size_t)item * L + i) * c_in;
+    float *yp = y + ((size_t)item * L + i) * 2;
+    yp[0] = xp[0] * g0;
+    yp[1] = xp[c_in - 1] * g1;
+}

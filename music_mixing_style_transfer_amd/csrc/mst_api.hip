@@ -1188,6 +1188,29 @@ extern "C" int mst_fx_gain(const float *x, float *y, int n_items, long L, int C,
     return MST_OK;
 }
 
+extern "C" int mst_fx_haas(const float *x, float *y, int n_items, long L, int c_in, long delay, double feedback,
+                           int wet_channel, void *stream) {
+    if (!x || !y || n_items < 1 || L < 1) return fail(MST_ERR_ARG, "mst_fx_haas: bad argument");
+    if (c_in != 1 && c_in != 2) return fail(MST_ERR_ARG, "mst_fx_haas: Haas effect only works with monaural or stereo audio");
+    if (wet_channel != 0 && wet_channel != 1) return fail(MST_ERR_ARG, "mst_fx_haas: wet_channel must be 0 (left) or 1 (right)");
+    if (x == y) return fail(MST_ERR_ARG, "mst_fx_haas: in-place operation is not supported (circular read)");
+    long shift = delay % L;
+    if (shift < 0) shift += L;
+    MST_LAUNCH(fx_haas_kernel, dim3((unsigned)((L + 255) / 256), n_items), dim3(256), stream, x, y, L, c_in, shift,
+               (float)feedback, wet_channel);
+    MST_CHECK_LAUNCH("fx_haas_kernel");
+    return MST_OK;
+}
+
+extern "C" int mst_fx_panner(const float *x, float *y, int n_items, long L, int c_in, float g0, float g1, void *stream) {
+    if (!x || !y || n_items < 1 || L < 1) return fail(MST_ERR_ARG, "mst_fx_panner: bad argument");
+    if (c_in != 1 && c_in != 2) return fail(MST_ERR_ARG, "mst_fx_panner: Panner only works with monaural or stereo audio");
+    if (x == y && c_in != 2) return fail(MST_ERR_ARG, "mst_fx_panner: in-place needs a stereo input");
+    MST_LAUNCH(fx_panner_kernel, dim3((unsigned)((L + 255) / 256), n_items), dim3(256), stream, x, y, L, c_in, g0, g1);
+    MST_CHECK_LAUNCH("fx_panner_kernel");
+    return MST_OK;
+}
+
 extern "C" int mst_fx_rms_normalize(const float *x, float *y, int n_items, long L, int C, double *scratch, void *stream) {
     if (!x || !y || !scratch || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_rms_normalize: bad argument");
     const long per = L * C;

@@ -375,8 +375,9 @@ __global__ __launch_bounds__(256, 1) void tcn_block_bf16_persist_kernel(TcnBlock
 
         // one k-step (NQ MFMAs) of tap j, input-channel chunk kc; refills the B ring for k-step +2 and the A ring for
         // tap j+2.  j's parity and kc must be compile-time constants at every call site (static register indices).
-        auto kstep = [&](auto PAR, int j, int kc) {
+        auto kstep = [&](auto PAR, int j, int kc, auto PINNED) {
             constexpr int par = decltype(PAR)::value;                   // j & 1
+            constexpr bool pin = decltype(PINNED)::value;               // false: the caller emits its own interleave pattern
             const int jb = (kc >= 6) ? (j < 14 ? j + 1 : 14) : j;      // tap of k-step +2
             const int kcn = (kc + 2) & 7;
             const int rbn = jb * P + ln;
@@ -385,14 +386,16 @@ __global__ __launch_bounds__(256, 1) void tcn_block_bf16_persist_kernel(TcnBlock
             for (int q = 0; q < NQ; ++q) {
                 acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[par][kc], bf[kc & 1][q], acc[q], 0, 0, 0);
                 bf[kc & 1][q] = *(const bf16x8 *)(np + q * 8192);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // keep "MFMA, then its ring refill" in program
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // order (the scheduler otherwise sinks the reads)
+                if constexpr (pin) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // keep "MFMA, then its ring refill" in program
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // order (the scheduler otherwise sinks the reads)
+                }
             }
             const int ja = j + 2 < 15 ? j + 2 : 14;
             af[par][kc] = wp[(ja * 8 + kc) * 256];
         };
-        auto kstep_even = [&](int j, int kc) { kstep(std::integral_constant<int, 0>{}, j, kc); };
-        auto kstep_odd = [&](int j, int kc) { kstep(std::integral_constant<int, 1>{}, j, kc); };
+        auto kstep_even = [&](int j, int kc) { kstep(std::integral_constant<int, 0>{}, j, kc, std::true_type{}); };
+        auto kstep_odd = [&](int j, int kc) { kstep(std::integral_constant<int, 1>{}, j, kc, std::true_type{}); };
 
         // ---- taps 0..1: epilogue math of the previous tile, one unit (g, q) per k-step -> buffer B.
         // Buffer B still holds the previous tile's input: its centre-tap rows are the residual input.  Each wave only
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void tcn_block_bf16_persist_kernel(TcnBlock
                 const f32x4 rs = *(const f32x4 *)(par + 128 + co0);
                 const f32x4 fr = *(const f32x4 *)(par + 256 + co0);
                 const f32x4 fb = *(const f32x4 *)(par + 384 + co0);
-                kstep(PAR, j, kc);     // the residual / parameter loads above complete under these MFMAs
+                kstep(PAR, j, kc, std::false_type{});     // the residual / parameter loads above complete under these MFMAs
                 bf16x4 out;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -420,6 +423,15 @@ __global__ __launch_bounds__(256, 1) void tcn_block_bf16_persist_kernel(TcnBlock
                     out[i] = (__bf16)v;
                 }
                 *(bf16x4 *)(bufo + o * 256 + (((co0 >> 3) ^ (o & 15)) << 4) + 8 * h) = out;
+                // desired issue order of this k-step: each MFMA followed by its ring refill and a slice of the epilogue VALU
+                __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);      // residual + parameter reads first
+#pragma unroll
+                for (int q2 = 0; q2 < NQ; ++q2) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
         };
         e_phase(std::integral_constant<int, 0>{}, 0);

@@ -258,6 +258,78 @@ class Gain(Processor):
         return d.out(y)
 
 
+class Haas(Processor):
+    """Haas effect: one channel gets `feedback` times a circularly delayed copy of itself added (reference
+    common_audioeffects.py:768-856; np.roll wraps around, the delay may be negative).  Mono input becomes stereo."""
+
+    def __init__(self, sample_rate, delay_range=(-0.040, 0.040), name="Haas", parameters=None):
+        super().__init__(name, parameters=parameters, block_size=None, sample_rate=sample_rate)
+        if not parameters:
+            self.parameters = ParameterList()
+            self.parameters.add(Parameter("delay", int(delay_range[1] * sample_rate), "int", units="samples",
+                                          minimum=int(delay_range[0] * sample_rate), maximum=int(delay_range[1] * sample_rate)))
+            self.parameters.add(Parameter("feedback", 0.35, "float", minimum=0.33, maximum=0.66))
+            self.parameters.add(Parameter("wet_channel", "left", "string", options=["left", "right"]))
+
+    def process(self, x):
+        d = _Dev(x)
+        assert d.C == 1 or d.C == 2, "Haas effect only works with monaural or stereo audio."
+        wet = self.parameters.wet_channel.value
+        y = torch.empty((d.n, d.L, 2), dtype=torch.float32, device=d.x.device)
+        if wet not in ("left", "right"):          # the reference's if/elif falls through: plain copy (:782-785)
+            y.copy_(d.x.expand(d.n, d.L, 2))
+            return d.out(y)
+        d.lib.check(d.lib.mst_fx_haas(d.x.data_ptr(), y.data_ptr(), d.n, d.L, d.C, int(self.parameters.delay.value),
+                                      float(self.parameters.feedback.value), 0 if wet == "left" else 1, d.stream),
+                    "mst_fx_haas")
+        return d.out(y)
+
+    def update(self, parameter_name=None):
+        self.reset_state()
+
+    def reset_state(self):
+        pass                                       # the reference's ring buffer fields are never read by process()
+
+
+class Panner(Processor):
+    """Stereo panner, pan in [0, 1] (0 = left), laws '-4.5dB' (default), 'linear', 'constant_power'
+    (reference common_audioeffects.py:860-952).  Mono input becomes stereo."""
+
+    def __init__(self, name="Panner", parameters=None):
+        super().__init__(name, parameters=parameters, block_size=None, sample_rate=None)
+        if not parameters:
+            self.parameters = ParameterList()
+            self.parameters.add(Parameter("pan", 0.5, "float", minimum=0.0, maximum=1.0))
+            self.parameters.add(Parameter("pan_law", "-4.5dB", "string", options=["-4.5dB", "linear", "constant_power"]))
+        self.update()
+
+    def _calculate_pan_coefficents(self):
+        """Left/right gains of the chosen law; kept in the processor dtype (float32) like the reference's self.gains."""
+        frac = float(self.parameters.pan.value)                  # 0 = hard left ... 1 = hard right
+        theta = frac * (np.pi / 2)
+        lin = np.array([((np.pi / 2) - theta) * (2 / np.pi), theta * (2 / np.pi)])
+        trig = np.array([np.cos(theta), np.sin(theta)])
+        law = self.parameters.pan_law.value
+        table = {"linear": lambda: lin, "constant_power": lambda: trig, "-4.5dB": lambda: np.sqrt(lin * trig)}
+        if law not in table:
+            raise ValueError(f"Invalid pan_law {law}.")
+        self.gains = table[law]().astype(self.dtype)
+
+    def process(self, x):
+        d = _Dev(x)
+        assert d.C == 1 or d.C == 2, "Panner only works with monaural or stereo audio."
+        y = torch.empty((d.n, d.L, 2), dtype=torch.float32, device=d.x.device)
+        d.lib.check(d.lib.mst_fx_panner(d.x.data_ptr(), y.data_ptr(), d.n, d.L, d.C, float(self.gains[0]),
+                                        float(self.gains[1]), d.stream), "mst_fx_panner")
+        return d.out(y)
+
+    def update(self, parameter_name=None):
+        self._calculate_pan_coefficents()
+
+    def reset_state(self):
+        self.update()
+
+
 class AugmentationChain:
     """Apply (processor, probability, rms_normalize) entries in order to every array of a list; optional shuffle
     and parallel dry/wet mix - the reference's chain semantics (:156-192)."""

@@ -59,6 +59,8 @@ struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return {x, y}; }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }   // rounded product, never contracted
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 
 namespace emu {
 void launch(dim3 grid, dim3 block, const std::function<void()> &body);

@@ -174,3 +174,34 @@ def test_fx_emulated(emu_default):
     xb = np.stack([x, 0.5 * x[::-1].copy()])
     yb = comp.process(xb)
     assert np.abs(yb[1] - F.compressor(xb[1].copy(), -20.0, 2.0, 100.0, 4.0)).max() <= 2e-7
+
+
+def test_haas_panner_emulated(emu_default):
+    """a-D7: bit-exact against the reference's own outputs (tests/golden/fx.npz) and the oracle."""
+    import os
+    from music_mixing_style_transfer_amd.mixing_manipulator import Haas, Panner
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fx.npz"))
+    x = g["x"]
+    hp = Haas(44100)
+    assert hp.parameters.delay.value == 1764 and hp.parameters.feedback.value == 0.35
+    for key, delay, fb, wet in (("haas_left", 37, 0.35, "left"), ("haas_right", -12, 0.5, "right")):
+        hp.parameters.delay.value, hp.parameters.feedback.value, hp.parameters.wet_channel.value = delay, fb, wet
+        y = hp.process(x.copy())
+        assert y.dtype == np.float32 and np.array_equal(y, g[key])
+    # delays beyond the signal length wrap like np.roll; mono input is repeated to stereo
+    hp.parameters.delay.value = -3 * len(x) - 5
+    assert np.array_equal(hp.process(x.copy()), F.haas(x.copy(), -3 * len(x) - 5, 0.5, "right"))
+    mono = x[:, :1].copy()
+    assert np.array_equal(hp.process(mono), F.haas(np.repeat(mono, 2, axis=1), -3 * len(x) - 5, 0.5, "right"))
+    pn = Panner()
+    for i, (pan, law) in enumerate(((0.3, "-4.5dB"), (0.8, "linear"), (0.5, "constant_power"))):
+        pn.parameters.pan.value, pn.parameters.pan_law.value = pan, law
+        pn.update()
+        assert np.array_equal(pn.gains, g[f"pan_gains_{i}"]) and pn.gains.dtype == np.float32
+        assert np.array_equal(pn.process(x.copy()), x * F.panner_gains(pan, law))
+        assert np.array_equal(pn.process(mono), np.repeat(mono, 2, axis=1) * F.panner_gains(pan, law))
+    pn.parameters.pan_law.value = "-3dB"
+    with pytest.raises(ValueError):
+        pn.update()
+    with pytest.raises(AssertionError):
+        hp.process(np.zeros((16, 3), np.float32))

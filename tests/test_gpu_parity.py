@@ -230,6 +230,31 @@ def test_fx_processors_vs_oracle(oracle_fx_lib):
         assert np.abs(out[i] - F.rms_normalize(xn[i], F.gain(xn[i], 5.0))).max() <= 1e-5
 
 
+def test_haas_panner_vs_golden_and_oracle():
+    """a-D7 on the device: bit-exact vs the reference's outputs (golden) and vs the oracle at full segment size."""
+    import os
+    from music_mixing_style_transfer_amd.mixing_manipulator import Haas, Panner
+    from oracle import fx_ref as F
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fx.npz"))
+    hp, pn = Haas(44100), Panner()
+    for key, delay, fb, wet in (("haas_left", 37, 0.35, "left"), ("haas_right", -12, 0.5, "right")):
+        hp.parameters.delay.value, hp.parameters.feedback.value, hp.parameters.wet_channel.value = delay, fb, wet
+        assert np.array_equal(hp.process(g["x"].copy()), g[key])
+    n, L = 3, 131072
+    x = (0.1 * torch.randn(n, L, 2, generator=torch.Generator().manual_seed(3))).clamp_(-1, 1)
+    xn = x.numpy()
+    hp.parameters.delay.value, hp.parameters.feedback.value, hp.parameters.wet_channel.value = 1764, 0.35, "left"
+    y = hp.process(x.cuda()).cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(y[i], F.haas(xn[i].copy(), 1764, 0.35, "left"))
+    for pan, law in ((0.3, "-4.5dB"), (0.8, "linear"), (0.5, "constant_power")):
+        pn.parameters.pan.value, pn.parameters.pan_law.value = pan, law
+        pn.update()
+        assert np.array_equal(pn.process(x.cuda()).cpu().numpy(), xn * F.panner_gains(pan, law))
+    mono = x[0, :, :1].contiguous()
+    assert np.array_equal(pn.process(mono.cuda()).cpu().numpy(), np.repeat(mono.numpy(), 2, axis=1) * F.panner_gains(0.5, "constant_power"))
+
+
 def test_product_fails_loudly_on_cpu_tensor(nets):
     with pytest.raises(RuntimeError):
         nets["tcn"](torch.zeros(1, 2, 1024), torch.zeros(1, 2048))
