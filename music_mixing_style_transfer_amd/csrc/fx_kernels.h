@@ -362,9 +362,10 @@ __global__ __launch_bounds__(256) void fx_haas_kernel(const float *x, float *y, 
     float l = xp[i * c_in], r = xp[i * c_in + (c_in - 1)];
     long k = i - shift;
     if (k < 0) k += L;
-    const float wet = __fmul_rn(fb, xp[k * c_in + (c_in == 2 ? ch : 0)]);
-    if (ch == 0) l = __fadd_rn(l, wet);
-    else r = __fadd_rn(r, wet);
+    float wet = fb * xp[k * c_in + (c_in == 2 ? ch : 0)];
+    MST_NO_CONTRACT(wet);              // numpy rounds the product, then the sum: keep hipcc from fusing them into an fma
+    if (ch == 0) l += wet;
+    else r += wet;
     yp[0] = l;
     yp[1] = r;
 }

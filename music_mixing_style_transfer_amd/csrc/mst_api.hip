@@ -326,25 +326,20 @@ int choose_phases(int d, int L, int precision) {
     return P;
 }
 
-int bf16_persist() {      // experimental persistent kernel (MST_TCN_PERSIST=<workgroups>), off by default
-    static const int v = [] {
-        const char *e = getenv("MST_TCN_PERSIST");
-        return e ? atoi(e) : 0;
-    }();
-    return v;
+int bf16_duo() {     // experimental two-set persistent kernel (MST_TCN_DUO=<workgroups>), off by default; read per launch
+    const char *e = getenv("MST_TCN_DUO");
+    return e ? atoi(e) : 0;
 }
 
 template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream) {
     TcnBlockArgs a = a0;
     if constexpr (P <= 4) {
-        if (precision == MST_PREC_BF16 && bf16_persist() > 0 && a.y_out == nullptr) {
-            // the persistent kernel tiles 128 output times per workgroup pass
-            const long nsteps = ((long)a.L + a.d - 1) / a.d;
-            a.tiles_step = (int)((nsteps + 128 / P - 1) / (128 / P));
-            const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
-            const int pg = (int)(ntiles < bf16_persist() ? ntiles : bf16_persist());
-            MST_LAUNCH((tcn_block_bf16_persist_kernel<P>), dim3(pg), dim3(256), stream, a);
-            MST_CHECK_LAUNCH("tcn_block_bf16_persist_kernel");
+        if (precision == MST_PREC_BF16 && bf16_duo() > 0 && a.y_out == nullptr) {
+            const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;          // 256-time tiles, two per workgroup round
+            const long want = (ntiles + 1) / 2;
+            const int pg = (int)(want < bf16_duo() ? want : bf16_duo());
+            MST_LAUNCH((tcn_block_bf16_duo_kernel<P, 8>), dim3(pg), dim3(512), stream, a);
+            MST_CHECK_LAUNCH("tcn_block_bf16_duo_kernel");
             return MST_OK;
         }
     }
@@ -499,6 +494,10 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         a.y_out = fuse_out ? y : nullptr;
         a.nout = t->d.noutputs;
         a.prof = nullptr;
+        static const int stagger = getenv("MST_TCN_STAGGER") ? atoi(getenv("MST_TCN_STAGGER")) : 0;
+        static const int stagger2 = getenv("MST_TCN_STAGGER2") ? atoi(getenv("MST_TCN_STAGGER2")) : 0;
+        a.stagger = stagger;
+        a.stagger2 = stagger2;
         // developer hook: MST_TCN_PROF_BLOCK=n MST_TCN_PROF_FILE=path dumps per-workgroup phase clock stamps of block n
         static const char *prof_file = getenv("MST_TCN_PROF_FILE");
         static const int prof_block = getenv("MST_TCN_PROF_BLOCK") ? atoi(getenv("MST_TCN_PROF_BLOCK")) : -1;

@@ -17,6 +17,26 @@ __device__ __forceinline__ int mfma32_row(int reg, int lane) { return (reg & 3) 
 // slope < 1: max(v, slope*v) == (v > 0 ? v : slope*v), one multiply + one max (packs into v_pk_mul / v_pk_max)
 __device__ __forceinline__ float leaky_relu(float v) { return fmaxf(v, MST_LEAKY * v); }
 
+// TCN block epilogue for 4 consecutive channels of one output time: y = r * LeakyReLU(v) + (b + s * x) rounded to bf16, where v is
+// the accumulator (dilated conv + BN shift), r/b the FiLM pair and s the residual scale (reference architectures.py:225-233).
+// Written on float pairs so that it compiles to v_pk_mul_f32 / v_pk_fma_f32: 4 VALU instructions per element.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16x4 tcn_epilogue4(const float *v, f32x4 fr, f32x4 fb, f32x4 rs, bf16x4 xin) {
+    bf16x4 out;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        f32x2 vv = {v[2 * p], v[2 * p + 1]};
+        const f32x2 t = vv * MST_LEAKY;
+        vv = f32x2{mst_fmax(vv.x, t.x), mst_fmax(vv.y, t.y)};
+        const f32x2 xx = {(float)xin[2 * p], (float)xin[2 * p + 1]};
+        const f32x2 c = f32x2{rs[2 * p], rs[2 * p + 1]} * xx + f32x2{fb[2 * p], fb[2 * p + 1]};
+        const f32x2 y = f32x2{fr[2 * p], fr[2 * p + 1]} * vv + c;
+        out[2 * p] = (__bf16)y.x;
+        out[2 * p + 1] = (__bf16)y.y;
+    }
+    return out;
+}
+
 __device__ __forceinline__ long long mst_clock() { return (long long)__builtin_readcyclecounter(); }
 
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {

@@ -16,3 +16,16 @@
 __device__ __forceinline__ unsigned mst_wave_slot() { return __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)); }
 __device__ __forceinline__ unsigned mst_hw_id() { return __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); }
 __device__ __forceinline__ unsigned mst_xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); }
+
+// value barrier: the compiler may not fuse the operation that produced `v` with the one that consumes it (fp contraction)
+#define MST_NO_CONTRACT(v) asm volatile("" : "+v"(v))
+
+// plain v_max_f32 (fmaxf() on a raw MFMA result costs a second v_max that only quiets NaNs)
+__device__ __forceinline__ float mst_fmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// opaque identity on an integer in a vector register: values derived from it are recomputed rather than kept live
+#define MST_LAUNDER(v) asm volatile("" : "+v"(v))

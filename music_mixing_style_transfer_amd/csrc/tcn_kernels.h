@@ -42,6 +42,7 @@ struct TcnBlockArgs {
     float *y_out;
     int nout;
     long long *prof;      // developer hook: per-workgroup shader-clock stamps at phase boundaries (null = off)
+    int stagger, stagger2; // developer hook: first-generation start delays (clocks): spread over CUs / extra for the 2nd workgroup of a CU
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -54,6 +55,7 @@ template <int P, int PIPE, bool FUSE_OUT, int NQ>
 __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1))) void tcn_block_bf16_kernel(TcnBlockArgs a) {
     constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P;
     __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
+    __shared__ __attribute__((aligned(16))) float par[4 * 128];     // shift | FiLM r | FiLM b | res of this block / batch item
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ln = lane & 31, h = lane >> 5;
 
@@ -65,7 +67,21 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
     const int m0 = mg * MT, phi0 = pg * P;
     const __bf16 *xb = (const __bf16 *)a.x + (size_t)b * a.Lp * 128;
     __bf16 *yb = (__bf16 *)a.y + (size_t)b * a.Lp * 128;
+    if ((a.stagger | a.stagger2) && blockIdx.x < 512) {
+        const long long t0 = mst_clock();
+        const long long wait = (long long)(blockIdx.x % 256) * a.stagger / 256 + (blockIdx.x >= 256 ? a.stagger2 : 0);
+        while (mst_clock() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
     if (a.prof && tid == 0) { a.prof[(size_t)blockIdx.x * 10 + 0] = mst_clock(); a.prof[(size_t)blockIdx.x * 10 + 4] = mst_hw_id(); a.prof[(size_t)blockIdx.x * 10 + 5] = mst_xcc_id(); }
+    // per-channel epilogue parameters -> LDS while the tile is staged (one broadcast ds_read_b128 each in the epilogue
+    // instead of four exposed L2 round trips)
+    if (tid < 128) {
+        const float *frow0 = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+        par[tid] = a.shift[tid];
+        par[128 + tid] = frow0[tid];
+        par[256 + tid] = frow0[128 + tid];
+        par[384 + tid] = a.res[tid];
+    }
     // ---- stage the (256 + 14P) input rows: 16 lanes x 16 B per row, XOR-swizzled 16-B slots so that the
     //      32 consecutive rows of one B-fragment read hit 16 distinct slots per ds_read_b128 lane group
     {
@@ -90,11 +106,16 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
     __syncthreads();
     if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 1] = mst_clock();
 
+    // the accumulators start from the BN shift of their channel (row (i&3) + 8 (i>>2) + 4 h of the wave's 32): no add later
     f32x16 acc[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 sh = *(const f32x4 *)(par + 32 * w + 8 * g + 4 * h);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[q][4 * g + i] = sh[i];
+    }
 
     // A fragments: wpk[ks = j*8 + kc][wave][lane] = 8 bf16 = W'[32w + ln][16kc + 8h + e][j]
     const bf16x8 *wp = (const bf16x8 *)a.wpk + (w * 64 + lane);
@@ -126,9 +147,12 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
         // software pipeline: the B fragments of k-step ks+1 are requested from LDS right behind the MFMAs of
         // k-step ks that free their registers (ring of 8 fragments, one full k-step = 8 MFMAs of latency cover);
         // the A fragment of (j+1, kc) is requested from L2 as soon as (j, kc) has been consumed.
+        // A fragment addresses = uniform (scalar) base of the k-step + a fixed 32-bit lane offset: no per-load vector address math
+        const unsigned char *wbase = (const unsigned char *)a.wpk;
+        const unsigned aoff = (unsigned)(w * 64 + lane) * 16u;
         bf16x8 af[8], bf[NQ];
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc) af[kc] = wp[kc * 256];
+        for (int kc = 0; kc < 8; ++kc) af[kc] = *(const bf16x8 *)(wbase + (size_t)kc * 4096 + aoff);
         {
             const unsigned char *rp0 = smem + ln * 256 + ((h ^ (ln & 15)) << 4);
 #pragma unroll
@@ -165,14 +189,13 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                 }
-                af[kc] = wp[(jn * 8 + kc) * 256];
+                af[kc] = *(const bf16x8 *)(wbase + (size_t)(jn * 8 + kc) * 4096 + aoff);
             }
         }
     }
 
     // ---- fused epilogue
     if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 2] = mst_clock();
-    const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
     // residual inputs (centre tap rows) -> registers, then the input tile is dead and LDS is reused to transpose
     // the output tile so that global stores are whole 256-byte rows, 16 B per lane
     bf16x4 xin[4][NQ];
@@ -193,10 +216,9 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int co0 = 32 * w + 8 * g + 4 * h;
-        const f32x4 sh = *(const f32x4 *)(a.shift + co0);
-        const f32x4 fr = *(const f32x4 *)(frow + co0);
-        const f32x4 fb = *(const f32x4 *)(frow + 128 + co0);
-        const f32x4 rs = *(const f32x4 *)(a.res + co0);
+        const f32x4 fr = *(const f32x4 *)(par + 128 + co0);
+        const f32x4 fb = *(const f32x4 *)(par + 256 + co0);
+        const f32x4 rs = *(const f32x4 *)(par + 384 + co0);
         f32x4 ow0 = {0.0f, 0.0f, 0.0f, 0.0f}, ow1 = {0.0f, 0.0f, 0.0f, 0.0f};
         if constexpr (FUSE_OUT) {
             ow0 = *(const f32x4 *)(a.out_w + co0);
@@ -205,14 +227,11 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int o = 32 * q + ln;
-            bf16x4 out;
+            const float v4[4] = {acc[q][4 * g], acc[q][4 * g + 1], acc[q][4 * g + 2], acc[q][4 * g + 3]};
+            const bf16x4 out = tcn_epilogue4(v4, fr, fb, rs, xin[g][q]);
+            if constexpr (FUSE_OUT) {          // the head reads the bf16-rounded activation, like the separate output kernel
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = leaky_relu(acc[q][4 * g + i] + sh[i]);
-                v = fr[i] * v + fb[i];
-                v += rs[i] * (float)xin[g][q][i];
-                out[i] = (__bf16)v;
-                if constexpr (FUSE_OUT) {      // the head reads the bf16-rounded activation, like the separate output kernel
+                for (int i = 0; i < 4; ++i) {
                     hs0[q] = fmaf(ow0[i], (float)out[i], hs0[q]);
                     hs1[q] = fmaf(ow1[i], (float)out[i], hs1[q]);
                 }
@@ -260,32 +279,42 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Persistent form of the bf16 block kernel: ONE workgroup per CU (4 waves, one per SIMD) walks the tiles.
-// Measured on the non-persistent kernel: two co-resident workgroups run their phases in lock-step, and epilogue
-// VALU work starves (5x slower) beside the other workgroup's back-to-back MFMA stream.  Here everything that is
-// not MFMA rides in the MFMA issue gaps of the SAME wave:
-//   * two LDS tile buffers: while tile i is computed from buffer A, the results of tile i-1 are transposed
-//     through buffer B and stored, then tile i+1 is staged into buffer B;
-//   * two accumulator sets: `accp` holds tile i-1 while `acc` accumulates tile i; the epilogue math of tile i-1
-//     is spread one (channel-group, column-tile) unit per k-step over the first taps.
-// Tile = 128 output times (4 accumulator tiles per wave) so that both accumulator sets, the A/B fragment rings
-// and the staging registers fit the 256 architectural VGPRs without spilling.
-// Same arithmetic, tiling rule and weight packing as tcn_block_bf16_kernel<P, 2>.
+// "Duo" form of the bf16 block kernel (MST_TCN_DUO=<workgroups>, experimental): ONE persistent 512-thread workgroup per CU
+// holds two wave sets (one wave of each set per SIMD), each with its own LDS tile buffer and its own stream of tiles.
+// What the micro-benchmarks (tools/micro) and the phase stamps of the kernel above say about gfx950:
+//   * two waves per SIMD that BOTH stream MFMAs share the matrix pipe at 24-28 clocks per MFMA; one wave alone gets 32-35;
+//   * VALU / LDS / VMEM instructions of a wave are starved (4-20x) while the other wave of its SIMD streams MFMAs, and even a
+//     wave's own VALU work does not hide behind its MFMAs beyond ~2 instructions per MFMA.  Non-MFMA work therefore cannot be
+//     overlapped with MFMA work on a SIMD by running the two waves in different phases (an anti-phase "ping-pong" variant of
+//     this kernel measured 1.75 ms against 1.66 ms); it can only be kept short, and memory LATENCY can be overlapped with it;
+//   * with two independent workgroups per CU the older one wins more MFMA slots, finishes its main loop ~20 k clocks early
+//     and then crawls through its epilogue beside the other's MFMA tail.
+// So here both sets run every phase together (one s_barrier per phase, optionally one per tap to keep the two MFMA streams
+// level), the rows of the NEXT tile are requested from HBM before the epilogue math of the current one and land in LDS after
+// it, parameters are read once, and nothing is re-dispatched.  Everything outside the main loop is wave-local (wave w stages,
+// transposes and stores only the 64-byte channel slice [32w, 32w+32) of each row, the slice its accumulators produce), so
+// the epilogue needs no barrier of its own.  Same arithmetic, tiling rule and weight packing as above.
 // ------------------------------------------------------------------------------------------------
-template <int P>
-__global__ __launch_bounds__(256, 1) void tcn_block_bf16_persist_kernel(TcnBlockArgs a) {
-    constexpr int NQ = 4, T = 32 * NQ, R = T + 14 * P, MT = T / P, NPASS = (R + 15) / 16;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * R * 256];
-    __shared__ __attribute__((aligned(16))) float par[4 * 128];     // shift | res | FiLM r | FiLM b of the block
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int ln = lane & 31, h = lane >> 5;
-    const int slot = tid & 15, prow = tid >> 4;
+template <int P, int NQ>
+__global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs a) {
+    static_assert(16 % P == 0, "row passes advance by a whole number of steps");
+    constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NPASS = (R + 15) / 16, NPART = (NPASS + 3) / 4, STEP = 16 / P;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_all[2 * R * 256];
+    __shared__ __attribute__((aligned(16))) float par_all[2 * 384];      // per set: FiLM r | FiLM b | res of its batch item
+    const int set = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);               // wave-uniform: lives in a scalar register
+    unsigned char *smem = smem_all + set * (R * 256);
+    float *par = par_all + set * 384;
     const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
-    long tile = blockIdx.x;
-    if (tile >= ntiles) return;
+    const long per_round = 2L * gridDim.x, first = 2L * blockIdx.x;
+    if (first >= ntiles) return;
+    const int n_max = (int)((ntiles - first + per_round - 1) / per_round);                       // tiles of set 0 (>= set 1's)
+    const int n_mine = first + set < ntiles ? (int)((ntiles - first - set + per_round - 1) / per_round) : 0;
+    const bool stamp_wg = a.prof && tid == 0;
 
     struct Coord { int b, m0, phi0; };
-    auto decode = [&](long t) {
+    auto decode = [&](int k) {
+        long t = (long)k * per_round + first + set;
         Coord c;
         const int mg = (int)(t % a.tiles_step);
         t /= a.tiles_step;
@@ -294,254 +323,172 @@ __global__ __launch_bounds__(256, 1) void tcn_block_bf16_persist_kernel(TcnBlock
         c.m0 = mg * MT;
         return c;
     };
-    // row i*16 + prow of a tile: 16 bytes (slot) of the input row, zeros outside the segment
-    auto stage_load = [&](int i, const Coord &c, bool live) {
-        const int r = prow + 16 * i;
-        const long t = (long)(c.m0 + r / P - 7) * a.d + c.phi0 + (r % P);
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (live && r < R && t >= 0 && t < a.L)
-            v = *(const bf16x8 *)((const __bf16 *)a.x + ((size_t)c.b * a.Lp + t) * 128 + slot * 8);
-        return v;
-    };
-    auto stage_store = [&](unsigned char *buf, int i, bf16x8 v) {
-        const int r = prow + 16 * i;
-        if (r < R) *(bf16x8 *)(buf + r * 256 + ((slot ^ (r & 15)) << 4)) = v;
-    };
-
-    // per-channel epilogue parameters live in LDS: one ds_read_b128 each instead of an L2 round trip inside the MFMA loop
     int par_b = -1;
-    auto load_params = [&](int b) {
-        const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+    auto load_params = [&](int b) {             // visible to the set after the next workgroup barrier
         if (tid < 128) {
-            par[tid] = a.shift[tid];
-            par[128 + tid] = a.res[tid];
-            par[256 + tid] = frow[tid];
-            par[384 + tid] = frow[128 + tid];
+            const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+            par[tid] = frow[tid];
+            par[128 + tid] = frow[128 + tid];
+            par[256 + tid] = a.res[tid];
         }
         par_b = b;
     };
-    Coord cc = decode(tile);
-    load_params(cc.b);
-    {
-        bf16x8 v[NPASS];
-#pragma unroll
-        for (int i = 0; i < NPASS; ++i) v[i] = stage_load(i, cc, true);
-#pragma unroll
-        for (int i = 0; i < NPASS; ++i) stage_store(smem, i, v[i]);
-    }
-    __syncthreads();
 
-    f32x16 acc[NQ], accp[NQ];
+    // Wave-local row pieces: pass i of a lane covers row prow + 16 i, 16-byte slot pslot = 4 w + lane % 4 (channels 8 pslot ..).
+    // Consecutive passes are STEP dilation steps apart in time, one 4096-byte stride apart in LDS (the XOR swizzle depends on
+    // row & 15 = prow only): running pointers instead of per-row address arithmetic.
+    // rows [i0, i1) of tile c -> v; zeros outside the segment / beyond the tile
+    auto stage_load = [&](const Coord &c, bool live, bf16x8 (&v)[NPASS], int lane_v, int i0, int i1) {
+        const int prow = lane_v >> 2, pslot = 4 * w + (lane_v & 3);
+        const long dt = (long)STEP * a.d;
+        long t = (long)(c.m0 + prow / P - 7) * a.d + c.phi0 + (prow % P) + i0 * dt;
+        const __bf16 *p = (const __bf16 *)a.x + ((size_t)c.b * a.Lp + t) * 128 + pslot * 8;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) accp[q][i] = 0.0f;
-    Coord pc = {0, 1 << 28, 0};          // "previous tile" of the first iteration: every time >= L, nothing is stored
-    int cur = 0;
-    const bf16x8 *wp = (const bf16x8 *)a.wpk + (w * 64 + lane);
-
-    for (; tile < ntiles; tile += gridDim.x) {
-        cc = decode(tile);
-        const bool stamp = a.prof && tid == 0 && tile == (long)blockIdx.x + 2 * (long)gridDim.x;   // third tile of this workgroup
-        if (stamp) a.prof[(size_t)blockIdx.x * 10 + 0] = mst_clock();
-        const bool has_next = tile + gridDim.x < ntiles;
-        const Coord nc = decode(has_next ? tile + gridDim.x : tile);
-        unsigned char *bufc = smem + cur * (R * 256), *bufo = smem + (cur ^ 1) * (R * 256);
-        if (a.film_rows > 1 && pc.m0 < (1 << 28) && pc.b != par_b) {     // per-item FiLM rows: refresh when the batch item changes
-            __syncthreads();
-            load_params(pc.b);
-            __syncthreads();
-        }
-        __bf16 *ybp = (__bf16 *)a.y + (size_t)pc.b * a.Lp * 128;
-
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
-        // With one wave per SIMD nothing else hides latency, so the operand rings run deep: A fragments are requested
-        // two taps (16 k-steps) ahead of their use, B fragments two k-steps (8 MFMAs) ahead.
-        bf16x8 af[2][8], bf[2][NQ];
-#pragma unroll
-        for (int kc = 0; kc < 8; ++kc) {
-            af[0][kc] = wp[kc * 256];
-            af[1][kc] = wp[(8 + kc) * 256];
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const unsigned char *rp0 = bufc + ln * 256 + (((2 * s2 + h) ^ (ln & 15)) << 4);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) bf[s2][q] = *(const bf16x8 *)(rp0 + q * 8192);
-        }
-
-        // one k-step (NQ MFMAs) of tap j, input-channel chunk kc; refills the B ring for k-step +2 and the A ring for
-        // tap j+2.  j's parity and kc must be compile-time constants at every call site (static register indices).
-        auto kstep = [&](auto PAR, int j, int kc, auto PINNED) {
-            constexpr int par = decltype(PAR)::value;                   // j & 1
-            constexpr bool pin = decltype(PINNED)::value;               // false: the caller emits its own interleave pattern
-            const int jb = (kc >= 6) ? (j < 14 ? j + 1 : 14) : j;      // tap of k-step +2
-            const int kcn = (kc + 2) & 7;
-            const int rbn = jb * P + ln;
-            const unsigned char *np = bufc + rbn * 256 + (((2 * kcn + h) ^ (rbn & 15)) << 4);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[par][kc], bf[kc & 1][q], acc[q], 0, 0, 0);
-                bf[kc & 1][q] = *(const bf16x8 *)(np + q * 8192);
-                if constexpr (pin) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // keep "MFMA, then its ring refill" in program
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // order (the scheduler otherwise sinks the reads)
-                }
+        for (int i = i0; i < i1; ++i) {
+            if (i < NPASS) {
+                v[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (live && prow + 16 * i < R && t >= 0 && t < a.L) v[i] = *(const bf16x8 *)p;
             }
-            const int ja = j + 2 < 15 ? j + 2 : 14;
-            af[par][kc] = wp[(ja * 8 + kc) * 256];
-        };
-        auto kstep_even = [&](int j, int kc) { kstep(std::integral_constant<int, 0>{}, j, kc, std::true_type{}); };
-        auto kstep_odd = [&](int j, int kc) { kstep(std::integral_constant<int, 1>{}, j, kc, std::true_type{}); };
+            t += dt;
+            p += dt * 128;
+        }
+    };
+    auto stage_store = [&](const bf16x8 (&v)[NPASS], int lane_v) {
+        const int prow = lane_v >> 2, pslot = 4 * w + (lane_v & 3);
+        unsigned char *q = smem + prow * 256 + ((pslot ^ (prow & 15)) << 4);
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i)
+            if (prow + 16 * i < R) *(bf16x8 *)(q + i * 4096) = v[i];
+    };
 
-        // ---- taps 0..1: epilogue math of the previous tile, one unit (g, q) per k-step -> buffer B.
-        // Buffer B still holds the previous tile's input: its centre-tap rows are the residual input.  Each wave only
-        // touches its own 4 channel slots of a row (same row swizzle for the input and the output image), and a unit
-        // reads rows [32q+7P, +32) before writing rows [32q, +32): no cross-unit hazard (the lanes of a wave execute
-        // each LDS instruction together, and consecutive units are separated by MFMAs).
-        auto e_phase = [&](auto PAR, int j) {
+    auto main_loop = [&](f32x16 (&acc)[NQ], int lane_v) {
+        const int ln = lane_v & 31, h = lane_v >> 5;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {           // accumulators start from the BN shift, like the default kernel
+            const f32x4 sh = *(const f32x4 *)(a.shift + 32 * w + 8 * g + 4 * h);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[q][4 * g + i] = sh[i];
+        }
+        const bf16x8 *wp = (const bf16x8 *)a.wpk + (w * 64 + lane_v);
+        bf16x8 af[8], bf[NQ];
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) af[kc] = wp[kc * 256];
+        {
+            const unsigned char *rp0 = smem + ln * 256 + ((h ^ (ln & 15)) << 4);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 8192);
+        }
+        for (int j = 0; j < 15; ++j) {
+            const int jn = j < 14 ? j + 1 : 14;
+            const int rb0 = j * P + ln, rb1 = jn * P + ln;
 #pragma unroll
             for (int kc = 0; kc < 8; ++kc) {
-                const int g = 2 * j + (kc >> 2), q = kc & 3;
-                const int co0 = 32 * w + 8 * g + 4 * h;
-                const int o = 32 * q + ln, row = o + 7 * P;
-                const bf16x4 xr = *(const bf16x4 *)(bufo + row * 256 + (((co0 >> 3) ^ (row & 15)) << 4) + 8 * h);
-                const f32x4 sh = *(const f32x4 *)(par + co0);
-                const f32x4 rs = *(const f32x4 *)(par + 128 + co0);
-                const f32x4 fr = *(const f32x4 *)(par + 256 + co0);
-                const f32x4 fb = *(const f32x4 *)(par + 384 + co0);
-                kstep(PAR, j, kc, std::false_type{});     // the residual / parameter loads above complete under these MFMAs
-                bf16x4 out;
+                const int rbn = (kc == 7) ? rb1 : rb0;
+                const int kcn = (kc + 1) & 7;
+                const unsigned char *np = smem + rbn * 256 + (((2 * kcn + h) ^ (rbn & 15)) << 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = leaky_relu(accp[q][4 * g + i] + sh[i]);
-                    v = fr[i] * v + fb[i];
-                    v += rs[i] * (float)xr[i];
-                    out[i] = (__bf16)v;
-                }
-                *(bf16x4 *)(bufo + o * 256 + (((co0 >> 3) ^ (o & 15)) << 4) + 8 * h) = out;
-                // desired issue order of this k-step: each MFMA followed by its ring refill and a slice of the epilogue VALU
-                __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);      // residual + parameter reads first
-#pragma unroll
-                for (int q2 = 0; q2 < NQ; ++q2) {
+                for (int q = 0; q < NQ; ++q) {
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kc], bf[q], acc[q], 0, 0, 0);
+                    bf[q] = *(const bf16x8 *)(np + q * 8192);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                af[kc] = wp[(jn * 8 + kc) * 256];
             }
-        };
-        e_phase(std::integral_constant<int, 0>{}, 0);
-        e_phase(std::integral_constant<int, 1>{}, 1);
-        if (stamp) a.prof[(size_t)blockIdx.x * 10 + 1] = mst_clock();
-        __syncthreads();
-        if (stamp) a.prof[(size_t)blockIdx.x * 10 + 2] = mst_clock();
-        // ---- tap 2: whole-row stores of the previous tile from buffer B (T*16/256 = 8 pieces per thread)
-#pragma unroll
-        for (int kc = 0; kc < 8; ++kc) {
-            kstep_even(2, kc);
-            const int o = prow + 16 * kc;
-            const long t = (long)(pc.m0 + o / P) * a.d + pc.phi0 + (o % P);
-            if (t < a.L) *(bf16x8 *)(ybp + t * 128 + slot * 8) = *(const bf16x8 *)(bufo + o * 256 + ((slot ^ (o & 15)) << 4));
+            if (a.stagger2 & 2) __builtin_amdgcn_s_barrier();      // developer knob: keep the two MFMA streams of a SIMD level
         }
-        if (stamp) a.prof[(size_t)blockIdx.x * 10 + 3] = mst_clock();
-        __syncthreads();
-        if (stamp) a.prof[(size_t)blockIdx.x * 10 + 4] = mst_clock();
-        // ---- staging of the next tile into buffer B: 6 row loads in tap jA, their LDS writes in tap jA+2 (a longer
-        // hold needs more registers than the wave has: holding all rows for 8 taps spilled and ran slower)
-        if (stamp) a.prof[(size_t)blockIdx.x * 10 + 5] = mst_clock();
+    };
+
+    // epilogue of tile c; the row loads of the next tile cn are issued in four parts, one per finished channel group, into the
+    // registers that group's accumulators just freed (no global load of the epilogue itself sits behind them: parameters come
+    // from LDS, so nothing waits on HBM until stage_store)
+    auto epilogue = [&](const f32x16 (&acc)[NQ], const Coord &c, bool live, const Coord &cn, bool next_live, bf16x8 (&vn)[NPASS], int lane_v) {
+        const int ln = lane_v & 31, h = lane_v >> 5;
+        const unsigned char *xr = smem + (ln + 7 * P) * 256 + 8 * h;      // residual rows (centre tap), + q * 8192
+        unsigned char *ow = smem + ln * 256 + 8 * h;                       // output rows, + q * 8192
+        const int sx = (ln + 7 * P) & 15, so = ln & 15;
+        f32x4 fr[4], fb[4], rs[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co0 = 32 * w + 8 * g + 4 * h;
+            fr[g] = *(const f32x4 *)(par + co0);
+            fb[g] = *(const f32x4 *)(par + 128 + co0);
+            rs[g] = *(const f32x4 *)(par + 256 + co0);
+        }
+        // column tile by column tile, ascending: tile q reads its residual inputs from rows [32q + 7P, 32q + 7P + 32) and then
+        // overwrites rows [32q, 32q + 32) of the wave's slice - rows nobody reads any more (reads always run ahead of writes).
+        // Each finished tile frees its 16 accumulator registers; the next tile's row loads are issued into them.
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q > 0 && (q & 1) == 0 && q / 2 <= 4) {         // two finished tiles = 32 free registers = one part (<= 5 rows)
+                __builtin_amdgcn_sched_barrier(0);
+                stage_load(cn, next_live, vn, lane_v, (q / 2 - 1) * NPART, (q / 2) * NPART);
+            }
+            bf16x4 xin[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xin[g] = *(const bf16x4 *)(xr + q * 8192 + (((4 * w + g) ^ sx) << 4));
+            __builtin_amdgcn_wave_barrier();       // every lane's residual reads are issued before any lane overwrites rows of this tile
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float v4[4] = {acc[q][4 * g], acc[q][4 * g + 1], acc[q][4 * g + 2], acc[q][4 * g + 3]};
+                *(bf16x4 *)(ow + q * 8192 + (((4 * w + g) ^ so) << 4)) = tcn_epilogue4(v4, fr[g], fb[g], rs[g], xin[g]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        stage_load(cn, next_live, vn, lane_v, ((NQ - 1) / 2) * NPART, 4 * NPART);      // the parts not issued above
+        __builtin_amdgcn_wave_barrier();           // the transposed slice of this wave is complete
         {
-            bf16x8 s0[6], s1[6];
+            const int prow = lane_v >> 2, pslot = 4 * w + (lane_v & 3);
+            const long dt = (long)STEP * a.d;
+            long t = (long)(c.m0 + prow / P) * a.d + c.phi0 + (prow % P);
+            __bf16 *yp = (__bf16 *)a.y + ((size_t)c.b * a.Lp + t) * 128 + pslot * 8;
+            const unsigned char *q = smem + prow * 256 + ((pslot ^ (prow & 15)) << 4);
 #pragma unroll
-            for (int kc = 0; kc < 8; ++kc) {
-                kstep_odd(3, kc);
-                if (kc < 6) s0[kc] = stage_load(kc, nc, has_next && kc < NPASS);
-            }
-#pragma unroll
-            for (int kc = 0; kc < 8; ++kc) {
-                kstep_even(4, kc);
-                if (kc < 6) s1[kc] = stage_load(6 + kc, nc, has_next && 6 + kc < NPASS);
-            }
-#pragma unroll
-            for (int kc = 0; kc < 8; ++kc) {
-                kstep_odd(5, kc);
-                if (kc < 6 && kc < NPASS) stage_store(bufo, kc, s0[kc]);
-            }
-#pragma unroll
-            for (int kc = 0; kc < 8; ++kc) {
-                kstep_even(6, kc);
-                if (kc < 6 && 6 + kc < NPASS) stage_store(bufo, 6 + kc, s1[kc]);
-            }
-            if (NPASS > 12) {
-#pragma unroll
-                for (int i = 12; i < NPASS; ++i) stage_store(bufo, i, stage_load(i, nc, has_next));
+            for (int i = 0; i < T / 16; ++i) {
+                if (live && t < a.L) *(bf16x8 *)yp = *(const bf16x8 *)(q + i * 4096);
+                t += dt;
+                yp += dt * 128;
             }
         }
-#pragma unroll 1
-        for (int jp = 7; jp < 15; jp += 2) {                  // (odd, even) tap pairs keep the A-ring index static
-#pragma unroll
-            for (int kc = 0; kc < 8; ++kc) kstep_odd(jp, kc);
-#pragma unroll
-            for (int kc = 0; kc < 8; ++kc) kstep_even(jp + 1, kc);
-        }
+        __builtin_amdgcn_wave_barrier();           // ... and read back before this wave restages the buffer
+    };
 
-        // ---- hand the tile over to the next iteration (its input rows stay in this buffer for the residual)
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) accp[q] = acc[q];
-        pc = cc;
-        if (stamp) a.prof[(size_t)blockIdx.x * 10 + 6] = mst_clock();
-        __syncthreads();
-        if (stamp) a.prof[(size_t)blockIdx.x * 10 + 7] = mst_clock();
-        cur ^= 1;
-    }
-
-    // ---- drain: epilogue of the last tile of this workgroup; its input tile sits in buffer cur^1
     {
-        unsigned char *bufo = smem + (cur ^ 1) * (R * 256);
-        const float *frow = a.film + (a.film_rows > 1 ? (size_t)pc.b * 256 : 0);
-        __bf16 *ybp = (__bf16 *)a.y + (size_t)pc.b * a.Lp * 128;
-        bf16x4 xin[4][NQ];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int co0 = 32 * w + 8 * g + 4 * h;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int row = 32 * q + ln + 7 * P;
-                xin[g][q] = *(const bf16x4 *)(bufo + row * 256 + (((co0 >> 3) ^ (row & 15)) << 4) + 8 * h);
-            }
-        }
+        const Coord c0 = decode(0);
+        if (n_mine > 0) load_params(c0.b);
+        bf16x8 v[NPASS];
+        stage_load(c0, n_mine > 0, v, (int)threadIdx.x & 63, 0, NPASS);
+        stage_store(v, (int)threadIdx.x & 63);
+    }
+    __syncthreads();
+#pragma nounroll
+    for (int k = 0; k < n_max; ++k) {
+        int lane_v = threadIdx.x & 63;
+        MST_LAUNDER(lane_v);               // per-lane index math is recomputed per tile instead of living (and spilling) across the loop
+        const bool mine = k < n_mine;
+        const bool stamp = stamp_wg && k == 2;
+        long long *pr = a.prof + ((size_t)blockIdx.x * 2 + set) * 10;
+        const Coord c = decode(k);
+        // per-item FiLM rows: refresh when the batch item changes (nobody reads `par` during the main loop; the barrier
+        // behind it publishes the new values to the epilogue)
+        if (mine && a.film_rows > 1 && c.b != par_b) load_params(c.b);
+        if (stamp) pr[0] = pr[1] = mst_clock();
+        // a set without a tile in the last round (odd tile count) runs the same instruction stream on its stale buffer and
+        // stores nothing: no divergent control flow around the accumulators, whose registers the epilogue hands to the prefetch
+        f32x16 acc[NQ];
+        main_loop(acc, lane_v);
+        if (stamp) pr[2] = mst_clock();
+        __syncthreads();               // every wave's B-fragment reads of this tile are done: the buffers may be overwritten
+        if (stamp) pr[6] = mst_clock();
+        bf16x8 v[NPASS];                                   // the next tile's rows travel while the epilogue runs
+        const Coord cn = decode(k + 1);
+        epilogue(acc, c, mine, cn, k + 1 < n_mine, v, lane_v);
+        if (stamp) pr[7] = mst_clock();
+        stage_store(v, lane_v);
+        if (stamp) pr[3] = mst_clock();
         __syncthreads();
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int co0 = 32 * w + 8 * g + 4 * h;
-            const f32x4 sh = *(const f32x4 *)(a.shift + co0);
-            const f32x4 fr = *(const f32x4 *)(frow + co0);
-            const f32x4 fb = *(const f32x4 *)(frow + 128 + co0);
-            const f32x4 rs = *(const f32x4 *)(a.res + co0);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const int o = 32 * q + ln;
-                bf16x4 out;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = leaky_relu(accp[q][4 * g + i] + sh[i]);
-                    v = fr[i] * v + fb[i];
-                    v += rs[i] * (float)xin[g][q][i];
-                    out[i] = (__bf16)v;
-                }
-                *(bf16x4 *)(bufo + o * 256 + (((co0 >> 3) ^ (o & 15)) << 4) + 8 * h) = out;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < T / 16; ++i) {
-            const int o = prow + 16 * i;
-            const long t = (long)(pc.m0 + o / P) * a.d + pc.phi0 + (o % P);
-            if (t < a.L) *(bf16x8 *)(ybp + t * 128 + slot * 8) = *(const bf16x8 *)(bufo + o * 256 + ((slot ^ (o & 15)) << 4));
-        }
     }
 }
 

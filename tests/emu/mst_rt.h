@@ -59,8 +59,9 @@ struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return {x, y}; }
-static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }   // rounded product, never contracted
-static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float mst_fmax(float a, float b) { return fmaxf(a, b); }
+#define MST_LAUNDER(v) asm volatile("" : "+r"(v))
+#define MST_NO_CONTRACT(v) asm volatile("" : "+x"(v))      // value barrier: no fp contraction across it
 
 namespace emu {
 void launch(dim3 grid, dim3 block, const std::function<void()> &body);
@@ -133,6 +134,9 @@ template <typename T> static inline T __shfl_down(T v, int d, int = 64) {
 template <typename T> static inline T __shfl(T v, int src, int = 64) { return emu_shfl(v, src); }
 #define __builtin_amdgcn_readfirstlane(v) emu_shfl((v), 0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_amdgcn_s_barrier() __syncthreads()
+#define __builtin_amdgcn_wave_barrier() ((void)emu_shfl(0, 0))       // lanes of a wave meet (the emulator runs them one by one)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 

@@ -205,3 +205,19 @@ def test_haas_panner_emulated(emu_default):
         pn.update()
     with pytest.raises(AssertionError):
         hp.process(np.zeros((16, 3), np.float32))
+
+
+def test_tcn_duo_kernel_matches_default_emulated(emu_default, monkeypatch):
+    """The experimental two-set persistent bf16 block kernel (MST_TCN_DUO) does the same arithmetic in the same order as the default
+    kernel: its activations must be bit-identical, for ragged tile counts, more workgroups than tiles and B > 1."""
+    m, sd = _tcn(4)
+    m.precision = "bf16"
+    cond = synth.synth_audio((1, 64), seed=2)
+    for shape, wgs in (((2, 2, 777), 2), ((1, 2, 300), 5), ((3, 2, 1100), 1)):
+        x = synth.synth_audio(shape, seed=shape[2])
+        monkeypatch.delenv("MST_TCN_DUO", raising=False)
+        ref = [m.forward_blocks(x, cond, n).clone() for n in (2, 3, 4)]
+        monkeypatch.setenv("MST_TCN_DUO", str(wgs))
+        for n, r in zip((2, 3, 4), ref):
+            assert torch.equal(m.forward_blocks(x, cond, n), r), (shape, wgs, n)
+    monkeypatch.delenv("MST_TCN_DUO", raising=False)
