@@ -181,6 +181,19 @@ int mst_fx_haas(const float *x_dev, float *y_dev, int n_items, long L, int c_in,
  * the caller (float32, like the reference's self.gains); c_in = 1 or 2, y is [n_items, L, 2]. */
 int mst_fx_panner(const float *x_dev, float *y_dev, int n_items, long L, int c_in, float gain_left, float gain_right,
                   void *stream);
+/* ConvolutionalReverb.process (:727-764): y = dry * x + wet * (x (*) h)[offset : offset + L] per channel, x (*) h the FULL
+ * linear convolution (scipy.signal.oaconvolve(x, h, mode='full', axes=0) in the reference).  Computed as one FFT convolution of
+ * n_fft = next power of two >= L + Lh_max - 1 per (item, channel) with hipFFT (loaded on first use) + three HIP kernels.
+ * The caller resolves what the reference does on the host: IR choice / decay fade (:704-725), mono <-> stereo IR (:739-742),
+ * offset = argmax_t max_c |h| + pre-delay samples, clipped to [0, Lh-1] (:757-761).  x/y: [n_items, L, C]; h: [Lh, C] device
+ * float32, one impulse response for all items (apply_same_processor, :150-154).  All L + Lh - 1 samples are exact linear
+ * convolution (no circular wrap).  A convolver owns its FFT plans; workspace is caller memory. */
+typedef struct MstConvolver MstConvolver;
+int mst_fx_convolver_create(long L, long Lh_max, int n_items, int C, MstConvolver **out);
+void mst_fx_convolver_destroy(MstConvolver *cv);
+size_t mst_fx_convolver_workspace_bytes(const MstConvolver *cv);
+int mst_fx_convolve(MstConvolver *cv, const float *x_dev, const float *h_dev, long Lh, float *y_dev, long offset, double dry,
+                    double wet, void *workspace_dev, size_t workspace_bytes, void *stream);
 /* Gain.process (:1041-1051) */
 int mst_fx_gain(const float *x_dev, float *y_dev, int n_items, long L, int C, double gain_db, int invert, void *stream);
 /* AugmentationChain.apply_processor rms_normalize branch (:143-146): y *= sqrt(mean(x^2)/max(1e-7, mean(y^2)))

@@ -380,3 +380,34 @@ __global__ __launch_bounds__(256) void fx_panner_kernel(const float *x, float *y
     yp[0] = xp[0] * g0;
     yp[1] = xp[c_in - 1] * g1;
 }
+
+// ---- FFT convolution reverb (ConvolutionalReverb.process, common_audioeffects.py:727-764) -------------------------
+// The two FFTs and the inverse run in hipFFT (plain library transforms); everything around them is here.
+// pack: interleaved [n_items][L][C] -> one zero-padded real sequence of n_fft samples per (item, channel)
+__global__ __launch_bounds__(256) void fx_conv_pack_kernel(const float *x, float *seq, long L, int C, long n_fft) {
+    const int sq = blockIdx.y, item = sq / C, c = sq % C;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_fft) return;
+    seq[(size_t)sq * n_fft + i] = i < L ? x[((size_t)item * L + i) * C + c] : 0.0f;
+}
+
+// spectrum product X[s][k] *= H[s % C][k] / n_fft (hipFFT's inverse is unnormalised)
+__global__ __launch_bounds__(256) void fx_conv_mul_kernel(float2 *X, const float2 *H, long nbin, int C, float scale) {
+    const int sq = blockIdx.y;
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nbin) return;
+    const float2 a = X[(size_t)sq * nbin + k], b = H[(size_t)(sq % C) * nbin + k];
+    X[(size_t)sq * nbin + k] = make_float2((a.x * b.x - a.y * b.y) * scale, (a.x * b.y + a.y * b.x) * scale);
+}
+
+// y[item][t][c] = dry * x[item][t][c] + wet * conv[item, c][offset + t]   (the reference cuts y[idx : idx + len(x)], :754-761)
+__global__ __launch_bounds__(256) void fx_conv_mix_kernel(const float *x, const float *seq, float *y, long L, int C, long n_fft,
+                                                          long offset, float dry, float wet) {
+    const int item = blockIdx.y;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;          // element of the [L][C] item
+    if (e >= L * C) return;
+    const long t = e / C;
+    const int c = (int)(e % C);
+    const float v = seq[((size_t)item * C + c) * n_fft + offset + t];
+    y[(size_t)item * L * C + e] = dry * x[(size_t)item * L * C + e] + wet * v;
+}

@@ -1210,6 +1210,105 @@ extern "C" int mst_fx_panner(const float *x, float *y, int n_items, long L, int 
     return MST_OK;
 }
 
+// ---- FFT convolution (ConvolutionalReverb) ---------------------------------------------------------------------------
+struct MstConvolver {
+    long L = 0, Lh_max = 0, n_fft = 0;
+    int n_items = 0, C = 0;
+    void *plan_x = nullptr, *plan_h = nullptr, *plan_inv = nullptr;       // hipfftHandle: R2C batch n_items*C, R2C batch C, C2R
+};
+
+namespace {
+// hipFFT is bound at first use (dlopen), so that the library itself has no link-time dependency on it; the SIMT emulator
+// build (tests/emu/mst_rt.h) supplies host transforms under the same five names instead.
+struct FftApi {
+    int (*plan_many)(void **, int, int *, int *, int, int, int *, int, int, int, int) = nullptr;
+    int (*set_stream)(void *, hipStream_t) = nullptr;
+    int (*exec_r2c)(void *, float *, float2 *) = nullptr;
+    int (*exec_c2r)(void *, float2 *, float *) = nullptr;
+    int (*destroy)(void *) = nullptr;
+    bool ok = false;
+};
+const FftApi &fft_api() {
+    static const FftApi api = [] {
+        FftApi a;
+        if (!mst_fft_bind((void **)&a.plan_many, (void **)&a.set_stream, (void **)&a.exec_r2c, (void **)&a.exec_c2r, (void **)&a.destroy))
+            return a;
+        a.ok = true;
+        return a;
+    }();
+    return api;
+}
+constexpr int kFftR2C = 0x2a, kFftC2R = 0x2c;       // HIPFFT_R2C / HIPFFT_C2R
+}  // namespace
+
+extern "C" int mst_fx_convolver_create(long L, long Lh_max, int n_items, int C, MstConvolver **out) {
+    if (!out || L < 1 || Lh_max < 1 || n_items < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_convolver_create: bad argument");
+    const FftApi &f = fft_api();
+    if (!f.ok) return fail(MST_ERR_HIP, "mst_fx_convolver_create: cannot load hipFFT (libhipfft.so)");
+    long n = 1;
+    while (n < L + Lh_max - 1) n <<= 1;
+    if (n > (1L << 30)) return fail(MST_ERR_UNSUPPORTED, "mst_fx_convolver_create: transform longer than 2^30 samples");
+    auto *cv = new MstConvolver;
+    cv->L = L; cv->Lh_max = Lh_max; cv->n_fft = n; cv->n_items = n_items; cv->C = C;
+    int nn = (int)n;
+    if (f.plan_many(&cv->plan_x, 1, &nn, nullptr, 1, 0, nullptr, 1, 0, kFftR2C, n_items * C) ||
+        f.plan_many(&cv->plan_h, 1, &nn, nullptr, 1, 0, nullptr, 1, 0, kFftR2C, C) ||
+        f.plan_many(&cv->plan_inv, 1, &nn, nullptr, 1, 0, nullptr, 1, 0, kFftC2R, n_items * C)) {
+        mst_fx_convolver_destroy(cv);
+        return fail(MST_ERR_HIP, "mst_fx_convolver_create: hipfftPlanMany failed");
+    }
+    *out = cv;
+    return MST_OK;
+}
+
+extern "C" void mst_fx_convolver_destroy(MstConvolver *cv) {
+    if (!cv) return;
+    const FftApi &f = fft_api();
+    if (f.ok) {
+        if (cv->plan_x) f.destroy(cv->plan_x);
+        if (cv->plan_h) f.destroy(cv->plan_h);
+        if (cv->plan_inv) f.destroy(cv->plan_inv);
+    }
+    delete cv;
+}
+
+extern "C" size_t mst_fx_convolver_workspace_bytes(const MstConvolver *cv) {
+    if (!cv) return 0;
+    const size_t nbin = (size_t)cv->n_fft / 2 + 1, seqs = (size_t)cv->n_items * cv->C + cv->C;
+    return seqs * (size_t)cv->n_fft * sizeof(float) + seqs * nbin * sizeof(float2) + 256;
+}
+
+extern "C" int mst_fx_convolve(MstConvolver *cv, const float *x, const float *h, long Lh, float *y, long offset, double dry,
+                               double wet, void *ws, size_t ws_bytes, void *stream) {
+    if (!cv || !x || !h || !y || !ws) return fail(MST_ERR_ARG, "mst_fx_convolve: bad argument");
+    if (Lh < 1 || Lh > cv->Lh_max) return fail(MST_ERR_ARG, "mst_fx_convolve: impulse response longer than the convolver was created for");
+    if (offset < 0 || offset > Lh - 1) return fail(MST_ERR_ARG, "mst_fx_convolve: offset outside [0, Lh-1]");
+    if (ws_bytes < mst_fx_convolver_workspace_bytes(cv)) return fail(MST_ERR_WORKSPACE, "mst_fx_convolve: workspace too small");
+    const FftApi &f = fft_api();
+    const long n = cv->n_fft, nbin = n / 2 + 1;
+    const int nseq = cv->n_items * cv->C, C = cv->C;
+    float *rx = (float *)ws, *rh = rx + (size_t)nseq * n;
+    float2 *cx = (float2 *)(((uintptr_t)(rh + (size_t)C * n) + 255) & ~(uintptr_t)255), *ch = cx + (size_t)nseq * nbin;
+    const unsigned gb = (unsigned)((n + 255) / 256);
+    MST_LAUNCH(fx_conv_pack_kernel, dim3(gb, nseq), dim3(256), stream, x, rx, cv->L, C, n);
+    MST_CHECK_LAUNCH("fx_conv_pack_kernel");
+    MST_LAUNCH(fx_conv_pack_kernel, dim3(gb, C), dim3(256), stream, h, rh, Lh, C, n);       // the IR is one [Lh][C] "item"
+    MST_CHECK_LAUNCH("fx_conv_pack_kernel");
+    if (f.set_stream(cv->plan_x, (hipStream_t)stream) || f.set_stream(cv->plan_h, (hipStream_t)stream) ||
+        f.set_stream(cv->plan_inv, (hipStream_t)stream))
+        return fail(MST_ERR_HIP, "mst_fx_convolve: hipfftSetStream failed");
+    if (f.exec_r2c(cv->plan_x, rx, cx) || f.exec_r2c(cv->plan_h, rh, ch)) return fail(MST_ERR_HIP, "mst_fx_convolve: hipfftExecR2C failed");
+    MST_LAUNCH(fx_conv_mul_kernel, dim3((unsigned)((nbin + 255) / 256), nseq), dim3(256), stream, cx, (const float2 *)ch, nbin, C,
+               1.0f / (float)n);
+    MST_CHECK_LAUNCH("fx_conv_mul_kernel");
+    if (f.exec_c2r(cv->plan_inv, cx, rx)) return fail(MST_ERR_HIP, "mst_fx_convolve: hipfftExecC2R failed");
+    const long per = cv->L * C;
+    MST_LAUNCH(fx_conv_mix_kernel, dim3((unsigned)((per + 255) / 256), cv->n_items), dim3(256), stream, x, (const float *)rx, y, cv->L,
+               C, n, offset, (float)dry, (float)wet);
+    MST_CHECK_LAUNCH("fx_conv_mix_kernel");
+    return MST_OK;
+}
+
 extern "C" int mst_fx_rms_normalize(const float *x, float *y, int n_items, long L, int C, double *scratch, void *stream) {
     if (!x || !y || !scratch || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_rms_normalize: bad argument");
     const long per = L * C;

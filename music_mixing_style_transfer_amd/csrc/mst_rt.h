@@ -29,3 +29,18 @@ __device__ __forceinline__ float mst_fmax(float a, float b) {
 
 // opaque identity on an integer in a vector register: values derived from it are recomputed rather than kept live
 #define MST_LAUNDER(v) asm volatile("" : "+v"(v))
+
+// hipFFT entry points bound at first use (no link-time dependency); returns false when the library cannot be loaded
+#include <dlfcn.h>
+static inline bool mst_fft_bind(void **plan_many, void **set_stream, void **exec_r2c, void **exec_c2r, void **destroy) {
+    void *lib = nullptr;
+    for (const char *name : {"libhipfft.so.0", "libhipfft.so", "/opt/rocm/lib/libhipfft.so"})
+        if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) return false;
+    *plan_many = dlsym(lib, "hipfftPlanMany");
+    *set_stream = dlsym(lib, "hipfftSetStream");
+    *exec_r2c = dlsym(lib, "hipfftExecR2C");
+    *exec_c2r = dlsym(lib, "hipfftExecC2R");
+    *destroy = dlsym(lib, "hipfftDestroy");
+    return *plan_many && *set_stream && *exec_r2c && *exec_c2r && *destroy;
+}

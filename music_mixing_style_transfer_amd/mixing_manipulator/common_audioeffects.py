@@ -258,6 +258,96 @@ class Gain(Processor):
         return d.out(y)
 
 
+class ConvolutionalReverb(Processor):
+    """Convolution reverb (reference common_audioeffects.py:665-764): the input is convolved (full linear convolution, per
+    channel) with one of the given impulse responses, the wet signal is cut out starting at the IR's peak (+ pre-delay) and
+    mixed `dry * x + wet * y`.  The convolution runs on the device (mst_fx_convolve: hipFFT transforms + HIP kernels);
+    IR selection, the optional decay fade and the mono/stereo adaptation are the reference's host-side steps.
+
+    impulse_responses: list (one entry per RT60 group) of lists of dicts whose 'impulse_response' entry is a callable
+    returning an [n_samples, n_channels] array - the structure `create_dataset` produces in the reference."""
+
+    def __init__(self, impulse_responses, sample_rate, name="ConvolutionalReverb", parameters=None):
+        super().__init__(name, parameters=parameters, block_size=None, sample_rate=sample_rate)
+        if impulse_responses is None:
+            raise ValueError("List of impulse responses must be provided for ConvolutionalReverb processor.")
+        self.impulse_responses = impulse_responses
+        self._convolvers = {}
+        if not parameters:
+            self.parameters = ParameterList()
+            self.max_ir_num = len(max(impulse_responses, key=len))
+            self.parameters.add(Parameter("index", 0, "int", minimum=0, maximum=len(impulse_responses)))
+            self.parameters.add(Parameter("index_ir", 0, "int", minimum=0, maximum=self.max_ir_num))
+            self.parameters.add(Parameter("wet", 1.0, "float", minimum=1.0, maximum=1.0))
+            self.parameters.add(Parameter("dry", 0.0, "float", minimum=0.0, maximum=0.0))
+            self.parameters.add(Parameter("decay", 1.0, "float", minimum=1.0, maximum=1.0))
+            self.parameters.add(Parameter("pre_delay", 0, "int", units="ms", minimum=0, maximum=0))
+
+    def update(self, parameter_name=None):
+        group = self.impulse_responses[self.parameters.index.value]
+        entry = group[self.parameters.index_ir.value % len(group)]
+        h = np.array(entry["impulse_response"](), copy=True)
+        decay = self.parameters.decay.value
+        if decay < 1.0:          # fade the tail out over 20 ms, starting `decay` of the way from the peak to the end
+            n = h.shape[0]
+            peak = int(np.argmax(np.max(np.abs(h), axis=1), axis=0))
+            # np.minimum yields NumPy integers: the ramp then promotes exactly like the reference's (float64 under NumPy 2)
+            fstart = np.minimum(n, peak + int(decay * (n - peak)))
+            fstop = np.minimum(n, fstart + int(0.020 * self.sample_rate))
+            flen = fstop - fstart
+            ramp = np.arange(1, flen + 1, dtype=self.dtype) / flen
+            h[fstart:fstop, :] *= np.power(0.1, ramp * 5)[:, np.newaxis]
+            h = h[:fstop]
+        self.h = h
+
+    def __del__(self):
+        try:
+            lib = _lib.lib()
+            for cv, _ in self._convolvers.values():
+                lib.mst_fx_convolver_destroy(cv)
+        except Exception:
+            pass
+
+    def _convolver(self, lib, L, Lh, n, Cn, device):
+        key = (lib.path, L, n, Cn, str(device))
+        cur = self._convolvers.get(key)
+        if cur is None or cur[1] < Lh:
+            if cur is not None:
+                lib.mst_fx_convolver_destroy(cur[0])
+            h = C.c_void_p()
+            cap = max(Lh, 1 << max(0, (Lh - 1).bit_length()))      # room for longer IRs of later calls
+            lib.check(lib.mst_fx_convolver_create(L, cap, n, Cn, C.byref(h)), "mst_fx_convolver_create")
+            cur = (h, cap)
+            self._convolvers[key] = cur
+        return cur[0]
+
+    def process(self, x):
+        d = _Dev(x)
+        if not hasattr(self, "h"):
+            self.update()
+        if self.h.shape[1] == 1 and d.C > 1:
+            self.h = np.hstack([self.h] * d.C)                      # mono IR on multi-channel audio
+        if self.h.shape[1] > 1 and d.C == 1:
+            self.h = self.h[:, np.random.randint(self.h.shape[1]), np.newaxis]     # one IR channel, chosen at random
+        if self.parameters.wet.value == 0.0:
+            return d.out(d.x.clone())
+        if self.h.shape[1] != d.C:
+            raise ValueError(f"impulse response has {self.h.shape[1]} channels, audio has {d.C}")
+        h32 = np.ascontiguousarray(self.h, dtype=np.float32)
+        idx = int(np.argmax(np.max(np.abs(self.h), axis=1), axis=0))
+        idx += int(0.001 * np.abs(self.parameters.pre_delay.value) * self.sample_rate)
+        idx = int(np.clip(idx, 0, h32.shape[0] - 1))
+        hd = torch.from_numpy(h32).to(d.x.device)
+        cv = self._convolver(d.lib, d.L, h32.shape[0], d.n, d.C, d.x.device)
+        nbytes = d.lib.mst_fx_convolver_workspace_bytes(cv)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=d.x.device)
+        y = torch.empty_like(d.x)
+        d.lib.check(d.lib.mst_fx_convolve(cv, d.x.data_ptr(), hd.data_ptr(), h32.shape[0], y.data_ptr(), idx,
+                                          float(self.parameters.dry.value), float(self.parameters.wet.value), ws.data_ptr(),
+                                          nbytes, d.stream), "mst_fx_convolve")
+        return d.out(y)
+
+
 class Haas(Processor):
     """Haas effect: one channel gets `feedback` times a circularly delayed copy of itself added (reference
     common_audioeffects.py:768-856; np.roll wraps around, the delay may be negative).  Mono input becomes stereo."""

@@ -123,6 +123,39 @@ def panner_gains(pan, pan_law="-4.5dB", dtype=np.float32):
     return g
 
 
+# ----------------------------------------------------------------------------- convolution reverb
+def reverb_fade(h, decay, sample_rate, dtype=np.float32):
+    """ConvolutionalReverb.update (common_audioeffects.py:714-725): 20 ms fade-out of the IR tail, starting `decay` of the way
+    from the peak to the end; the IR is cut at the end of the fade."""
+    h = np.array(h, copy=True)
+    if decay >= 1.0:
+        return h
+    n = h.shape[0]
+    peak = int(np.argmax(np.max(np.abs(h), axis=1), axis=0))
+    # np.minimum yields NumPy integers: the ramp below then promotes exactly like the reference's (float64 under NumPy 2)
+    fstart = np.minimum(n, peak + int(decay * (n - peak)))
+    fstop = np.minimum(n, fstart + int(0.020 * sample_rate))
+    flen = fstop - fstart
+    fade = np.power(0.1, (np.arange(1, flen + 1, dtype=dtype) / flen) * 5)
+    h[fstart:fstop, :] *= fade[:, np.newaxis]
+    return h[:fstop]
+
+
+def conv_reverb(x, h, dry=0.0, wet=1.0, pre_delay_ms=0, sample_rate=44100):
+    """ConvolutionalReverb.process (:727-764) in float64: full linear convolution per channel (the reference calls
+    scipy.signal.oaconvolve in the input precision), wet signal cut at the IR peak (+ pre-delay), dry/wet mix."""
+    from scipy.signal import fftconvolve
+    x64, h64 = np.asarray(x, np.float64), np.asarray(h, np.float64)
+    if h64.shape[1] == 1 and x64.shape[1] > 1:
+        h64 = np.hstack([h64] * x64.shape[1])
+    if wet == 0.0:
+        return np.asarray(x)
+    y = fftconvolve(x64, h64, mode="full", axes=0)
+    idx = int(np.argmax(np.max(np.abs(h64), axis=1), axis=0)) + int(0.001 * abs(pre_delay_ms) * sample_rate)
+    idx = int(np.clip(idx, 0, h64.shape[0] - 1))
+    return dry * x64 + wet * y[idx:idx + x64.shape[0], :]
+
+
 # ----------------------------------------------------------------------------- equaliser (UNPINNED)
 def rbj_biquad(filter_type, gain_db, q, fc, rate):
     """RBJ cookbook biquad -> (b[3], a[3]) normalised so a[0] == 1, float64."""

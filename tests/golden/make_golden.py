@@ -14,6 +14,7 @@ Fixtures:
                     strided index set + fp64 checksums, per-block probes
   bookkeeping.npz   batchwise_segmentization tables for edge-case lengths
   fx.npz            compressor / imager / gain / haas / panner / rms-normalise vectors
+  fx_reverb.npz     ConvolutionalReverb outputs (python tests/golden/make_golden.py reverb regenerates only this one)
 """
 import os
 import sys
@@ -292,5 +293,43 @@ def main():
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
 
+def reverb_goldens():
+    """fx_reverb.npz: ConvolutionalReverb (common_audioeffects.py:665-764, scipy.signal.oaconvolve inside) on seeded
+    audio and synthetic impulse responses: stereo IR; mono IR with decay fade, pre-delay and a dry/wet mix."""
+    import importlib.util
+    install_stubs()
+    sys.path.insert(0, os.path.join(REF, "mixing_style_transfer", "mixing_manipulator"))
+    spec = importlib.util.spec_from_file_location(
+        "ref_fx", os.path.join(REF, "mixing_style_transfer", "mixing_manipulator", "common_audioeffects.py"))
+    fxm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fxm)
+    Lf = 4096
+    xs = (0.25 * synth.synth_music(2, Lf, seed=4).numpy().T + 0.05 * synth.synth_audio((Lf, 2), seed=5).numpy()).astype(np.float32)
+    t = np.arange(1500, dtype=np.float64)
+    env = np.exp(-t / 300.0)
+    h2 = (synth.synth_audio((1500, 2), seed=6).numpy().astype(np.float64) * env[:, None] * 0.2).astype(np.float32)
+    h2[37] = (0.9, -0.8)                       # a clear peak away from index 0
+    h1 = (synth.synth_audio((900, 1), seed=7).numpy().astype(np.float64) * np.exp(-np.arange(900) / 150.0)[:, None] * 0.3).astype(np.float32)
+    h1[5] = 0.7
+    irs = [[{"impulse_response": (lambda: h2)}], [{"impulse_response": (lambda: h1)}, {"impulse_response": (lambda: h2)}]]
+    out = {"x": xs, "h_stereo": h2, "h_mono": h1}
+    rv = fxm.ConvolutionalReverb(irs, 44100)
+    rv.update()
+    out["y_stereo"] = rv.process(xs.copy())
+    rv.parameters.index.value, rv.parameters.index_ir.value = 1, 2          # group 1, 2 % 2 = entry 0: the mono IR
+    rv.parameters.decay.value, rv.parameters.pre_delay.value = 0.5, 3
+    rv.parameters.dry.value, rv.parameters.wet.value = 0.3, 0.7
+    rv.update()
+    out["h_mono_faded"] = np.array(rv.h)
+    out["y_mono_fade_predelay_mix"] = rv.process(xs.copy())
+    out["y_mono_input"] = rv.process(xs[:, :1].copy())                      # mono audio, (now stereo-stacked) IR -> random channel
+    np.savez_compressed(os.path.join(HERE, "fx_reverb.npz"), **out)
+    print("fx_reverb.npz", os.path.getsize(os.path.join(HERE, "fx_reverb.npz")), {k: (v.shape, v.dtype) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "reverb":
+        reverb_goldens()
+    else:
+        main()
+        reverb_goldens()

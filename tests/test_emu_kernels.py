@@ -221,3 +221,114 @@ def test_tcn_duo_kernel_matches_default_emulated(emu_default, monkeypatch):
         for n, r in zip((2, 3, 4), ref):
             assert torch.equal(m.forward_blocks(x, cond, n), r), (shape, wgs, n)
     monkeypatch.delenv("MST_TCN_DUO", raising=False)
+
+
+def test_conv_reverb_emulated(emu_default):
+    """f-3: ConvolutionalReverb through mst_fx_convolve (host FFT stand-ins in the emulator) vs the reference's outputs."""
+    import os
+    from music_mixing_style_transfer_amd.mixing_manipulator import ConvolutionalReverb
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fx_reverb.npz"))
+    x, h2, h1 = g["x"], g["h_stereo"], g["h_mono"]
+    irs = [[{"impulse_response": (lambda: h2)}], [{"impulse_response": (lambda: h1)}, {"impulse_response": (lambda: h2)}]]
+    rv = ConvolutionalReverb(irs, 44100)
+    rv.update()
+    y = rv.process(x.copy())
+    assert y.dtype == np.float32 and np.abs(y - g["y_stereo"]).max() <= 5e-6 * np.abs(g["y_stereo"]).max()
+    rv.parameters.index.value, rv.parameters.index_ir.value = 1, 2
+    rv.parameters.decay.value, rv.parameters.pre_delay.value = 0.5, 3
+    rv.parameters.dry.value, rv.parameters.wet.value = 0.3, 0.7
+    rv.update()
+    assert np.array_equal(rv.h, g["h_mono_faded"])
+    y = rv.process(x.copy())
+    assert np.abs(y - g["y_mono_fade_predelay_mix"]).max() <= 5e-6 * np.abs(g["y_mono_fade_predelay_mix"]).max()
+    y = rv.process(x[:, :1].copy())
+    assert y.shape == (len(x), 1) and np.abs(y - g["y_mono_input"]).max() <= 5e-6 * np.abs(g["y_mono_input"]).max()
+    # batched items share the impulse response; wet = 0 returns the input
+    xb = np.stack([x, 0.5 * x[::-1].copy()])
+    rv2 = ConvolutionalReverb(irs, 44100)
+    yb = rv2.process(xb)
+    assert np.abs(yb[1] - F.conv_reverb(xb[1], h2)).max() <= 5e-6 * np.abs(yb[1]).max()
+    rv2.parameters.wet.value = 0.0
+    assert np.array_equal(rv2.process(x.copy()), x)
+    with pytest.raises(ValueError):
+        ConvolutionalReverb(None, 44100)
+
+
+def _oracle_replay(chain, x_list):
+    """Re-apply an AugmentationChain that has just run (probabilities 1) with the oracle, reading the parameter values its
+    processors ended up with: the device chain and the numpy oracle must agree effect by effect."""
+    from music_mixing_style_transfer_amd.mixing_manipulator import (AugmentationChain, Compressor, ConvolutionalReverb, Equaliser,
+                                                                     Gain, MidSideImager, Panner)
+    y_list = list(x_list)
+    for fx, p, rms in chain.fxs:
+        assert p >= 1
+        if isinstance(fx, AugmentationChain):
+            y_list = _oracle_replay(fx, y_list)
+            continue
+        out = []
+        for x in y_list:
+            P = fx.parameters
+            if isinstance(fx, Equaliser):
+                prm = {b: (getattr(P, b + "_gain").value, getattr(P, b + "_freq").value,
+                           getattr(P, b + "_q").value if hasattr(P, b + "_q") else 0.707) for b in fx.bands}
+                y = F.equaliser(x, prm, bands=fx.bands)
+            elif isinstance(fx, Compressor):
+                y = F.compressor(x, P.threshold.value, P.attack_time.value, P.release_time.value, P.ratio.value)
+            elif isinstance(fx, Panner):
+                y = x * F.panner_gains(P.pan.value, P.pan_law.value)
+            elif isinstance(fx, MidSideImager):
+                y = F.midside_imager(x, P.bal.value)
+            elif isinstance(fx, ConvolutionalReverb):
+                y = F.conv_reverb(x, fx.h, P.dry.value, P.wet.value, P.pre_delay.value).astype(np.float32)
+            elif isinstance(fx, Gain):
+                y = F.gain(x, P.gain.value, P.invert.value)
+            else:
+                raise AssertionError(type(fx))
+            out.append(F.rms_normalize(x, y).astype(np.float32) if rms else np.asarray(y, np.float32))
+        y_list = out
+    if chain.parallel:
+        w = chain.parallel_weight_factor
+        y_list = [w * x + (1 - w) * y for x, y in zip(x_list, y_list)]
+    return y_list
+
+
+def test_fx_manipulator_chains_emulated(emu_default, tmp_path):
+    """f-3: the instrument FX chains (create_inst_effects_augmentation_chain) - structure like the reference's, and the
+    whole drums chain (shuffled eq/comp, pan/imager, low/high parallel convolution reverb, gain) against an oracle replay."""
+    import os
+    import random
+    from music_mixing_style_transfer_amd.data_loader import save_wav_pcm16
+    from music_mixing_style_transfer_amd.mixing_manipulator import (AugmentationChain, create_effects_augmentation_chain,
+                                                                     create_inst_effects_augmentation_chain, load_impulse_responses)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fx_reverb.npz"))
+    for rt, name, h in (("300-600", "roomA", g["h_stereo"][:400]), ("300-600", "roomB", g["h_mono"][:300]),
+                        ("3000-6000", "hall", g["h_stereo"][:500]), ("0-300", "ignored", g["h_mono"][:50])):
+        d = tmp_path / "IR_set1" / "RT60_avg" / rt / name
+        d.mkdir(parents=True)
+        save_wav_pcm16(str(d / "impulse_response.wav"), h)
+    ir_dir = str(tmp_path / "IR_")
+    groups = load_impulse_responses(ir_dir)
+    assert [len(gr) for gr in groups] == [2, 1]            # "0-300" is skipped by the reference's glob, >= 3000 ms merged last
+    assert groups[0][1]["impulse_response"]().shape == (300, 1) and groups[1][0]["impulse_response"]().shape == (500, 2)
+    probs = {"eq": 1, "comp": 1, "pan": 1, "imager": 1, "reverb": 100, "gain": 1}      # reverb * 0.01 = 1 on the low branch
+    chain = create_inst_effects_augmentation_chain("drums", probs, ir_dir_path=ir_dir)
+    eq_comp, pan_img, rev, gain = chain.fxs
+    assert eq_comp[0].shuffle and pan_img[0].shuffle and not eq_comp[2] and gain[0].name == "Gain" and gain[2] is False
+    assert [type(f[0]).__name__ for f in eq_comp[0].fxs] == ["Equaliser", "Compressor"] and all(f[2] for f in eq_comp[0].fxs)
+    low, high = rev[0].fxs[0][0], rev[0].fxs[1][0]
+    assert low.parallel and low.parallel_weight_factor == 0.8 and high.parallel_weight_factor == 0.6
+    assert low.fxs[0][0].bands == ["high_shelf"] and high.fxs[0][0].bands == ["low_shelf"] and low.fxs[1][1] == 1.0
+    other = create_inst_effects_augmentation_chain("vocals", probs, ir_dir_path=ir_dir)
+    assert other.fxs[2][0].parallel and other.fxs[2][0].parallel_weight_factor is None
+    with pytest.raises(NotImplementedError):
+        create_inst_effects_augmentation_chain("bass", probs)                          # algorithmic reverb: not on this path
+    with pytest.raises(ValueError):
+        create_effects_augmentation_chain(["flanger"])
+    np.random.seed(3)
+    random.seed(3)
+    x = g["x"][:1200].copy()
+    y = chain([x.copy(), 0.5 * x[::-1].copy()])
+    ref = _oracle_replay(chain, [x.copy(), 0.5 * x[::-1].copy()])
+    for a, b in zip(y, ref):
+        assert a.shape == x.shape and np.isfinite(a).all()
+        assert np.abs(a - b).max() <= 2e-5 * max(1e-3, np.abs(b).max())

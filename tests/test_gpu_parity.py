@@ -255,6 +255,39 @@ def test_haas_panner_vs_golden_and_oracle():
     assert np.array_equal(pn.process(mono.cuda()).cpu().numpy(), np.repeat(mono.numpy(), 2, axis=1) * F.panner_gains(0.5, "constant_power"))
 
 
+def test_conv_reverb_vs_golden_and_oracle():
+    """f-3 on the device (hipFFT + HIP kernels): the reference's own ConvolutionalReverb outputs (golden), and a full-size
+    case (8 segments of 131072 x 2, 1.5 s impulse response) against the float64 oracle.  Tolerance 1e-5 * max|y|: float32 FFTs
+    of 2**18 points on both sides (the reference itself convolves in float32 through scipy.signal.oaconvolve)."""
+    from music_mixing_style_transfer_amd.mixing_manipulator import ConvolutionalReverb
+    from music_mixing_style_transfer_amd.utils import synth
+    from oracle import fx_ref as F
+    g = np.load(os.path.join(GOLD, "fx_reverb.npz"))
+    x, h2, h1 = g["x"], g["h_stereo"], g["h_mono"]
+    irs = [[{"impulse_response": (lambda: h2)}], [{"impulse_response": (lambda: h1)}, {"impulse_response": (lambda: h2)}]]
+    rv = ConvolutionalReverb(irs, 44100)
+    rv.update()
+    assert np.abs(rv.process(x.copy()) - g["y_stereo"]).max() <= 5e-6 * np.abs(g["y_stereo"]).max()
+    rv.parameters.index.value, rv.parameters.index_ir.value = 1, 2
+    rv.parameters.decay.value, rv.parameters.pre_delay.value = 0.5, 3
+    rv.parameters.dry.value, rv.parameters.wet.value = 0.3, 0.7
+    rv.update()
+    y = rv.process(x.copy())
+    assert np.abs(y - g["y_mono_fade_predelay_mix"]).max() <= 5e-6 * np.abs(g["y_mono_fade_predelay_mix"]).max()
+    # full segment size, long impulse response, batched
+    n, L, Lh = 8, 131072, 66150
+    xs = (0.1 * torch.randn(n, L, 2, generator=torch.Generator().manual_seed(5))).clamp_(-1, 1)
+    env = np.exp(-np.arange(Lh) / 12000.0)[:, None]
+    hl = (synth.synth_audio((Lh, 2), seed=9).numpy().astype(np.float64) * env * 0.05).astype(np.float32)
+    hl[441] = (0.8, 0.7)
+    big = ConvolutionalReverb([[{"impulse_response": (lambda: hl)}]], 44100)
+    big.update()
+    yd = big.process(xs.cuda()).cpu().numpy()
+    for i in (0, n - 1):
+        ref = F.conv_reverb(xs[i].numpy(), hl)
+        assert np.abs(yd[i] - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
 def test_product_fails_loudly_on_cpu_tensor(nets):
     with pytest.raises(RuntimeError):
         nets["tcn"](torch.zeros(1, 2, 1024), torch.zeros(1, 2048))
@@ -313,6 +346,41 @@ def test_style_transfer_cli_end_to_end(tmp_path):
     assert mix.shape == (2, L_in)
     # fp32 path: waveform deviation <= 1e-4, plus one 16-bit quantisation step of the written file
     assert np.abs(mix - np.clip(ref_mix, -1, 1)).max() <= 1e-4 + 1.0 / 32767
+
+
+def test_config2_three_minute_stem_at_full_segment_length(nets):
+    """BASELINE config 2 at its real sizes: one 3-minute stereo stem pair (7 938 000 samples), segment_length 2**19 =>
+    16 segments (15 full + zero-padded tail) for both roles, fp32 mode.  The whole converted stem is checked through
+    size-independent properties (shape, crop, clamp, bit-identical recomputation of a segment on its own); the mean
+    embedding and the zero-padded TAIL segment are checked against the oracle (<= 1e-4, north_star's tolerance)."""
+    from music_mixing_style_transfer_amd.inference import StyleTransferEngine
+    from music_mixing_style_transfer_amd.utils import synth
+    from oracle import networks_ref as R
+    from oracle import segmentation_ref as O
+    seg_len, L = 2 ** 19, 7_938_000
+    x_in = synth.synth_music(2, L, seed=21)
+    x_ref = synth.synth_music(2, L, seed=22)
+    eng = StyleTransferEngine(nets["enc"], nets["tcn"])
+    y = eng.transfer_stem(x_in.cuda(), x_ref.cuda(), seg_len, seg_len).cpu()
+    assert y.shape == (2, L) and float(y.abs().max()) <= 1.0 and bool(torch.isfinite(y).all())
+    # bookkeeping at this size (bit-exact, from the oracle's table): 16 segments, the last one zero padded
+    plan = O.segment_plan(L, seg_len, 1 << 30)
+    assert plan["n_seg"] == 16 and plan["pad"] == 16 * seg_len - L
+    # mean embedding vs oracle over all 16 reference segments (incl. the zero-padded tail, quirk 9)
+    rb = O.reference_batches(x_ref.numpy(), seg_len, seg_len, 4)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    embs = [R.fxencoder_forward(nets["enc_sd"], nets["enc_cfg"], torch.from_numpy(b)).numpy() for b in rb]
+    emb = torch.from_numpy(O.mean_embedding(embs))
+    _, emb_dev = eng.reference_embedding(torch.from_numpy(np.concatenate(rb, 0)).cuda())
+    assert float((emb_dev.cpu() - emb).abs().max()) <= 1e-4 * max(1.0, float(emb.abs().max()))
+    # the tail segment through the oracle TCN with the oracle's embedding
+    tail = np.zeros((1, 2, seg_len), np.float32)
+    tail[0, :, :L - 15 * seg_len] = x_in.numpy()[:, 15 * seg_len:]
+    y_tail = R.tcn_forward(nets["tcn_sd"], torch.from_numpy(tail), emb[None])[0, :, :L - 15 * seg_len]
+    assert float((y[:, 15 * seg_len:] - y_tail).abs().max()) <= 1e-4
+    # segments are independent: segment 7 recomputed alone is bit-identical to its slice of the full run
+    alone = nets["tcn"](x_in[None, :, 7 * seg_len:8 * seg_len].cuda(), emb_dev[None]).cpu()[0]
+    assert torch.equal(alone, y[:, 7 * seg_len:8 * seg_len])
 
 
 def test_feature_extraction_cli(tmp_path):

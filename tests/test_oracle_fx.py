@@ -60,3 +60,18 @@ def test_eq_flat_is_identity_and_chain_runs():
     assert np.abs(F.equaliser(x, {}) - x).max() <= 1e-6      # 0 dB on every band
     y = F.fx_chain(x)
     assert y.shape == x.shape and y.dtype == np.float32 and np.isfinite(y).all()
+
+
+def test_conv_reverb_matches_reference():
+    """oracle/fx_ref.conv_reverb + reverb_fade vs the reference's ConvolutionalReverb outputs (tests/golden/fx_reverb.npz).
+    The reference convolves in float32 (scipy oaconvolve); the float64 oracle agrees to float32 FFT round-off."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fx_reverb.npz"))
+    x = g["x"]
+    y = F.conv_reverb(x, g["h_stereo"])
+    assert np.abs(y - g["y_stereo"]).max() <= 2e-6 * np.abs(g["y_stereo"]).max()
+    hf = F.reverb_fade(g["h_mono"], 0.5, 44100)
+    assert np.array_equal(hf, g["h_mono_faded"])
+    y = F.conv_reverb(x, hf, dry=0.3, wet=0.7, pre_delay_ms=3)
+    assert np.abs(y - g["y_mono_fade_predelay_mix"]).max() <= 2e-6 * np.abs(g["y_mono_fade_predelay_mix"]).max()
+    y = F.conv_reverb(x[:, :1], hf, dry=0.3, wet=0.7, pre_delay_ms=3)
+    assert np.abs(y - g["y_mono_input"]).max() <= 2e-6 * np.abs(g["y_mono_input"]).max()
