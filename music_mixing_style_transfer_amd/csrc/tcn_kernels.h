@@ -43,6 +43,8 @@ struct TcnBlockArgs {
     int nout;
     long long *prof;      // developer hook: per-workgroup shader-clock stamps at phase boundaries (null = off)
     int stagger, stagger2; // developer hook: first-generation start delays (clocks): spread over CUs / extra for the 2nd workgroup of a CU
+    int xcd_tiles;        // > 0: tiles per XCD; workgroup i (dispatched to XCD i % 8) takes tile (i % 8) * xcd_tiles + i / 8, so that
+                          // neighbouring time tiles (which share their halo rows) run on the same XCD and meet in its L2
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ln = lane & 31, h = lane >> 5;
 
-    int tile = blockIdx.x;
+    int tile = a.xcd_tiles > 0 ? (int)(blockIdx.x & 7) * a.xcd_tiles + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int mg = tile % a.tiles_step;
     tile /= a.tiles_step;
     const int pg = tile % a.tiles_phase;
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void tcn_block_f32_kernel(TcnBlockArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ln = lane & 31, h = lane >> 5;
 
-    int tile = blockIdx.x;
+    int tile = a.xcd_tiles > 0 ? (int)(blockIdx.x & 7) * a.xcd_tiles + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int mg = tile % a.tiles_step;
     tile /= a.tiles_step;
     const int pg = tile % a.tiles_phase;
