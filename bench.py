@@ -157,7 +157,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"configs[1]: batch={B} segments of 2x{SEG_LEN} per GPU, FXencoder+MixFXcloner forward, "
                                    f"default configs.yaml nets, synthetic weights; TCN dense blocks {args.precision} MFMA "
-                                   f"(fp32 accumulate), FXencoder convs {args.precision} MFMA (fp32 activations)",
+                                   f"(fp32 accumulate), FXencoder convs {args.precision} MFMA",
                        "segments_per_gpu": B, "segment_length": SEG_LEN,
                        "parallelism": f"segment-sharded x{world}, all-gather of embeddings"},
             "roofline": {"kernel": "tcn_block_%s_kernel (dilated 128x128x15 conv + fused BN/LeakyReLU/FiLM/residual)" %

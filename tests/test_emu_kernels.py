@@ -215,12 +215,17 @@ def test_tcn_duo_kernel_matches_default_emulated(emu_default, monkeypatch):
     cond = synth.synth_audio((1, 64), seed=2)
     for shape, wgs in (((2, 2, 777), 2), ((1, 2, 300), 5), ((3, 2, 1100), 1)):
         x = synth.synth_audio(shape, seed=shape[2])
-        monkeypatch.delenv("MST_TCN_DUO", raising=False)
-        ref = [m.forward_blocks(x, cond, n).clone() for n in (2, 3, 4)]
-        monkeypatch.setenv("MST_TCN_DUO", str(wgs))
-        for n, r in zip((2, 3, 4), ref):
-            assert torch.equal(m.forward_blocks(x, cond, n), r), (shape, wgs, n)
+        for cnd in (cond, synth.synth_audio((shape[0], 64), seed=9)):          # broadcast row / one FiLM row per batch item
+            monkeypatch.delenv("MST_TCN_DUO", raising=False)
+            ref = [m.forward_blocks(x, cnd, n).clone() for n in (2, 3, 4)]
+            monkeypatch.setenv("MST_TCN_DUO", str(wgs))
+            for n, r in zip((2, 3, 4), ref):
+                assert torch.equal(m.forward_blocks(x, cnd, n), r), (shape, wgs, n)
     monkeypatch.delenv("MST_TCN_DUO", raising=False)
+    # bf16, per-item rows vs the oracle (default kernel)
+    x = synth.synth_audio((2, 2, 500), seed=3)
+    cB = synth.synth_audio((2, 64), seed=10)
+    assert float((m(x, cB) - R.tcn_forward(sd, x, cB, nblocks=4)).abs().max()) <= 4e-2
 
 
 def test_conv_reverb_emulated(emu_default):

@@ -91,6 +91,12 @@ def test_tcn_bf16_vs_oracle(nets):
             assert err <= 3e-2 * float(col[n - 1].abs().max()), f"block {n}: {err}"
         y = tcn(x.cuda(), cond.cuda()).cpu()
         assert float((y - y_ref).abs().max()) <= 5e-2
+        # per-item condition rows (cond [B, 2048]): the block kernels pick the FiLM row of their tile's batch item
+        condB = synth.synth_audio((2, 2048), seed=8, amp=0.5).abs()
+        yB = tcn(x.cuda(), condB.cuda()).cpu()
+        assert float((yB - R.tcn_forward(nets["tcn_sd"], x, condB)).abs().max()) <= 5e-2
+        for i in range(2):      # ... and equals running that item alone with its own row, bit for bit
+            assert torch.equal(tcn(x[i:i + 1].cuda(), condB[i:i + 1].cuda()).cpu()[0], yB[i])
     finally:
         tcn.precision = "fp32"
 
