@@ -15,6 +15,7 @@ Fixtures:
   bookkeeping.npz   batchwise_segmentization tables for edge-case lengths
   fx.npz            compressor / imager / gain / haas / panner / rms-normalise vectors
   fx_reverb.npz     ConvolutionalReverb outputs (python tests/golden/make_golden.py reverb regenerates only this one)
+  interp.npz        inference_interpolation orchestration with stand-in networks (... make_golden.py interp)
 """
 import os
 import sys
@@ -327,9 +328,82 @@ def reverb_goldens():
     print("fx_reverb.npz", os.path.getsize(os.path.join(HERE, "fx_reverb.npz")), {k: (v.shape, v.dtype) for k, v in out.items()})
 
 
+def interpolation_goldens():
+    """interp.npz: the reference's inference_interpolation (style_transfer.py:181-270) run on small deterministic stems with
+    stand-in networks (an 'encoder' and a 'converter' that are cheap closed-form functions of their inputs), so that the
+    fixture pins the ORCHESTRATION: L//S+1 input segmentation, per-batch-index blend weights, reference B cut by
+    segment_length, stack/mean of embeddings, concatenation, crop and remix.  sf.write is captured instead of writing files."""
+    import importlib.util
+    install_stubs()
+    sys.path.insert(0, os.path.join(REF, "mixing_style_transfer"))
+    sys.path.insert(0, os.path.join(REF, "inference"))
+    spec = importlib.util.spec_from_file_location("ref_style_transfer", os.path.join(REF, "inference", "style_transfer.py"))
+    st = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(st)
+    written = {}
+    st.sf = types.SimpleNamespace(write=lambda path, data, sr, subtype: written.__setitem__(os.path.basename(path), np.array(data)))
+
+    class Enc:
+        def eval(self):
+            return self
+
+        def __call__(self, x):          # [b, 2, L] -> [b, 6]: a few time statistics per channel
+            return torch.cat([x.mean(-1), x.abs().mean(-1), (x * x).mean(-1)], dim=1)
+
+    class Conv:
+        def eval(self):
+            return self
+
+        def __call__(self, x, cond):    # depends on every entry of the blended embedding
+            c = cond[0]
+            return x * (1.0 + c[0] - 0.5 * c[3]) + 0.1 * c[1] - 0.2 * c[4] + 0.05 * (c[2] + c[5]) * torch.flip(x, dims=(1,))
+
+    out = {}
+    cases = [dict(L=1000, La=500, Lb=900, S=7, seg=256, seg_ref=300, bs=2), dict(L=513, La=200, Lb=1200, S=4, seg=128, seg_ref=256, bs=1)]
+    for ci, c in enumerate(cases):
+        g = torch.Generator().manual_seed(40 + ci)
+        stems = lambda L: (0.5 * torch.rand(1, 4, 2, L, generator=g) - 0.25)
+        inp, ra, rb = stems(c["L"]), stems(c["La"]), stems(c["Lb"])
+        args = types.SimpleNamespace(normalize_input=False, instruments=["drums", "bass", "other", "vocals"], interpolate_segments=c["S"],
+                                     segment_length=c["seg"], segment_length_ref=c["seg_ref"], batch_size=c["bs"], save_each_inst=True,
+                                     sample_rate=44100)
+        fake = types.SimpleNamespace(args=args, data_loader=[(inp, ra, rb, ["/data/song/"])], target_dir="/data/",
+                                     output_dir=os.path.join("/tmp", "mst_golden_interp") + "/", device=torch.device("cpu"),
+                                     models={"effects_encoder": Enc(), "mixing_converter": Conv()})
+        fake.batchwise_segmentization = types.MethodType(st.Mixing_Style_Transfer_Inference.batchwise_segmentization, fake)
+        written.clear()
+        st.Mixing_Style_Transfer_Inference.inference_interpolation(fake)
+        out[f"c{ci}_cfg"] = np.array([c[k] for k in ("L", "La", "Lb", "S", "seg", "seg_ref", "bs")], dtype=np.int64)
+        out[f"c{ci}_input"], out[f"c{ci}_ref_a"], out[f"c{ci}_ref_b"] = inp[0].numpy(), ra[0].numpy(), rb[0].numpy()
+        for name, data in written.items():
+            out[f"c{ci}_{name}"] = data
+    # the plain inference() loop (:112-177) the same way: segmented / unsegmented input, reference above / below 2 * segment_length
+    for ni, c in enumerate([dict(L=1000, Lr=1200, seg=256, seg_ref=325, bs=2), dict(L=200, Lr=500, seg=256, seg_ref=128, bs=3)]):
+        g = torch.Generator().manual_seed(60 + ni)
+        stems = lambda L: (0.5 * torch.rand(1, 4, 2, L, generator=g) - 0.25)
+        inp, ref = stems(c["L"]), stems(c["Lr"])
+        args = types.SimpleNamespace(normalize_input=False, instruments=["drums", "bass", "other", "vocals"], segment_length=c["seg"],
+                                     segment_length_ref=c["seg_ref"], batch_size=c["bs"], save_each_inst=True, sample_rate=44100)
+        fake = types.SimpleNamespace(args=args, data_loader=[(inp, ref, ["/data/song/"])], target_dir="/data/",
+                                     output_dir=os.path.join("/tmp", "mst_golden_interp") + "/", device=torch.device("cpu"),
+                                     models={"effects_encoder": Enc(), "mixing_converter": Conv()})
+        fake.batchwise_segmentization = types.MethodType(st.Mixing_Style_Transfer_Inference.batchwise_segmentization, fake)
+        written.clear()
+        st.Mixing_Style_Transfer_Inference.inference(fake)
+        out[f"n{ni}_cfg"] = np.array([c[k] for k in ("L", "Lr", "seg", "seg_ref", "bs")], dtype=np.int64)
+        out[f"n{ni}_input"], out[f"n{ni}_ref"] = inp[0].numpy(), ref[0].numpy()
+        for name, data in written.items():
+            out[f"n{ni}_{name}"] = data
+    np.savez_compressed(os.path.join(HERE, "interp.npz"), **out)
+    print("interp.npz", os.path.getsize(os.path.join(HERE, "interp.npz")), sorted(out.keys()))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "reverb":
         reverb_goldens()
+    elif len(sys.argv) > 1 and sys.argv[1] == "interp":
+        interpolation_goldens()
     else:
         main()
         reverb_goldens()
+        interpolation_goldens()

@@ -79,3 +79,62 @@ def test_shard_range_partitions():
             r = [S.shard_range(n, k, w) for k in range(w)]
             assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+
+
+def test_inference_and_interpolation_orchestration_match_reference(emu_default, monkeypatch):
+    """Rows a-A8 / f-2: inference_interpolation against the REFERENCE's own run (tests/golden/interp.npz: the reference method
+    executed with closed-form stand-in networks): L//S+1 input segmentation, blend weight per BATCH index, reference B cut by
+    segment_length, stack/mean of segment embeddings, concatenation, crop, per-stem and mixture outputs."""
+    import types
+    import torch
+    from music_mixing_style_transfer_amd.inference import style_transfer as st
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "interp.npz"))
+
+    class Enc:
+        def __call__(self, x):
+            return torch.cat([x.mean(-1), x.abs().mean(-1), (x * x).mean(-1)], dim=1)
+
+    class Conv:
+        def __call__(self, x, cond):
+            c = cond[0]
+            return x * (1.0 + c[0] - 0.5 * c[3]) + 0.1 * c[1] - 0.2 * c[4] + 0.05 * (c[2] + c[5]) * torch.flip(x, dims=(1,))
+
+    written = {}
+    monkeypatch.setattr(st, "save_wav_pcm16", lambda path, data, sr: written.__setitem__(os.path.basename(path), np.array(data)))
+    monkeypatch.setattr(st.os, "makedirs", lambda *a, **k: None)
+    for ci in (0, 1):
+        L, La, Lb, S, seg_len, seg_ref, bs = (int(v) for v in g[f"c{ci}_cfg"])
+        args = types.SimpleNamespace(normalize_input=False, instruments=["drums", "bass", "other", "vocals"], interpolate_segments=S,
+                                     segment_length=seg_len, segment_length_ref=seg_ref, batch_size=bs, save_each_inst=True,
+                                     sample_rate=44100)
+        runner = object.__new__(st.Mixing_Style_Transfer_Inference)
+        runner.args, runner.device = args, torch.device("cpu")
+        runner.target_dir, runner.output_dir = "/data/", "/tmp/mst_interp_out/"
+        runner.models = {"effects_encoder": Enc(), "mixing_converter": Conv()}
+        runner.data_loader = [(torch.from_numpy(g[f"c{ci}_input"]), torch.from_numpy(g[f"c{ci}_ref_a"]),
+                               torch.from_numpy(g[f"c{ci}_ref_b"]), "/data/song/")]
+        written.clear()
+        runner.inference_interpolation()
+        names = [k[len(f"c{ci}_"):] for k in g.files if k.startswith(f"c{ci}_") and k.endswith(".wav")]
+        assert sorted(written) == sorted(names) and len(names) == 5
+        for name in names:
+            ref = g[f"c{ci}_{name}"]
+            assert written[name].shape == ref.shape == (L, 2)
+            # same bookkeeping and weights; the mean embedding is summed in canonical row order on the device path
+            assert np.abs(written[name] - ref).max() <= 2e-6
+    # the plain inference() loop (style_transfer.py:112-177): segmented and unsegmented input / reference
+    for ni in (0, 1):
+        L, Lr, seg_len, seg_ref, bs = (int(v) for v in g[f"n{ni}_cfg"])
+        args = types.SimpleNamespace(normalize_input=False, instruments=["drums", "bass", "other", "vocals"], segment_length=seg_len,
+                                     segment_length_ref=seg_ref, batch_size=bs, save_each_inst=True, sample_rate=44100)
+        runner = object.__new__(st.Mixing_Style_Transfer_Inference)
+        runner.args, runner.device = args, torch.device("cpu")
+        runner.target_dir, runner.output_dir = "/data/", "/tmp/mst_interp_out/"
+        runner.models = {"effects_encoder": Enc(), "mixing_converter": Conv()}
+        runner.data_loader = [(torch.from_numpy(g[f"n{ni}_input"]), torch.from_numpy(g[f"n{ni}_ref"]), "/data/song/")]
+        written.clear()
+        runner.inference()
+        names = [k[len(f"n{ni}_"):] for k in g.files if k.startswith(f"n{ni}_") and k.endswith(".wav")]
+        assert sorted(written) == sorted(names) and len(names) == 5
+        for name in names:
+            assert np.abs(written[name] - g[f"n{ni}_{name}"]).max() <= 2e-6
