@@ -231,7 +231,8 @@ __global__ __launch_bounds__(64) void fx_comp_smooth_kernel(CompArgs a, double *
     double prev = 0.0;
     // full batches of 16 samples without per-element predicates, the next batch's loads in flight behind the current
     // recursion.  (Predicated loads made hipcc drain vmcnt(0) every batch: 14.3 ms; this form: 7.6 ms; a 4-deep ring of
-    // batches: 9.0 ms - with 2 active waves the chip sits in a low clock state and the recursion itself dominates.)
+    // batches: 9.0 ms; 64-step chunks moved cooperatively through LDS with coalesced rows and a register-only recursion:
+    // 12.6 ms - with 2 active waves the chip sits in a low clock state and the recursion itself dominates.)
     constexpr int NB = 16;
     const long nfull = a.L / NB;
     double nx[NB];
