@@ -201,79 +201,116 @@ __global__ __launch_bounds__(256) void fx_compressor_kernel(CompArgs a) {
 // The same compressor split by dependency structure (needs 8 bytes of scratch per sample):
 //   fx_comp_gain_kernel    every sample in parallel: x_l = x_g - y_g (log10 + static curve), float64
 //   fx_comp_smooth_kernel  one lane per sequence: ONLY the branchy one-pole recursion (2 FMAs + compare + select per
-//                          sample, loads batched 16 ahead), y_l written over x_l
+//                          sample), y_l written over x_l
 //   fx_comp_apply_kernel   every sample in parallel: y = x * 10^((makeup - y_l) / 20)
 // Same float64 arithmetic per sample; the serial part shrinks to the recursion itself.
+// Scratch layout: xl[n][seq] (TIME-major): the 64 lanes of the serial kernel - one sequence each - read and write 512
+// contiguous bytes per step.  (Sequence-major, every lane touched its own cache line: 2 x 64 addresses per step through
+// the texture addresser at one per clock = 140 clocks per step for a ~30-clock recursion, 7.6 ms per 128 x 131072 samples.)
+// The two parallel kernels move 64 x 64 (time x sequence) tiles through LDS so that both their audio side
+// ([item][n][c], time-contiguous) and their scratch side (sequence-contiguous) are coalesced.
 // ------------------------------------------------------------------------------------------------
-// scratch layout: xl[seq][n] (sequence-major) so that the serial kernel streams whole cache lines per lane
-__global__ __launch_bounds__(256) void fx_comp_gain_kernel(CompArgs a, double *xl) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // index into x[item][n][c]
-    if (i >= (size_t)a.n_seq * a.L) return;
-    const int c = (int)(i % a.C);
-    const size_t fr = i / a.C;
-    const long n = (long)(fr % a.L);
-    const int item = (int)(fr / a.L);
-    const double ax = fabs((double)a.x[i]);
+__device__ __forceinline__ double fx_comp_level_diff(const CompArgs &a, float x) {
+    const double ax = fabs((double)x);
     const double xg = (ax < 0.000001) ? -120.0 : 20.0 * log10(ax);
     double yg = 0.0;
     if (a.ratio > 1.0)
         yg = (xg >= a.threshold) ? a.threshold + (xg - a.threshold) / a.ratio : xg;
     else if (a.ratio < 1.0)
         yg = (xg <= a.threshold) ? a.threshold + (xg - a.threshold) / (1.0 / a.ratio) : xg;
-    xl[((size_t)item * a.C + c) * a.L + n] = xg - yg;
+    return xg - yg;
+}
+
+// grid (ceil(L / 64), ceil(n_seq / 64)), 256 threads
+__global__ __launch_bounds__(256) void fx_comp_gain_kernel(CompArgs a, double *xl) {
+    __shared__ double t[64][65];
+    const long n0 = (long)blockIdx.x * 64;
+    const int s0 = blockIdx.y * 64;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {                       // audio side: lanes run along time within one sequence
+        const int idx = k * 256 + threadIdx.x, sl = idx >> 6, nl = idx & 63;
+        const int seq = s0 + sl;
+        const long n = n0 + nl;
+        double v = 0.0;
+        if (seq < a.n_seq && n < a.L) v = fx_comp_level_diff(a, a.x[((size_t)(seq / a.C) * a.L + n) * a.C + seq % a.C]);
+        t[nl][sl] = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {                       // scratch side: lanes run along the sequences of one time step
+        const int idx = k * 256 + threadIdx.x, nl = idx >> 6, sl = idx & 63;
+        if (s0 + sl < a.n_seq && n0 + nl < a.L) xl[(size_t)(n0 + nl) * a.n_seq + s0 + sl] = t[nl][sl];
+    }
 }
 
 __global__ __launch_bounds__(64) void fx_comp_smooth_kernel(CompArgs a, double *xl) {
     const int seq = blockIdx.x * 64 + threadIdx.x;
-    if (seq >= a.n_seq) return;
-    double *p = xl + (size_t)seq * a.L;
+    const bool live = seq < a.n_seq;
+    // y <- alpha y + (1 - alpha) x, alpha = attack coefficient when x > y else release, evaluated as y + c (x - y) with
+    // c = 1 - alpha picked by the sign of d = x - y: three float64 operations per step (add, compare, fma) instead of five plus
+    // 64-bit address arithmetic.  A float64 VALU op issues in 8 clocks on gfx950 and the steps are one dependent chain:
+    // measured 140 clocks per step with per-lane cache lines, 99 with the time-major layout and the two-product form, 85 with
+    // this one (computing both candidates and selecting afterwards is not faster: 88).  Same value up to float64 rounding.
+    // Addresses are a uniform base + a 32-bit byte offset (scratch < 4 GiB is checked by the host).
+    unsigned char *base = (unsigned char *)xl;
+    const unsigned row = (unsigned)a.n_seq * 8u;                       // bytes per time step
+    const unsigned off0 = (unsigned)(live ? seq : a.n_seq - 1) * 8u;   // idle lanes of the last wave shadow a live one, store nothing
     const double ca = 1.0 - a.alpha_att, cr = 1.0 - a.alpha_rel;
     double prev = 0.0;
-    // full batches of 16 samples without per-element predicates, the next batch's loads in flight behind the current
-    // recursion.  (Predicated loads made hipcc drain vmcnt(0) every batch: 14.3 ms; this form: 7.6 ms; a 4-deep ring of
-    // batches: 9.0 ms; 64-step chunks moved cooperatively through LDS with coalesced rows and a register-only recursion:
-    // 12.6 ms - with 2 active waves the chip sits in a low clock state and the recursion itself dominates.)
     constexpr int NB = 16;
     const long nfull = a.L / NB;
     double nx[NB];
     if (nfull > 0) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) nx[i] = p[i];
+        for (int i = 0; i < NB; ++i) nx[i] = *(const double *)(base + (size_t)(off0 + (unsigned)i * row));
     }
     for (long bt = 0; bt < nfull; ++bt) {
         double v[NB];
 #pragma unroll
         for (int i = 0; i < NB; ++i) v[i] = nx[i];
-        const long nn = (bt + 1 < nfull) ? (bt + 1) * NB : bt * NB;      // last batch: harmless reload
+        const unsigned nn = (unsigned)((bt + 1 < nfull) ? (bt + 1) * NB : bt * NB);      // last batch: harmless reload
 #pragma unroll
-        for (int i = 0; i < NB; ++i) nx[i] = p[nn + i];
+        for (int i = 0; i < NB; ++i) nx[i] = *(const double *)(base + (size_t)(off0 + (nn + (unsigned)i) * row));
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const double ya = a.alpha_att * prev + ca * v[i];
-            const double yr = a.alpha_rel * prev + cr * v[i];
-            prev = (v[i] > prev) ? ya : yr;
+            const double d = v[i] - prev;
+            prev = fma(d > 0.0 ? ca : cr, d, prev);
             v[i] = prev;
         }
+        if (live) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) p[bt * NB + i] = v[i];
+            for (int i = 0; i < NB; ++i) *(double *)(base + (size_t)(off0 + ((unsigned)(bt * NB) + (unsigned)i) * row)) = v[i];
+        }
     }
     for (long n = nfull * NB; n < a.L; ++n) {
-        const double v = p[n];
-        const double ya = a.alpha_att * prev + ca * v;
-        const double yr = a.alpha_rel * prev + cr * v;
-        prev = (v > prev) ? ya : yr;
-        p[n] = prev;
+        double *q = (double *)(base + (size_t)(off0 + (unsigned)n * row));
+        const double d = *q - prev;
+        prev = fma(d > 0.0 ? ca : cr, d, prev);
+        if (live) *q = prev;
     }
 }
 
+// grid (ceil(L / 64), ceil(n_seq / 64)), 256 threads
 __global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const double *yl) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)a.n_seq * a.L) return;
-    const int c = (int)(i % a.C);
-    const size_t fr = i / a.C;
-    const long n = (long)(fr % a.L);
-    const int item = (int)(fr / a.L);
-    a.y[i] = (float)((double)a.x[i] * pow(10.0, (a.makeup - yl[((size_t)item * a.C + c) * a.L + n]) / 20.0));
+    __shared__ double t[64][65];
+    const long n0 = (long)blockIdx.x * 64;
+    const int s0 = blockIdx.y * 64;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int idx = k * 256 + threadIdx.x, nl = idx >> 6, sl = idx & 63;
+        t[nl][sl] = (s0 + sl < a.n_seq && n0 + nl < a.L) ? yl[(size_t)(n0 + nl) * a.n_seq + s0 + sl] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int idx = k * 256 + threadIdx.x, sl = idx >> 6, nl = idx & 63;
+        const int seq = s0 + sl;
+        const long n = n0 + nl;
+        if (seq < a.n_seq && n < a.L) {
+            const size_t e = ((size_t)(seq / a.C) * a.L + n) * a.C + seq % a.C;
+            a.y[e] = (float)((double)a.x[e] * pow(10.0, (a.makeup - t[nl][sl]) / 20.0));
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1147,12 +1147,14 @@ extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, 
     if (scratch) {
         if (scratch_bytes < mst_fx_compressor_scratch_bytes(n_items, L, C))
             return fail(MST_ERR_WORKSPACE, "mst_fx_compressor: scratch too small");
-        const size_t total = (size_t)a.n_seq * L;
-        MST_LAUNCH(fx_comp_gain_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, a, scratch);
+        if ((size_t)a.n_seq * (size_t)L * sizeof(double) >= (1ull << 32))      // the serial kernel addresses the scratch with 32-bit offsets
+            return fail(MST_ERR_UNSUPPORTED, "mst_fx_compressor: more than 2^29 samples per call (split the batch)");
+        const dim3 tiles((unsigned)((L + 63) / 64), (unsigned)((a.n_seq + 63) / 64));      // 64 x 64 (time x sequence) tiles
+        MST_LAUNCH(fx_comp_gain_kernel, tiles, dim3(256), stream, a, scratch);
         MST_CHECK_LAUNCH("fx_comp_gain_kernel");
         MST_LAUNCH(fx_comp_smooth_kernel, dim3((a.n_seq + 63) / 64), dim3(64), stream, a, scratch);
         MST_CHECK_LAUNCH("fx_comp_smooth_kernel");
-        MST_LAUNCH(fx_comp_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, a, (const double *)scratch);
+        MST_LAUNCH(fx_comp_apply_kernel, tiles, dim3(256), stream, a, (const double *)scratch);
         MST_CHECK_LAUNCH("fx_comp_apply_kernel");
         return MST_OK;
     }
