@@ -1097,12 +1097,35 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         MST_HIP_TRY(hipMemcpyAsync(am_dev, am.data(), am.size() * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)stream));
         MST_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));      // `am` is a stack-lifetime host buffer
         const long lanes = (long)a.n_seq * nchunks;
-        MST_LAUNCH((fx_biquad_chunk_kernel<false>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), stream, a);
+        const dim3 cg((unsigned)((lanes + 63) / 64));
+        auto launch_chunks = [&](auto APPLY) {         // the band count is a template parameter: no per-band branches in the recursion
+            constexpr bool ap = decltype(APPLY)::value;
+            switch (n_bands) {
+                case 1: MST_LAUNCH((fx_biquad_chunk_kernel<ap, 1>), cg, dim3(64), stream, a); break;
+                case 2: MST_LAUNCH((fx_biquad_chunk_kernel<ap, 2>), cg, dim3(64), stream, a); break;
+                case 3: MST_LAUNCH((fx_biquad_chunk_kernel<ap, 3>), cg, dim3(64), stream, a); break;
+                case 4: MST_LAUNCH((fx_biquad_chunk_kernel<ap, 4>), cg, dim3(64), stream, a); break;
+                case 5: MST_LAUNCH((fx_biquad_chunk_kernel<ap, 5>), cg, dim3(64), stream, a); break;
+                case 6: MST_LAUNCH((fx_biquad_chunk_kernel<ap, 6>), cg, dim3(64), stream, a); break;
+                case 7: MST_LAUNCH((fx_biquad_chunk_kernel<ap, 7>), cg, dim3(64), stream, a); break;
+                default: MST_LAUNCH((fx_biquad_chunk_kernel<ap, 8>), cg, dim3(64), stream, a); break;
+            }
+        };
+        launch_chunks(std::false_type{});
         MST_CHECK_LAUNCH("fx_biquad_chunk_kernel<state>");
-        MST_LAUNCH(fx_biquad_scan_kernel, dim3((a.n_seq + 63) / 64), dim3(64), stream, (const double *)ends, starts,
-                   (const double *)am_dev, a.n_seq, (int)nchunks, n_bands);
+        const dim3 sg((a.n_seq + 63) / 64);
+        switch (n_bands) {
+            case 1: MST_LAUNCH((fx_biquad_scan_kernel<1>), sg, dim3(64), stream, (const double *)ends, starts, (const double *)am_dev, a.n_seq, (int)nchunks); break;
+            case 2: MST_LAUNCH((fx_biquad_scan_kernel<2>), sg, dim3(64), stream, (const double *)ends, starts, (const double *)am_dev, a.n_seq, (int)nchunks); break;
+            case 3: MST_LAUNCH((fx_biquad_scan_kernel<3>), sg, dim3(64), stream, (const double *)ends, starts, (const double *)am_dev, a.n_seq, (int)nchunks); break;
+            case 4: MST_LAUNCH((fx_biquad_scan_kernel<4>), sg, dim3(64), stream, (const double *)ends, starts, (const double *)am_dev, a.n_seq, (int)nchunks); break;
+            case 5: MST_LAUNCH((fx_biquad_scan_kernel<5>), sg, dim3(64), stream, (const double *)ends, starts, (const double *)am_dev, a.n_seq, (int)nchunks); break;
+            case 6: MST_LAUNCH((fx_biquad_scan_kernel<6>), sg, dim3(64), stream, (const double *)ends, starts, (const double *)am_dev, a.n_seq, (int)nchunks); break;
+            case 7: MST_LAUNCH((fx_biquad_scan_kernel<7>), sg, dim3(64), stream, (const double *)ends, starts, (const double *)am_dev, a.n_seq, (int)nchunks); break;
+            default: MST_LAUNCH((fx_biquad_scan_kernel<8>), sg, dim3(64), stream, (const double *)ends, starts, (const double *)am_dev, a.n_seq, (int)nchunks); break;
+        }
         MST_CHECK_LAUNCH("fx_biquad_scan_kernel");
-        MST_LAUNCH((fx_biquad_chunk_kernel<true>), dim3((unsigned)((lanes + 63) / 64)), dim3(64), stream, a);
+        launch_chunks(std::true_type{});
         MST_CHECK_LAUNCH("fx_biquad_chunk_kernel<apply>");
         return MST_OK;
     }
