@@ -323,6 +323,157 @@ __global__ __launch_bounds__(64) void fx_comp_smooth_kernel(CompArgs a, double *
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The smoother, parallel in time.  One step is y <- f_x(y) = (x > y) ? aA y + cA x : aR y + cR x.  With aA <= aR (attack faster
+// than release - every parameter range of the reference) f_x(y) = max(aA y + cA x, aR y + cR x): an increasing, convex,
+// piecewise-linear map, and so is every composition F = f_xT o ... o f_x1 of a chunk - with at most T + 1 linear pieces
+// (aA > aR: the same with min / concave).  Three kernels replace the 131072 dependent steps per sequence:
+//   fx_comp_map_kernel    one lane per (sequence, chunk of T steps): the pieces (a_i, b_i) of the chunk's map F, F(y) = max_i
+//                         (a_i y + b_i).  Step x: pieces whose range of values lies below x take the attack transform, above x
+//                         the release transform, the piece that crosses x is split there (f_x(x) = x).  All in registers.
+//   fx_comp_chain_kernel  one WAVE per sequence walks the chunks: lanes = pieces, y <- max over lanes of a_i y + b_i.
+//   fx_comp_fill_kernel   one lane per (sequence, chunk): the plain recursion inside the chunk from its true start value.
+// Exact arithmetic gives the serial result; in float64 the chunk start values differ from it by rounding (~1e-15 relative).
+// ------------------------------------------------------------------------------------------------
+#define MST_COMP_T 32                      // steps per chunk: T + 1 pieces of 4 doubles live in registers
+#define MST_COMP_NP (MST_COMP_T + 1)
+
+struct CompMapArgs {
+    const double *xl;     // [L][n_seq]  level differences (time-major)
+    double *maps;         // [n_seq][nchunks][MST_COMP_NP][2]  (a, b) per piece
+    double *ystart;       // [nchunks][n_seq]  smoother value at the start of each chunk
+    int n_seq, nchunks;
+    long L;
+    double aA, aR;        // attack / release coefficients alpha
+    int use_min;          // aA > aR: concave maps, F = min over pieces
+};
+
+// grid (nchunks, ceil(n_seq / 64)), 64 threads: lanes = sequences of one chunk (coalesced time-major loads)
+__global__ __launch_bounds__(64) void fx_comp_map_kernel(CompMapArgs a) {
+    const int k = blockIdx.x;
+    const int seq = blockIdx.y * 64 + threadIdx.x;
+    const bool live = seq < a.n_seq;
+    const size_t sq = live ? seq : a.n_seq - 1;
+    const double cA = 1.0 - a.aA, cR = 1.0 - a.aR;
+    const double dead = a.use_min ? 1e300 : -1e300;
+    // piece i: F = pa y + pb on the part of the chunk's input range where its VALUE lies in [lo, hi]
+    double pa[MST_COMP_NP], pb[MST_COMP_NP], lo[MST_COMP_NP], hi[MST_COMP_NP];
+    pa[0] = 1.0; pb[0] = 0.0; lo[0] = -1e300; hi[0] = 1e300;         // the identity before the first step
+#pragma unroll
+    for (int t = 0; t < MST_COMP_T; ++t) {
+        const long n = (long)k * MST_COMP_T + t;
+        if (n < a.L) {                                             // uniform over the wave
+            const double x = a.xl[(size_t)n * a.n_seq + sq];
+            const double oA = cA * x, oR = cR * x;
+            double na = 0.0, nb = dead, nlo = 1e300, nhi = 1e300;   // the upper part of the split piece, if any piece crosses x
+#pragma unroll
+            for (int i = 0; i <= t; ++i) {
+                const bool att = lo[i] < x;                         // values below x: the attack branch applies
+                const bool cross = att && x < hi[i];
+                const double coef = att ? a.aA : a.aR, off = att ? oA : oR;
+                if (cross) {
+                    na = a.aR * pa[i];
+                    nb = a.aR * pb[i] + oR;
+                    nlo = x;
+                    nhi = a.aR * hi[i] + oR;
+                }
+                pa[i] = coef * pa[i];
+                pb[i] = coef * pb[i] + off;
+                lo[i] = coef * lo[i] + off;
+                hi[i] = cross ? x : coef * hi[i] + off;
+            }
+            pa[t + 1] = na; pb[t + 1] = nb; lo[t + 1] = nlo; hi[t + 1] = nhi;
+        } else {
+            pa[t + 1] = 0.0; pb[t + 1] = dead; lo[t + 1] = 1e300; hi[t + 1] = 1e300;
+        }
+    }
+    if (live) {
+        double *m = a.maps + ((size_t)seq * a.nchunks + k) * (MST_COMP_NP * 2);
+#pragma unroll
+        for (int i = 0; i < MST_COMP_NP; ++i) {
+            m[2 * i] = pa[i];
+            m[2 * i + 1] = pb[i];
+        }
+    }
+}
+
+// grid n_seq, 64 threads: one wave per sequence, lanes = pieces.  The pieces of CB chunks at a time are staged through LDS
+// (one coalesced sweep per batch, the next batch's loads in flight during the current one): a chunk step then costs one
+// LDS read, one fma and the DPP reduction instead of a global-memory round trip (measured 1300 clocks per chunk without).
+__global__ __launch_bounds__(64) void fx_comp_chain_kernel(CompMapArgs a) {
+    constexpr int CB = 32, PER = MST_COMP_NP * 2, NLD = (CB * PER + 63) / 64;      // doubles per chunk / loads per lane per batch
+    __shared__ double buf[2][CB * PER];
+    __shared__ double ys[2][CB];
+    const int seq = blockIdx.x, lane = threadIdx.x;
+    const double dead = a.use_min ? 1e300 : -1e300;
+    const double *m = a.maps + (size_t)seq * a.nchunks * PER;
+    const size_t total = (size_t)a.nchunks * PER;
+    const bool has = lane < MST_COMP_NP;
+    const int nbatch = (a.nchunks + CB - 1) / CB;
+    double r[NLD];
+    auto load = [&](int bt) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const size_t e = (size_t)bt * CB * PER + (size_t)i * 64 + lane;
+            r[i] = m[e < total ? e : total - 1];
+        }
+    };
+    auto put = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if (i * 64 + lane < CB * PER) buf[b][i * 64 + lane] = r[i];
+    };
+    load(0);
+    put(0);
+    __builtin_amdgcn_wave_barrier();
+    double y = 0.0;                                              // yL_prev = 0 on entry (common_audioeffects.py:553)
+    int cur = 0;
+    for (int bt = 0; bt < nbatch; ++bt) {
+        if (bt + 1 < nbatch) load(bt + 1);
+        const int nc = a.nchunks - bt * CB < CB ? a.nchunks - bt * CB : CB;
+        double pa = has ? buf[cur][2 * lane] : 0.0, pb = has ? buf[cur][2 * lane + 1] : dead;
+        for (int c = 0; c < nc; ++c) {
+            if (lane == 0) ys[cur][c] = y;
+            const int cn = c + 1 < nc ? c + 1 : c;                // next chunk's pieces: LDS latency behind the reduction
+            const double na = has ? buf[cur][cn * PER + 2 * lane] : 0.0, nb = has ? buf[cur][cn * PER + 2 * lane + 1] : dead;
+            y = mst_wave_extreme_f64(pa * y + pb, a.use_min != 0);
+            pa = na;
+            pb = nb;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nc) a.ystart[(size_t)(bt * CB + lane) * a.n_seq + seq] = ys[cur][lane];
+        if (bt + 1 < nbatch) put(cur ^ 1);
+        __builtin_amdgcn_wave_barrier();
+        cur ^= 1;
+    }
+}
+
+// grid (nchunks, ceil(n_seq / 64)), 64 threads: the recursion inside each chunk, y_l written over x_l
+__global__ __launch_bounds__(64) void fx_comp_fill_kernel(CompMapArgs a, double *xl) {
+    const int k = blockIdx.x;
+    const int seq = blockIdx.y * 64 + threadIdx.x;
+    if (seq >= a.n_seq) return;
+    const double cA = 1.0 - a.aA, cR = 1.0 - a.aR;
+    double prev = a.ystart[(size_t)k * a.n_seq + seq];
+    double v[MST_COMP_T];
+#pragma unroll
+    for (int t = 0; t < MST_COMP_T; ++t) {
+        const long n = (long)k * MST_COMP_T + t;
+        v[t] = xl[(size_t)(n < a.L ? n : a.L - 1) * a.n_seq + seq];
+    }
+#pragma unroll
+    for (int t = 0; t < MST_COMP_T; ++t) {
+        const double d = v[t] - prev;
+        prev = fma(d > 0.0 ? cA : cR, d, prev);
+        v[t] = prev;
+    }
+#pragma unroll
+    for (int t = 0; t < MST_COMP_T; ++t) {
+        const long n = (long)k * MST_COMP_T + t;
+        if (n < a.L) xl[(size_t)n * a.n_seq + seq] = v[t];
+    }
+}
+
 // grid (ceil(L / 64), ceil(n_seq / 64)), 256 threads
 __global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const double *yl) {
     __shared__ double t[64][65];

@@ -1142,9 +1142,24 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
     return MST_OK;
 }
 
+namespace {
+// scratch = level differences [L][n_seq] | chunk maps [n_seq][nchunks][NP][2] | chunk start values [nchunks][n_seq]
+struct CompScratch { size_t xl, maps, ystart, total; long nchunks; };
+CompScratch comp_scratch(int n_items, long L, int C) {
+    CompScratch c;
+    const size_t n_seq = (size_t)n_items * C;
+    c.nchunks = (L + MST_COMP_T - 1) / MST_COMP_T;
+    c.xl = n_seq * (size_t)L * sizeof(double);
+    c.maps = n_seq * (size_t)c.nchunks * MST_COMP_NP * 2 * sizeof(double);
+    c.ystart = n_seq * (size_t)c.nchunks * sizeof(double);
+    c.total = c.xl + c.maps + c.ystart;
+    return c;
+}
+}  // namespace
+
 extern "C" size_t mst_fx_compressor_scratch_bytes(int n_items, long L, int C) {
     if (n_items < 1 || L < 1 || C < 1) return 0;
-    return (size_t)n_items * L * C * sizeof(double);
+    return comp_scratch(n_items, L, C).total;
 }
 
 extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, int C, double threshold_db,
@@ -1175,8 +1190,30 @@ extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, 
         const dim3 tiles((unsigned)((L + 63) / 64), (unsigned)((a.n_seq + 63) / 64));      // 64 x 64 (time x sequence) tiles
         MST_LAUNCH(fx_comp_gain_kernel, tiles, dim3(256), stream, a, scratch);
         MST_CHECK_LAUNCH("fx_comp_gain_kernel");
-        MST_LAUNCH(fx_comp_smooth_kernel, dim3((a.n_seq + 63) / 64), dim3(64), stream, a, scratch);
-        MST_CHECK_LAUNCH("fx_comp_smooth_kernel");
+        static const bool serial = getenv("MST_FX_COMP_SERIAL") && atoi(getenv("MST_FX_COMP_SERIAL")) > 0;   // developer knob
+        const CompScratch cs = comp_scratch(n_items, L, C);
+        if (serial || cs.nchunks < 4) {
+            MST_LAUNCH(fx_comp_smooth_kernel, dim3((a.n_seq + 63) / 64), dim3(64), stream, a, scratch);
+            MST_CHECK_LAUNCH("fx_comp_smooth_kernel");
+        } else {       // the smoother parallel in time: chunk maps (convex piecewise-linear), a chain over chunks, a fill pass
+            CompMapArgs m;
+            m.xl = scratch;
+            m.maps = (double *)((unsigned char *)scratch + cs.xl);
+            m.ystart = (double *)((unsigned char *)scratch + cs.xl + cs.maps);
+            m.n_seq = a.n_seq;
+            m.nchunks = (int)cs.nchunks;
+            m.L = L;
+            m.aA = a.alpha_att;
+            m.aR = a.alpha_rel;
+            m.use_min = a.alpha_att > a.alpha_rel ? 1 : 0;
+            const dim3 cg((unsigned)cs.nchunks, (unsigned)((a.n_seq + 63) / 64));
+            MST_LAUNCH(fx_comp_map_kernel, cg, dim3(64), stream, m);
+            MST_CHECK_LAUNCH("fx_comp_map_kernel");
+            MST_LAUNCH(fx_comp_chain_kernel, dim3(a.n_seq), dim3(64), stream, m);
+            MST_CHECK_LAUNCH("fx_comp_chain_kernel");
+            MST_LAUNCH(fx_comp_fill_kernel, cg, dim3(64), stream, m, scratch);
+            MST_CHECK_LAUNCH("fx_comp_fill_kernel");
+        }
         MST_LAUNCH(fx_comp_apply_kernel, tiles, dim3(256), stream, a, (const double *)scratch);
         MST_CHECK_LAUNCH("fx_comp_apply_kernel");
         return MST_OK;

@@ -44,3 +44,28 @@ static inline bool mst_fft_bind(void **plan_many, void **set_stream, void **exec
     *destroy = dlsym(lib, "hipfftDestroy");
     return *plan_many && *set_stream && *exec_r2c && *exec_c2r && *destroy;
 }
+
+// wave-wide max (or min) of a double, returned in every lane.  DPP row shifts / row broadcasts (VALU speed) instead of
+// ds_bpermute shuffles: a 64-bit __shfl_xor is two LDS-crossbar round trips per level, ~1.6 k clocks for six levels.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double mst_dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);      // lanes without a source keep their own value
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double mst_wave_extreme_f64(double v, bool use_min) {
+#define MST_RED_STEP(CTRL, MASK)                      \
+    {                                                 \
+        const double o = mst_dpp_f64<CTRL, MASK>(v);  \
+        v = use_min ? fmin(v, o) : fmax(v, o);        \
+    }
+    MST_RED_STEP(0x111, 0xf)      // row_shr:1
+    MST_RED_STEP(0x112, 0xf)      // row_shr:2
+    MST_RED_STEP(0x114, 0xf)      // row_shr:4
+    MST_RED_STEP(0x118, 0xf)      // row_shr:8   -> lane 15 of every row holds its row's extreme
+    MST_RED_STEP(0x142, 0xa)      // row_bcast:15 into rows 1 and 3
+    MST_RED_STEP(0x143, 0xc)      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's extreme
+#undef MST_RED_STEP
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}

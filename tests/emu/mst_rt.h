@@ -127,6 +127,13 @@ template <typename T> static inline T emu_shfl(T v, int src) {
     return out;
 }
 template <typename T> static inline T __shfl_xor(T v, int mask, int = 64) { return emu_shfl(v, emu::lane_id() ^ mask); }
+static inline double mst_wave_extreme_f64(double v, bool use_min) {
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double o = __shfl_xor(v, m);
+        v = use_min ? fmin(v, o) : fmax(v, o);
+    }
+    return v;
+}
 template <typename T> static inline T __shfl_down(T v, int d, int = 64) {
     const int l = emu::lane_id();
     return emu_shfl(v, l + d < 64 ? l + d : l);

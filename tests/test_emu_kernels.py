@@ -153,6 +153,12 @@ def test_fx_emulated(emu_default):
         c.parameters.threshold.value, c.parameters.attack_time.value = th, at
         c.parameters.release_time.value, c.parameters.ratio.value = rt, ra
         assert np.abs(c.process(x.copy()) - F.compressor(x.copy(), th, at, rt, ra)).max() <= 2e-7
+    # attack slower than release (outside the reference's parameter ranges): the chunk maps of the time-parallel smoother
+    # are concave instead of convex; equal coefficients: linear
+    for th, at, rt, ra in ((-25.0, 300.0, 40.0, 6.0), (-25.0, 80.0, 80.0, 3.0)):
+        c.parameters.threshold.value, c.parameters.attack_time.value = th, at
+        c.parameters.release_time.value, c.parameters.ratio.value = rt, ra
+        assert np.abs(c.process(x.copy()) - F.compressor(x.copy(), th, at, rt, ra)).max() <= 2e-7
     eq = Equaliser(2, 44100)
     for band, (gg, fc, q) in F.CONFIG4["eq"].items():
         getattr(eq.parameters, band + "_gain").value = gg
