@@ -140,14 +140,17 @@ __global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) 
 
 // s_0 = 0 ; s_k = A^M s_{k-1} + e_{k-1}.  One lane per sequence; AM is [S][S] row-major with S = 2*n_bands, state order
 // (z1, z2) per band.  ends / starts are laid out [chunk][state][sequence] so that the 64 lanes of this serial kernel move
-// contiguous rows; A^M sits in LDS (broadcast reads) and the next chunk's end states are requested one chunk ahead.
+// contiguous rows; A^M arrives in the kernel arguments (no staging copy, no host synchronisation), sits in LDS (broadcast
+// reads), and the next chunk's end states are requested one chunk ahead.
 // (Sequence-major tables with A^M re-read from global memory: 1.02 ms for 128 sequences x 256 chunks.)
+struct BiquadPowArgs { double am[4 * MST_MAX_BANDS * MST_MAX_BANDS]; };      // A^M, [S][S] row-major, by value in the kernel arguments
+
 template <int NBANDS>
-__global__ __launch_bounds__(64) void fx_biquad_scan_kernel(const double *ends, double *starts, const double *AM, int n_seq,
+__global__ __launch_bounds__(64) void fx_biquad_scan_kernel(const double *ends, double *starts, BiquadPowArgs pw, int n_seq,
                                                            int nchunks) {
     constexpr int SM = 2 * MST_MAX_BANDS, S = 2 * NBANDS;       // table row stride / live states
     __shared__ double am[S * S];
-    for (int i = threadIdx.x; i < S * S; i += 64) am[i] = AM[i];
+    for (int i = threadIdx.x; i < S * S; i += 64) am[i] = pw.am[i];
     __syncthreads();
     const int seq = blockIdx.x * 64 + threadIdx.x;
     const bool live = seq < n_seq;

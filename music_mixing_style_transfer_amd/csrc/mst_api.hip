@@ -1074,12 +1074,13 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         a.n_bands = n_bands;
         biquad_coefs(coef, n_bands, a.coef);
         const size_t states = (size_t)a.n_seq * nchunks * 2 * MST_MAX_BANDS;
-        double *ends = scratch, *starts = scratch + states, *am_dev = scratch + 2 * states;
+        double *ends = scratch, *starts = scratch + states;
         a.ends = ends;
         a.starts = starts;
         // A^M column by column: run the cascade M steps on zero input from each unit state (host, float64)
         const int S = 2 * n_bands;
-        std::vector<double> am((size_t)S * S);
+        BiquadPowArgs pw;
+        double *am = pw.am;
         for (int col = 0; col < S; ++col) {
             std::vector<double> z(S, 0.0);
             z[col] = 1.0;
@@ -1094,8 +1095,6 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
             }
             for (int row = 0; row < S; ++row) am[(size_t)row * S + col] = z[row];
         }
-        MST_HIP_TRY(hipMemcpyAsync(am_dev, am.data(), am.size() * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)stream));
-        MST_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));      // `am` is a stack-lifetime host buffer
         const long lanes = (long)a.n_seq * nchunks;
         const dim3 cg((unsigned)((lanes + 63) / 64));
         auto launch_chunks = [&](auto APPLY) {         // the band count is a template parameter: no per-band branches in the recursion
@@ -1115,14 +1114,14 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         MST_CHECK_LAUNCH("fx_biquad_chunk_kernel<state>");
         const dim3 sg((a.n_seq + 63) / 64);
         switch (n_bands) {
-            case 1: MST_LAUNCH((fx_biquad_scan_kernel<1>), sg, dim3(64), stream, (const double *)ends, starts, (const double *)am_dev, a.n_seq, (int)nchunks); break;
-            case 2: MST_LAUNCH((fx_biquad_scan_kernel<2>), sg, dim3(64), stream, (const double *)ends, starts, (const double *)am_dev, a.n_seq, (int)nchunks); break;
-            case 3: MST_LAUNCH((fx_biquad_scan_kernel<3>), sg, dim3(64), stream, (const double *)ends, starts, (const double *)am_dev, a.n_seq, (int)nchunks); break;
-            case 4: MST_LAUNCH((fx_biquad_scan_kernel<4>), sg, dim3(64), stream, (const double *)ends, starts, (const double *)am_dev, a.n_seq, (int)nchunks); break;
-            case 5: MST_LAUNCH((fx_biquad_scan_kernel<5>), sg, dim3(64), stream, (const double *)ends, starts, (const double *)am_dev, a.n_seq, (int)nchunks); break;
-            case 6: MST_LAUNCH((fx_biquad_scan_kernel<6>), sg, dim3(64), stream, (const double *)ends, starts, (const double *)am_dev, a.n_seq, (int)nchunks); break;
-            case 7: MST_LAUNCH((fx_biquad_scan_kernel<7>), sg, dim3(64), stream, (const double *)ends, starts, (const double *)am_dev, a.n_seq, (int)nchunks); break;
-            default: MST_LAUNCH((fx_biquad_scan_kernel<8>), sg, dim3(64), stream, (const double *)ends, starts, (const double *)am_dev, a.n_seq, (int)nchunks); break;
+            case 1: MST_LAUNCH((fx_biquad_scan_kernel<1>), sg, dim3(64), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
+            case 2: MST_LAUNCH((fx_biquad_scan_kernel<2>), sg, dim3(64), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
+            case 3: MST_LAUNCH((fx_biquad_scan_kernel<3>), sg, dim3(64), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
+            case 4: MST_LAUNCH((fx_biquad_scan_kernel<4>), sg, dim3(64), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
+            case 5: MST_LAUNCH((fx_biquad_scan_kernel<5>), sg, dim3(64), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
+            case 6: MST_LAUNCH((fx_biquad_scan_kernel<6>), sg, dim3(64), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
+            case 7: MST_LAUNCH((fx_biquad_scan_kernel<7>), sg, dim3(64), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
+            default: MST_LAUNCH((fx_biquad_scan_kernel<8>), sg, dim3(64), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
         }
         MST_CHECK_LAUNCH("fx_biquad_scan_kernel");
         launch_chunks(std::true_type{});
