@@ -331,14 +331,29 @@ int bf16_duo() {     // experimental two-set persistent kernel (MST_TCN_DUO=<wor
     return e ? atoi(e) : 0;
 }
 
+int bf16_solo() {    // experimental: MST_TCN_SOLO=<workgroups> (256 = one per CU), 512-time tiles, one wave per SIMD; read per launch
+    const char *e = getenv("MST_TCN_SOLO");
+    return e ? atoi(e) : 0;
+}
+
 template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream) {
     TcnBlockArgs a = a0;
     if constexpr (P <= 4) {
+        if (precision == MST_PREC_BF16 && bf16_solo() > 0 && a.y_out == nullptr) {
+            // one 256-thread workgroup per CU on 512-time tiles: 16 accumulator tiles per wave (AGPRs), half the weight loads per MFMA
+            const long nsteps = ((long)a.L + a.d - 1) / a.d;
+            a.tiles_step = (int)((nsteps + 512 / P - 1) / (512 / P));
+            const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
+            const int pg = (int)(ntiles < bf16_solo() ? ntiles : bf16_solo());
+            MST_LAUNCH((tcn_block_bf16_duo_kernel<P, 16, 1>), dim3(pg), dim3(256), stream, a);
+            MST_CHECK_LAUNCH("tcn_block_bf16_duo_kernel<solo>");
+            return MST_OK;
+        }
         if (precision == MST_PREC_BF16 && bf16_duo() > 0 && a.y_out == nullptr) {
             const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;          // 256-time tiles, two per workgroup round
             const long want = (ntiles + 1) / 2;
             const int pg = (int)(want < bf16_duo() ? want : bf16_duo());
-            MST_LAUNCH((tcn_block_bf16_duo_kernel<P, 8>), dim3(pg), dim3(512), stream, a);
+            MST_LAUNCH((tcn_block_bf16_duo_kernel<P, 8, 2>), dim3(pg), dim3(512), stream, a);
             MST_CHECK_LAUNCH("tcn_block_bf16_duo_kernel");
             return MST_OK;
         }

@@ -69,3 +69,11 @@ __device__ __forceinline__ double mst_wave_extreme_f64(double v, bool use_min) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
 }
+
+// read one accumulator element out of its AGPR exactly here (256-accumulator kernels: hipcc otherwise copies every
+// accumulator to VGPRs right after the main loop and spills most of them)
+__device__ __forceinline__ float mst_acc_read(float x) {
+    float r;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(x));
+    return r;
+}

@@ -297,18 +297,18 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
 // transposes and stores only the 64-byte channel slice [32w, 32w+32) of each row, the slice its accumulators produce), so
 // the epilogue needs no barrier of its own.  Same arithmetic, tiling rule and weight packing as above.
 // ------------------------------------------------------------------------------------------------
-template <int P, int NQ>
-__global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs a) {
+template <int P, int NQ, int NSETS>
+__global__ __launch_bounds__(256 * NSETS, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs a) {
     static_assert(16 % P == 0, "row passes advance by a whole number of steps");
     constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NPASS = (R + 15) / 16, NPART = (NPASS + 3) / 4, STEP = 16 / P;
-    __shared__ __attribute__((aligned(16))) unsigned char smem_all[2 * R * 256];
-    __shared__ __attribute__((aligned(16))) float par_all[2 * 384];      // per set: FiLM r | FiLM b | res of its batch item
-    const int set = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_all[NSETS * R * 256];
+    __shared__ __attribute__((aligned(16))) float par_all[NSETS * 384];  // per set: FiLM r | FiLM b | res of its batch item
+    const int set = NSETS > 1 ? threadIdx.x >> 8 : 0, tid = threadIdx.x & 255;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);               // wave-uniform: lives in a scalar register
     unsigned char *smem = smem_all + set * (R * 256);
     float *par = par_all + set * 384;
     const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
-    const long per_round = 2L * gridDim.x, first = 2L * blockIdx.x;
+    const long per_round = (long)NSETS * gridDim.x, first = (long)NSETS * blockIdx.x;
     if (first >= ntiles) return;
     const int n_max = (int)((ntiles - first + per_round - 1) / per_round);                       // tiles of set 0 (>= set 1's)
     const int n_mine = first + set < ntiles ? (int)((ntiles - first - set + per_round - 1) / per_round) : 0;
@@ -424,9 +424,9 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
         // Each finished tile frees its 16 accumulator registers; the next tile's row loads are issued into them.
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            if (q > 0 && (q & 1) == 0 && q / 2 <= 4) {         // two finished tiles = 32 free registers = one part (<= 5 rows)
+            if (q > 0 && q % (NQ / 4) == 0) {                  // a quarter of the tiles finished: their registers take one part of the rows
                 __builtin_amdgcn_sched_barrier(0);
-                stage_load(cn, next_live, vn, lane_v, (q / 2 - 1) * NPART, (q / 2) * NPART);
+                stage_load(cn, next_live, vn, lane_v, (q / (NQ / 4) - 1) * NPART, (q / (NQ / 4)) * NPART);
             }
             bf16x4 xin[4];
 #pragma unroll
@@ -434,12 +434,14 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
             __builtin_amdgcn_wave_barrier();       // every lane's residual reads are issued before any lane overwrites rows of this tile
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float v4[4] = {acc[q][4 * g], acc[q][4 * g + 1], acc[q][4 * g + 2], acc[q][4 * g + 3]};
+                float v4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v4[i] = NQ > 8 ? mst_acc_read(acc[q][4 * g + i]) : acc[q][4 * g + i];
                 *(bf16x4 *)(ow + q * 8192 + (((4 * w + g) ^ so) << 4)) = tcn_epilogue4(v4, fr[g], fb[g], rs[g], xin[g]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        stage_load(cn, next_live, vn, lane_v, ((NQ - 1) / 2) * NPART, 4 * NPART);      // the parts not issued above
+        stage_load(cn, next_live, vn, lane_v, 3 * NPART, 4 * NPART);      // the last part
         __builtin_amdgcn_wave_barrier();           // the transposed slice of this wave is complete
         {
             const int prow = lane_v >> 2, pslot = 4 * w + (lane_v & 3);
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
         MST_LAUNDER(lane_v);               // per-lane index math is recomputed per tile instead of living (and spilling) across the loop
         const bool mine = k < n_mine;
         const bool stamp = stamp_wg && k == 2;
-        long long *pr = a.prof + ((size_t)blockIdx.x * 2 + set) * 10;
+        long long *pr = a.prof + ((size_t)blockIdx.x * NSETS + set) * 10;
         const Coord c = decode(k);
         // per-item FiLM rows: refresh when the batch item changes (nobody reads `par` during the main loop; the barrier
         // behind it publishes the new values to the epilogue)

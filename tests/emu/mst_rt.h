@@ -60,6 +60,7 @@ struct float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return {x, y}; }
 static inline float mst_fmax(float a, float b) { return fmaxf(a, b); }
+static inline float mst_acc_read(float x) { return x; }
 #define MST_LAUNDER(v) asm volatile("" : "+r"(v))
 #define MST_NO_CONTRACT(v) asm volatile("" : "+x"(v))      // value barrier: no fp contraction across it
 

@@ -228,6 +228,16 @@ def test_tcn_duo_kernel_matches_default_emulated(emu_default, monkeypatch):
             for n, r in zip((2, 3, 4), ref):
                 assert torch.equal(m.forward_blocks(x, cnd, n), r), (shape, wgs, n)
     monkeypatch.delenv("MST_TCN_DUO", raising=False)
+    # the one-set form on 512-time tiles (MST_TCN_SOLO): 16 accumulator tiles per wave, same arithmetic again
+    for shape, wgs in (((2, 2, 1500), 3), ((1, 2, 700), 1)):
+        x = synth.synth_audio(shape, seed=shape[2])
+        for cnd in (cond, synth.synth_audio((shape[0], 64), seed=9)):
+            monkeypatch.delenv("MST_TCN_SOLO", raising=False)
+            ref = [m.forward_blocks(x, cnd, n).clone() for n in (2, 3, 4)]
+            monkeypatch.setenv("MST_TCN_SOLO", str(wgs))
+            for n, r in zip((2, 3, 4), ref):
+                assert torch.equal(m.forward_blocks(x, cnd, n), r), (shape, wgs, n)
+    monkeypatch.delenv("MST_TCN_SOLO", raising=False)
     # bf16, per-item rows vs the oracle (default kernel)
     x = synth.synth_audio((2, 2, 500), seed=3)
     cB = synth.synth_audio((2, 64), seed=10)
