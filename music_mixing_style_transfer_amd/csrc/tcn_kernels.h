@@ -301,11 +301,12 @@ template <int P, int NQ, int NSETS>
 __global__ __launch_bounds__(256 * NSETS, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs a) {
     static_assert(16 % P == 0, "row passes advance by a whole number of steps");
     constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NPASS = (R + 15) / 16, NPART = (NPASS + 3) / 4, STEP = 16 / P;
-    __shared__ __attribute__((aligned(16))) unsigned char smem_all[NSETS * R * 256];
+    constexpr int RP = NSETS == 1 ? NPASS * 16 : R;          // one set: room for whole passes, so that staging stores need no row predicate
+    __shared__ __attribute__((aligned(16))) unsigned char smem_all[NSETS * RP * 256];
     __shared__ __attribute__((aligned(16))) float par_all[NSETS * 384];  // per set: FiLM r | FiLM b | res of its batch item
     const int set = NSETS > 1 ? threadIdx.x >> 8 : 0, tid = threadIdx.x & 255;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);               // wave-uniform: lives in a scalar register
-    unsigned char *smem = smem_all + set * (R * 256);
+    unsigned char *smem = smem_all + set * (RP * 256);
     float *par = par_all + set * 384;
     const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
     const long per_round = (long)NSETS * gridDim.x, first = (long)NSETS * blockIdx.x;
@@ -345,11 +346,15 @@ __global__ __launch_bounds__(256 * NSETS, 1) void tcn_block_bf16_duo_kernel(TcnB
         const long dt = (long)STEP * a.d;
         long t = (long)(c.m0 + prow / P - 7) * a.d + c.phi0 + (prow % P) + i0 * dt;
         const __bf16 *p = (const __bf16 *)a.x + ((size_t)c.b * a.Lp + t) * 128 + pslot * 8;
+        const __bf16 *safe = (const __bf16 *)a.x + pslot * 8;           // any valid address: rows outside the segment load it and are zeroed
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
             if (i < NPASS) {
-                v[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (live && prow + 16 * i < R && t >= 0 && t < a.L) v[i] = *(const bf16x8 *)p;
+                // never a predicated load: hipcc puts a branch and an s_waitcnt vmcnt(0) behind each one (measured: the
+                // prefetch of 36 rows cost ~18 k clocks that way); load from a clamped address, select afterwards
+                const bool ok = live && prow + 16 * i < R && t >= 0 && t < a.L;
+                const bf16x8 ld = *(const bf16x8 *)(ok ? p : safe);
+                v[i] = ok ? ld : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
             t += dt;
             p += dt * 128;
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(256 * NSETS, 1) void tcn_block_bf16_duo_kernel(TcnB
         unsigned char *q = smem + prow * 256 + ((pslot ^ (prow & 15)) << 4);
 #pragma unroll
         for (int i = 0; i < NPASS; ++i)
-            if (prow + 16 * i < R) *(bf16x8 *)(q + i * 4096) = v[i];
+            if (RP > R || prow + 16 * i < R) *(bf16x8 *)(q + i * 4096) = v[i];
     };
 
     auto main_loop = [&](f32x16 (&acc)[NQ], int lane_v) {
@@ -422,6 +427,9 @@ __global__ __launch_bounds__(256 * NSETS, 1) void tcn_block_bf16_duo_kernel(TcnB
         // column tile by column tile, ascending: tile q reads its residual inputs from rows [32q + 7P, 32q + 7P + 32) and then
         // overwrites rows [32q, 32q + 32) of the wave's slice - rows nobody reads any more (reads always run ahead of writes).
         // Each finished tile frees its 16 accumulator registers; the next tile's row loads are issued into them.
+        bf16x4 xnext[4];                           // residual inputs are read one tile ahead (their rows lie above every row written so far)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xnext[g] = *(const bf16x4 *)(xr + (((4 * w + g) ^ sx) << 4));
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             if (q > 0 && q % (NQ / 4) == 0) {                  // a quarter of the tiles finished: their registers take one part of the rows
@@ -430,15 +438,17 @@ __global__ __launch_bounds__(256 * NSETS, 1) void tcn_block_bf16_duo_kernel(TcnB
             }
             bf16x4 xin[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) xin[g] = *(const bf16x4 *)(xr + q * 8192 + (((4 * w + g) ^ sx) << 4));
+            for (int g = 0; g < 4; ++g) {
+                xin[g] = xnext[g];
+                if (q + 1 < NQ) xnext[g] = *(const bf16x4 *)(xr + (q + 1) * 8192 + (((4 * w + g) ^ sx) << 4));
+            }
+            float va[16];                          // the tile's 16 accumulators: read out of their AGPRs back to back (NQ > 8), used below
+#pragma unroll
+            for (int e = 0; e < 16; ++e) va[e] = NQ > 8 ? mst_acc_read(acc[q][e]) : acc[q][e];
             __builtin_amdgcn_wave_barrier();       // every lane's residual reads are issued before any lane overwrites rows of this tile
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v4[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v4[i] = NQ > 8 ? mst_acc_read(acc[q][4 * g + i]) : acc[q][4 * g + i];
-                *(bf16x4 *)(ow + q * 8192 + (((4 * w + g) ^ so) << 4)) = tcn_epilogue4(v4, fr[g], fb[g], rs[g], xin[g]);
-            }
+            for (int g = 0; g < 4; ++g)
+                *(bf16x4 *)(ow + q * 8192 + (((4 * w + g) ^ so) << 4)) = tcn_epilogue4(va + 4 * g, fr[g], fb[g], rs[g], xin[g]);
         }
         __builtin_amdgcn_sched_barrier(0);
         stage_load(cn, next_live, vn, lane_v, 3 * NPART, 4 * NPART);      // the last part
@@ -450,10 +460,16 @@ __global__ __launch_bounds__(256 * NSETS, 1) void tcn_block_bf16_duo_kernel(TcnB
             __bf16 *yp = (__bf16 *)a.y + ((size_t)c.b * a.Lp + t) * 128 + pslot * 8;
             const unsigned char *q = smem + prow * 256 + ((pslot ^ (prow & 15)) << 4);
 #pragma unroll
-            for (int i = 0; i < T / 16; ++i) {
-                if (live && t < a.L) *(bf16x8 *)yp = *(const bf16x8 *)(q + i * 4096);
-                t += dt;
-                yp += dt * 128;
+            for (int i0 = 0; i0 < T / 16; i0 += 8) {          // eight rows out of LDS, then eight stores: one LDS latency per group
+                bf16x8 rows[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rows[i] = *(const bf16x8 *)(q + (i0 + i) * 4096);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (live && t < a.L) *(bf16x8 *)yp = rows[i];
+                    t += dt;
+                    yp += dt * 128;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();           // ... and read back before this wave restages the buffer
