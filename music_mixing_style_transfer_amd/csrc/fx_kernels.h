@@ -403,12 +403,13 @@ __global__ __launch_bounds__(64) void fx_comp_map_kernel(CompMapArgs a) {
 // grid n_seq, 64 threads: one wave per sequence, lanes = pieces.  The pieces of CB chunks at a time are staged through LDS
 // (one coalesced sweep per batch, the next batch's loads in flight during the current one): a chunk step then costs one
 // LDS read, one fma and the DPP reduction instead of a global-memory round trip (measured 1300 clocks per chunk without).
+template <bool USE_MIN>
 __global__ __launch_bounds__(64) void fx_comp_chain_kernel(CompMapArgs a) {
     constexpr int CB = 32, PER = MST_COMP_NP * 2, NLD = (CB * PER + 63) / 64;      // doubles per chunk / loads per lane per batch
     __shared__ double buf[2][CB * PER];
     __shared__ double ys[2][CB];
     const int seq = blockIdx.x, lane = threadIdx.x;
-    const double dead = a.use_min ? 1e300 : -1e300;
+    const double dead = USE_MIN ? 1e300 : -1e300;
     const double *m = a.maps + (size_t)seq * a.nchunks * PER;
     const size_t total = (size_t)a.nchunks * PER;
     const bool has = lane < MST_COMP_NP;
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(64) void fx_comp_chain_kernel(CompMapArgs a) {
             if (lane == 0) ys[cur][c] = y;
             const int cn = c + 1 < nc ? c + 1 : c;                // next chunk's pieces: LDS latency behind the reduction
             const double na = has ? buf[cur][cn * PER + 2 * lane] : 0.0, nb = has ? buf[cur][cn * PER + 2 * lane + 1] : dead;
-            y = mst_wave_extreme_f64(pa * y + pb, a.use_min != 0);
+            y = mst_wave_extreme_f64<USE_MIN>(pa * y + pb);
             pa = na;
             pb = nb;
         }

@@ -1223,7 +1223,8 @@ extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, 
             const dim3 cg((unsigned)cs.nchunks, (unsigned)((a.n_seq + 63) / 64));
             MST_LAUNCH(fx_comp_map_kernel, cg, dim3(64), stream, m);
             MST_CHECK_LAUNCH("fx_comp_map_kernel");
-            MST_LAUNCH(fx_comp_chain_kernel, dim3(a.n_seq), dim3(64), stream, m);
+            if (m.use_min) MST_LAUNCH((fx_comp_chain_kernel<true>), dim3(a.n_seq), dim3(64), stream, m);
+            else MST_LAUNCH((fx_comp_chain_kernel<false>), dim3(a.n_seq), dim3(64), stream, m);
             MST_CHECK_LAUNCH("fx_comp_chain_kernel");
             MST_LAUNCH(fx_comp_fill_kernel, cg, dim3(64), stream, m, scratch);
             MST_CHECK_LAUNCH("fx_comp_fill_kernel");

@@ -53,11 +53,13 @@ template <int CTRL, int ROW_MASK> __device__ __forceinline__ double mst_dpp_f64(
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double mst_wave_extreme_f64(double v, bool use_min) {
-#define MST_RED_STEP(CTRL, MASK)                      \
-    {                                                 \
-        const double o = mst_dpp_f64<CTRL, MASK>(v);  \
-        v = use_min ? fmin(v, o) : fmax(v, o);        \
+template <bool USE_MIN> __device__ __forceinline__ double mst_wave_extreme_f64(double v) {
+    // plain v_max_f64 / v_min_f64: fmax()/fmin() cost an extra canonicalising v_max per operand
+#define MST_RED_STEP(CTRL, MASK)                                                    \
+    {                                                                               \
+        const double o = mst_dpp_f64<CTRL, MASK>(v);                                \
+        if (USE_MIN) asm("v_min_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o));        \
+        else asm("v_max_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o));                \
     }
     MST_RED_STEP(0x111, 0xf)      // row_shr:1
     MST_RED_STEP(0x112, 0xf)      // row_shr:2

@@ -128,10 +128,10 @@ template <typename T> static inline T emu_shfl(T v, int src) {
     return out;
 }
 template <typename T> static inline T __shfl_xor(T v, int mask, int = 64) { return emu_shfl(v, emu::lane_id() ^ mask); }
-static inline double mst_wave_extreme_f64(double v, bool use_min) {
+template <bool USE_MIN> static inline double mst_wave_extreme_f64(double v) {
     for (int m = 32; m >= 1; m >>= 1) {
         const double o = __shfl_xor(v, m);
-        v = use_min ? fmin(v, o) : fmax(v, o);
+        v = USE_MIN ? fmin(v, o) : fmax(v, o);
     }
     return v;
 }
