@@ -395,14 +395,15 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
         const int joff = a.stab[(kc * 8 + slot) * 2], ci0 = a.stab[(kc * 8 + slot) * 2 + 1];
 #pragma unroll
         for (int e = 0; e < NL; ++e) {
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ci0 >= 0 && rowb[e] >= 0) {
-                int ti = rowt[e] + joff;
-                if (ti < 0) ti = -ti;
-                if (ti >= a.Lin) ti = 2 * (a.Lin - 1) - ti;
-                v = *(const bf16x8 *)(a.x + ((size_t)rowb[e] * a.Lin + ti) * a.Cin + ci0);
-            }
-            breg[e] = v;
+            // never a predicated load (hipcc branches around it and drains vmcnt(0) behind it): rows / k-slots outside the
+            // problem read element 0 of the activation and are zeroed by a select
+            const bool ok = ci0 >= 0 && rowb[e] >= 0;
+            int ti = rowt[e] + joff;
+            if (ti < 0) ti = -ti;
+            if (ti >= a.Lin) ti = 2 * (a.Lin - 1) - ti;
+            const size_t off = ok ? ((size_t)rowb[e] * a.Lin + ti) * a.Cin + ci0 : 0;
+            const bf16x8 ld = *(const bf16x8 *)(a.x + off);
+            breg[e] = ok ? ld : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         }
     };
 
