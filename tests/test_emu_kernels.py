@@ -353,3 +353,35 @@ def test_fx_manipulator_chains_emulated(emu_default, tmp_path):
     for a, b in zip(y, ref):
         assert a.shape == x.shape and np.isfinite(a).all()
         assert np.abs(a - b).max() <= 2e-5 * max(1e-3, np.abs(b).max())
+
+
+@pytest.mark.parametrize("L,n_items,C", [(97, 1, 2), (128, 3, 1), (1000, 2, 2), (2049, 33, 2), (4100, 70, 1)])
+def test_time_parallel_fx_shapes_emulated(emu_default, L, n_items, C):
+    """The time-parallel compressor (chunk maps / chain / fill) and equaliser (chunk scan) against the oracle over ragged
+    lengths (below four chunks -> serial form, exact multiples, ragged tails), mono audio and more sequences than one
+    wave (n_items * C > 64, not a multiple of 64)."""
+    from music_mixing_style_transfer_amd.mixing_manipulator import Compressor, Equaliser
+    rng = np.random.default_rng(L + n_items)
+    x = (0.2 * rng.standard_normal((n_items, L, C))).astype(np.float32)
+    x[0, L // 3:L // 3 + 5] = 0.0                       # |x| < 1e-6 -> -120 dB floor
+    c = Compressor(44100)
+    for th, at, rt, ra in ((-30.0, 1.5, 60.0, 8.0), (-18.0, 15.0, 400.0, 0.6)):
+        c.parameters.threshold.value, c.parameters.attack_time.value = th, at
+        c.parameters.release_time.value, c.parameters.ratio.value = rt, ra
+        y = c.process(x.copy())
+        for i in (0, n_items - 1):
+            ref = F.compressor(x[i].copy(), th, at, rt, ra)
+            assert np.abs(y[i] - ref).max() <= 3e-7 * max(1.0, np.abs(ref).max()), (L, n_items, C, i)
+    for bands in (("low_shelf",), ("first_band", "third_band"), ("low_shelf", "first_band", "second_band", "third_band", "high_shelf")):
+        eq = Equaliser(C, 44100, bands=bands)
+        prm = {}
+        for k, b in enumerate(bands):
+            g = float(rng.uniform(-12, 12))
+            getattr(eq.parameters, b + "_gain").value = g
+            fc = getattr(eq.parameters, b + "_freq").value
+            q = getattr(eq.parameters, b + "_q").value if hasattr(eq.parameters, b + "_q") else 0.707
+            prm[b] = (g, fc, q)
+        y = eq.process(x.copy())
+        for i in (0, n_items - 1):
+            ref = F.equaliser(x[i].copy(), prm, bands=bands)
+            assert np.abs(y[i] - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (L, bands, i)

@@ -236,6 +236,38 @@ def test_fx_processors_vs_oracle(oracle_fx_lib):
         assert np.abs(out[i] - F.rms_normalize(xn[i], F.gain(xn[i], 5.0))).max() <= 1e-5
 
 
+def test_time_parallel_fx_ragged_shapes(oracle_fx_lib):
+    """Compressor (chunk maps / chain / fill) and equaliser (chunk scan) on the device at a ragged length, with more sequences
+    than one wave and mono audio, against the oracle (compressor: its C restatement)."""
+    import ctypes as C
+    from music_mixing_style_transfer_amd.mixing_manipulator import Compressor, Equaliser
+    from oracle import fx_ref as F
+    fp = C.POINTER(C.c_float)
+    for n, L, ch in ((33, 70001, 2), (70, 9973, 1)):
+        x = (0.15 * torch.randn(n, L, ch, generator=torch.Generator().manual_seed(L))).clamp_(-1, 1)
+        xn = x.numpy()
+        for th, at, rt, ra in ((-28.0, 1.0, 70.0, 10.0), (-15.0, 12.0, 300.0, 0.7), (-20.0, 200.0, 60.0, 4.0)):
+            c = Compressor(44100)
+            c.parameters.threshold.value, c.parameters.attack_time.value = th, at
+            c.parameters.release_time.value, c.parameters.ratio.value = rt, ra
+            y = c.process(x.cuda()).cpu().numpy()
+            for i in (0, n // 2, n - 1):
+                xi = np.ascontiguousarray(xn[i])
+                ref = np.empty_like(xi)
+                oracle_fx_lib.ref_compressor(xi.ctypes.data_as(fp), ref.ctypes.data_as(fp), C.c_long(L), ch, C.c_double(th), C.c_double(at),
+                                             C.c_double(rt), C.c_double(ra), C.c_double(0.0), C.c_double(44100.0))
+                assert np.abs(y[i] - ref).max() <= 2e-6 * max(1e-3, np.abs(ref).max()), (n, L, ch, th, i)
+        eq = Equaliser(ch, 44100, bands=("low_shelf", "second_band", "high_shelf"))
+        prm = {}
+        for b, g in zip(eq.bands, (6.0, -9.0, 4.0)):
+            getattr(eq.parameters, b + "_gain").value = g
+            prm[b] = (g, getattr(eq.parameters, b + "_freq").value, getattr(eq.parameters, b + "_q").value if hasattr(eq.parameters, b + "_q") else 0.707)
+        y = eq.process(x.cuda()).cpu().numpy()
+        for i in (0, n - 1):
+            ref = F.equaliser(xn[i], prm, bands=eq.bands)
+            assert np.abs(y[i] - ref).max() <= 2e-6 * max(1e-3, np.abs(ref).max())
+
+
 def test_haas_panner_vs_golden_and_oracle():
     """a-D7 on the device: bit-exact vs the reference's outputs (golden) and vs the oracle at full segment size."""
     import os
