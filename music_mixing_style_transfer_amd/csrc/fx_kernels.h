@@ -368,24 +368,28 @@ __global__ __launch_bounds__(64) void fx_comp_map_kernel(CompMapArgs a) {
         if (n < a.L) {                                             // uniform over the wave
             const double x = a.xl[(size_t)n * a.n_seq + sq];
             const double oA = cA * x, oR = cR * x;
-            double na = 0.0, nb = dead, nlo = 1e300, nhi = 1e300;   // the upper part of the split piece, if any piece crosses x
+            // the piece that crosses x (at most one) is remembered with selects and split after the loop: no divergent region
+            double ca = 0.0, cb = 0.0, chi = 0.0;
+            bool any = false;
 #pragma unroll
             for (int i = 0; i <= t; ++i) {
                 const bool att = lo[i] < x;                         // values below x: the attack branch applies
                 const bool cross = att && x < hi[i];
                 const double coef = att ? a.aA : a.aR, off = att ? oA : oR;
-                if (cross) {
-                    na = a.aR * pa[i];
-                    nb = a.aR * pb[i] + oR;
-                    nlo = x;
-                    nhi = a.aR * hi[i] + oR;
-                }
+                ca = cross ? pa[i] : ca;
+                cb = cross ? pb[i] : cb;
+                chi = cross ? hi[i] : chi;
+                any = any || cross;
                 pa[i] = coef * pa[i];
                 pb[i] = coef * pb[i] + off;
                 lo[i] = coef * lo[i] + off;
                 hi[i] = cross ? x : coef * hi[i] + off;
             }
-            pa[t + 1] = na; pb[t + 1] = nb; lo[t + 1] = nlo; hi[t + 1] = nhi;
+            // its upper part takes the release transform and becomes piece t + 1 (a dead piece when nothing crossed)
+            pa[t + 1] = any ? a.aR * ca : 0.0;
+            pb[t + 1] = any ? a.aR * cb + oR : dead;
+            lo[t + 1] = any ? x : 1e300;
+            hi[t + 1] = any ? a.aR * chi + oR : 1e300;
         } else {
             pa[t + 1] = 0.0; pb[t + 1] = dead; lo[t + 1] = 1e300; hi[t + 1] = 1e300;
         }
