@@ -54,6 +54,7 @@ class Mixing_Style_Transfer_Inference:
         self.reload_weights({"effects_encoder": args.ckpt_path_enc, "mixing_converter": args.ckpt_path_conv},
                             ddp=trained_w_ddp)
         self.data_loader = Song_Dataset_Inference(args)
+        self.save_args(args)
         if not args.do_not_separate:
             raise NotImplementedError("source separation (demucs) is not part of this build: pass --do_not_separate True "
                                       "and provide the separated stems")
@@ -66,6 +67,21 @@ class Mixing_Style_Transfer_Inference:
                 state[k[7:] if ddp else k] = v          # strip 'module.' of DDP-trained checkpoints
             model.load_state_dict(state)                 # strict, like the reference
             print(f"---reloaded checkpoint weights : {name} ---")
+
+    def save_args(self, params):
+        """The run's arguments, grouped like the command line's help, into
+        <output_dir>style_transfer_inference_configurations.txt (reference style_transfer.py:305-322)."""
+        info = "\n[args]\n"
+        for group in build_parser()._action_groups:
+            if group.title in ("positional arguments", "optional arguments", "options"):
+                continue
+            info += f"  {group.title} ({len(group._group_actions)})\n"
+            for action in group._group_actions:
+                info += f"      - {action.dest:20s}: {getattr(params, action.dest, None)}\n"
+        info += "\n"
+        os.makedirs(self.output_dir, exist_ok=True)
+        with open(f"{self.output_dir}style_transfer_inference_configurations.txt", "w") as f:
+            np.savetxt(f, [info], delimiter=" ", fmt="%s")
 
     # ---- hot loops -----------------------------------------------------------------------------
     @torch.no_grad()

@@ -138,3 +138,17 @@ def test_inference_and_interpolation_orchestration_match_reference(emu_default, 
         assert sorted(written) == sorted(names) and len(names) == 5
         for name in names:
             assert np.abs(written[name] - g[f"n{ni}_{name}"]).max() <= 2e-6
+
+
+def test_save_args_record(tmp_path):
+    """The configuration record the reference writes next to its outputs (style_transfer.py:305-322): same file name, one
+    block per argument group, one '- name: value' line per argument."""
+    from music_mixing_style_transfer_amd.inference import style_transfer as stm
+    args = stm.build_parser().parse_args(["--target_dir", "/data/", "--batch_size", "3", "--do_not_separate", "True"])
+    runner = object.__new__(stm.Mixing_Style_Transfer_Inference)
+    runner.output_dir = str(tmp_path) + "/"
+    runner.save_args(args)
+    txt = open(tmp_path / "style_transfer_inference_configurations.txt").read()
+    assert txt.startswith("\n[args]\n  Directory args (") and "  Inference args (" in txt and "  Device args (" in txt
+    assert "      - batch_size          : 3\n" in txt and "      - target_dir          : /data/\n" in txt
+    assert "      - segment_length      : 524288\n" in txt
