@@ -36,6 +36,21 @@ class FXencoder_Inference:
         self.models = {"effects_encoder": FXencoder(args.cfg_encoder).to(self.device).eval()}
         self.models["effects_encoder"].precision = getattr(args, "precision", "fp32")
         self.reload_weights({"effects_encoder": args.ckpt_path_enc}, ddp=trained_w_ddp)
+        self.save_args(args)
+
+    def save_args(self, params):
+        """<output_dir>feature_extraction_inference_configurations.txt, grouped like the help text (reference :144-161)."""
+        info = "\n[args]\n"
+        for group in build_parser()._action_groups:
+            if group.title in ("positional arguments", "optional arguments", "options"):
+                continue
+            info += f"  {group.title} ({len(group._group_actions)})\n"
+            for action in group._group_actions:
+                info += f"      - {action.dest:20s}: {getattr(params, action.dest, None)}\n"
+        info += "\n"
+        os.makedirs(self.output_dir, exist_ok=True)
+        with open(f"{self.output_dir}feature_extraction_inference_configurations.txt", "w") as f:
+            np.savetxt(f, [info], delimiter=" ", fmt="%s")
 
     def reload_weights(self, ckpt_paths, ddp=True):
         for name, model in self.models.items():
