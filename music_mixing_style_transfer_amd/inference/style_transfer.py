@@ -1,10 +1,10 @@
 """Music mixing style transfer inference on MI355X - the orchestration of inference/style_transfer.py
 (reference :27-177 Mixing_Style_Transfer_Inference, :181-270 interpolation, :344-389 arguments).
 
-Same command-line flags and defaults, same directory layout, same checkpoint format; the two networks run on
-libmst_hip.so.  Differences that do not change results: all segments of a stem go through the device in
-batches that stay resident (no per-batch host round trip), and with torch.distributed initialised the segments
-of each stem are sharded across the GPUs of the node with one all-gather of segment embeddings.
+Same command-line flags and defaults, same directory layout, same checkpoint format, same configuration record; the
+two networks run on libmst_hip.so.  This command-line runner drives one GPU, batch by batch like the reference; the
+multi-GPU form of the same two loops (segments of a stem sharded across the GPUs of a node, one all-gather of segment
+embeddings) is `inference/engine.py::StyleTransferEngine.transfer_stem`, which `bench.py --gpus N` measures.
 Not implemented: Demucs separation (pass --do_not_separate True) and the input FX normaliser
 (--normalize_input False); both are outside the accelerated hot path.
 
