@@ -226,6 +226,17 @@ extern "C" int mst_tcn_load_block(MstTcn *t, int n, const float *conv_w, const f
             for (int j = 0; j < K; ++j)
                 for (int co = 0; co < C; ++co) w0[((size_t)ci * K + j) * C + co] = W(co, ci, j);
         if ((rc = upload(&b.w_f32, w0))) return rc;
+        if (cin == 2 && K == 15) {        // bf16 A fragments of the matrix-core block-0 kernel: [s][wave][lane][e], k = ci * 15 + j
+            std::vector<__bf16> wb((size_t)2 * 4 * 64 * 8);
+            for (int sI = 0; sI < 2; ++sI)
+                for (int w = 0; w < 4; ++w)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 8; ++e) {
+                            const int k = 16 * sI + 8 * (l >> 5) + e;
+                            wb[(((size_t)sI * 4 + w) * 64 + l) * 8 + e] = k < 30 ? (__bf16)W(32 * w + (l & 31), k / 15, k % 15) : (__bf16)0.0f;
+                        }
+            if ((rc = upload((__bf16 **)&b.w_bf16, wb))) return rc;
+        }
     } else {
         // bf16 A fragments of v_mfma_f32_32x32x16_bf16: [ks = j*8 + kc][wave][lane][e]
         std::vector<__bf16> wb((size_t)120 * 4 * 64 * 8);
@@ -481,8 +492,12 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         a.B = B;
         a.L = L;
         a.Lp = Lp;
-        const int grid = B * ((L + 63) / 64);
-        if (precision == MST_PREC_BF16)
+        const int grid = B * ((L + 511) / 512);      // 8 tiles of 64 steps per workgroup
+        a.wpk16 = t->blk[0].w_bf16;
+        static const bool b0_valu = getenv("MST_TCN_BLOCK0_VALU") && atoi(getenv("MST_TCN_BLOCK0_VALU")) > 0;   // developer knob
+        if (precision == MST_PREC_BF16 && a.wpk16 && !b0_valu)
+            MST_LAUNCH(tcn_block0_mfma_kernel, dim3(B * ((L + 255) / 256)), dim3(256), stream, a);
+        else if (precision == MST_PREC_BF16)
             MST_LAUNCH((tcn_block0_kernel<__bf16>), dim3(grid), dim3(256), stream, a);
         else
             MST_LAUNCH((tcn_block0_kernel<float>), dim3(grid), dim3(256), stream, a);

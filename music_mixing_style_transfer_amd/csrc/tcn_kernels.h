@@ -627,48 +627,128 @@ struct TcnBlock0Args {
     const float *w;       // [2][15][128] BN-folded
     const float *shift, *film, *res;
     int film_rows, B, L, Lp;
+    const void *wpk16;    // bf16 MFMA form: A fragments [k-step s = 0, 1][wave][lane][8], k = ci * 15 + j (30 of 32 used)
 };
+
+// ------------------------------------------------------------------------------------------------
+// block 0 on the matrix cores (bf16 mode).  The scalar kernel below runs at the fp32 FMA peak of the vector ALUs (32 GFLOP
+// in 0.45 ms = 71 of 78.6 TFLOP/s; v_pk_fma_f32 issues at half rate and does not help), so the 2 x 15 taps become one
+// K = 32 contraction: D[co][t] = sum_k W'[co][k] X[k][t], X[ci * 15 + j][t] = x[ci][t + j - 7].  The waveform is split
+// x = hi + lo into two bf16 operands (16 significant bits), the folded weights are bf16 like every other block's.
+// A workgroup owns 256 output times: wave w builds the B fragments of column tiles 2w, 2w+1 once for all four waves
+// (through LDS), then every wave runs 32 MFMAs for its 32 channels and the usual fused epilogue; HBM-bound on the write.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void tcn_block0_mfma_kernel(TcnBlock0Args a) {
+    constexpr int T = 256, XW = T + 14;
+    __shared__ float xs[2][XW + 2];
+    __shared__ __attribute__((aligned(16))) unsigned char buf[T * 256];       // B fragments (32 KB), later the transposed output tile
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, ln = lane & 31, h = lane >> 5;
+    const int tiles_t = (a.L + T - 1) / T;
+    const int b = blockIdx.x / tiles_t;
+    const int t0 = (blockIdx.x % tiles_t) * T;
+    for (int i = tid; i < 2 * XW; i += 256) {
+        const int ci = i / XW, k = i % XW;
+        const long t = (long)t0 - 7 + k;
+        xs[ci][k] = (t >= 0 && t < a.L) ? a.x[((size_t)b * 2 + ci) * a.L + t] : 0.0f;
+    }
+    const bf16x8 *wp = (const bf16x8 *)a.wpk16 + (w * 64 + lane);
+    const bf16x8 af0 = wp[0], af1 = wp[256];
+    __syncthreads();
+    // B fragments: fragment (q, s, part) at buf + (((q * 2 + s) * 2 + part) * 64 + lane) * 16, part 0 = hi, 1 = lo
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+        const int q = 2 * w + qq;
+#pragma unroll
+        for (int sI = 0; sI < 2; ++sI) {
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 16 * sI + 8 * h + e;               // ci = k / 15, tap j = k % 15; k >= 30 is padding
+                const int ci = k >= 15 ? 1 : 0, j = k - 15 * ci;
+                const float v = k < 30 ? xs[ci][32 * q + ln + j] : 0.0f;
+                const __bf16 vh = (__bf16)v;
+                hi[e] = vh;
+                lo[e] = (__bf16)(v - (float)vh);
+            }
+            *(bf16x8 *)(buf + (((q * 2 + sI) * 2 + 0) * 64 + lane) * 16) = hi;
+            *(bf16x8 *)(buf + (((q * 2 + sI) * 2 + 1) * 64 + lane) * 16) = lo;
+        }
+    }
+    __syncthreads();
+    f32x16 acc[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 sh = *(const f32x4 *)(a.shift + 32 * w + 8 * g + 4 * h);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[q][4 * g + i] = sh[i];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int sI = 0; sI < 2; ++sI) {
+            const bf16x8 bh = *(const bf16x8 *)(buf + (((q * 2 + sI) * 2 + 0) * 64 + lane) * 16);
+            const bf16x8 bl = *(const bf16x8 *)(buf + (((q * 2 + sI) * 2 + 1) * 64 + lane) * 16);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sI ? af1 : af0, bh, acc[q], 0, 0, 0);
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sI ? af1 : af0, bl, acc[q], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                   // every wave has read its fragments: the buffer becomes the output tile
+    const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+    const int cin = w >> 1;                            // grouped residual: channels 0..63 read input 0, 64..127 input 1
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int co0 = 32 * w + 8 * g + 4 * h;
+        const f32x4 fr = *(const f32x4 *)(frow + co0);
+        const f32x4 fb = *(const f32x4 *)(frow + 128 + co0);
+        const f32x4 rs = *(const f32x4 *)(a.res + co0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int o = 32 * q + ln;
+            const float xres = xs[cin][o + 7];
+            bf16x4 out;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = acc[q][4 * g + i];
+                out[i] = (__bf16)(fr[i] * mst_fmax(v, MST_LEAKY * v) + (fb[i] + rs[i] * xres));
+            }
+            *(bf16x4 *)(buf + o * 256 + (((co0 >> 3) ^ (o & 15)) << 4) + 8 * h) = out;
+        }
+    }
+    __syncthreads();
+    __bf16 *yb = (__bf16 *)a.y + (size_t)b * a.Lp * 128;
+    const int slot = tid & 15;
+#pragma unroll
+    for (int i = 0; i < T / 16; ++i) {
+        const int o = (tid >> 4) + 16 * i;
+        const long t = (long)t0 + o;
+        if (t < a.L) *(bf16x8 *)(yb + t * 128 + slot * 8) = *(const bf16x8 *)(buf + o * 256 + ((slot ^ (o & 15)) << 4));
+    }
+}
 
 template <typename OutT>
 __global__ __launch_bounds__(256) void tcn_block0_kernel(TcnBlock0Args a) {
-    constexpr int TT = 64, XW = TT + 14;
+    // a workgroup stages the 15 KB of folded weights once and walks NSUB consecutive 64-step tiles with them (one tile per
+    // workgroup spent as much on staging the weights as on the 960 FMAs per thread: 0.44 ms per 32 segments)
+    constexpr int TT = 64, XW = TT + 14, NSUB = 8;
     __shared__ __attribute__((aligned(16))) float ws[2 * 15 * 128];
-    __shared__ float xs[2 * XW];
+    __shared__ float xs[2][2 * XW];
     const int tid = threadIdx.x;
-    const int tiles_t = (a.L + TT - 1) / TT;
+    const int tiles_t = (a.L + TT * NSUB - 1) / (TT * NSUB);
     const int b = blockIdx.x / tiles_t;
-    const int t0 = (blockIdx.x % tiles_t) * TT;
+    const int tbase = (blockIdx.x % tiles_t) * TT * NSUB;
     for (int i = tid; i < 2 * 15 * 128 / 4; i += 256) ((f32x4 *)ws)[i] = ((const f32x4 *)a.w)[i];
-    if (tid < 2 * XW) {
-        const int ci = tid / XW, k = tid % XW;
-        const long t = (long)t0 - 7 + k;
-        xs[tid] = (t >= 0 && t < a.L) ? a.x[((size_t)b * 2 + ci) * a.L + t] : 0.0f;
-    }
-    __syncthreads();
+    auto stage_x = [&](int buf, int t0) {
+        if (tid < 2 * XW) {
+            const int ci = tid / XW, k = tid % XW;
+            const long t = (long)t0 - 7 + k;
+            xs[buf][tid] = (t >= 0 && t < a.L) ? a.x[((size_t)b * 2 + ci) * a.L + t] : 0.0f;
+        }
+    };
+    stage_x(0, tbase);
     const int cg = tid & 15, tg = tid >> 4;
     const int co0 = cg * 8;
-    float acc[4][8];
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[tt][c] = 0.0f;
-    for (int ci = 0; ci < 2; ++ci) {
-        const float *xrow = xs + ci * XW + 4 * tg;
-#pragma unroll 3
-        for (int j = 0; j < 15; ++j) {
-            const f32x4 w0 = *(const f32x4 *)(ws + (ci * 15 + j) * 128 + co0);
-            const f32x4 w1 = *(const f32x4 *)(ws + (ci * 15 + j) * 128 + co0 + 4);
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const float xv = xrow[tt + j];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    acc[tt][c] = fmaf(w0[c], xv, acc[tt][c]);
-                    acc[tt][c + 4] = fmaf(w1[c], xv, acc[tt][c + 4]);
-                }
-            }
-        }
-    }
     const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
     float sh[8], fr[8], fb[8], rs[8];
 #pragma unroll
@@ -680,19 +760,56 @@ __global__ __launch_bounds__(256) void tcn_block0_kernel(TcnBlock0Args a) {
     }
     const int cin = co0 >> 6;
     OutT *yb = (OutT *)a.y + (size_t)b * a.Lp * 128;
+    for (int sub = 0; sub < NSUB; ++sub) {
+        const int t0 = tbase + sub * TT;
+        if (t0 >= a.L) break;                              // uniform
+        __syncthreads();                                   // this tile's samples (and, first time, the weights) are in LDS
+        if (sub + 1 < NSUB) stage_x((sub + 1) & 1, t0 + TT);     // the next tile's samples travel during the arithmetic
+        const float *xt = xs[sub & 1];
+        // channel pairs on v_pk_fma_f32 (the scalar form runs at the non-packed VALU peak: 71 of 78.6 TFLOP/s measured)
+        f32x2 acc2[4][4];
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-        const int t = t0 + 4 * tg + tt;
-        if (t < a.L) {
-            const float xin = xs[cin * XW + 4 * tg + tt + 7];
-            float o8[8];
+        for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                float v = leaky_relu(acc[tt][c] + sh[c]);
-                v = fr[c] * v + fb[c];
-                o8[c] = v + rs[c] * xin;
+            for (int c = 0; c < 4; ++c) acc2[tt][c] = f32x2{0.0f, 0.0f};
+        for (int ci = 0; ci < 2; ++ci) {
+            const float *xrow = xt + ci * XW + 4 * tg;
+#pragma unroll 3
+            for (int j = 0; j < 15; ++j) {
+                const f32x4 w0 = *(const f32x4 *)(ws + (ci * 15 + j) * 128 + co0);
+                const f32x4 w1 = *(const f32x4 *)(ws + (ci * 15 + j) * 128 + co0 + 4);
+                const f32x2 wp[4] = {f32x2{w0[0], w0[1]}, f32x2{w0[2], w0[3]}, f32x2{w1[0], w1[1]}, f32x2{w1[2], w1[3]}};
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const float xs1 = xrow[tt + j];
+                    const f32x2 xv = {xs1, xs1};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc2[tt][c] = wp[c] * xv + acc2[tt][c];
+                }
             }
-            store8(yb + (size_t)t * 128 + co0, o8);
+        }
+        float acc[4][8];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[tt][2 * c] = acc2[tt][c].x;
+                acc[tt][2 * c + 1] = acc2[tt][c].y;
+            }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int t = t0 + 4 * tg + tt;
+            if (t < a.L) {
+                const float xin = xt[cin * XW + 4 * tg + tt + 7];
+                float o8[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    float v = leaky_relu(acc[tt][c] + sh[c]);
+                    v = fr[c] * v + fb[c];
+                    o8[c] = v + rs[c] * xin;
+                }
+                store8(yb + (size_t)t * 128 + co0, o8);
+            }
         }
     }
 }
