@@ -288,7 +288,7 @@ template <bool OUT_NLC, int CM>
 __global__ __launch_bounds__(256) void enc_direct_kernel(EncDirectArgs a) {
     constexpr int XS_MAX = 4 * (256 * 8 + 64);
     __shared__ float xs[XS_MAX];
-    __shared__ float ws[CM * 4 * 64];
+    __shared__ __attribute__((aligned(16))) float ws[CM * 4 * 64];
     const int tid = threadIdx.x;
     const int tiles = (a.Lout + 255) / 256;
     const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * 256;
@@ -300,7 +300,13 @@ __global__ __launch_bounds__(256) void enc_direct_kernel(EncDirectArgs a) {
         if (ti >= a.Lin) ti = 2 * (a.Lin - 1) - ti;
         xs[i] = (ti >= 0 && ti < a.Lin) ? a.x[((size_t)b * a.Cin + ci) * a.Lin + ti] : 0.0f;
     }
-    for (int i = tid; i < a.Cout * a.Cin * a.ksz; i += 256) ws[i] = a.w[i];
+    // weights tap-major [ci * ksz + j][CM] (zero padded): one vector LDS read per 4 (2) channels instead of one read per
+    // channel and tap (850 LDS reads per output at 2 -> 16 channels, k = 25)
+    static_assert(CM >= 2, "channel tile");
+    for (int i = tid; i < a.Cin * a.ksz * CM; i += 256) {
+        const int co = i % CM, tap = i / CM;
+        ws[i] = co < a.Cout ? a.w[(size_t)co * a.Cin * a.ksz + tap] : 0.0f;
+    }
     __syncthreads();
     const int to = t0 + tid;
     float acc[CM];
@@ -309,9 +315,18 @@ __global__ __launch_bounds__(256) void enc_direct_kernel(EncDirectArgs a) {
     for (int ci = 0; ci < a.Cin; ++ci)
         for (int j = 0; j < a.ksz; ++j) {
             const float xv = xs[ci * span + tid * a.stride + j * a.dil];
+            const float *wt = ws + (ci * a.ksz + j) * CM;
+            if constexpr (CM >= 4) {
 #pragma unroll
-            for (int co = 0; co < CM; ++co)
-                if (co < a.Cout) acc[co] = fmaf(ws[(co * a.Cin + ci) * a.ksz + j], xv, acc[co]);
+                for (int c4 = 0; c4 < CM / 4; ++c4) {
+                    const f32x4 wv = *(const f32x4 *)(wt + 4 * c4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[4 * c4 + i] = fmaf(wv[i], xv, acc[4 * c4 + i]);
+                }
+            } else {
+                acc[0] = fmaf(wt[0], xv, acc[0]);
+                acc[1] = fmaf(wt[1], xv, acc[1]);
+            }
         }
     if (to >= a.Lout) return;
 #pragma unroll
