@@ -365,6 +365,7 @@ struct EncNlcArgs {
     const int *stab;     // [nchunks*8][2]: 16-byte slot -> (j*dil - pad_l, ci0); ci0 = -1 beyond K
     int B, Cin, Lin, Cout, Lout, stride, nchunks, residual, S;
     long Ntot;
+    int ksz, pad_l;      // enc_conv_rows_kernel only
 };
 
 // implicit-GEMM convolution on NLC bf16 activations, v_mfma_f32_32x32x16_bf16, K-chunk = 64 (8 slots per row).
@@ -467,6 +468,78 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
                         for (int i = 0; i < 4; ++i) o[i] = (__bf16)(fmaxf(acc[q][4 * g + i] + sh[i], 0.0f) + (float)r[i]);
                         *(bf16x4 *)(a.y + ((size_t)b * a.Lout + to) * a.Cout + co0) = o;
                     }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same convolution for the long early layers, with the input rows of a tile RESIDENT in LDS.  The im2col form above
+// stages a fresh 64-k slice of the B operand per chunk, i.e. it reads every input row ksz times (and once more per
+// channel tile) from L2: 3.6 GB per encoder pass, the bound of those launches.  Here a workgroup owns NT consecutive
+// output times of ONE batch item, stages the (NT-1)*stride + ksz input rows it needs once (reflection applied while
+// staging), and every k-step of 16 = one tap x 16 input channels reads its B fragment straight from those rows: no
+// barrier in the main loop, A fragments stream from L2 as before.  Rows are stored phase-major (row r at phase r % stride,
+// index r / stride) with a pitch of Cin*2 + 16 bytes, so that the 32 rows of a fragment - stride apart in time - are
+// consecutive LDS rows an odd number of 16-byte units apart: conflict-free ds_read_b128.
+// Host-side eligibility: Cin % 16 == 0, no split-K (>= 512 tiles), Lout >= NT, rows fit 64 KB.
+// ------------------------------------------------------------------------------------------------
+template <int MW>
+__global__ __launch_bounds__(256, 2) void enc_conv_rows_kernel(EncNlcArgs a) {
+    constexpr int NW = 4 / MW, MT = 32 * MW, NT = 128 * NW;
+    __shared__ __attribute__((aligned(16))) unsigned char rows[64 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ln = lane & 31, h = lane >> 5;
+    const int mi = w % MW, ni = w / MW;
+    const int tiles_item = (a.Lout + NT - 1) / NT;
+    const int b = blockIdx.x / tiles_item, to0 = (blockIdx.x % tiles_item) * NT;
+    const int cot = blockIdx.y;
+    const int s = a.stride, pitch = a.Cin * 2 + 16, c8n = a.Cin / 8;
+    const int R = (NT - 1) * s + a.ksz, rpp = (R + s - 1) / s;
+    const __bf16 *xb = a.x + (size_t)b * a.Lin * a.Cin;
+    for (int p = tid; p < R * c8n; p += 256) {
+        const int r = p / c8n, c8 = p - r * c8n;
+        int ti = to0 * s - a.pad_l + r;
+        if (ti < 0) ti = -ti;
+        if (ti >= a.Lin) ti = 2 * (a.Lin - 1) - ti;
+        const bool ok = ti >= 0 && ti < a.Lin;                       // rows of a ragged last tile can fall outside even after reflection
+        const bf16x8 ld = *(const bf16x8 *)(xb + (size_t)(ok ? ti : 0) * a.Cin + c8 * 8);
+        *(bf16x8 *)(rows + ((r % s) * rpp + r / s) * pitch + c8 * 16) = ok ? ld : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
+    const bf16x8 *wtile = (const bf16x8 *)a.wpk + (size_t)cot * a.nchunks * 4 * MW * 64 + mi * 64 + lane;
+    const int nks = (a.Cin * a.ksz) / 16;                             // k-steps that carry weights (K = Cin * ksz is a multiple of 16)
+    bf16x8 anext = wtile[0];
+    __syncthreads();
+    const unsigned char *lanebase = rows + (128 * ni + ln) * pitch + 16 * h;
+    for (int ks = 0; ks < nks; ++ks) {
+        const bf16x8 acur = anext;
+        if (ks + 1 < nks) anext = wtile[(size_t)(ks + 1) * MW * 64];
+        const int k0 = ks * 16, j = k0 / a.Cin, ci0 = k0 - j * a.Cin;
+        const unsigned char *bp = lanebase + ((j % s) * rpp + j / s) * pitch + ci0 * 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur, *(const bf16x8 *)(bp + 32 * q * pitch), acc[q], 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int to = to0 + 128 * ni + 32 * q + ln;
+        if (to < a.Lout) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co0 = cot * MT + 32 * mi + 8 * g + 4 * h;
+                if (co0 < a.Cout) {
+                    const f32x4 sh = *(const f32x4 *)(a.shift + co0);
+                    bf16x4 o, r = {0, 0, 0, 0};
+                    if (a.residual) r = *(const bf16x4 *)(xb + (size_t)to * a.Cin + co0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (__bf16)(fmaxf(acc[q][4 * g + i] + sh[i], 0.0f) + (float)r[i]);
+                    *(bf16x4 *)(a.y + ((size_t)b * a.Lout + to) * a.Cout + co0) = o;
                 }
             }
         }

@@ -951,6 +951,28 @@ int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scrat
     a.Ntot = (long)B * Lout;
     const int MT = 32 * c.mw, NT = 128 * (4 / c.mw);
     const long ntiles = (a.Ntot + NT - 1) / NT, cotiles = (c.cout + MT - 1) / MT;
+    a.ksz = c.ksz;
+    a.pad_l = c.pad_l;
+    {
+        // long early layers: the tile's input rows resident in LDS instead of an im2col slice per k-chunk (MST_ENC_ROWS=0 disables)
+        const int rows_mode = getenv("MST_ENC_ROWS") ? atoi(getenv("MST_ENC_ROWS")) : 1;      // 0 off, 1 default, 2 also for small grids (tests)
+        const bool rows_on = rows_mode > 0;
+        const long tiles_item = (Lout + NT - 1) / NT;
+        const long R = (long)(NT - 1) * c.stride + c.ksz, rpp = (R + c.stride - 1) / c.stride;
+        const long lds = (long)c.stride * rpp * (c.cin * 2 + 16);
+        if (rows_on && c.dil == 1 && c.cin % 16 == 0 && Lout >= NT && lds <= 64 * 1024 && ((long)B * tiles_item * cotiles >= 512 || rows_mode > 1)) {
+            a.S = 1;
+            a.part = nullptr;
+            const dim3 grid((unsigned)(B * tiles_item), (unsigned)cotiles);
+            switch (c.mw) {
+                case 1: MST_LAUNCH((enc_conv_rows_kernel<1>), grid, dim3(256), stream, a); break;
+                case 2: MST_LAUNCH((enc_conv_rows_kernel<2>), grid, dim3(256), stream, a); break;
+                default: MST_LAUNCH((enc_conv_rows_kernel<4>), grid, dim3(256), stream, a); break;
+            }
+            MST_CHECK_LAUNCH("enc_conv_rows_kernel");
+            return MST_OK;
+        }
+    }
     a.S = enc_splitk(ntiles * cotiles, c.nchunks64);
     a.part = a.S > 1 ? scratch : nullptr;
     const dim3 grid((unsigned)ntiles, (unsigned)cotiles, (unsigned)a.S);

@@ -385,3 +385,25 @@ def test_time_parallel_fx_shapes_emulated(emu_default, L, n_items, C):
         for i in (0, n_items - 1):
             ref = F.equaliser(x[i].copy(), prm, bands=bands)
             assert np.abs(y[i] - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (L, bands, i)
+
+
+def test_encoder_rows_kernel_matches_im2col_emulated(emu_default, monkeypatch):
+    """bf16 FXencoder: the LDS-resident-rows convolution kernel (long early layers) against the im2col kernel it replaces -
+    same operands in the same k order, so bit-identical - over strides 1 / 2 / 4, even kernels, ragged last tiles."""
+    from music_mixing_style_transfer_amd.networks import FXencoder
+    cfg = {"channels": [16, 32, 32, 64], "kernels": [25, 10, 15, 5], "strides": [4, 2, 1, 2], "dilation": [1, 1, 1, 1],
+           "bias": True, "norm": "batch", "conv_block": "res", "activation": "relu"}
+    sd = synth.fxencoder_state_dict(cfg, seed=11)
+    enc = FXencoder({k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()})
+    enc.load_state_dict(sd)
+    enc.precision = "bf16"
+    for shape in ((2, 2, 5000), (1, 2, 4097)):
+        x = synth.synth_audio(shape, seed=shape[2])
+        monkeypatch.setenv("MST_ENC_ROWS", "0")
+        ref = enc(x).clone()
+        monkeypatch.setenv("MST_ENC_ROWS", "2")
+        got = enc(x)
+        assert torch.equal(got, ref), shape
+        emb = R.fxencoder_forward(sd, cfg, x)
+        assert float((got - emb).abs().max()) <= 3e-2 * float(emb.abs().max())
+    monkeypatch.delenv("MST_ENC_ROWS", raising=False)
