@@ -729,8 +729,8 @@ __global__ __launch_bounds__(256, 2) void tcn_block0_mfma_kernel(TcnBlock0Args a
 
 template <typename OutT>
 __global__ __launch_bounds__(256) void tcn_block0_kernel(TcnBlock0Args a) {
-    // a workgroup stages the 15 KB of folded weights once and walks NSUB consecutive 64-step tiles with them (one tile per
-    // workgroup spent as much on staging the weights as on the 960 FMAs per thread: 0.44 ms per 32 segments)
+    // exact-fp32 form (the parity mode; bf16 mode runs tcn_block0_mfma_kernel).  A workgroup stages the 15 KB of folded weights
+    // once and walks NSUB consecutive 64-step tiles with them.  VALU-bound: 960 FMAs per thread and tile, 71 of 78.6 TFLOP/s.
     constexpr int TT = 64, XW = TT + 14, NSUB = 8;
     __shared__ __attribute__((aligned(16))) float ws[2 * 15 * 128];
     __shared__ float xs[2][2 * XW];
@@ -766,36 +766,28 @@ __global__ __launch_bounds__(256) void tcn_block0_kernel(TcnBlock0Args a) {
         __syncthreads();                                   // this tile's samples (and, first time, the weights) are in LDS
         if (sub + 1 < NSUB) stage_x((sub + 1) & 1, t0 + TT);     // the next tile's samples travel during the arithmetic
         const float *xt = xs[sub & 1];
-        // channel pairs on v_pk_fma_f32 (the scalar form runs at the non-packed VALU peak: 71 of 78.6 TFLOP/s measured)
-        f32x2 acc2[4][4];
+        float acc[4][8];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc2[tt][c] = f32x2{0.0f, 0.0f};
+            for (int c = 0; c < 8; ++c) acc[tt][c] = 0.0f;
         for (int ci = 0; ci < 2; ++ci) {
             const float *xrow = xt + ci * XW + 4 * tg;
 #pragma unroll 3
             for (int j = 0; j < 15; ++j) {
                 const f32x4 w0 = *(const f32x4 *)(ws + (ci * 15 + j) * 128 + co0);
                 const f32x4 w1 = *(const f32x4 *)(ws + (ci * 15 + j) * 128 + co0 + 4);
-                const f32x2 wp[4] = {f32x2{w0[0], w0[1]}, f32x2{w0[2], w0[3]}, f32x2{w1[0], w1[1]}, f32x2{w1[2], w1[3]}};
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
-                    const float xs1 = xrow[tt + j];
-                    const f32x2 xv = {xs1, xs1};
+                    const float xv = xrow[tt + j];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) acc2[tt][c] = wp[c] * xv + acc2[tt][c];
+                    for (int c = 0; c < 4; ++c) {
+                        acc[tt][c] = fmaf(w0[c], xv, acc[tt][c]);
+                        acc[tt][c + 4] = fmaf(w1[c], xv, acc[tt][c + 4]);
+                    }
                 }
             }
         }
-        float acc[4][8];
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc[tt][2 * c] = acc2[tt][c].x;
-                acc[tt][2 * c + 1] = acc2[tt][c].y;
-            }
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             const int t = t0 + 4 * tg + tt;
