@@ -89,21 +89,26 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
     {
         // all (R+15)/16 row loads of a thread are issued back to back (one exposed memory latency per tile;
         // the accumulators are not live yet, so the registers are free), then written to LDS
-        const int slot = tid & 15;
+        // consecutive passes of a thread are 16 / P dilation steps apart in time and 4096 bytes apart in LDS (the XOR
+        // swizzle depends on row & 15 = the thread's first row only): running pointers, no per-row address arithmetic
+        static_assert(16 % P == 0, "row passes advance by a whole number of steps");
+        const int slot = tid & 15, prow = tid >> 4;
         constexpr int NPASS = (R + 15) / 16;
+        const long dt = (long)(16 / P) * a.d;
+        long t = (long)(m0 + prow / P - 7) * a.d + phi0 + (prow % P);
+        const __bf16 *src = xb + t * 128 + slot * 8;
         bf16x8 v[NPASS];
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            const int r = (tid >> 4) + 16 * i;
-            const long t = (long)(m0 + r / P - 7) * a.d + phi0 + (r % P);
             v[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (r < R && t >= 0 && t < a.L) v[i] = *(const bf16x8 *)(xb + t * 128 + slot * 8);
+            if (prow + 16 * i < R && t >= 0 && t < a.L) v[i] = *(const bf16x8 *)src;
+            t += dt;
+            src += dt * 128;
         }
+        unsigned char *dst = smem + prow * 256 + ((slot ^ (prow & 15)) << 4);
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            const int r = (tid >> 4) + 16 * i;
-            if (r < R) *(bf16x8 *)(smem + r * 256 + ((slot ^ (r & 15)) << 4)) = v[i];
-        }
+        for (int i = 0; i < NPASS; ++i)
+            if (prow + 16 * i < R) *(bf16x8 *)(dst + i * 4096) = v[i];
     }
     __syncthreads();
     if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 1] = mst_clock();
@@ -269,12 +274,16 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
     } else {
         __syncthreads();
         if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 7] = mst_clock();
-        const int slot = tid & 15;
+        const int slot = tid & 15, prow = tid >> 4;
+        const long dt = (long)(16 / P) * a.d;
+        long t = (long)(m0 + prow / P) * a.d + phi0 + (prow % P);
+        __bf16 *dstp = yb + t * 128 + slot * 8;
+        const unsigned char *srcp = smem + prow * 256 + ((slot ^ (prow & 15)) << 4);
 #pragma unroll
         for (int i = 0; i < T / 16; ++i) {
-            const int o = (tid >> 4) + 16 * i;
-            const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
-            if (t < a.L) *(bf16x8 *)(yb + t * 128 + slot * 8) = *(const bf16x8 *)(smem + o * 256 + ((slot ^ (o & 15)) << 4));
+            if (t < a.L) *(bf16x8 *)dstp = *(const bf16x8 *)(srcp + i * 4096);
+            t += dt;
+            dstp += dt * 128;
         }
     }
     if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 3] = mst_clock();
