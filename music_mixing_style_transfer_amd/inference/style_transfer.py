@@ -2,9 +2,10 @@
 (reference :27-177 Mixing_Style_Transfer_Inference, :181-270 interpolation, :344-389 arguments).
 
 Same command-line flags and defaults, same directory layout, same checkpoint format, same configuration record; the
-two networks run on libmst_hip.so.  This command-line runner drives one GPU, batch by batch like the reference; the
-multi-GPU form of the same two loops (segments of a stem sharded across the GPUs of a node, one all-gather of segment
-embeddings) is `inference/engine.py::StyleTransferEngine.transfer_stem`, which `bench.py --gpus N` measures.
+two networks run on libmst_hip.so.  Run plainly it drives one GPU, batch by batch like the reference; launched under
+`python -m torch.distributed.run --nproc-per-node N` with an initialised process group (main() initialises "nccl" when
+WORLD_SIZE > 1) every stem's segments are sharded across the N GPUs (`inference/engine.py::StyleTransferEngine.transfer_stem`:
+one all-gather of segment embeddings, canonical-order mean, so the result does not depend on N) and rank 0 writes the files.
 Not implemented: Demucs separation (pass --do_not_separate True) and the input FX normaliser
 (--normalize_input False); both are outside the accelerated hot path.
 
@@ -30,7 +31,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 class Mixing_Style_Transfer_Inference:
     def __init__(self, args, trained_w_ddp=True):
         if args.inference_device != "cpu" and torch.cuda.is_available():
-            self.device = torch.device("cuda:0")
+            self.device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if self._world() is not None else 0)
+            torch.cuda.set_device(self.device)
         else:
             raise RuntimeError("this build runs the networks on an MI355X only (no CPU path); no GPU is visible")
         self.args = args
@@ -97,35 +99,71 @@ class Mixing_Style_Transfer_Inference:
             outs.append(self.models["mixing_converter"](b.to(self.device), emb.unsqueeze(0)))
         return outs
 
+    # ---- multi-GPU: launched under torch.distributed.run, every rank owns a contiguous shard of each stem's segments ----
+    @staticmethod
+    def _world():
+        import torch.distributed as dist
+        return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+
+    @torch.no_grad()
+    def _transfer_sharded(self, dist, input_stem, reference_stem, name):
+        """One stem over all ranks (StyleTransferEngine.transfer_stem: sharded encoder pass, one all-gather of segment
+        embeddings, sharded converter pass), then the converted segments are gathered so that every rank holds the stem."""
+        from .engine import StyleTransferEngine
+        a = self.args
+        eng = StyleTransferEngine(self.models["effects_encoder"], self.models["mixing_converter"])
+        out, (lo, hi) = eng.transfer_stem(input_stem.to(self.device), reference_stem.to(self.device), a.segment_length,
+                                          a.segment_length_ref, name)
+        world, n_seg = dist.get_world_size(), seg.segment_input(input_stem, name, a.segment_length, 1 << 30)[0].shape[0]
+        counts = [seg.shard_range(n_seg, r, world) for r in range(world)]
+        mx = max(h - l for l, h in counts)
+        seg_len = out.shape[-1] if out.numel() else seg.segment_input(input_stem, name, a.segment_length, 1 << 30)[0].shape[-1]
+        padded = torch.zeros(mx, 2, seg_len, dtype=torch.float32, device=self.device)
+        padded[:hi - lo] = out
+        gathered = torch.empty(world * mx, 2, seg_len, dtype=torch.float32, device=self.device)
+        dist.all_gather_into_tensor(gathered, padded)
+        full = torch.cat([gathered[r * mx:r * mx + (h - l)] for r, (l, h) in enumerate(counts)], 0)
+        return seg.reassemble([full.cpu()], input_stem.shape[-1])
+
     def inference(self):
         print("\n======= Start to inference music mixing style transfer =======")
         tag = "output" if self.args.normalize_input else "output_notnormed"
         a = self.args
+        dist = self._world()
+        writer = dist is None or dist.get_rank() == 0
         for input_stems, reference_stems, dir_name in self.data_loader:
             print(f"---inference file name : {dir_name}---")
             out_dir = dir_name.replace(self.target_dir, self.output_dir)
-            os.makedirs(out_dir, exist_ok=True)
+            if writer:
+                os.makedirs(out_dir, exist_ok=True)
             inst_outputs = []
             for i, inst in enumerate(a.instruments):
                 print(f"\t{inst}...")
-                in_b = seg.segment_input(input_stems[i], dir_name, a.segment_length, a.batch_size)
-                ref_b = seg.segment_reference(reference_stems[i], dir_name, a.segment_length, a.segment_length_ref, a.batch_size)
-                emb = self._embed(ref_b)
-                outs = self._convert(in_b, lambda idx: emb)
-                stem_out = seg.reassemble([o.cpu() for o in outs], input_stems[i].shape[-1]).numpy()
+                if dist is not None:
+                    stem_out = self._transfer_sharded(dist, input_stems[i], reference_stems[i], dir_name).numpy()
+                else:
+                    in_b = seg.segment_input(input_stems[i], dir_name, a.segment_length, a.batch_size)
+                    ref_b = seg.segment_reference(reference_stems[i], dir_name, a.segment_length, a.segment_length_ref, a.batch_size)
+                    emb = self._embed(ref_b)
+                    outs = self._convert(in_b, lambda idx: emb)
+                    stem_out = seg.reassemble([o.cpu() for o in outs], input_stems[i].shape[-1]).numpy()
                 inst_outputs.append(stem_out)
-                if a.save_each_inst:
+                if a.save_each_inst and writer:
                     save_wav_pcm16(os.path.join(out_dir, f"{inst}_{tag}.wav"), stem_out.transpose(-1, -2), a.sample_rate)
             mix = sum(inst_outputs)
-            save_wav_pcm16(os.path.join(out_dir, f"mixture_{tag}.wav"), mix.transpose(-1, -2), a.sample_rate)
+            if writer:
+                save_wav_pcm16(os.path.join(out_dir, f"mixture_{tag}.wav"), mix.transpose(-1, -2), a.sample_rate)
 
     def inference_interpolation(self):
         print("\n======= Start to inference interpolation examples =======")
         tag = "output_interpolation" if self.args.normalize_input else "output_notnormed_interpolation"
         a = self.args
+        dist = self._world()
+        writer = dist is None or dist.get_rank() == 0        # interpolation is not sharded: every rank computes, rank 0 writes
         for input_stems, ref_a, ref_b, dir_name in self.data_loader:
             out_dir = dir_name.replace(self.target_dir, self.output_dir)
-            os.makedirs(out_dir, exist_ok=True)
+            if writer:
+                os.makedirs(out_dir, exist_ok=True)
             inst_outputs = []
             for i, inst in enumerate(a.instruments):
                 seg_len = input_stems[i].shape[1] // a.interpolate_segments + 1
@@ -144,9 +182,10 @@ class Mixing_Style_Transfer_Inference:
                 outs = self._convert(in_b, emb_for)
                 stem_out = seg.reassemble([o.cpu() for o in outs], input_stems[i].shape[-1]).numpy()
                 inst_outputs.append(stem_out)
-                if a.save_each_inst:
+                if a.save_each_inst and writer:
                     save_wav_pcm16(os.path.join(out_dir, f"{inst}_{tag}.wav"), stem_out.transpose(-1, -2), a.sample_rate)
-            save_wav_pcm16(os.path.join(out_dir, f"mixture_{tag}.wav"), sum(inst_outputs).transpose(-1, -2), a.sample_rate)
+            if writer:
+                save_wav_pcm16(os.path.join(out_dir, f"mixture_{tag}.wav"), sum(inst_outputs).transpose(-1, -2), a.sample_rate)
 
 
 def str2bool(v):
@@ -199,6 +238,11 @@ def main(argv=None):
         configs = yaml.full_load(f)
     args.cfg_encoder = configs["Effects_Encoder"]["default"]
     args.cfg_converter = configs["TCN"]["default"]
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:             # one process per GPU (torch.distributed.run): RCCL over xGMI
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
     runner = Mixing_Style_Transfer_Inference(args)
     if args.interpolation:
         runner.inference_interpolation()

@@ -71,3 +71,59 @@ def test_two_ranks_equal_one(tmp_path, emu):
     stitched = S.reassemble([torch.cat([p[2] for p in parts], 0)], L_IN)
     assert stitched.shape == full.shape == (2, L_IN)
     assert torch.equal(stitched, full)
+
+
+def _cli_worker(rank, world, port, out_path):
+    """The style_transfer runner's inference() loop: plain (world 1) or sharded over the ranks (world 2)."""
+    import types
+    import numpy as np
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MST_EMU_THREADS="2")
+    torch.set_num_threads(1)
+    from music_mixing_style_transfer_amd import _lib
+    from music_mixing_style_transfer_amd.inference import style_transfer as st
+    from music_mixing_style_transfer_amd.utils import synth
+    b = _lib.bind(os.path.join(REPO, "tests", "emu", "libmst_emu.so"))
+    b.emulated = True
+    _lib.set_default_binding(b)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    enc, tcn = _models()
+    runner = object.__new__(st.Mixing_Style_Transfer_Inference)
+    runner.args = types.SimpleNamespace(normalize_input=False, instruments=["drums", "bass"], segment_length=SEG,
+                                        segment_length_ref=SEG, batch_size=1, save_each_inst=True, sample_rate=44100)
+    runner.device = torch.device("cpu")
+    runner.target_dir, runner.output_dir = "/data/", "/tmp/mst_cli_dist_out/"
+    runner.models = {"effects_encoder": enc, "mixing_converter": tcn}
+    stems_in = torch.stack([synth.synth_audio((2, L_IN), seed=5), synth.synth_audio((2, L_IN), seed=7)])
+    stems_ref = torch.stack([synth.synth_audio((2, L_REF), seed=6), synth.synth_audio((2, L_REF), seed=8)])
+    runner.data_loader = [(stems_in, stems_ref, "/data/song/")]
+    written = {}
+    st.save_wav_pcm16 = lambda path, data, sr: written.__setitem__(os.path.basename(path), np.array(data))
+    st.os.makedirs = lambda *a, **k: None
+    runner.inference()
+    if world == 1 or rank == 0:
+        torch.save(written, out_path)
+    else:
+        assert not written                      # only rank 0 writes
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_cli_runner_sharded_equals_single(tmp_path, emu):
+    """`style_transfer` launched on two ranks shards every stem's segments and rank 0 writes the same stems / mixture as
+    the single-process run, bit for bit."""
+    from music_mixing_style_transfer_amd import _lib
+    from music_mixing_style_transfer_amd.inference import style_transfer as st
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    prev, prev_save, prev_mk = _lib._default, st.save_wav_pcm16, st.os.makedirs
+    try:
+        _cli_worker(0, 1, 0, one)
+    finally:
+        _lib.set_default_binding(prev)
+        st.save_wav_pcm16, st.os.makedirs = prev_save, prev_mk
+    mp.spawn(_cli_worker, args=(2, 29653, two), nprocs=2, join=True)
+    a, b = torch.load(one, weights_only=False), torch.load(two, weights_only=False)
+    assert sorted(a) == sorted(b) == ["bass_output_notnormed.wav", "drums_output_notnormed.wav", "mixture_output_notnormed.wav"]
+    for k in a:
+        assert a[k].shape == (L_IN, 2) and (a[k] == b[k]).all(), k
