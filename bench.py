@@ -1,23 +1,35 @@
 #!/usr/bin/env python
 """bench.py - headline benchmark: stereo 44.1 kHz segments/sec, FXencoder + MixFXcloner forward.
 
-Workload (BASELINE.json configs[1]): batch = 32 segments of 2 x 131072 samples per GPU, default configs.yaml
-architectures, deterministic synthetic weights, synthetic audio; one step = FXencoder on the 32 reference
-segments -> (all-gather of segment embeddings when N > 1) -> mean -> FiLM factors -> TCN on the 32 input
-segments.  Inputs are resident in HBM before the timed region.  Weak scaling: every rank owns 32 segments.
+Headline workload (BASELINE.json configs[1]): batch = 32 segments of 2 x 131072 samples per GPU, default configs.yaml
+architectures, deterministic synthetic weights, synthetic audio; one step = FXencoder on the 32 reference segments ->
+(all-gather of segment embeddings when N > 1) -> mean -> FiLM factors -> TCN on the 32 input segments.  Inputs are
+resident in HBM before the timed region.  Weak scaling: every rank owns 32 segments.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|fp32] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision bf16|fp32] [--workload all|configs1|track60]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel = the dilated 128x128x15 TCN block
-conv, timed with HIP events on its stream inside the timed region) and "cpu_baseline" (the oracle's torch-CPU
-restatement on a bounded sample, rank 0, N = 1 only).
+Prints ONE JSON line (rank 0).  Objects carried by the line:
+  "roofline"      dominant kernel = the dilated 128x128x15 TCN block conv, timed with HIP events on its stream inside
+                  the timed region;
+  "track60"       BASELINE configs[4]: ONE 60-minute stereo stem (158 760 000 samples = 1212 segments of 131072 for the
+                  reference and the input role) through StyleTransferEngine.transfer_stem, the 1212 segments split over
+                  the N ranks (STRONG scaling; the only collective is the all-gather of segment embeddings).  Reported with
+                  the stems resident in HBM ("value") and host-to-host from / to pinned memory ("pcie_inclusive": per-rank
+                  shard H2D + D2H overlapped with the networks).  N > 1 also times the same track on rank 0 alone
+                  ("t1_ms_same_job") so that T1 / (N * TN) can be read off one line;
+  "parity_mode"   (N = 1) the same configs[1] step in the exact-fp32 mode that meets north_star's 1e-4 tolerance, its
+                  dominant kernel against the fp32 MFMA peak, and the max-abs deviation of the HIP path from the oracle;
+  "fx_chain"      (N = 1) BASELINE configs[3]: EQ -> rms -> compressor -> rms -> imager -> rms -> gain on 64 segments;
+  "cpu_baseline"  (N = 1) the oracle (torch-CPU restatement of the reference) on a bounded sample, all cores and 1 thread.
+With --workload track60 the track IS the headline ("scaling": "strong").
 """
 import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,8 +40,10 @@ sys.path.insert(0, REPO)
 
 SEG_LEN = 131072
 BATCH = 32
+TRACK_SAMPLES = 60 * 60 * 44100                         # 158 760 000 -> 1211 full segments + a zero-padded tail
 TCN_FLOP_PER_SAMPLE_BLOCK = 2 * 128 * 128 * 15          # one dense TCN block, per output time step
 PEAK = {"bf16": 2500.0, "fp32": 157.3}                  # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0
 
 
 def load_cfg():
@@ -39,22 +53,204 @@ def load_cfg():
     return c["Effects_Encoder"]["default"], c["TCN"]["default"]
 
 
-def cpu_baseline(enc_cfg, enc_sd, tcn_sd, seconds_budget=25.0):
-    """Oracle (torch-CPU fp32 restatement of the reference) on a bounded sample of the same workload."""
+# ------------------------------------------------------------------------------------------------ CPU baseline (oracle)
+def cpu_baseline(enc_cfg, enc_sd, tcn_sd):
+    """Oracle (torch-CPU fp32 restatement of the reference) on a bounded sample of the configs[1] workload: one warm-up
+    + the median of 3 segments on all cores; one thread on an eighth of a segment (the TCN is linear in the length)."""
     from oracle import networks_ref as R
     from music_mixing_style_transfer_amd.utils import synth
     cfg = dict(enc_cfg)
-    x = synth.synth_audio((1, 2, SEG_LEN), seed=1)
-    n, t0 = 0, time.time()
-    while True:
+
+    def one(x):
+        t0 = time.perf_counter()
         emb = R.fxencoder_forward(enc_sd, cfg, x)
         R.tcn_forward(tcn_sd, x, emb.mean(0, keepdim=True))
-        n += 1
-        if time.time() - t0 > seconds_budget * 0.5 or n >= 4:
-            break
-    dt = time.time() - t0
-    return {"value": n / dt, "unit": "segments/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} segment(s) of 2x{SEG_LEN}, FXencoder+TCN fp32, oracle/networks_ref.py (torch-CPU), batch 1"}
+        return time.perf_counter() - t0
+
+    cores = torch.get_num_threads()
+    x = synth.synth_audio((1, 2, SEG_LEN), seed=1)
+    one(x)                                                           # warm-up (allocator, oneDNN primitive cache)
+    ts = [one(x) for _ in range(3)]
+    xs = synth.synth_audio((1, 2, SEG_LEN // 8), seed=1)
+    torch.set_num_threads(1)
+    try:
+        one(xs)
+        t1 = statistics.median([one(xs) for _ in range(2)]) * 8.0
+    finally:
+        torch.set_num_threads(cores)
+    return {"value": 1.0 / statistics.median(ts), "unit": "segments/s", "cores": cores, "kind": "port",
+            "samples_s": [round(t, 3) for t in ts], "value_1thread": 1.0 / t1,
+            "sample": f"warm median of 3 x 1 segment of 2x{SEG_LEN} (FXencoder+TCN fp32, oracle/networks_ref.py, torch-CPU, "
+                      f"{cores} threads); 1 thread: median of 2 x 1/8 segment (2x{SEG_LEN // 8}) scaled by 8"}
+
+
+# ------------------------------------------------------------------------------------------------ configs[1] step
+def bench_configs1(engine, tcn, lib, ref, inp, steps, warmup, world, dist, dev):
+    """K timed steps between barriers; returns (seconds max over ranks, per-block kernel ms, forwards timed)."""
+    for _ in range(warmup):
+        engine.step(ref, inp)
+    torch.cuda.synchronize()
+    lib.check(lib.mst_tcn_timing_begin(tcn._handle, steps), "timing_begin")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        engine.step(ref, inp)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    nb = tcn.hparams.nblocks
+    ms = (C.c_float * (nb + 1))()
+    nf = C.c_int(0)
+    lib.check(lib.mst_tcn_timing_end(tcn._handle, ms, C.byref(nf)), "timing_end")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return float(tmax.item()), [float(v) for v in ms], int(nf.value)
+
+
+def roofline(block_ms, nb, B, precision, traffic=None):
+    dense = block_ms[1:nb]                                   # the 13 dilated 128->128 blocks
+    avg_ms = sum(dense) / len(dense)
+    flop = TCN_FLOP_PER_SAMPLE_BLOCK * B * SEG_LEN
+    achieved = flop / (avg_ms * 1e-3) / 1e12
+    return {"kernel": "tcn_block_%s_kernel (dilated 128x128x15 conv + fused BN/LeakyReLU/FiLM/residual)" %
+                      ("bf16" if precision == "bf16" else "f32"),
+            "bound": "mfma", "achieved": achieved, "peak": PEAK[precision], "unit": "TFLOP/s",
+            "frac": achieved / PEAK[precision], "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": nb - 1,
+            "flop_per_launch": flop, "per_block_ms": block_ms}
+
+
+# ------------------------------------------------------------------------------------------------ 60-minute track
+def bench_track60(enc, tcn, world, rank, dist, dev, steps, warmup, with_host=True, with_t1=True):
+    """One 60-minute stem (reference + input role), its 1212 segments split over the ranks."""
+    from music_mixing_style_transfer_amd.inference import StyleTransferEngine
+    from music_mixing_style_transfer_amd.inference import segmentation as seg
+    g = torch.Generator(device=dev).manual_seed(1234)             # the same track on every rank
+    x_in = (torch.rand(2, TRACK_SAMPLES, generator=g, device=dev) * 2 - 1)
+    x_ref = (torch.rand(2, TRACK_SAMPLES, generator=g, device=dev) * 2 - 1)
+    n_seg = seg.segment_count(TRACK_SAMPLES, SEG_LEN)
+
+    def timed(engine, a, b, k, w, sync_ranks):
+        for _ in range(w):
+            engine.transfer_stem(a, b, SEG_LEN, SEG_LEN)
+        torch.cuda.synchronize()
+        if sync_ranks:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            engine.transfer_stem(a, b, SEG_LEN, SEG_LEN)
+        torch.cuda.synchronize()
+        if sync_ranks:
+            dist.barrier()
+        dt = (time.perf_counter() - t0) / k
+        if sync_ranks:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    eng = StyleTransferEngine(enc, tcn)
+    t_res = timed(eng, x_in, x_ref, steps, warmup, world > 1)
+    lo, hi = seg.shard_range(n_seg, rank, world)
+    out = {"workload": f"configs[4]: one 60-min stereo stem = {n_seg} segments of 2x{SEG_LEN} (reference and input role), "
+                       f"contiguous segment shards over {world} GPU(s), all-gather of [{n_seg}, 2048] embeddings, "
+                       f"passes of <= {eng.pass_samples // SEG_LEN} segments",
+           "scaling": "strong", "segments": n_seg, "segments_rank0": hi - lo, "n_gpus": world,
+           "value": n_seg / t_res, "unit": "segments/s", "t_ms": t_res * 1e3}
+    if with_host:
+        h_in, h_ref = x_in.cpu().pin_memory(), x_ref.cpu().pin_memory()
+        t_host = timed(eng, h_in, h_ref, max(1, steps // 2), 1, world > 1)
+        out["pcie_inclusive"] = {"value": n_seg / t_host, "unit": "segments/s", "t_ms": t_host * 1e3,
+                                 "what": "stems in pinned host memory -> each rank uploads / converts / downloads only its "
+                                         "shard (copy streams overlap the networks) -> converted shard in pinned host memory"}
+        del h_in, h_ref
+    if world > 1 and with_t1:
+        if rank == 0:
+            solo = StyleTransferEngine(enc, tcn)
+            solo.dist, solo.world, solo.rank = None, 1, 0          # the same track on this GPU alone
+            t1 = timed(solo, x_in, x_ref, 1, 1, False)
+            out["t1_ms_same_job"] = t1 * 1e3
+            out["efficiency_t1_over_n_tn"] = t1 / (world * t_res)
+        dist.barrier()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ parity mode (fp32)
+def bench_parity_mode(engine, enc, tcn, lib, ref, inp, dev, enc_cfg, enc_sd, tcn_sd):
+    from music_mixing_style_transfer_amd.utils import synth
+    from oracle import networks_ref as R
+    enc.precision = tcn.precision = "fp32"
+    try:
+        dt, block_ms, _ = bench_configs1(engine, tcn, lib, ref, inp, 2, 1, 1, None, dev)
+        L = 16384
+        pr, pi = synth.synth_audio((2, 2, L), seed=5), synth.synth_audio((2, 2, L), seed=6)
+        y, _ = engine.step(pr.to(dev), pi.to(dev))
+        _, _, y_ref = R.style_transfer_segments(enc_sd, dict(enc_cfg), tcn_sd, pr, pi)
+        err = float((y.cpu() - y_ref).abs().max())
+    finally:
+        enc.precision = tcn.precision = "bf16"
+    return {"dtype": "f32", "value": BATCH * 2 / dt, "unit": "segments/s", "ms_per_step": dt / 2 * 1e3,
+            "roofline": roofline(block_ms, tcn.hparams.nblocks, BATCH, "fp32"),
+            "max_abs_vs_oracle": err, "probe": f"2 reference + 2 input segments of 2x{L} vs oracle/networks_ref.py", "tolerance": 1e-4}
+
+
+# ------------------------------------------------------------------------------------------------ FX chain (config 4)
+def bench_fx_chain(dev, steps=5):
+    import numpy as np
+    from music_mixing_style_transfer_amd.mixing_manipulator import (AugmentationChain, Compressor, Equaliser, Gain,
+                                                                    MidSideImager)
+    from oracle import fx_ref as F
+    n, L = 64, SEG_LEN
+    g = torch.Generator().manual_seed(0)
+    x = (0.1 * torch.randn(n, L, 2, generator=g)).clamp_(-1, 1).to(dev)
+    eq = Equaliser(2, 44100)
+    for band, (gg, _, _) in F.CONFIG4["eq"].items():
+        getattr(eq.parameters, band + "_gain").value = gg
+    comp, im, gn = Compressor(44100), MidSideImager(), Gain()
+    for k, v in F.CONFIG4["comp"].items():
+        getattr(comp.parameters, k).value = v
+    im.parameters.bal.value = F.CONFIG4["imager_bal"]
+    gn.parameters.gain.value = F.CONFIG4["gain_db"]
+    chain = AugmentationChain(fxs=[(eq, 1.0, True), (comp, 1.0, True), (im, 1.0, True), (gn, 1.0, False)],
+                              randomize_param_value=False)
+    out = chain([x])[0]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = chain([x])[0]
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ref = F.fx_chain(x[17].cpu().numpy(), compressor_fn=_oracle_c_compressor())
+    dev_max = float(np.abs(out[17].cpu().numpy() - ref).max())
+    alg = 144 * L * n                       # SURVEY.md 8d: unfused per-processor read + write bytes of the chain
+    return {"workload": "configs[3]: EQ -> rms -> compressor -> rms -> imager -> rms -> gain on 64 segments of [131072, 2]",
+            "value": n / dt, "unit": "segments/s", "ms_per_chain": dt * 1e3,
+            "roofline": {"bound": "hbm", "achieved": alg / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": alg / dt / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": alg,
+                         "fused_lower_bound_bytes": 16 * L * n},
+            "max_abs_vs_oracle": dev_max, "probe": "item 17 vs oracle/fx_ref.py chain (EQ parity unpinned, see DESIGN.md)",
+            "tolerance": "2e-6 * max|ref|"}
+
+
+def _oracle_c_compressor():
+    import subprocess
+    import numpy as np
+    subprocess.run(["make", "-C", os.path.join(REPO, "oracle")], check=True, capture_output=True)
+    lib = C.CDLL(os.path.join(REPO, "oracle", "libfx_ref.so"))
+    fp = C.POINTER(C.c_float)
+
+    def c_comp(xx, threshold, attack_time, release_time, ratio, sample_rate):
+        xx = np.ascontiguousarray(xx, dtype=np.float32)
+        yy = np.empty_like(xx)
+        lib.ref_compressor(xx.ctypes.data_as(fp), yy.ctypes.data_as(fp), C.c_long(xx.shape[0]), xx.shape[1],
+                           C.c_double(threshold), C.c_double(attack_time), C.c_double(release_time), C.c_double(ratio),
+                           C.c_double(0.0), C.c_double(sample_rate))
+        return yy
+    return c_comp
 
 
 def main():
@@ -64,6 +260,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--workload", default="all", choices=["all", "configs1", "track60"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -98,75 +295,57 @@ def main():
     enc.load_state_dict(enc_sd)
     tcn.load_state_dict(tcn_sd)
     engine = StyleTransferEngine(enc, tcn)
-
-    B = args.batch
-    ref = synth.synth_audio((B, 2, SEG_LEN), seed=100 + rank).to(dev)      # resident in HBM before timing
-    inp = synth.synth_audio((B, 2, SEG_LEN), seed=200 + rank).to(dev)
-
     lib = _lib.lib()
     enc._get_runner()._ensure(lib)      # weight folding / packing is setup, not part of a step
     tcn._ensure(lib)
-    for _ in range(args.warmup):
-        engine.step(ref, inp)
-    torch.cuda.synchronize()
-
-    lib.check(lib.mst_tcn_timing_begin(tcn._handle, args.steps), "timing_begin")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        y, _ = engine.step(ref, inp)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
     nb = tcn.hparams.nblocks
-    ms = (C.c_float * (nb + 1))()
-    nf = C.c_int(0)
-    lib.check(lib.mst_tcn_timing_end(tcn._handle, ms, C.byref(nf)), "timing_end")
+    B = args.batch
+    dtype = args.precision if args.precision == "bf16" else "f32"
+    base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
+            "dtype": dtype, "data": "synthetic"}
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    if args.workload == "track60":
+        tr = bench_track60(enc, tcn, world, rank, dist, dev, args.steps, args.warmup)
+        if rank == 0:
+            out = dict(base, metric="stereo 44.1 kHz segments/sec (FXencoder+MixFXcloner fwd)", value=tr["value"],
+                       unit="segments/s", ms_per_step=tr["t_ms"], scaling="strong",
+                       config={"workload": tr["workload"], "segment_length": SEG_LEN, "segments": tr["segments"],
+                               "parallelism": f"segment-sharded x{world}, all-gather of embeddings"}, track60=tr)
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ref = synth.synth_audio((B, 2, SEG_LEN), seed=100 + rank).to(dev)      # resident in HBM before timing
+    inp = synth.synth_audio((B, 2, SEG_LEN), seed=200 + rank).to(dev)
+    dt, block_ms, nf = bench_configs1(engine, tcn, lib, ref, inp, args.steps, args.warmup, world, dist, dev)
+    track = None
+    if args.workload == "all" and args.precision == "bf16":
+        track = bench_track60(enc, tcn, world, rank, dist, dev, 2, 1)
 
     if rank == 0:
         traffic = None      # HBM bytes per launch of the dominant kernel: offline rocprofv3 --pmc passes (tools/pmc_traffic.py)
-        tpath = os.path.join(REPO, "profiles", "r01_tcn_block_bf16_traffic.json")
-        if args.precision == "bf16" and B == BATCH and os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get("traffic_bytes")
-        block_ms = [float(v) for v in ms]
-        dense = block_ms[1:nb]                                   # the 13 dilated 128->128 blocks
-        avg_ms = sum(dense) / len(dense)
-        flop_per_launch = TCN_FLOP_PER_SAMPLE_BLOCK * B * SEG_LEN
-        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12
-        out = {
-            "metric": "stereo 44.1 kHz segments/sec (FXencoder+MixFXcloner fwd)",
-            "value": world * B * args.steps / dt,
-            "unit": "segments/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": args.precision if args.precision == "bf16" else "f32",
-            "data": "synthetic",
-            "config": {"workload": f"configs[1]: batch={B} segments of 2x{SEG_LEN} per GPU, FXencoder+MixFXcloner forward, "
-                                   f"default configs.yaml nets, synthetic weights; TCN dense blocks {args.precision} MFMA "
-                                   f"(fp32 accumulate), FXencoder convs {args.precision} MFMA",
-                       "segments_per_gpu": B, "segment_length": SEG_LEN,
-                       "parallelism": f"segment-sharded x{world}, all-gather of embeddings"},
-            "roofline": {"kernel": "tcn_block_%s_kernel (dilated 128x128x15 conv + fused BN/LeakyReLU/FiLM/residual)" %
-                                   ("bf16" if args.precision == "bf16" else "f32"),
-                         "bound": "mfma", "achieved": achieved, "peak": PEAK[args.precision], "unit": "TFLOP/s",
-                         "frac": achieved / PEAK[args.precision], "traffic": traffic,
-                         "avg_launch_ms": avg_ms, "launches_per_step": nb - 1, "timed_forwards": int(nf.value),
-                         "flop_per_launch": flop_per_launch, "per_block_ms": block_ms},
-        }
+        for name in ("r02_tcn_block_bf16_traffic.json", "r01_tcn_block_bf16_traffic.json"):
+            tpath = os.path.join(REPO, "profiles", name)
+            if args.precision == "bf16" and B == BATCH and os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get("traffic_bytes")
+                break
+        rl = roofline(block_ms, nb, B, args.precision, traffic)
+        rl["timed_forwards"] = nf
+        out = dict(base, metric="stereo 44.1 kHz segments/sec (FXencoder+MixFXcloner fwd)",
+                   value=world * B * args.steps / dt, unit="segments/s", ms_per_step=dt / args.steps * 1e3, scaling="weak",
+                   config={"workload": f"configs[1]: batch={B} segments of 2x{SEG_LEN} per GPU, FXencoder+MixFXcloner forward, "
+                                       f"default configs.yaml nets, synthetic weights; TCN dense blocks {args.precision} MFMA "
+                                       f"(fp32 accumulate), FXencoder convs {args.precision} MFMA",
+                           "segments_per_gpu": B, "segment_length": SEG_LEN,
+                           "parallelism": f"segment-sharded x{world}, all-gather of embeddings"},
+                   roofline=rl)
+        if track is not None:
+            out["track60"] = track
+        if world == 1 and args.workload == "all" and args.precision == "bf16" and B == BATCH:
+            out["parity_mode"] = bench_parity_mode(engine, enc, tcn, lib, ref, inp, dev, enc_cfg, enc_sd, tcn_sd)
+            out["fx_chain"] = bench_fx_chain(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(enc_cfg, enc_sd, tcn_sd)
         print(json.dumps(out), flush=True)

@@ -95,6 +95,28 @@ class Binding:
             fn.argtypes = args
             setattr(self, name, fn)
 
+    def require_device(self, t, what):
+        """The kernels run on the MI355X only: a tensor that is not in HBM is an error (there is no CPU path)."""
+        if not t.is_cuda:
+            raise RuntimeError(f"{what}: input must live on the MI355X (a CUDA/HIP tensor); there is no CPU path")
+
+    def to_device(self, t):
+        """Host arrays handed to a processor travel to the MI355X (numpy in -> numpy out at that boundary)."""
+        if t.is_cuda:
+            return t
+        if not torch.cuda.is_available():
+            raise RuntimeError("the kernels run on the MI355X only; no GPU is visible and there is no CPU path")
+        return t.cuda()
+
+    def stream_ptr(self, t):
+        """The caller's current HIP stream for tensor t's device (what every entry point takes as `stream`)."""
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+    def device_ctx(self, t):
+        """Context that makes t's device the current HIP device: handles, weights and the FiLM table are allocated on,
+        and kernels launched on, the device the data lives on (not whatever device happens to be current)."""
+        return torch.cuda.device(t.device)
+
     def check(self, status, what=""):
         if status != MST_OK:
             msg = self.mst_last_error()

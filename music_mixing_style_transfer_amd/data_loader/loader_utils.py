@@ -2,8 +2,11 @@
 
 16/32-bit PCM -> float64 in [-1, 1) exactly like the reference (int16 / 2**15, int32 / 2**31), stereo
 de-interleaved to [2, L] (axis=0) or [L, 2] (axis=1).  Same ValueErrors for a wrong sample rate / bit depth.
-soundfile is not a dependency: writing uses the standard `wave` module (PCM_16).
+soundfile is not a dependency: writing uses the standard `wave` module (PCM_16); `SlicedWavWriter` lets every rank of a
+multi-GPU run write the time range it produced straight into the output file (no gather of the audio to one rank).
 """
+import os
+import struct
 import wave
 
 import numpy as np
@@ -40,9 +43,46 @@ def save_wav_pcm16(audio_path, data, sample_rate=44100):
     data = np.asarray(data)
     if data.ndim == 1:
         data = data[:, None]
-    pcm = np.clip(np.rint(data * 32767.0), -32768, 32767).astype("<i2")
+    pcm = pcm16(data)
     with wave.open(audio_path, "w") as w:
         w.setnchannels(pcm.shape[1])
         w.setsampwidth(2)
         w.setframerate(sample_rate)
         w.writeframes(pcm.tobytes())
+
+
+def pcm16(data):
+    """float [-1, 1] -> little-endian int16 exactly like save_wav_pcm16 (elementwise: slices convert independently)."""
+    return np.clip(np.rint(np.asarray(data) * 32767.0), -32768, 32767).astype("<i2")
+
+
+class SlicedWavWriter:
+    """A 16-bit PCM wav file of known length written in time slices, possibly by several processes of one node:
+    `create()` (one process) writes the 44-byte RIFF header the `wave` module would write and sizes the file;
+    `write(t0, data[L_slice, C])` (any process, after create) stores rows [t0, t0 + L_slice).  The finished file is
+    byte-identical to save_wav_pcm16 of the whole signal."""
+
+    def __init__(self, path, n_frames, n_channels=2, sample_rate=44100):
+        self.path, self.n_frames, self.nch, self.sr = path, int(n_frames), int(n_channels), int(sample_rate)
+
+    def create(self):
+        nbytes = self.n_frames * self.nch * 2
+        header = b"RIFF" + struct.pack("<L4s4sLHHLLHH4sL", 36 + nbytes, b"WAVE", b"fmt ", 16, 1, self.nch, self.sr,
+                                       self.nch * self.sr * 2, self.nch * 2, 16, b"data", nbytes)
+        with open(self.path, "wb") as f:
+            f.write(header)
+            f.truncate(44 + nbytes)
+
+    def write(self, t0, data):
+        data = np.asarray(data)
+        if data.ndim == 1:
+            data = data[:, None]
+        if data.shape[1] != self.nch or t0 < 0 or t0 + data.shape[0] > self.n_frames:
+            raise ValueError("SlicedWavWriter.write: slice outside the file")
+        if data.shape[0] == 0:
+            return
+        fd = os.open(self.path, os.O_WRONLY)
+        try:
+            os.pwrite(fd, pcm16(data).tobytes(), 44 + int(t0) * self.nch * 2)
+        finally:
+            os.close(fd)

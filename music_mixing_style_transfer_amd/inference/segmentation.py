@@ -5,6 +5,36 @@ reference): inference/style_transfer.py:274-301 (batchwise_segmentization), :126
 import torch
 
 
+def _check_duration(length, min_length, song_name):
+    assert length >= min_length, \
+        f"Error : Insufficient duration!\n\t \
+                Target song's length is shorter than segment length.\n\t \
+                Song name : {song_name}\n\t \
+                Consider changing the 'segment_length' or song with sufficient duration"
+
+
+def segment_count(length, segment_length):
+    """Number of segments batchwise_segmentization cuts (discard_last=False): pad = seg - L % seg zeros are appended,
+    so an exact multiple gets one extra all-zero segment (:286-293)."""
+    return (length + segment_length - length % segment_length) // segment_length
+
+
+def plan_input(length, song_name, segment_length):
+    """(n_segments, segment_length) of an input stem, or (1, None) when it runs as one [1, 2, L] item (:126-132)."""
+    if length > segment_length:
+        _check_duration(length, segment_length, song_name)
+        return segment_count(length, segment_length), segment_length
+    return 1, None
+
+
+def plan_reference(length, song_name, segment_length, segment_length_ref):
+    """(n_segments, segment_length_ref) of a reference stem, or (1, None) when it is encoded whole (:133-139)."""
+    if length > 2 * segment_length:
+        _check_duration(length, segment_length, song_name)
+        return segment_count(length, segment_length_ref), segment_length_ref
+    return 1, None
+
+
 def batchwise_segmentization(target_song, song_name, segment_length, batch_size, min_length=None, discard_last=False):
     """[2, L] tensor -> list of [b, 2, segment_length] batches (last one may be ragged).
 
@@ -13,11 +43,7 @@ def batchwise_segmentization(target_song, song_name, segment_length, batch_size,
       * pad = seg - L % seg: an exact multiple gets one extra all-zero segment.
     """
     min_length = segment_length if min_length is None else min_length
-    assert target_song.shape[-1] >= min_length, \
-        f"Error : Insufficient duration!\n\t \
-                Target song's length is shorter than segment length.\n\t \
-                Song name : {song_name}\n\t \
-                Consider changing the 'segment_length' or song with sufficient duration"
+    _check_duration(target_song.shape[-1], min_length, song_name)
     if discard_last:
         target_song = target_song[:, :target_song.shape[-1] - target_song.shape[-1] % segment_length]
     else:
@@ -53,6 +79,17 @@ def stack_embeddings(emb_batches):
     """[n_batches] x [b, D] -> [n, D]; like the reference's torch.stack this requires equal batch shapes (:152)."""
     stacked = torch.stack(emb_batches)
     return stacked.reshape(stacked.shape[0] * stacked.shape[1], stacked.shape[2])
+
+
+def check_stackable(ref_length, segment_length, segment_length_ref, batch_size):
+    """The reference stacks the per-batch embeddings with torch.stack (:152), which raises when the last batch of
+    reference segments is ragged; the runner keeps that error (feature_extraction.py uses torch.cat and does not)."""
+    if ref_length <= 2 * segment_length:
+        return
+    n = segment_count(ref_length, segment_length_ref)
+    if n > batch_size and n % batch_size:
+        raise RuntimeError(f"stack expects each tensor to be equal size, but got [{batch_size}, 2048] at entry 0 and "
+                           f"[{n % batch_size}, 2048] at entry {n // batch_size}")
 
 
 def shard_range(n_items, rank, world_size):

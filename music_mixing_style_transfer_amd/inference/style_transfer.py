@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import yaml
 
-from ..data_loader import Song_Dataset_Inference, save_wav_pcm16
+from ..data_loader import SlicedWavWriter, Song_Dataset_Inference, save_wav_pcm16
 from ..networks import FXencoder, TCNModel
 from . import segmentation as seg
 from .engine import embedding_mean
@@ -35,6 +35,9 @@ class Mixing_Style_Transfer_Inference:
             torch.cuda.set_device(self.device)
         else:
             raise RuntimeError("this build runs the networks on an MI355X only (no CPU path); no GPU is visible")
+        if not args.do_not_separate:                 # checked before any model is built or checkpoint read
+            raise NotImplementedError("source separation (demucs) is not part of this build: pass --do_not_separate True "
+                                      "and provide the separated stems")
         self.args = args
         self.segment_length = args.segment_length
         self.batch_size = args.batch_size
@@ -56,10 +59,8 @@ class Mixing_Style_Transfer_Inference:
         self.reload_weights({"effects_encoder": args.ckpt_path_enc, "mixing_converter": args.ckpt_path_conv},
                             ddp=trained_w_ddp)
         self.data_loader = Song_Dataset_Inference(args)
-        self.save_args(args)
-        if not args.do_not_separate:
-            raise NotImplementedError("source separation (demucs) is not part of this build: pass --do_not_separate True "
-                                      "and provide the separated stems")
+        if self._world() is None or self._world().get_rank() == 0:
+            self.save_args(args)
 
     def reload_weights(self, ckpt_paths, ddp=True):
         for name, model in self.models.items():
@@ -105,54 +106,61 @@ class Mixing_Style_Transfer_Inference:
         import torch.distributed as dist
         return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
 
-    @torch.no_grad()
-    def _transfer_sharded(self, dist, input_stem, reference_stem, name):
-        """One stem over all ranks (StyleTransferEngine.transfer_stem: sharded encoder pass, one all-gather of segment
-        embeddings, sharded converter pass), then the converted segments are gathered so that every rank holds the stem."""
+    def _engine(self):
         from .engine import StyleTransferEngine
-        a = self.args
-        eng = StyleTransferEngine(self.models["effects_encoder"], self.models["mixing_converter"])
-        out, (lo, hi) = eng.transfer_stem(input_stem.to(self.device), reference_stem.to(self.device), a.segment_length,
-                                          a.segment_length_ref, name)
-        world, n_seg = dist.get_world_size(), seg.segment_input(input_stem, name, a.segment_length, 1 << 30)[0].shape[0]
-        counts = [seg.shard_range(n_seg, r, world) for r in range(world)]
-        mx = max(h - l for l, h in counts)
-        seg_len = out.shape[-1] if out.numel() else seg.segment_input(input_stem, name, a.segment_length, 1 << 30)[0].shape[-1]
-        padded = torch.zeros(mx, 2, seg_len, dtype=torch.float32, device=self.device)
-        padded[:hi - lo] = out
-        gathered = torch.empty(world * mx, 2, seg_len, dtype=torch.float32, device=self.device)
-        dist.all_gather_into_tensor(gathered, padded)
-        full = torch.cat([gathered[r * mx:r * mx + (h - l)] for r, (l, h) in enumerate(counts)], 0)
-        return seg.reassemble([full.cpu()], input_stem.shape[-1])
+        return StyleTransferEngine(self.models["effects_encoder"], self.models["mixing_converter"], device=self.device)
+
+    def _host(self, stem):
+        """Stems go to the engine in page-locked host memory: its passes overlap H2D / compute / D2H."""
+        return stem.pin_memory() if self.device.type == "cuda" and not stem.is_pinned() else stem
 
     def inference(self):
+        """reference :112-177.  Every stem runs through StyleTransferEngine.transfer_stem: all of the stem's segments are
+        in flight (passes bounded by the engine's sample budget, not by --batch_size, which only keeps the reference's
+        ragged-`torch.stack` error), a rank reads / uploads / converts only its own shard of segments, and writes the time
+        range it produced straight into the output files (SlicedWavWriter) - the audio is never gathered."""
         print("\n======= Start to inference music mixing style transfer =======")
         tag = "output" if self.args.normalize_input else "output_notnormed"
         a = self.args
         dist = self._world()
-        writer = dist is None or dist.get_rank() == 0
+        rank = dist.get_rank() if dist is not None else 0
+        eng = self._engine()
         for input_stems, reference_stems, dir_name in self.data_loader:
             print(f"---inference file name : {dir_name}---")
             out_dir = dir_name.replace(self.target_dir, self.output_dir)
-            if writer:
+            L = input_stems.shape[-1]
+            names = [f"{inst}_{tag}.wav" for inst in a.instruments] if a.save_each_inst else []
+            writers = {n: SlicedWavWriter(os.path.join(out_dir, n), L, 2, a.sample_rate) for n in names + [f"mixture_{tag}.wav"]}
+            if dist is not None:
+                if rank == 0:
+                    os.makedirs(out_dir, exist_ok=True)
+                    for w in writers.values():
+                        w.create()
+                dist.barrier()
+            else:
                 os.makedirs(out_dir, exist_ok=True)
-            inst_outputs = []
+            inst_outputs, t_range = [], (0, L)
             for i, inst in enumerate(a.instruments):
                 print(f"\t{inst}...")
-                if dist is not None:
-                    stem_out = self._transfer_sharded(dist, input_stems[i], reference_stems[i], dir_name).numpy()
-                else:
-                    in_b = seg.segment_input(input_stems[i], dir_name, a.segment_length, a.batch_size)
-                    ref_b = seg.segment_reference(reference_stems[i], dir_name, a.segment_length, a.segment_length_ref, a.batch_size)
-                    emb = self._embed(ref_b)
-                    outs = self._convert(in_b, lambda idx: emb)
-                    stem_out = seg.reassemble([o.cpu() for o in outs], input_stems[i].shape[-1]).numpy()
+                seg.check_stackable(reference_stems[i].shape[-1], a.segment_length, a.segment_length_ref, a.batch_size)
+                res = eng.transfer_stem(self._host(input_stems[i]), self._host(reference_stems[i]), a.segment_length,
+                                        a.segment_length_ref, dir_name)
+                stem_out, t_range = (res, (0, L)) if dist is None else res
+                stem_out = stem_out.cpu().numpy()
                 inst_outputs.append(stem_out)
-                if a.save_each_inst and writer:
-                    save_wav_pcm16(os.path.join(out_dir, f"{inst}_{tag}.wav"), stem_out.transpose(-1, -2), a.sample_rate)
-            mix = sum(inst_outputs)
-            if writer:
-                save_wav_pcm16(os.path.join(out_dir, f"mixture_{tag}.wav"), mix.transpose(-1, -2), a.sample_rate)
+                if a.save_each_inst:
+                    self._write(dist, writers[f"{inst}_{tag}.wav"], t_range[0], stem_out)
+            self._write(dist, writers[f"mixture_{tag}.wav"], t_range[0], sum(inst_outputs))
+            if dist is not None:
+                dist.barrier()
+
+    @staticmethod
+    def _write(dist, writer, t0, data):
+        """data [2, n]: the whole stem (one process: the plain wav writer) or this rank's time range starting at t0."""
+        if dist is None:
+            save_wav_pcm16(writer.path, data.transpose(-1, -2), writer.sr)
+        else:
+            writer.write(t0, data.transpose(-1, -2))
 
     def inference_interpolation(self):
         print("\n======= Start to inference interpolation examples =======")

@@ -86,13 +86,9 @@ class _Dev:
             t = t[:, None]
         if not self.batched:
             t = t[None]
-        if not t.is_cuda and not getattr(self.lib, "emulated", False):
-            if not torch.cuda.is_available():
-                raise RuntimeError("FX processors run on the MI355X only; no GPU is visible and there is no CPU path")
-            t = t.cuda()
-        self.x = t.contiguous()
+        self.x = self.lib.to_device(t).contiguous()
         self.n, self.L, self.C = self.x.shape
-        self.stream = C.c_void_p(torch.cuda.current_stream(self.x.device).cuda_stream) if self.x.is_cuda else C.c_void_p(0)
+        self.stream = self.lib.stream_ptr(self.x)
 
     def scratch(self, n_doubles):
         return torch.empty(n_doubles, dtype=torch.float64, device=self.x.device)

@@ -29,15 +29,12 @@ class _HParams(dict):
 
 
 def _stream_ptr(t):
-    if t.is_cuda:
-        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
-    return C.c_void_p(0)
+    return _lib.lib().stream_ptr(t)
 
 
 def _check_device(t, what):
     b = _lib.lib()
-    if not t.is_cuda and not getattr(b, "emulated", False):
-        raise RuntimeError(f"{what}: input must live on the MI355X (a CUDA/HIP tensor); there is no CPU path")
+    b.require_device(t, what)
     if t.dtype != torch.float32:
         raise TypeError(f"{what}: float32 input expected, got {t.dtype}")
     return b

@@ -26,12 +26,9 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def emu():
     """The C ABI compiled for the host against the SIMT emulator (tests/emu) - same sources as libmst_hip.so."""
-    from music_mixing_style_transfer_amd import _lib
-    d = os.path.join(REPO, "tests", "emu")
-    subprocess.run(["make", "-C", d], check=True, capture_output=True)
-    b = _lib.bind(os.path.join(d, "libmst_emu.so"))
-    b.emulated = True
-    return b
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from emu_binding import bind_emulator
+    return bind_emulator()
 
 
 @pytest.fixture()

@@ -34,8 +34,9 @@ def _worker(rank, world, port, out_path):
     from music_mixing_style_transfer_amd import _lib
     from music_mixing_style_transfer_amd.inference import StyleTransferEngine
     from music_mixing_style_transfer_amd.utils import synth
-    b = _lib.bind(os.path.join(REPO, "tests", "emu", "libmst_emu.so"))
-    b.emulated = True
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from emu_binding import bind_emulator
+    b = bind_emulator(build=False)
     _lib.set_default_binding(b)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -47,11 +48,13 @@ def _worker(rank, world, port, out_path):
     if world == 1:
         torch.save({"full": res}, out_path)
     else:
-        out, (lo, hi) = res
-        gathered = [None] * world
-        dist.all_gather_object(gathered, (lo, hi, out))
+        y, rng = res                               # this rank's time range only
+        ranges = [None] * world
+        dist.all_gather_object(ranges, tuple(rng))
+        full = eng.gather_stem(y, rng, L_IN)       # collected on rank 0 only
+        assert (full is None) == (rank != 0)
         if rank == 0:
-            torch.save({"parts": gathered}, out_path)
+            torch.save({"full": full, "ranges": ranges}, out_path)
         dist.destroy_process_group()
 
 
@@ -66,25 +69,25 @@ def test_two_ranks_equal_one(tmp_path, emu):
         _lib.set_default_binding(prev)
     mp.spawn(_worker, args=(2, 29641, two), nprocs=2, join=True)
     full = torch.load(one)["full"]
-    parts = sorted(torch.load(two, weights_only=False)["parts"], key=lambda p: p[0])
-    assert parts[0][0] == 0 and parts[0][1] == parts[1][0] and parts[1][1] == 5          # contiguous shards of 5 segments
-    stitched = S.reassemble([torch.cat([p[2] for p in parts], 0)], L_IN)
-    assert stitched.shape == full.shape == (2, L_IN)
-    assert torch.equal(stitched, full)
+    res = torch.load(two, weights_only=False)
+    # contiguous shards of the 5 input segments: rank 0 owns segments [0, 2), rank 1 [2, 5) -> time ranges cropped to L_IN
+    assert res["ranges"] == [(0, 2 * SEG), (2 * SEG, L_IN)]
+    assert res["full"].shape == full.shape == (2, L_IN)
+    assert torch.equal(res["full"], full)
 
 
 def _cli_worker(rank, world, port, out_path):
     """The style_transfer runner's inference() loop: plain (world 1) or sharded over the ranks (world 2)."""
     import types
-    import numpy as np
     sys.path.insert(0, REPO)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MST_EMU_THREADS="2")
     torch.set_num_threads(1)
     from music_mixing_style_transfer_amd import _lib
     from music_mixing_style_transfer_amd.inference import style_transfer as st
     from music_mixing_style_transfer_amd.utils import synth
-    b = _lib.bind(os.path.join(REPO, "tests", "emu", "libmst_emu.so"))
-    b.emulated = True
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from emu_binding import bind_emulator
+    b = bind_emulator(build=False)
     _lib.set_default_binding(b)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -93,37 +96,31 @@ def _cli_worker(rank, world, port, out_path):
     runner.args = types.SimpleNamespace(normalize_input=False, instruments=["drums", "bass"], segment_length=SEG,
                                         segment_length_ref=SEG, batch_size=1, save_each_inst=True, sample_rate=44100)
     runner.device = torch.device("cpu")
-    runner.target_dir, runner.output_dir = "/data/", "/tmp/mst_cli_dist_out/"
+    runner.target_dir, runner.output_dir = "/data/", out_path + "/"
     runner.models = {"effects_encoder": enc, "mixing_converter": tcn}
     stems_in = torch.stack([synth.synth_audio((2, L_IN), seed=5), synth.synth_audio((2, L_IN), seed=7)])
     stems_ref = torch.stack([synth.synth_audio((2, L_REF), seed=6), synth.synth_audio((2, L_REF), seed=8)])
     runner.data_loader = [(stems_in, stems_ref, "/data/song/")]
-    written = {}
-    st.save_wav_pcm16 = lambda path, data, sr: written.__setitem__(os.path.basename(path), np.array(data))
-    st.os.makedirs = lambda *a, **k: None
-    runner.inference()
-    if world == 1 or rank == 0:
-        torch.save(written, out_path)
-    else:
-        assert not written                      # only rank 0 writes
+    runner.inference()                          # one process: plain wav writer; two: every rank writes its own time range
     if world > 1:
         dist.destroy_process_group()
 
 
 def test_cli_runner_sharded_equals_single(tmp_path, emu):
-    """`style_transfer` launched on two ranks shards every stem's segments and rank 0 writes the same stems / mixture as
-    the single-process run, bit for bit."""
+    """`style_transfer` launched on two ranks shards every stem's segments, each rank writes the time range it produced
+    into the output files, and the files are byte-identical to the single-process run's."""
     from music_mixing_style_transfer_amd import _lib
-    from music_mixing_style_transfer_amd.inference import style_transfer as st
-    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
-    prev, prev_save, prev_mk = _lib._default, st.save_wav_pcm16, st.os.makedirs
+    from music_mixing_style_transfer_amd.data_loader import load_wav_length
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    prev = _lib._default
     try:
         _cli_worker(0, 1, 0, one)
     finally:
         _lib.set_default_binding(prev)
-        st.save_wav_pcm16, st.os.makedirs = prev_save, prev_mk
     mp.spawn(_cli_worker, args=(2, 29653, two), nprocs=2, join=True)
-    a, b = torch.load(one, weights_only=False), torch.load(two, weights_only=False)
-    assert sorted(a) == sorted(b) == ["bass_output_notnormed.wav", "drums_output_notnormed.wav", "mixture_output_notnormed.wav"]
-    for k in a:
-        assert a[k].shape == (L_IN, 2) and (a[k] == b[k]).all(), k
+    names = ["bass_output_notnormed.wav", "drums_output_notnormed.wav", "mixture_output_notnormed.wav"]
+    assert sorted(os.listdir(os.path.join(one, "song"))) == sorted(os.listdir(os.path.join(two, "song"))) == names
+    for k in names:
+        a, b = os.path.join(one, "song", k), os.path.join(two, "song", k)
+        assert load_wav_length(a) == L_IN
+        assert open(a, "rb").read() == open(b, "rb").read(), k
