@@ -198,8 +198,9 @@ int mst_fx_convolve(MstConvolver *cv, const float *x_dev, const float *h_dev, lo
 /* Gain.process (:1041-1051) */
 int mst_fx_gain(const float *x_dev, float *y_dev, int n_items, long L, int C, double gain_db, int invert, void *stream);
 /* AugmentationChain.apply_processor rms_normalize branch (:143-146): y *= sqrt(mean(x^2)/max(1e-7, mean(y^2)))
- * per item; scratch_dev: >= n_items*4 doubles */
-int mst_fx_rms_normalize(const float *x_dev, float *y_dev, int n_items, long L, int C, double *scratch_dev, void *stream);
+ * per item; per_x / per_y = samples per item of x and of y (L * channels each: the means are scalars over each array, and a
+ * processor such as Panner / Haas may turn mono into stereo); scratch_dev: >= n_items*4 doubles */
+int mst_fx_rms_normalize(const float *x_dev, float *y_dev, int n_items, long per_x, long per_y, double *scratch_dev, void *stream);
 
 #ifdef __cplusplus
 }

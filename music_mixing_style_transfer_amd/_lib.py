@@ -67,7 +67,7 @@ SIGNATURES = {
     "mst_fx_gain": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_double, C.c_int, _P]),
     "mst_fx_haas": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_long, C.c_double, C.c_int, _P]),
     "mst_fx_panner": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_float, C.c_float, _P]),
-    "mst_fx_rms_normalize": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, _P, _P]),
+    "mst_fx_rms_normalize": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_long, _P, _P]),
     "mst_fx_convolver_create": (C.c_int, [C.c_long, C.c_long, C.c_int, C.c_int, C.POINTER(_P)]),
     "mst_fx_convolver_destroy": (None, [_P]),
     "mst_fx_convolver_workspace_bytes": (C.c_size_t, [_P]),

@@ -567,11 +567,11 @@ __global__ __launch_bounds__(256) void fx_imager_apply_kernel(const float *x, fl
 // Gain.process (:1041-1051) and the final multiply of the rms normalise (:145-146)
 // mode 0: y = g * x ; mode 1: y *= sqrt(ex / max(1e-7, ey)) with ex = acc_x/per_item, ey = acc_y/per_item
 __global__ __launch_bounds__(256) void fx_scale_kernel(const float *x, float *y, long per_item, float g,
-                                                       const double *acc_x, const double *acc_y, int mode) {
+                                                       const double *acc_x, const double *acc_y, int mode, long per_x) {
     const int item = blockIdx.y;
     float scale = g;
-    if (mode == 1) {
-        const double ex = acc_x[item * 2] / (double)per_item, ey = acc_y[item * 2] / (double)per_item;
+    if (mode == 1) {        // mean(x^2) over x's own size, mean(y^2) over y's (a processor may change the channel count)
+        const double ex = acc_x[item * 2] / (double)per_x, ey = acc_y[item * 2] / (double)per_item;
         scale = (float)sqrt(ex / fmax(1e-7, ey));
     }
     const long i = (long)blockIdx.x * 256 + threadIdx.x;

@@ -1304,7 +1304,7 @@ extern "C" int mst_fx_gain(const float *x, float *y, int n_items, long L, int C,
     if (invert) g = -g;
     const long per = L * C;
     MST_LAUNCH(fx_scale_kernel, dim3((unsigned)((per + 255) / 256), n_items), dim3(256), stream, x, y, per, (float)g,
-               (const double *)nullptr, (const double *)nullptr, 0);
+               (const double *)nullptr, (const double *)nullptr, 0, per);
     MST_CHECK_LAUNCH("fx_scale_kernel");
     return MST_OK;
 }
@@ -1431,14 +1431,13 @@ extern "C" int mst_fx_convolve(MstConvolver *cv, const float *x, const float *h,
     return MST_OK;
 }
 
-extern "C" int mst_fx_rms_normalize(const float *x, float *y, int n_items, long L, int C, double *scratch, void *stream) {
-    if (!x || !y || !scratch || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_rms_normalize: bad argument");
-    const long per = L * C;
+extern "C" int mst_fx_rms_normalize(const float *x, float *y, int n_items, long per_x, long per_y, double *scratch, void *stream) {
+    if (!x || !y || !scratch || n_items < 1 || per_x < 1 || per_y < 1) return fail(MST_ERR_ARG, "mst_fx_rms_normalize: bad argument");
     int rc;
-    if ((rc = energy(x, scratch, n_items, per, 0, stream))) return rc;
-    if ((rc = energy(y, scratch + 2 * n_items, n_items, per, 0, stream))) return rc;
-    MST_LAUNCH(fx_scale_kernel, dim3((unsigned)((per + 255) / 256), n_items), dim3(256), stream, x, y, per, 1.0f,
-               (const double *)scratch, (const double *)(scratch + 2 * n_items), 1);
+    if ((rc = energy(x, scratch, n_items, per_x, 0, stream))) return rc;
+    if ((rc = energy(y, scratch + 2 * n_items, n_items, per_y, 0, stream))) return rc;
+    MST_LAUNCH(fx_scale_kernel, dim3((unsigned)((per_y + 255) / 256), n_items), dim3(256), stream, x, y, per_y, 1.0f,
+               (const double *)scratch, (const double *)(scratch + 2 * n_items), 1, per_x);
     MST_CHECK_LAUNCH("fx_scale_kernel");
     return MST_OK;
 }

@@ -29,7 +29,9 @@ class Parameter:
         if self.kind == "float":
             self.value = random.uniform(self.min, self.max)
         elif self.kind == "int":
-            self.value = random.randint(self.min, self.max)
+            # exclusive upper bound (pymixconsole draws np.random.randint(min, max)): ConvolutionalReverb declares
+            # index.maximum = len(impulse_responses) and indexes the list with the drawn value
+            self.value = random.randrange(self.min, self.max) if self.max > self.min else self.min
         elif self.kind == "bool":
             self.value = random.random() < 0.5
         elif self.kind == "string":
@@ -102,14 +104,15 @@ class _Dev:
 def rms_normalize_(x, y):
     """In-place on y: y *= sqrt(mean(x^2) / max(1e-7, mean(y^2))) per item (reference apply_processor :143-146)."""
     d = _Dev(x)
-    yt = y if isinstance(y, torch.Tensor) else torch.from_numpy(y)
-    yy = yt.reshape(d.n, d.L, d.C).contiguous()
-    if yy.device != d.x.device:
-        yy = yy.to(d.x.device)
+    dy = _Dev(y)                 # y may have another channel count than x (Panner / Haas turn mono into stereo): the
+    if dy.x.device != d.x.device:    # reference takes scalar means over each array, so each side uses its own size
+        dy.x = dy.x.to(d.x.device)
+    if dy.n != d.n:
+        raise ValueError("rms_normalize_: x and y hold different numbers of items")
     sc = d.scratch(4 * d.n)
-    d.lib.check(d.lib.mst_fx_rms_normalize(d.x.data_ptr(), yy.data_ptr(), d.n, d.L, d.C, sc.data_ptr(), d.stream),
+    d.lib.check(d.lib.mst_fx_rms_normalize(d.x.data_ptr(), dy.x.data_ptr(), d.n, d.L * d.C, dy.L * dy.C, sc.data_ptr(), d.stream),
                 "mst_fx_rms_normalize")
-    return d.out(yy)
+    return dy.out(dy.x)
 
 
 # ---------------------------------------------------------------------------------------------- processors

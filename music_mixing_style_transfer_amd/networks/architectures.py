@@ -17,12 +17,18 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
-from .network_utils import Conv1d_layer, ConvBlock, FiLM, Res_ConvBlock  # noqa: F401  (star-export parity)
+from .network_utils import Conv1d_layer, ConvBlock, FiLM, Res_ConvBlock, _DeviceState  # noqa: F401  (star-export parity)
 
 
 class _HParams(dict):
-    """Attribute-style access like Lightning's save_hyperparameters() namespace."""
-    __getattr__ = dict.__getitem__
+    """Attribute-style access like Lightning's save_hyperparameters() namespace (hasattr / copy.deepcopy / pickle work:
+    a missing name is an AttributeError, not a KeyError)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k) from None
 
     def __setattr__(self, k, v):
         self[k] = v
@@ -113,6 +119,10 @@ class _EncoderRunner:
         prec = _lib.PRECISIONS[precision]
         if x.dim() != 3 or x.shape[1] != self.blocks[0].conv1.in_channels:
             raise ValueError(f"FXencoder.forward: expected [B, {self.blocks[0].conv1.in_channels}, L], got {tuple(x.shape)}")
+        with b.device_ctx(x):          # handle, weights, workspace and launches on the device the data lives on
+            return self._run(b, x, pooled, n_run, prec)
+
+    def _run(self, b, x, pooled, n_run, prec):
         self._ensure(b)
         x = x.contiguous()
         B, _, L = x.shape
@@ -132,7 +142,9 @@ class _EncoderRunner:
         return out
 
 
-class FXencoder(nn.Module):
+class FXencoder(_DeviceState, nn.Module):
+    _DEVICE_STATE = (("_runner", None),)
+
     """Audio-effects encoder: stereo waveform [B, 2, L] -> FX embedding [B, channels[-1]]."""
 
     def __init__(self, config):
@@ -204,7 +216,9 @@ class TCNBlock(nn.Module):
         raise NotImplementedError("TCNBlock runs fused inside TCNModel.forward on MI355X; there is no torch fallback")
 
 
-class TCNModel(nn.Module):
+class TCNModel(_DeviceState, nn.Module):
+    _DEVICE_STATE = (("_handle", None), ("_lib", None), ("_sig", None), ("_ws", lambda: _Workspace()))
+
     """Temporal convolutional network with FiLM conditioning (the MixFXcloner).
 
     forward(x [B, ninputs, L], cond [1|B, cond_dim] or list of nblocks such tensors) -> [B, noutputs, L] in [-1, 1].
@@ -311,6 +325,10 @@ class TCNModel(nn.Module):
 
     def _run(self, x, cond, n_run):
         b = _check_device(x, "TCNModel.forward")
+        with b.device_ctx(x):          # handle, weights, FiLM table, workspace and launches on the device the data lives on
+            return self._run_on(b, x, cond, n_run)
+
+    def _run_on(self, b, x, cond, n_run):
         hp = self.hparams
         if x.dim() != 3 or x.shape[1] != hp.ninputs:
             raise ValueError(f"TCNModel.forward: expected [B, {hp.ninputs}, L], got {tuple(x.shape)}")

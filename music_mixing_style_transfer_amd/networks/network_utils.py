@@ -25,6 +25,18 @@ def same_padding(kernel_size, dilation=1):
     return total // 2, total - total // 2
 
 
+class _DeviceState:
+    """Mixin for modules that cache a library handle: the handle, its workspace and the binding are per-process device
+    state and never travel through copy.deepcopy / pickle (the copy rebuilds them on first use)."""
+    _DEVICE_STATE = ()
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k, v in self._DEVICE_STATE:
+            state[k] = v() if callable(v) else v
+        return state
+
+
 class _HipOnly(nn.Module):
     def forward(self, *args, **kwargs):  # pragma: no cover - guard
         raise NotImplementedError(
@@ -69,7 +81,9 @@ class Conv1d_layer(_HipOnly):
                     bn_var=f(bn.running_var), eps=float(bn.eps))
 
 
-class Res_ConvBlock(nn.Module):
+class Res_ConvBlock(_DeviceState, nn.Module):
+    _DEVICE_STATE = (("_runner", None),)
+
     """conv2(conv1(x) + x): the skip is added after conv1's activation; only conv2 strides / changes channels."""
 
     def __init__(self, dimension, in_channels, out_channels, kernel_size, stride=1, padding="SAME", dilation=1,
