@@ -40,7 +40,10 @@ typedef enum {
 /* arithmetic mode of the dense convolutions (TCN blocks 1..n-1, all FXencoder convs) */
 typedef enum {
     MST_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32, fp32 activations in HBM: the parity mode */
-    MST_PREC_BF16 = 1   /* v_mfma_f32_32x32x16_bf16, bf16 activations in HBM, fp32 accumulate */
+    MST_PREC_BF16 = 1,  /* v_mfma_f32_32x32x16_bf16, bf16 activations in HBM, fp32 accumulate */
+    MST_PREC_BF16X3 = 2 /* TCN: every fp32 operand split x = hi + lo into two bf16 values, three bf16 MFMAs per product
+                         * (hi*hi + hi*lo + lo*hi), fp32 activations in HBM: fp32-class accuracy (<= 1e-4 on the waveform)
+                         * at a third of the bf16 rate.  FXencoder: same as MST_PREC_F32. */
 } MstPrecision;
 
 #define MST_MAX_BLOCKS 32
@@ -201,6 +204,46 @@ int mst_fx_gain(const float *x_dev, float *y_dev, int n_items, long L, int C, do
  * per item; per_x / per_y = samples per item of x and of y (L * channels each: the means are scalars over each array, and a
  * processor such as Panner / Haas may turn mono into stereo); scratch_dev: >= n_items*4 doubles */
 int mst_fx_rms_normalize(const float *x_dev, float *y_dev, int n_items, long per_x, long per_y, double *scratch_dev, void *stream);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Kernels under the input normaliser Audio_Effects_Normalizer (mixing_manipulator/data_normalization.py:76-155), which
+ * inference/style_transfer.py applies to the input stems by default (data_loader.py:586-587).  The normaliser's control
+ * flow (feature tables, gating, FIR design, the search loop) is host code in the package; these entry points carry its
+ * sample-rate work.
+ * ---------------------------------------------------------------------------------------------- */
+/* The threshold x ratio search of get_comp_matching (utils_data_normalization.py:384-398): n_items candidate settings of
+ * compressor_process applied to ONE input signal x_dev [L, C]; item i uses (threshold_db_dev[i], ratio_dev[i]) (device
+ * float64 arrays) and writes y_dev[i] [L, C].  scratch as for mst_fx_compressor with n_items items.  peak_dev (n_items * 64
+ * doubles, may be NULL): when given, a candidate whose peak reaches 1.0 is clipped to [-1, 1] like `compress` does (:352-353). */
+int mst_fx_compressor_grid(const float *x_dev, float *y_dev, int n_items, long L, int C, const double *threshold_db_dev,
+                           const double *ratio_dev, double attack_ms, double release_ms, double sample_rate,
+                           double *scratch_dev, size_t scratch_bytes, double *peak_dev, void *stream);
+/* out_dev[r] = sum of squares (mode 0) or max |x| (mode 1), float64, over x_dev[item_dev[r]][lo_dev[r] : hi_dev[r]][channel]
+ * of a [n_items, L, C] batch.  Mode 0 gives the BS.1770 gating-block energies of lufs_normalize (fx_utils.py:220-238;
+ * pyloudnorm Meter.integrated_loudness), mode 1 the peak of every inter-onset interval of get_mean_peak
+ * (utils_data_normalization.py:316-321). */
+int mst_fx_range_reduce(const float *x_dev, long L, int C, int channel, const int *item_dev, const long *lo_dev,
+                        const long *hi_dev, int n_ranges, int mode, double *out_dev, void *stream);
+/* Onset-detection function of aubio.onset('hfc', buf_size = hop_size = win) as driven by get_mean_peak
+ * (utils_data_normalization.py:304-314), for every whole frame of `win` samples of channel `channel` of each item:
+ * out_dev[item][frame] = (hfc, mean square of the frame) as float pairs; hfc = sum_k (k+1) log(|X_k| + 1) over the
+ * hanningz-windowed frame's spectrum.  win in {256, 512, 1024, 2048}.  The peak picking over this short sequence is host code. */
+int mst_fx_onset_hfc(const float *x_dev, int n_items, long L, int C, int channel, int win, float *out_dev, void *stream);
+/* Mean STFT magnitude of get_eq_matching (utils_data_normalization.py:74-79: librosa.stft(center=False) with the given window,
+ * |.|, mean over frames): mean_dev[k], k = 0 .. n_fft/2, of channel `channel` of x_dev [L, C].  hipFFT transforms in batches
+ * of at most max_batch frames; the analysis window is host float32 [n_fft]. */
+typedef struct MstStft MstStft;
+int mst_fx_stft_create(long n_fft, long hop, const float *window_host, int max_batch, MstStft **out);
+void mst_fx_stft_destroy(MstStft *st);
+size_t mst_fx_stft_workspace_bytes(const MstStft *st);
+int mst_fx_stft_mean_magnitude(MstStft *st, const float *x_dev, long L, int C, int channel, float *mean_dev, void *workspace_dev,
+                               size_t workspace_bytes, void *stream);
+/* normalize_imager / process_balance (normalization_imager.py:22-99): out_dev[item] = (sum L^2, sum R^2, sum L*R) in float64 of a
+ * stereo batch [n_items, L, 2] - the mid / side / left / right energies of every step of the balancing follow from these -
+ * and y = M x per stereo sample, the composed re-mix (l', r') = (m00 l + m01 r, m10 l + m11 r). */
+int mst_fx_stereo_moments(const float *x_dev, int n_items, long L, double *out_dev, void *stream);
+int mst_fx_stereo_mix(const float *x_dev, float *y_dev, int n_items, long L, float m00, float m01, float m10, float m11, void *stream);
 
 #ifdef __cplusplus
 }

@@ -16,8 +16,9 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmst_hip.so")
 MST_OK = 0
 MST_PREC_F32 = 0
 MST_PREC_BF16 = 1
+MST_PREC_BF16X3 = 2
 MST_MAX_BLOCKS = 32
-PRECISIONS = {"fp32": MST_PREC_F32, "f32": MST_PREC_F32, "bf16": MST_PREC_BF16}
+PRECISIONS = {"fp32": MST_PREC_F32, "f32": MST_PREC_F32, "bf16": MST_PREC_BF16, "bf16x3": MST_PREC_BF16X3}
 
 STATUS_NAMES = {0: "MST_OK", -1: "MST_ERR_ARG", -2: "MST_ERR_UNSUPPORTED", -3: "MST_ERR_HIP", -4: "MST_ERR_STATE",
                 -5: "MST_ERR_WORKSPACE"}
@@ -71,6 +72,16 @@ SIGNATURES = {
     "mst_fx_convolver_create": (C.c_int, [C.c_long, C.c_long, C.c_int, C.c_int, C.POINTER(_P)]),
     "mst_fx_convolver_destroy": (None, [_P]),
     "mst_fx_convolver_workspace_bytes": (C.c_size_t, [_P]),
+    "mst_fx_compressor_grid": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, _F, _F, C.c_double, C.c_double, C.c_double, _P, C.c_size_t,
+                                         _P, _P]),
+    "mst_fx_range_reduce": (C.c_int, [_F, C.c_long, C.c_int, C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, _P]),
+    "mst_fx_onset_hfc": (C.c_int, [_F, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, _F, _P]),
+    "mst_fx_stft_create": (C.c_int, [C.c_long, C.c_long, C.POINTER(C.c_float), C.c_int, C.POINTER(_P)]),
+    "mst_fx_stft_destroy": (None, [_P]),
+    "mst_fx_stft_workspace_bytes": (C.c_size_t, [_P]),
+    "mst_fx_stft_mean_magnitude": (C.c_int, [_P, _F, C.c_long, C.c_int, C.c_int, _F, _P, C.c_size_t, _P]),
+    "mst_fx_stereo_moments": (C.c_int, [_F, C.c_int, C.c_long, _P, _P]),
+    "mst_fx_stereo_mix": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "mst_fx_convolve": (C.c_int, [_P, _F, _F, C.c_long, _F, C.c_long, C.c_double, C.c_double, _P, C.c_size_t, _P]),
 }
 

@@ -198,6 +198,10 @@ struct CompArgs {
     int n_seq, C;
     long L;
     double threshold, ratio, alpha_att, alpha_rel, makeup;
+    // parameter-grid form (the normaliser's threshold x ratio search, utils_data_normalization.py:384-398): item i runs with
+    // (thr_items[i], ratio_items[i]); with shared_x every item reads the SAME input signal (item 0 of x)
+    const double *thr_items = nullptr, *ratio_items = nullptr;
+    int shared_x = 0;
 };
 
 __global__ __launch_bounds__(256) void fx_compressor_kernel(CompArgs a) {
@@ -246,14 +250,15 @@ __global__ __launch_bounds__(256) void fx_compressor_kernel(CompArgs a) {
 // The two parallel kernels move 64 x 64 (time x sequence) tiles through LDS so that both their audio side
 // ([item][n][c], time-contiguous) and their scratch side (sequence-contiguous) are coalesced.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double fx_comp_level_diff(const CompArgs &a, float x) {
+__device__ __forceinline__ double fx_comp_level_diff(const CompArgs &a, float x, int item) {
+    const double threshold = a.thr_items ? a.thr_items[item] : a.threshold, ratio = a.ratio_items ? a.ratio_items[item] : a.ratio;
     const double ax = fabs((double)x);
     const double xg = (ax < 0.000001) ? -120.0 : 20.0 * log10(ax);
     double yg = 0.0;
-    if (a.ratio > 1.0)
-        yg = (xg >= a.threshold) ? a.threshold + (xg - a.threshold) / a.ratio : xg;
-    else if (a.ratio < 1.0)
-        yg = (xg <= a.threshold) ? a.threshold + (xg - a.threshold) / (1.0 / a.ratio) : xg;
+    if (ratio > 1.0)
+        yg = (xg >= threshold) ? threshold + (xg - threshold) / ratio : xg;
+    else if (ratio < 1.0)
+        yg = (xg <= threshold) ? threshold + (xg - threshold) / (1.0 / ratio) : xg;
     return xg - yg;
 }
 
@@ -268,7 +273,8 @@ __global__ __launch_bounds__(256) void fx_comp_gain_kernel(CompArgs a, double *x
         const int seq = s0 + sl;
         const long n = n0 + nl;
         double v = 0.0;
-        if (seq < a.n_seq && n < a.L) v = fx_comp_level_diff(a, a.x[((size_t)(seq / a.C) * a.L + n) * a.C + seq % a.C]);
+        if (seq < a.n_seq && n < a.L)
+            v = fx_comp_level_diff(a, a.x[((size_t)(a.shared_x ? 0 : seq / a.C) * a.L + n) * a.C + seq % a.C], seq / a.C);
         t[nl][sl] = v;
     }
     __syncthreads();
@@ -500,7 +506,8 @@ __global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const do
         const long n = n0 + nl;
         if (seq < a.n_seq && n < a.L) {
             const size_t e = ((size_t)(seq / a.C) * a.L + n) * a.C + seq % a.C;
-            a.y[e] = (float)((double)a.x[e] * pow(10.0, (a.makeup - t[nl][sl]) / 20.0));
+            const size_t ex = a.shared_x ? (size_t)n * a.C + seq % a.C : e;
+            a.y[e] = (float)((double)a.x[ex] * pow(10.0, (a.makeup - t[nl][sl]) / 20.0));
         }
     }
 }
@@ -640,4 +647,179 @@ __global__ __launch_bounds__(256) void fx_conv_mix_kernel(const float *x, const 
     const int c = (int)(e % C);
     const float v = seq[((size_t)item * C + c) * n_fft + offset + t];
     y[(size_t)item * L * C + e] = dry * x[(size_t)item * L * C + e] + wet * v;
+}
+
+// =================================================================================================
+// Kernels under the input normaliser (reference mixing_manipulator/data_normalization.py, utils_data_normalization.py,
+// fx_utils.py): reductions over sample ranges, the STFT front end of the EQ matching, the onset-detection function
+// of the compressor matching.
+// =================================================================================================
+
+// out[r] = sum of squares (mode 0, float64) or max |x| (mode 1) over x[item[r]][lo[r] .. hi[r])[ch]; one workgroup per
+// range.  Used for the BS.1770 gating-block energies (fx_utils.py:220-238 via the loudness meter) and for the peak of
+// every inter-onset interval (utils_data_normalization.py:316-321: x[onset_i + argmax |x[onset_i : onset_i+1]|]).
+__global__ __launch_bounds__(256) void fx_range_reduce_kernel(const float *x, long L, int C, int ch, const int *item,
+                                                              const long *lo, const long *hi, int mode, double *out) {
+    __shared__ double red[4];
+    const int r = blockIdx.x;
+    const float *xp = x + (size_t)item[r] * L * C + ch;
+    const long a = lo[r] < 0 ? 0 : lo[r], b = hi[r] > L ? L : hi[r];
+    double acc = 0.0;
+    for (long i = a + threadIdx.x; i < b; i += 256) {
+        const double v = (double)xp[i * C];
+        acc = mode == 0 ? acc + v * v : fmax(acc, fabs(v));
+    }
+    if (mode == 0) acc = wave_sum(acc);
+    else {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc = fmax(acc, __shfl_xor(acc, m));
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        out[r] = mode == 0 ? (red[0] + red[1]) + (red[2] + red[3]) : fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// STFT framing (librosa.stft(center=False) as called by common_miscellaneous.py:72): frames[f][i] = x[(f0 + f) * hop + i] * win[i]
+// for one channel of one [L][C] signal; frames past the last full one are zero (they add nothing to the magnitude sum).
+__global__ __launch_bounds__(256) void fx_stft_frame_kernel(const float *x, float *frames, const float *win, long L, int C, int ch,
+                                                            long n_fft, long hop, long f0, long n_frames_total) {
+    const long f = blockIdx.y;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_fft) return;
+    const long t = (f0 + f) * hop + i;
+    frames[(size_t)f * n_fft + i] = (f0 + f < n_frames_total && t < L) ? x[t * C + ch] * win[i] : 0.0f;
+}
+
+// acc[k] += sum over the batch's frames of |X[f][k]| (float32 magnitudes like the reference's complex64 STFT)
+__global__ __launch_bounds__(256) void fx_stft_mag_accum_kernel(const float2 *X, float *acc, long nbin, int n_frames) {
+    const long k = (long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nbin) return;
+    float s = acc[k];
+    for (int f = 0; f < n_frames; ++f) {
+        const float2 v = X[(size_t)f * nbin + k];
+        s += sqrtf(v.x * v.x + v.y * v.y);
+    }
+    acc[k] = s;
+}
+
+// Onset-detection function of aubio.onset('hfc', buf_size = hop_size = N) as get_mean_peak drives it
+// (utils_data_normalization.py:304-314): per hop of N samples
+//     phase vocoder frame = x[f*N .. (f+1)*N) * hanningz window (0.5 * (1 - cos(2 pi i / N))), halves swapped, FFT;
+//     norm_k = log(|X_k| + 1)           (the 'hfc' default: logarithmic magnitude compression, lambda = 1)
+//     hfc    = sum_{k=0..N/2} (k + 1) * norm_k
+// plus the frame's mean square (the silence gate compares 10 log10 of it with -70 dB).  One workgroup per frame, radix-2
+// FFT of N <= 2048 points in LDS, float32 like aubio.  out[f] = (hfc, mean square).
+template <int N>
+__global__ __launch_bounds__(256) void fx_onset_hfc_kernel(const float *x, long L, int C, int ch, long n_frames, float2 *out) {
+    __shared__ float re[N], im[N];
+    __shared__ float red[2][4];
+    constexpr int LOGN = N == 2048 ? 11 : (N == 1024 ? 10 : (N == 512 ? 9 : 8));
+    const long f = blockIdx.x % n_frames;
+    const int item = (int)(blockIdx.x / n_frames);
+    const float *xp = x + (size_t)item * L * C + ch + (size_t)f * N * C;
+    float ms = 0.0f;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const float v = xp[(size_t)i * C];
+        ms += v * v;
+        const float w = 0.5f * (1.0f - cosf(6.28318530717958647692f * (float)i / (float)N));
+        const int j = (i + N / 2) & (N - 1);                  // swapped halves (zero-phase windowing)
+        const int rj = (int)(__brev((unsigned)j) >> (32 - LOGN));   // bit-reversed slot for the in-place DIT transform
+        re[rj] = v * w;
+        im[rj] = 0.0f;
+    }
+    __syncthreads();
+    for (int s = 1; s <= LOGN; ++s) {
+        const int half = 1 << (s - 1);
+        for (int t = threadIdx.x; t < N / 2; t += 256) {
+            const int grp = t / half, pos = t % half;
+            const int i0 = grp * 2 * half + pos, i1 = i0 + half;
+            const float ang = -3.14159265358979323846f * (float)pos / (float)half;
+            const float c = cosf(ang), sn = sinf(ang);
+            const float tr = re[i1] * c - im[i1] * sn, ti = re[i1] * sn + im[i1] * c;
+            re[i1] = re[i0] - tr;
+            im[i1] = im[i0] - ti;
+            re[i0] += tr;
+            im[i0] += ti;
+        }
+        __syncthreads();
+    }
+    float hfc = 0.0f;
+    for (int k = threadIdx.x; k <= N / 2; k += 256) hfc += (float)(k + 1) * logf(sqrtf(re[k] * re[k] + im[k] * im[k]) + 1.0f);
+    hfc = wave_sum(hfc);
+    ms = wave_sum(ms);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = hfc;
+        red[1][threadIdx.x >> 6] = ms;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        out[(size_t)item * n_frames + f] = make_float2((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]),
+                                                       ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)N);
+}
+
+// peak[item][chunk] = max |y| over the chunk-th 1/64 of the item; grid (64, n_items)
+__global__ __launch_bounds__(256) void fx_item_peak_kernel(const float *y, long per_item, double *peak) {
+    __shared__ float red[4];
+    const int item = blockIdx.y, chunk = blockIdx.x;
+    const long per_chunk = (per_item + 63) / 64;
+    const long lo = chunk * per_chunk, hi = (lo + per_chunk < per_item) ? lo + per_chunk : per_item;
+    const float *p = y + (size_t)item * per_item;
+    float m = 0.0f;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) m = fmaxf(m, fabsf(p[i]));
+#pragma unroll
+    for (int k = 32; k >= 1; k >>= 1) m = fmaxf(m, __shfl_xor(m, k));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) peak[item * 64 + chunk] = (double)fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// hard clip of the items whose peak reached 1 (utils_data_normalization.py:352-353: `if max|y| >= 1: clip`)
+__global__ __launch_bounds__(256) void fx_clip_if_kernel(float *y, long per_item, const double *peak) {
+    const int item = blockIdx.y;
+    double pk = 0.0;
+    for (int c = 0; c < 64; ++c) pk = fmax(pk, peak[item * 64 + c]);
+    if (pk < 1.0) return;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_item) return;
+    float *p = y + (size_t)item * per_item + i;
+    *p = fminf(1.0f, fmaxf(-1.0f, *p));
+}
+
+__global__ __launch_bounds__(256) void fx_scale_inplace_kernel(float *v, long n, float g) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] *= g;
+}
+
+// second moments of a stereo signal, float64: acc[item] = (sum L^2, sum R^2, sum L R); grid (chunks, n_items), acc zeroed by the host.
+// Everything normalize_imager / process_balance need (normalization_imager.py:22-99): mid / side / left / right energies of
+// any 2x2 re-mix of (L, R) follow from these three numbers.
+__global__ __launch_bounds__(256) void fx_stereo_moments_kernel(const float *x, long L, double *acc) {
+    __shared__ double red[3][4];
+    const int item = blockIdx.y;
+    const long per_chunk = (L + gridDim.x - 1) / gridDim.x;
+    const long lo = (long)blockIdx.x * per_chunk, hi = (lo + per_chunk < L) ? lo + per_chunk : L;
+    const f32x2 *p = (const f32x2 *)(x + (size_t)item * L * 2);
+    double s[3] = {0.0, 0.0, 0.0};
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        const f32x2 v = p[i];
+        s[0] += (double)v.x * (double)v.x;
+        s[1] += (double)v.y * (double)v.y;
+        s[2] += (double)v.x * (double)v.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        s[k] = wave_sum(s[k]);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicAdd(&acc[item * 3 + threadIdx.x], (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]));
+}
+
+// y = M x per stereo sample: (l', r') = (m00 l + m01 r, m10 l + m11 r)
+__global__ __launch_bounds__(256) void fx_stereo_mix_kernel(const float *x, float *y, long n, float m00, float m01, float m10, float m11) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const f32x2 v = ((const f32x2 *)x)[i];
+    ((f32x2 *)y)[i] = f32x2{m00 * v.x + m01 * v.y, m10 * v.x + m11 * v.y};
 }

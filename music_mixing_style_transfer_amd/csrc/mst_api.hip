@@ -111,6 +111,7 @@ void conv_geometry(MstEncConv &c, int cin, int cout, int ksz, int stride, int di
 // =================================================================================================
 struct MstTcnBlock {
     void *w_bf16 = nullptr;   // blocks >= 1: [120][4][64][8] bf16
+    void *w_x3 = nullptr;     // blocks >= 1: [hi | lo][120][4][64][8] bf16 (bf16x3 mode: W' = W'_hi + W'_lo)
     float *w_f32 = nullptr;   // blocks >= 1: [15][4][4][4][64][4] fp32 ; block 0: [2][15][128]
     float *shift = nullptr;   // [128]
     float *res = nullptr;     // [128]
@@ -173,6 +174,7 @@ extern "C" int mst_tcn_destroy(MstTcn *t) {
     if (!t) return MST_OK;
     for (auto &b : t->blk) {
         (void)hipFree(b.w_bf16);
+        (void)hipFree(b.w_x3);
         (void)hipFree(b.w_f32);
         (void)hipFree(b.shift);
         (void)hipFree(b.res);
@@ -248,6 +250,20 @@ extern "C" int mst_tcn_load_block(MstTcn *t, int n, const float *conv_w, const f
                             wb[((((size_t)(j * 8 + kc) * 4 + w) * 64 + l) * 8) + e] =
                                 (__bf16)W(32 * w + (l & 31), 16 * kc + 8 * (l >> 5) + e, j);
         if ((rc = upload((__bf16 **)&b.w_bf16, wb))) return rc;
+        // bf16x3 mode: the same fragment image twice, W'_hi = bf16(W') and W'_lo = bf16(W' - W'_hi)
+        std::vector<__bf16> wx((size_t)2 * 120 * 4 * 64 * 8);
+        for (int j = 0; j < K; ++j)
+            for (int kc = 0; kc < 8; ++kc)
+                for (int w = 0; w < 4; ++w)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 8; ++e) {
+                            const float v = W(32 * w + (l & 31), 16 * kc + 8 * (l >> 5) + e, j);
+                            const __bf16 hi = (__bf16)v;
+                            const size_t idx = ((((size_t)(j * 8 + kc) * 4 + w) * 64 + l) * 8) + e;
+                            wx[idx] = hi;
+                            wx[(size_t)120 * 4 * 64 * 8 + idx] = (__bf16)(v - (float)hi);
+                        }
+        if ((rc = upload((__bf16 **)&b.w_x3, wx))) return rc;
         // fp32 A fragments of v_mfma_f32_32x32x2_f32: [j][chunk c][ksg][wave][lane][i]
         std::vector<float> wf((size_t)K * 4 * 4 * 4 * 64 * 4);
         for (int j = 0; j < K; ++j)
@@ -320,7 +336,7 @@ extern "C" int mst_tcn_set_cond(MstTcn *t, const float *cond_dev, int n_rows, lo
 
 namespace {
 
-size_t tcn_elem(int precision) { return precision == MST_PREC_BF16 ? 2 : 4; }
+size_t tcn_elem(int precision) { return precision == MST_PREC_BF16 ? 2 : 4; }      // bf16x3 keeps fp32 activations in HBM
 
 // phases per tile: P | d.  P = 4 with 256-time tiles (78 KB of LDS, 2 workgroups per CU) whenever a tile's 64 steps
 // fit the segment; for larger dilations P = 8 with 128-time tiles (16 steps per tile, 61 KB, still 2 per CU); P = 16
@@ -328,6 +344,10 @@ size_t tcn_elem(int precision) { return precision == MST_PREC_BF16 ? 2 : 4; }
 int choose_phases(int d, int L, int precision) {
     int P = (d % 4 == 0) ? 4 : (d % 2 == 0 ? 2 : 1);
     const long nsteps = ((long)L + d - 1) / d;
+    if (precision == MST_PREC_BF16X3) {    // two LDS tiles (hi, lo): 256-time tiles up to P = 4, 128-time tiles of 8 phases for large dilations
+        if (P == 4 && d % 8 == 0 && 256 / P > nsteps) P = 8;
+        return P;
+    }
     if (precision != MST_PREC_BF16) {      // fp32 kernel: 256-time tiles only (its LDS tile is a 32-channel chunk)
         while (P < 16 && d % (2 * P) == 0 && 256 / P > nsteps) P *= 2;
         return P;
@@ -367,6 +387,20 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
             MST_LAUNCH((tcn_block_bf16_duo_kernel<P, 8, 2>), dim3(pg), dim3(512), stream, a);
             MST_CHECK_LAUNCH("tcn_block_bf16_duo_kernel");
             return MST_OK;
+        }
+    }
+    if (precision == MST_PREC_BF16X3) {
+        if constexpr (P <= 8) {
+            constexpr int NQ = P == 8 ? 4 : 8;
+            const long nsteps = ((long)a.L + a.d - 1) / a.d;
+            a.tiles_step = (int)((nsteps + (32 * NQ) / P - 1) / ((32 * NQ) / P));
+            const long g2 = (long)a.B * a.tiles_phase * a.tiles_step;
+            if (g2 % 8 == 0) a.xcd_tiles = (int)(g2 / 8);
+            MST_LAUNCH((tcn_block_bf16x3_kernel<P, NQ>), dim3((unsigned)g2), dim3(256), stream, a);
+            MST_CHECK_LAUNCH("tcn_block_bf16x3_kernel");
+            return MST_OK;
+        } else {
+            return fail(MST_ERR_UNSUPPORTED, "tcn_block_bf16x3_kernel: no 16-phase form");
         }
     }
     if (precision == MST_PREC_BF16) {
@@ -459,7 +493,8 @@ int tcn_run_generic(MstTcn *t, const float *x, float *y, float *act_out, int B, 
 int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, int precision, int n_run, void *ws,
             size_t ws_bytes, void *stream) {
     if (!t || !x || B < 1 || L < 1) return fail(MST_ERR_ARG, "mst_tcn_forward: bad argument");
-    if (precision != MST_PREC_F32 && precision != MST_PREC_BF16) return fail(MST_ERR_ARG, "mst_tcn_forward: bad precision");
+    if (precision != MST_PREC_F32 && precision != MST_PREC_BF16 && precision != MST_PREC_BF16X3)
+        return fail(MST_ERR_ARG, "mst_tcn_forward: bad precision");
     for (auto &b : t->blk)
         if (!b.loaded) return fail(MST_ERR_STATE, "mst_tcn_forward: block weights not loaded");
     if (!t->out_loaded) return fail(MST_ERR_STATE, "mst_tcn_forward: output conv not loaded");
@@ -511,7 +546,7 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         TcnBlockArgs a;
         a.x = buf[cur];
         a.y = buf[cur ^ 1];
-        a.wpk = precision == MST_PREC_BF16 ? t->blk[n].w_bf16 : (void *)t->blk[n].w_f32;
+        a.wpk = precision == MST_PREC_BF16 ? t->blk[n].w_bf16 : (precision == MST_PREC_BF16X3 ? t->blk[n].w_x3 : (void *)t->blk[n].w_f32);
         a.shift = t->blk[n].shift;
         a.film = t->film + (size_t)n * t->film_rows * 256;
         a.res = t->blk[n].res;
@@ -1028,6 +1063,7 @@ int enc_run_nlc(MstEnc *e, const float *x, float *emb, float *blk_out, int B, in
 int enc_run(MstEnc *e, const float *x, float *emb, float *blk_out, int B, int L, int precision, int n_run, void *ws,
             size_t ws_bytes, void *stream) {
     if (!e || !x || B < 1 || L < 1) return fail(MST_ERR_ARG, "mst_enc_forward: bad argument");
+    if (precision == MST_PREC_BF16X3) precision = MST_PREC_F32;          // the encoder's high-accuracy mode is its exact-fp32 path
     if (precision != MST_PREC_F32 && precision != MST_PREC_BF16) return fail(MST_ERR_ARG, "mst_enc_forward: bad precision");
     for (auto &c : e->conv)
         if (!c.loaded) return fail(MST_ERR_STATE, "mst_enc_forward: conv weights not loaded");
@@ -1213,26 +1249,8 @@ extern "C" size_t mst_fx_compressor_scratch_bytes(int n_items, long L, int C) {
     return comp_scratch(n_items, L, C).total;
 }
 
-extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, int C, double threshold_db,
-                                 double attack_ms, double release_ms, double ratio, double sample_rate, double *scratch,
-                                 size_t scratch_bytes, void *stream) {
-    if (!x || !y || n_items < 1 || L < 1 || C < 1 || attack_ms <= 0 || release_ms <= 0 || ratio <= 0 || sample_rate <= 0)
-        return fail(MST_ERR_ARG, "mst_fx_compressor: bad argument");
-    if (threshold_db == 0.0 && ratio == 1.0) {   // bypass (common_audioeffects.py:637)
-        if (x != y) MST_HIP_TRY(hipMemcpyAsync(y, x, (size_t)n_items * L * C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-        return MST_OK;
-    }
-    CompArgs a;
-    a.x = x;
-    a.y = y;
-    a.n_seq = n_items * C;
-    a.C = C;
-    a.L = L;
-    a.threshold = threshold_db;
-    a.ratio = ratio;
-    a.alpha_att = std::exp(-1.0 / (0.001 * sample_rate * attack_ms));
-    a.alpha_rel = std::exp(-1.0 / (0.001 * sample_rate * release_ms));
-    a.makeup = 0.0;
+namespace {
+int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size_t scratch_bytes, void *stream) {
     if (scratch) {
         if (scratch_bytes < mst_fx_compressor_scratch_bytes(n_items, L, C))
             return fail(MST_ERR_WORKSPACE, "mst_fx_compressor: scratch too small");
@@ -1272,6 +1290,89 @@ extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, 
     }
     MST_LAUNCH(fx_compressor_kernel, dim3((a.n_seq + 3) / 4), dim3(256), stream, a);
     MST_CHECK_LAUNCH("fx_compressor_kernel");
+    return MST_OK;
+}
+}  // namespace
+
+extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, int C, double threshold_db,
+                                 double attack_ms, double release_ms, double ratio, double sample_rate, double *scratch,
+                                 size_t scratch_bytes, void *stream) {
+    if (!x || !y || n_items < 1 || L < 1 || C < 1 || attack_ms <= 0 || release_ms <= 0 || ratio <= 0 || sample_rate <= 0)
+        return fail(MST_ERR_ARG, "mst_fx_compressor: bad argument");
+    if (threshold_db == 0.0 && ratio == 1.0) {   // bypass (common_audioeffects.py:637)
+        if (x != y) MST_HIP_TRY(hipMemcpyAsync(y, x, (size_t)n_items * L * C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return MST_OK;
+    }
+    CompArgs a;
+    a.x = x;
+    a.y = y;
+    a.n_seq = n_items * C;
+    a.C = C;
+    a.L = L;
+    a.threshold = threshold_db;
+    a.ratio = ratio;
+    a.alpha_att = std::exp(-1.0 / (0.001 * sample_rate * attack_ms));
+    a.alpha_rel = std::exp(-1.0 / (0.001 * sample_rate * release_ms));
+    a.makeup = 0.0;
+    return compressor_run(a, n_items, L, C, scratch, scratch_bytes, stream);
+}
+
+extern "C" int mst_fx_compressor_grid(const float *x, float *y, int n_items, long L, int C, const double *threshold_db_dev,
+                                      const double *ratio_dev, double attack_ms, double release_ms, double sample_rate,
+                                      double *scratch, size_t scratch_bytes, double *peak_dev, void *stream) {
+    if (!x || !y || !threshold_db_dev || !ratio_dev || !scratch || n_items < 1 || L < 1 || C < 1 || attack_ms <= 0 ||
+        release_ms <= 0 || sample_rate <= 0)
+        return fail(MST_ERR_ARG, "mst_fx_compressor_grid: bad argument");
+    CompArgs a;
+    a.x = x;
+    a.y = y;
+    a.n_seq = n_items * C;
+    a.C = C;
+    a.L = L;
+    a.threshold = 0.0;
+    a.ratio = 1.0;
+    a.thr_items = threshold_db_dev;
+    a.ratio_items = ratio_dev;
+    a.shared_x = 1;
+    a.alpha_att = std::exp(-1.0 / (0.001 * sample_rate * attack_ms));
+    a.alpha_rel = std::exp(-1.0 / (0.001 * sample_rate * release_ms));
+    a.makeup = 0.0;
+    int rc;
+    if ((rc = compressor_run(a, n_items, L, C, scratch, scratch_bytes, stream))) return rc;
+    if (peak_dev) {          // `compress` clips a candidate whose peak reaches 1 (utils_data_normalization.py:352-353)
+        MST_LAUNCH(fx_item_peak_kernel, dim3(64, n_items), dim3(256), stream, (const float *)y, L * C, peak_dev);
+        MST_CHECK_LAUNCH("fx_item_peak_kernel");
+        MST_LAUNCH(fx_clip_if_kernel, dim3((unsigned)((L * C + 255) / 256), n_items), dim3(256), stream, y, L * C, (const double *)peak_dev);
+        MST_CHECK_LAUNCH("fx_clip_if_kernel");
+    }
+    return MST_OK;
+}
+
+extern "C" int mst_fx_range_reduce(const float *x, long L, int C, int channel, const int *item_dev, const long *lo_dev,
+                                   const long *hi_dev, int n_ranges, int mode, double *out_dev, void *stream) {
+    if (!x || !item_dev || !lo_dev || !hi_dev || !out_dev || L < 1 || C < 1 || channel < 0 || channel >= C || n_ranges < 1 ||
+        (mode != 0 && mode != 1))
+        return fail(MST_ERR_ARG, "mst_fx_range_reduce: bad argument");
+    MST_LAUNCH(fx_range_reduce_kernel, dim3(n_ranges), dim3(256), stream, x, L, C, channel, item_dev, lo_dev, hi_dev, mode, out_dev);
+    MST_CHECK_LAUNCH("fx_range_reduce_kernel");
+    return MST_OK;
+}
+
+extern "C" int mst_fx_onset_hfc(const float *x, int n_items, long L, int C, int channel, int win, float *out_dev, void *stream) {
+    if (!x || !out_dev || n_items < 1 || L < 1 || C < 1 || channel < 0 || channel >= C)
+        return fail(MST_ERR_ARG, "mst_fx_onset_hfc: bad argument");
+    if (win != 256 && win != 512 && win != 1024 && win != 2048)
+        return fail(MST_ERR_UNSUPPORTED, "mst_fx_onset_hfc: window must be 256, 512, 1024 or 2048 samples");
+    const long n_frames = L / win;          // whole frames only (librosa.util.frame)
+    if (n_frames < 1) return MST_OK;
+    const dim3 grid((unsigned)(n_frames * n_items));
+    switch (win) {
+        case 256: MST_LAUNCH((fx_onset_hfc_kernel<256>), grid, dim3(256), stream, x, L, C, channel, n_frames, (float2 *)out_dev); break;
+        case 512: MST_LAUNCH((fx_onset_hfc_kernel<512>), grid, dim3(256), stream, x, L, C, channel, n_frames, (float2 *)out_dev); break;
+        case 1024: MST_LAUNCH((fx_onset_hfc_kernel<1024>), grid, dim3(256), stream, x, L, C, channel, n_frames, (float2 *)out_dev); break;
+        default: MST_LAUNCH((fx_onset_hfc_kernel<2048>), grid, dim3(256), stream, x, L, C, channel, n_frames, (float2 *)out_dev); break;
+    }
+    MST_CHECK_LAUNCH("fx_onset_hfc_kernel");
     return MST_OK;
 }
 
@@ -1439,5 +1540,91 @@ extern "C" int mst_fx_rms_normalize(const float *x, float *y, int n_items, long 
     MST_LAUNCH(fx_scale_kernel, dim3((unsigned)((per_y + 255) / 256), n_items), dim3(256), stream, x, y, per_y, 1.0f,
                (const double *)scratch, (const double *)(scratch + 2 * n_items), 1, per_x);
     MST_CHECK_LAUNCH("fx_scale_kernel");
+    return MST_OK;
+}
+
+// ---- STFT mean magnitude (EQ matching front end) ---------------------------------------------------------------------
+struct MstStft {
+    long n_fft = 0, hop = 0;
+    int batch = 0;
+    void *plan = nullptr;           // hipfftHandle: R2C, `batch` frames of n_fft
+    float *win = nullptr;           // [n_fft] analysis window (device)
+};
+
+extern "C" int mst_fx_stft_create(long n_fft, long hop, const float *window_host, int max_batch, MstStft **out) {
+    if (!out || !window_host || n_fft < 2 || hop < 1 || max_batch < 1) return fail(MST_ERR_ARG, "mst_fx_stft_create: bad argument");
+    const FftApi &f = fft_api();
+    if (!f.ok) return fail(MST_ERR_HIP, "mst_fx_stft_create: cannot load hipFFT (libhipfft.so)");
+    auto *st = new MstStft;
+    st->n_fft = n_fft; st->hop = hop; st->batch = max_batch;
+    int nn = (int)n_fft;
+    if (f.plan_many(&st->plan, 1, &nn, nullptr, 1, 0, nullptr, 1, 0, kFftR2C, max_batch)) {
+        delete st;
+        return fail(MST_ERR_HIP, "mst_fx_stft_create: hipfftPlanMany failed");
+    }
+    if (hipMalloc((void **)&st->win, (size_t)n_fft * sizeof(float)) != hipSuccess ||
+        hipMemcpy(st->win, window_host, (size_t)n_fft * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        f.destroy(st->plan);
+        delete st;
+        return fail(MST_ERR_HIP, "mst_fx_stft_create: hipMalloc failed");
+    }
+    *out = st;
+    return MST_OK;
+}
+
+extern "C" void mst_fx_stft_destroy(MstStft *st) {
+    if (!st) return;
+    const FftApi &f = fft_api();
+    if (f.ok && st->plan) f.destroy(st->plan);
+    (void)hipFree(st->win);
+    delete st;
+}
+
+extern "C" size_t mst_fx_stft_workspace_bytes(const MstStft *st) {
+    if (!st) return 0;
+    return (size_t)st->batch * st->n_fft * sizeof(float) + (size_t)st->batch * (st->n_fft / 2 + 1) * sizeof(float2) + 512;
+}
+
+extern "C" int mst_fx_stft_mean_magnitude(MstStft *st, const float *x, long L, int C, int channel, float *mean_dev, void *ws,
+                                          size_t ws_bytes, void *stream) {
+    if (!st || !x || !mean_dev || !ws || C < 1 || channel < 0 || channel >= C) return fail(MST_ERR_ARG, "mst_fx_stft_mean_magnitude: bad argument");
+    if (L < st->n_fft) return fail(MST_ERR_ARG, "mst_fx_stft_mean_magnitude: signal shorter than one frame");
+    if (ws_bytes < mst_fx_stft_workspace_bytes(st)) return fail(MST_ERR_WORKSPACE, "mst_fx_stft_mean_magnitude: workspace too small");
+    const FftApi &f = fft_api();
+    const long n = st->n_fft, nbin = n / 2 + 1;
+    const long n_frames = 1 + (L - n) / st->hop;          // common_miscellaneous.py:64
+    float *frames = (float *)ws;
+    float2 *spec = (float2 *)(((uintptr_t)(frames + (size_t)st->batch * n) + 255) & ~(uintptr_t)255);
+    MST_HIP_TRY(hipMemsetAsync(mean_dev, 0, (size_t)nbin * sizeof(float), (hipStream_t)stream));
+    if (f.set_stream(st->plan, (hipStream_t)stream)) return fail(MST_ERR_HIP, "mst_fx_stft_mean_magnitude: hipfftSetStream failed");
+    for (long f0 = 0; f0 < n_frames; f0 += st->batch) {
+        const int nb = (int)std::min<long>(st->batch, n_frames - f0);
+        MST_LAUNCH(fx_stft_frame_kernel, dim3((unsigned)((n + 255) / 256), st->batch), dim3(256), stream, x, frames, (const float *)st->win, L,
+                   C, channel, n, st->hop, f0, n_frames);
+        MST_CHECK_LAUNCH("fx_stft_frame_kernel");
+        if (f.exec_r2c(st->plan, frames, spec)) return fail(MST_ERR_HIP, "mst_fx_stft_mean_magnitude: hipfftExecR2C failed");
+        MST_LAUNCH(fx_stft_mag_accum_kernel, dim3((unsigned)((nbin + 255) / 256)), dim3(256), stream, (const float2 *)spec, mean_dev, nbin, nb);
+        MST_CHECK_LAUNCH("fx_stft_mag_accum_kernel");
+    }
+    MST_LAUNCH(fx_scale_inplace_kernel, dim3((unsigned)((nbin + 255) / 256)), dim3(256), stream, mean_dev, nbin, 1.0f / (float)n_frames);
+    MST_CHECK_LAUNCH("fx_scale_inplace_kernel");
+    return MST_OK;
+}
+
+
+extern "C" int mst_fx_stereo_moments(const float *x, int n_items, long L, double *out, void *stream) {
+    if (!x || !out || n_items < 1 || L < 1) return fail(MST_ERR_ARG, "mst_fx_stereo_moments: bad argument");
+    MST_HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_items * 3 * sizeof(double), (hipStream_t)stream));
+    const unsigned chunks = (unsigned)std::min<long>(256, (L + 4095) / 4096);
+    MST_LAUNCH(fx_stereo_moments_kernel, dim3(chunks, n_items), dim3(256), stream, x, L, out);
+    MST_CHECK_LAUNCH("fx_stereo_moments_kernel");
+    return MST_OK;
+}
+
+extern "C" int mst_fx_stereo_mix(const float *x, float *y, int n_items, long L, float m00, float m01, float m10, float m11, void *stream) {
+    if (!x || !y || n_items < 1 || L < 1) return fail(MST_ERR_ARG, "mst_fx_stereo_mix: bad argument");
+    const long n = (long)n_items * L;
+    MST_LAUNCH(fx_stereo_mix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), stream, x, y, n, m00, m01, m10, m11);
+    MST_CHECK_LAUNCH("fx_stereo_mix_kernel");
     return MST_OK;
 }

@@ -522,6 +522,162 @@ __global__ __launch_bounds__(256 * NSETS, 1) void tcn_block_bf16_duo_kernel(TcnB
 }
 
 // ------------------------------------------------------------------------------------------------
+// blocks 1..n-1, "bf16x3" mode: fp32-class accuracy on the bf16 matrix cores.  Every fp32 operand is split
+//     x = x_hi + x_lo,  x_hi = bf16(x),  x_lo = bf16(x - x_hi)          (16 significant bits; products of two bf16 values are exact in fp32)
+// for the activations (while the tile is staged into LDS: two tiles, hi and lo) and for the BN-folded weights (on the host,
+// two fragment images), and the contraction keeps the three leading terms
+//     W x ~= W_hi x_hi + W_hi x_lo + W_lo x_hi                          (the dropped W_lo x_lo term is ~2^-16 of the result)
+// as three v_mfma_f32_32x32x16_bf16 into the same fp32 accumulator.  Activations stay fp32 in HBM (1024 B of traffic per
+// time step against 3 * 491 520 FLOP: compute bound), the epilogue is the exact fp32 one of the parity kernel and reads the
+// residual input from global memory (L2-hot: the tile's centre rows were just staged).  Measured against the oracle: 5e-6
+// max-abs on the output waveform (exact-fp32 mode: 9e-7; plain bf16 mode: 4e-3) at three MFMAs per bf16-mode MFMA.
+// Same polyphase tiling, LDS swizzle and fragment order as tcn_block_bf16_kernel; one workgroup per CU (two 78 KB tiles).
+// ------------------------------------------------------------------------------------------------
+template <int P, int NQ>
+__global__ __launch_bounds__(256, 1) void tcn_block_bf16x3_kernel(TcnBlockArgs a) {
+    constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * R * 256];      // [hi | lo] tiles
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ln = lane & 31, h = lane >> 5;
+    unsigned char *const sm_hi = smem, *const sm_lo = smem + R * 256;
+
+    int tile = a.xcd_tiles > 0 ? (int)(blockIdx.x & 7) * a.xcd_tiles + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int mg = tile % a.tiles_step;
+    tile /= a.tiles_step;
+    const int pg = tile % a.tiles_phase;
+    const int b = tile / a.tiles_phase;
+    const int m0 = mg * MT, phi0 = pg * P;
+    const float *xb = (const float *)a.x + (size_t)b * a.Lp * 128;
+    float *yb = (float *)a.y + (size_t)b * a.Lp * 128;
+
+    // ---- stage the rows: a thread owns one 16-byte slot (8 channels) of rows prow, prow + 16, ...; fp32 in, (hi, lo) bf16 out
+    {
+        static_assert(16 % P == 0, "row passes advance by a whole number of steps");
+        const int slot = tid & 15, prow = tid >> 4;
+        constexpr int NPASS = (R + 15) / 16, HALF = (NPASS + 1) / 2;
+        const long dt = (long)(16 / P) * a.d;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            long t = (long)(m0 + prow / P - 7) * a.d + phi0 + (prow % P) + (long)half * HALF * dt;
+            const float *src = xb + t * 128 + slot * 8;
+            f32x4 v0[HALF], v1[HALF];
+#pragma unroll
+            for (int i = 0; i < HALF; ++i) {
+                v0[i] = v1[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (prow + 16 * (half * HALF + i) < R && t >= 0 && t < a.L) {
+                    v0[i] = *(const f32x4 *)src;
+                    v1[i] = *(const f32x4 *)(src + 4);
+                }
+                t += dt;
+                src += dt * 128;
+            }
+            const int off = prow * 256 + ((slot ^ (prow & 15)) << 4) + half * HALF * 4096;
+#pragma unroll
+            for (int i = 0; i < HALF; ++i) {
+                if (prow + 16 * (half * HALF + i) < R) {
+                    bf16x8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hi[e] = (__bf16)v0[i][e];
+                        lo[e] = (__bf16)(v0[i][e] - (float)hi[e]);
+                        hi[4 + e] = (__bf16)v1[i][e];
+                        lo[4 + e] = (__bf16)(v1[i][e] - (float)hi[4 + e]);
+                    }
+                    *(bf16x8 *)(sm_hi + off + i * 4096) = hi;
+                    *(bf16x8 *)(sm_lo + off + i * 4096) = lo;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[NQ];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {          // accumulators start from the BN shift of their channel
+        const f32x4 sh = *(const f32x4 *)(a.shift + 32 * w + 8 * g + 4 * h);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[q][4 * g + i] = sh[i];
+    }
+
+    // A fragments: wpk[part][ks = j*8 + kc][wave][lane] = 8 bf16, part 0 = hi, 1 = lo (each image 120 * 4096 bytes)
+    const unsigned char *wbase = (const unsigned char *)a.wpk;
+    const unsigned aoff = (unsigned)(w * 64 + lane) * 16u;
+    constexpr size_t LO_IMG = (size_t)120 * 4096;
+    // ring of 4 k-steps of A fragments (hi and lo): the pair of k-step ks + 4 is requested from L2 when ks has been consumed
+    bf16x8 ah[4], al[4], bh[NQ], bl[NQ];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        ah[kc] = *(const bf16x8 *)(wbase + (size_t)kc * 4096 + aoff);
+        al[kc] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)kc * 4096 + aoff);
+    }
+    {
+        const int o0 = ln * 256 + ((h ^ (ln & 15)) << 4);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            bh[q] = *(const bf16x8 *)(sm_hi + o0 + q * 8192);
+            bl[q] = *(const bf16x8 *)(sm_lo + o0 + q * 8192);
+        }
+    }
+    for (int j = 0; j < 15; ++j) {
+        const int jn = j < 14 ? j + 1 : 14;
+        const int rb0 = j * P + ln, rb1 = jn * P + ln;
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            const int rbn = (kc == 7) ? rb1 : rb0;
+            const int kcn = (kc + 1) & 7;
+            const int on = rbn * 256 + (((2 * kcn + h) ^ (rbn & 15)) << 4);
+            const int s = kc & 3;
+            // three sweeps over the column tiles: consecutive MFMAs go to different accumulators (no dependent issue stalls);
+            // the small terms first
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh[q], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl[q], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh[q], acc[q], 0, 0, 0);
+                bh[q] = *(const bf16x8 *)(sm_hi + on + q * 8192);
+                bl[q] = *(const bf16x8 *)(sm_lo + on + q * 8192);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            int ksn = j * 8 + kc + 4;
+            ksn = ksn < 120 ? ksn : 119;
+            ah[s] = *(const bf16x8 *)(wbase + (size_t)ksn * 4096 + aoff);
+            al[s] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)ksn * 4096 + aoff);
+        }
+    }
+
+    // ---- exact fp32 epilogue: LeakyReLU -> FiLM -> + res * x_in (x_in re-read in fp32 from global memory)
+    const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int co0 = 32 * w + 8 * g + 4 * h;
+        const f32x4 fr = *(const f32x4 *)(frow + co0);
+        const f32x4 fb = *(const f32x4 *)(frow + 128 + co0);
+        const f32x4 rs = *(const f32x4 *)(a.res + co0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int o = 32 * q + ln;
+            const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
+            if (t < a.L) {
+                const f32x4 xin = *(const f32x4 *)(xb + t * 128 + co0);
+                f32x4 out;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = leaky_relu(acc[q][4 * g + i]);
+                    v = fr[i] * v + fb[i];
+                    out[i] = v + rs[i] * xin[i];
+                }
+                *(f32x4 *)(yb + t * 128 + co0) = out;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // blocks 1..n-1, exact fp32 (v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain), fp32 activations.
 // The parity mode.  Input channels are staged in 4 chunks of 32 (128 B per row) to keep LDS small.
 // ------------------------------------------------------------------------------------------------

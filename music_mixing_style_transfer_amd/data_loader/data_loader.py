@@ -3,9 +3,9 @@ directory <target_dir>/<song>/ load the 4 stems of the input and of the referenc
 <song>/<stem_level_directory_name>[/<separation_model>]/<input|reference>/<stem>.wav, clamp to [-1, 1] and stack to
 [4, 2, L] float32 tensors.
 
-The FX normaliser applied to the INPUT stems when args.normalize_input is set (Audio_Effects_Normalizer,
-mixing_manipulator/data_normalization.py) depends on pyloudnorm / librosa / aubio arithmetic that is not
-reachable offline; it is a "next" row of the scope table, so normalize_input=True raises here.
+When args.normalize_input is set (the reference CLI's default) the INPUT stems go through the FX normaliser
+(Audio_Effects_Normalizer, mixing_manipulator/data_normalization.py) with the features file
+args.precomputed_normalization_feature and the effect order args.normalization_order (reference :559-563, :586-587).
 """
 import os
 from glob import glob
@@ -29,21 +29,22 @@ class Song_Dataset_Inference:
         if self.interpolate:
             self.reference_name_B = args.reference_file_name_2interpolate
         if args.normalize_input:
-            raise NotImplementedError(
-                "normalize_input=True needs the Audio_Effects_Normalizer (pyloudnorm / librosa / aubio arithmetic), "
-                "which is outside the accelerated hot path of this build; pass --normalize_input False and feed "
-                "pre-normalised stems")
+            from ..mixing_manipulator.data_normalization import Audio_Effects_Normalizer
+            self.normalization_chain = Audio_Effects_Normalizer(precomputed_feature_path=args.precomputed_normalization_feature,
+                                                                STEMS=args.instruments, EFFECTS=args.normalization_order)
 
     def __len__(self):
         return len(self.data_dir_paths)
 
-    def _stem(self, idx, which, inst):
+    def _stem(self, idx, which, inst, normalize=False):
         path = os.path.join(self.data_dir_paths[idx], self.stem_level_directory_name, which, inst + ".wav")
         wav = load_wav_segment(path, axis=0, sample_rate=self.args.sample_rate)
+        if normalize:           # only the input stems are normalised (:586-587)
+            wav = self.normalization_chain.normalize_audio(wav.transpose(), src=inst).transpose()
         return torch.clamp(torch.from_numpy(wav).float(), min=-1, max=1)
 
     def __getitem__(self, idx):
-        inputs = [self._stem(idx, self.input_name, i) for i in self.instruments]
+        inputs = [self._stem(idx, self.input_name, i, normalize=self.args.normalize_input) for i in self.instruments]
         refs = [self._stem(idx, self.reference_name, i) for i in self.instruments]
         dir_name = os.path.dirname(self.data_dir_paths[idx])
         if self.interpolate:

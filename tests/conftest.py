@@ -19,6 +19,10 @@ def _ensure_hip_library():
 
 def pytest_configure(config):
     _ensure_hip_library()
+    # the oracle's torch-CPU convolutions run several times SLOWER with one thread per core of a 128-core host than with 16
+    # (measured on the GPU box: 6.7 s per segment at 128 threads, 3.5 s at 8): cap the intra-op pool for the whole session
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
     config.addinivalue_line("markers", "slow: long CPU test")
 

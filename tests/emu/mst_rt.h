@@ -168,6 +168,7 @@ static inline double atomicAdd(double *p, double v) {
     } while (!__atomic_compare_exchange_n((uint64_t *)p, &o, n, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
     return old;
 }
+static inline unsigned __brev(unsigned v) { unsigned r = 0; for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i); return r; }
 static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 

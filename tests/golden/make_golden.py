@@ -16,6 +16,8 @@ Fixtures:
   fx.npz            compressor / imager / gain / haas / panner / rms-normalise vectors
   fx_reverb.npz     ConvolutionalReverb outputs (python tests/golden/make_golden.py reverb regenerates only this one)
   interp.npz        inference_interpolation orchestration with stand-in networks (... make_golden.py interp)
+  normalizer.npz    input normaliser: the reference's imager normalisation as is; its EQ / compressor matching glue run with
+                    restated stand-ins for pyloudnorm / librosa / aubio (... make_golden.py normalizer)
 """
 import os
 import sys
@@ -398,12 +400,133 @@ def interpolation_goldens():
     print("interp.npz", os.path.getsize(os.path.join(HERE, "interp.npz")), sorted(out.keys()))
 
 
+def normalizer_goldens():
+    """normalizer.npz: the input normaliser (Audio_Effects_Normalizer, row F).
+
+    * imager_*: normalization_imager.normalize_imager / process_balance of the REFERENCE, imported as is (they need only
+      numpy) - these pin the oracle's and the product's imager arithmetic.
+    * eq_* / comp_*: the reference's get_eq_matching / get_comp_matching executed here with stand-ins for the three third-party
+      packages that are absent offline - `pyloudnorm` (Meter / normalize.*), `librosa` (stft(center=False), util.frame) and
+      `aubio` (onset 'hfc') are supplied by oracle/normalizer_ref.py's restatements of their published algorithms.  These
+      vectors therefore pin the REFERENCE'S OWN glue (gating, frequency grid, sqrt of the spectrum ratio, firwin2 / filtfilt
+      call, peak normalisation, the ratio x threshold scan order and its stopping rule, clipping) but NOT the third-party
+      arithmetic, which stays parity-unpinned."""
+    import importlib.util
+    import types
+    install_stubs()
+    mm = os.path.join(REF, "mixing_style_transfer", "mixing_manipulator")
+    sys.path.insert(0, mm)
+    sys.path.insert(0, REPO)
+    from oracle import normalizer_ref as N
+
+    # --- stand-ins for absent third parties (restated arithmetic from oracle/normalizer_ref.py)
+    pyln = types.ModuleType("pyloudnorm")
+
+    class Meter:
+        def __init__(self, rate):
+            self.rate = rate
+
+        def integrated_loudness(self, x):
+            return N.integrated_loudness(x, self.rate)
+    norm = types.ModuleType("pyloudnorm.normalize")
+
+    def _scalar_like(data, g):          # NumPy 1.x promotion (the reference's pinned numpy): a float32 array stays float32
+        return np.float32(g) if data.dtype == np.float32 else g
+    norm.loudness = lambda data, inp, tgt: data * _scalar_like(data, np.power(10.0, (tgt - inp) / 20.0))
+    norm.peak = lambda data, tgt: data * _scalar_like(data, np.power(10.0, tgt / 20.0) / np.max(np.abs(data)))
+    pyln.Meter, pyln.normalize = Meter, norm
+    lib = types.ModuleType("librosa")
+    lib.__path__ = []                     # a package: the reference also imports librosa.display (plotting, unused here)
+    sys.modules["librosa.display"] = types.ModuleType("librosa.display")
+
+    def stft(y, n_fft, hop_length, window, center):
+        assert center is False
+        n = 1 + (len(y) - n_fft) // hop_length
+        return np.stack([np.fft.rfft(y[f * hop_length:f * hop_length + n_fft] * window) for f in range(n)], 1).astype(np.complex64)
+    lib.stft = stft
+    lib.util = types.ModuleType("librosa.util")
+    lib.util.frame = lambda x, frame_length, hop_length: np.stack(
+        [x[i * hop_length:i * hop_length + frame_length] for i in range(1 + (len(x) - frame_length) // hop_length)], 1)
+    aub = types.ModuleType("aubio")
+
+    class onset:
+        """frame-at-a-time facade over the oracle's detector (which walks the frames itself)"""
+
+        def __init__(self, method, buf_size, hop_size, samplerate):
+            assert method == "hfc" and buf_size == hop_size
+            self.win, self.sr, self.frames = buf_size, samplerate, []
+
+        def __call__(self, frame):
+            self.frames.append(np.array(frame, np.float32))
+            on = N.onset_times(np.concatenate(self.frames), self.sr, self.win)
+            new = len(on) > getattr(self, "_n", 0)
+            self._n, self._last = len(on), (on[-1] if on else 0)
+            return new
+
+        def get_last(self):
+            return self._last
+    aub.onset = onset
+    sys.modules.update({"pyloudnorm": pyln, "pyloudnorm.normalize": norm, "librosa": lib, "librosa.util": lib.util, "aubio": aub,
+                        "soundfile": types.ModuleType("soundfile")})
+    for name in ("normalization_imager", "utils_data_normalization"):
+        spec = importlib.util.spec_from_file_location("ref_" + name, os.path.join(mm, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        globals()["ref_" + name] = mod
+    ni, un = globals()["ref_normalization_imager"], globals()["ref_utils_data_normalization"]
+    import scipy.signal
+    _firwin2 = scipy.signal.firwin2       # the reference passes nyq=None, a keyword newer scipy releases dropped (no arithmetic)
+    scipy.signal.firwin2 = lambda *a, nyq=None, **k: _firwin2(*a, **k)
+    out = {}
+    # imager (pure reference)
+    Lf = 30000
+    base = synth.synth_music(2, Lf, seed=11).numpy().T.astype(np.float32)
+    wide = np.stack([base[:, 0], 0.3 * base[:, 0] + 0.8 * np.roll(base[:, 1], 700)], 1).astype(np.float32)
+    narrow = np.stack([base[:, 0] + 0.05 * base[:, 1], base[:, 0] - 0.05 * base[:, 1]], 1).astype(np.float32)
+    out["imager_x_wide"], out["imager_x_narrow"] = wide, narrow
+    out["imager_wide_bal0.3"] = ni.normalize_imager(wide, target_side_mid_bal=0.3, mono_threshold=0.999)
+    out["imager_wide_bal0.8"] = ni.normalize_imager(wide, target_side_mid_bal=0.8, mono_threshold=0.999)
+    out["imager_narrow_bal0.6"] = ni.normalize_imager(narrow, target_side_mid_bal=0.6, mono_threshold=1.1)     # Haas never applied
+    pb = ni.process_balance(wide[:, 0], wide[:, 1], tgt_e1_bal=0.35, eps=1e-4)
+    out["balance_0.35"] = np.stack(pb, 1)
+    # EQ matching (reference glue; third-party stand-ins)
+    nfft, hop = 4096, 1024
+    x1 = (0.4 * synth.synth_music(1, 60000, seed=12).numpy()[0]).astype(np.float32)
+    k = np.arange(nfft // 2 + 1)
+    ref_spec = (30.0 / (1.0 + (k / 200.0) ** 1.5) + 0.05).astype(np.float64)
+    out["eq_x"], out["eq_ref_spec"], out["eq_cfg"] = x1, ref_spec, np.array([nfft, hop, 257])
+    out["eq_y"] = np.asarray(un.get_eq_matching(x1, ref_spec, sr=44100, n_fft=nfft, hop_length=hop, min_db=-40, ntaps=257, lufs=-30))
+    out["eq_quiet_y"] = np.asarray(un.get_eq_matching((x1 * 1e-3).astype(np.float32), ref_spec, sr=44100, n_fft=nfft, hop_length=hop,
+                                                      min_db=-40, ntaps=257, lufs=-30))          # below the gate: returned unchanged
+    # compressor matching (reference glue + the reference's own Compressor; onset detector stand-in)
+    n = 66150                       # drum-like hits: decaying noise + tone bursts (broadband attacks, what the HFC detector keys on)
+    xc = np.zeros(n, np.float32)
+    noise = synth.synth_audio((n,), seed=13).numpy()
+    for n0, amp in ((3000, 0.9), (14000, 0.5), (25000, 0.8), (36000, 0.3), (47000, 0.95), (58000, 0.6)):
+        seg = np.arange(n - n0)
+        xc[n0:] += (amp * np.exp(-seg / 1800.0) * (0.6 * noise[:n - n0] + 0.4 * np.sin(2 * np.pi * 180.0 * seg / 44100.0))).astype(np.float32)
+    xc += 1e-4 * synth.synth_audio((n,), seed=14).numpy()
+    out["comp_x"] = xc
+    pk0 = un.get_mean_peak(np.expand_dims(un.pyln.normalize.peak(xc, -10.0), 1), 44100)
+    out["comp_mean_peak"] = np.array(pk0)
+    for name, (rp, rs) in (("down", (pk0[0] - 6.0, 1.0)), ("inrange", (pk0[0], 2.0)), ("low", (pk0[0] + 8.0, 1.0))):
+        y = un.get_comp_matching(xc, rp, rs, 4, 10.0, 180.0, sr=44100, min_db=-40, comp_peak_norm=-10.0, min_th=-40, max_ratio=20,
+                                 n_mels=128, true_peak=False, percentile=75, expander=False)
+        out[f"comp_{name}_target"] = np.array([rp, rs])
+        out[f"comp_{name}_y"] = np.asarray(y, dtype=np.float32)
+    np.savez_compressed(os.path.join(HERE, "normalizer.npz"), **out)
+    print("normalizer.npz", os.path.getsize(os.path.join(HERE, "normalizer.npz")), {k: (np.shape(v), np.asarray(v).dtype) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "reverb":
         reverb_goldens()
     elif len(sys.argv) > 1 and sys.argv[1] == "interp":
         interpolation_goldens()
+    elif len(sys.argv) > 1 and sys.argv[1] == "normalizer":
+        normalizer_goldens()
     else:
         main()
         reverb_goldens()
         interpolation_goldens()
+        normalizer_goldens()

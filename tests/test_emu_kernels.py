@@ -19,7 +19,7 @@ def _tcn(nblocks, cond_dim=64, growth=2, seed=0):
     return m, sd
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 4e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("bf16", 4e-2), ("bf16x3", 3e-5)])
 def test_tcn_blocks_emulated(emu_default, prec, tol):
     m, sd = _tcn(4)
     m.precision = prec
@@ -48,6 +48,8 @@ def test_tcn_large_dilation_and_odd_growth_emulated(emu_default):
     assert float((m2(x, cond) - y_ref).abs().max()) <= 2e-5
     m2.precision = "bf16"
     assert float((m2(x, cond) - y_ref).abs().max()) <= 4e-2
+    m2.precision = "bf16x3"          # split-bf16 mode: 8-phase tiles of 128 times for the large dilations
+    assert float((m2(x, cond) - y_ref).abs().max()) <= 3e-5
 
 
 def test_tcn_condition_forms_emulated(emu_default):

@@ -419,7 +419,6 @@ def test_config2_three_minute_stem_at_full_segment_length(nets):
     assert plan["n_seg"] == 16 and plan["pad"] == 16 * seg_len - L
     # mean embedding vs oracle over all 16 reference segments (incl. the zero-padded tail, quirk 9)
     rb = O.reference_batches(x_ref.numpy(), seg_len, seg_len, 4)
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
     embs = [R.fxencoder_forward(nets["enc_sd"], nets["enc_cfg"], torch.from_numpy(b)).numpy() for b in rb]
     emb = torch.from_numpy(O.mean_embedding(embs))
     _, emb_dev = eng.reference_embedding(torch.from_numpy(np.concatenate(rb, 0)).cuda())
@@ -658,7 +657,6 @@ def test_config3_four_stem_cli_three_minutes(tmp_path, nets):
     # oracle for 'bass'
     xin = np.clip(rd(str(song / "input" / "bass.wav")), -1, 1).astype(np.float32)
     xref = np.clip(rd(str(song / "reference" / "bass.wav")), -1, 1).astype(np.float32)
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
     rb = O.reference_batches(xref, seg_len, seg_len, 1)
     emb = torch.from_numpy(O.mean_embedding([R.fxencoder_forward(nets["enc_sd"], enc_cfg, torch.from_numpy(b)).numpy() for b in rb]))
     ib = O.input_batches(xin, seg_len, 1)
@@ -699,7 +697,6 @@ def test_config5_sixty_minute_track_on_one_gpu(nets):
     y = eng.transfer_stem(x_in.pin_memory(), x_ref.pin_memory(), seg_len, seg_len)
     assert y.device.type == "cpu" and y.shape == (2, L) and bool(torch.isfinite(y).all()) and float(y.abs().max()) <= 1.0
     # mean embedding: the oracle encoder over all 1212 reference segments (zero-padded tail included)
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
     rb = O.reference_batches(x_ref.numpy(), seg_len, seg_len, 101)              # 12 equal batches
     emb = torch.from_numpy(O.mean_embedding([R.fxencoder_forward(nets["enc_sd"], nets["enc_cfg"], torch.from_numpy(b)).numpy() for b in rb]))
     emb_dev = eng.stem_embedding(x_ref.cuda(), seg_len, seg_len)
@@ -714,3 +711,136 @@ def test_config5_sixty_minute_track_on_one_gpu(nets):
         assert torch.equal(alone, y[:, lo:hi]), k
     y_dev = eng.transfer_stem(x_in.cuda(), x_ref.cuda(), seg_len, seg_len)
     assert y_dev.is_cuda and torch.equal(y_dev.cpu(), y)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# row F: the input normaliser on the MI355X
+# ---------------------------------------------------------------------------------------------------------------------
+def _norm_features():
+    k = np.arange(32769)
+    eq = lambda a, b: (a / (1.0 + (k / b) ** 1.3) + 0.02).astype(np.float64)
+    return {"eq": {"drums": eq(40.0, 900.0), "bass": eq(60.0, 150.0), "other": eq(30.0, 600.0), "vocals": eq(35.0, 700.0)},
+            "compression": {"drums": [-14.0, 2.0], "bass": [-12.0, 2.5], "other": [-15.0, 2.0], "vocals": [-13.0, 2.0]},
+            "imager": {"drums": 0.8, "bass": 0.95, "other": 0.7, "vocals": 0.85},
+            "loudness": {"drums": -20.0, "bass": -22.0, "other": -24.0, "vocals": -21.0}}
+
+
+def _drum_like(L, seed, hits):
+    from music_mixing_style_transfer_amd.utils import synth
+    noise = synth.synth_audio((L,), seed=seed).numpy()
+    x = np.zeros(L, np.float32)
+    for n0, amp in hits:
+        seg = np.arange(L - n0)
+        x[n0:] += (amp * np.exp(-seg / 1800.0) * (0.6 * noise[:L - n0] + 0.4 * np.sin(2 * np.pi * 180.0 * seg / 44100.0))).astype(np.float32)
+    return x + 1e-4 * synth.synth_audio((L,), seed=seed + 1).numpy()
+
+
+def _c_compress(oracle_fx_lib):
+    import ctypes as C
+    fp = C.POINTER(C.c_float)
+
+    def fn(x, sr, th, ratio, attack, release):
+        xx = np.ascontiguousarray(x, dtype=np.float32)
+        yy = np.empty_like(xx)
+        oracle_fx_lib.ref_compressor(xx.ctypes.data_as(fp), yy.ctypes.data_as(fp), C.c_long(xx.shape[0]), xx.shape[1], C.c_double(th),
+                                     C.c_double(attack), C.c_double(release), C.c_double(ratio), C.c_double(0.0), C.c_double(sr))
+        return np.clip(yy, -1.0, 1.0) if np.max(np.abs(yy)) >= 1.0 else yy
+    return fn
+
+
+def test_input_normalizer_pieces_vs_reference_goldens(oracle_fx_lib):
+    """Row F on the device against tests/golden/normalizer.npz: the reference's own imager normalisation (pinned), and its EQ /
+    compressor matching glue (third-party meter / onset detector restated, parity unpinned); the loudness meter and the onset
+    detection function against the oracle at a 3-minute length."""
+    from music_mixing_style_transfer_amd.mixing_manipulator import _device_ops as D
+    from music_mixing_style_transfer_amd.mixing_manipulator import fx_utils
+    from music_mixing_style_transfer_amd.mixing_manipulator.normalization_imager import normalize_imager
+    from music_mixing_style_transfer_amd.mixing_manipulator.utils_data_normalization import get_comp_matching, get_eq_matching, get_mean_peak
+    from oracle import normalizer_ref as N
+    g = np.load(os.path.join(GOLD, "normalizer.npz"))
+    rel = lambda a, b: float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / np.abs(b).max())
+    for key, x, bal in (("imager_wide_bal0.3", "imager_x_wide", 0.3), ("imager_wide_bal0.8", "imager_x_wide", 0.8),
+                        ("imager_narrow_bal0.6", "imager_x_narrow", 0.6)):
+        assert rel(normalize_imager(g[x], target_side_mid_bal=bal, mono_threshold=2.0), g[key]) <= 1e-5, key
+    nfft, hop, ntaps = (int(v) for v in g["eq_cfg"])
+    y = get_eq_matching(g["eq_x"], g["eq_ref_spec"], sr=44100, n_fft=nfft, hop_length=hop, min_db=-40, ntaps=ntaps, lufs=-30)
+    assert rel(y, g["eq_y"]) <= 2e-5
+    x = g["comp_x"]
+    gain = np.float32(np.power(10.0, -10.0 / 20.0) / np.max(np.abs(x)))
+    assert np.allclose(get_mean_peak(np.expand_dims(x * gain, 1), 44100), g["comp_mean_peak"], atol=1e-3)
+    for name in ("down", "inrange", "low"):
+        rp, rs = g[f"comp_{name}_target"]
+        yc = get_comp_matching(x, rp, rs, 4, 10.0, 180.0, sr=44100, min_db=-40, comp_peak_norm=-10.0, min_th=-40, max_ratio=20,
+                               percentile=75, expander=False)
+        assert yc.shape == g[f"comp_{name}_y"].shape and rel(yc, g[f"comp_{name}_y"]) <= 5e-6, name
+    # loudness meter + onset detection function at a 3-minute stem length vs the oracle
+    from music_mixing_style_transfer_amd.utils import synth
+    L = 7_938_000
+    xs = synth.synth_music(2, L, seed=5).numpy().T.copy()
+    assert abs(fx_utils.Meter(44100).integrated_loudness(xs) - N.integrated_loudness(xs, 44100)) <= 1e-3
+    od = D.onset_hfc(D.to_device(xs[:, :1])[None], 1024, 0)[0]
+    hfc, ms = N._hfc_frames(xs[:, 0], 1024)
+    assert rel(od[:, 0], hfc) <= 1e-4 and rel(od[:, 1], ms) <= 1e-5
+
+
+def test_input_normalizer_chain_and_cli_with_normalize_input(tmp_path, oracle_fx_lib):
+    """`--normalize_input True` (the reference CLI's default) end to end on the MI355X: the normaliser chain on one stem against the
+    oracle chain, then the runner on a 4-stem song with a features file against oracle normaliser + oracle networks."""
+    import copy
+    from music_mixing_style_transfer_amd.data_loader import load_wav_segment
+    from music_mixing_style_transfer_amd.mixing_manipulator.data_normalization import Audio_Effects_Normalizer
+    from music_mixing_style_transfer_amd.utils import synth
+    from oracle import networks_ref as R
+    from oracle import normalizer_ref as N
+    from oracle import segmentation_ref as O
+    order = ["loudness", "eq", "compression", "imager", "loudness"]
+    stems = ["drums", "bass", "other", "vocals"]
+    np.save(str(tmp_path / "features.npy"), _norm_features())
+    feats = N.smooth_features(copy.deepcopy(_norm_features()), stems, order)
+    cc = _c_compress(oracle_fx_lib)
+    L_in, L_ref, seg_len = 40000, 50000, 16384
+    hits = ((2000, 0.9), (9000, 0.6), (16000, 0.8), (23000, 0.5), (30000, 0.7), (36000, 0.4))
+
+    def stem(k, L):
+        base = synth.synth_music(2, L, seed=40 + k).numpy().T
+        d = _drum_like(L, 60 + 2 * k, [(n0 + 300 * k, a) for n0, a in hits if n0 + 300 * k < L - 2000])
+        return (0.25 * base + np.stack([d, (0.5 + 0.1 * k) * np.roll(d, 40 * k)], 1)).astype(np.float32)
+    norm = Audio_Effects_Normalizer(str(tmp_path / "features.npy"), STEMS=stems, EFFECTS=order)
+    x0 = stem(0, L_in)
+    y0 = norm.normalize_audio(x0, "drums")
+    r0 = N.normalize_audio(x0, "drums", feats, order, compress_fn=cc)
+    assert y0.shape == (L_in, 2) and float(np.abs(y0 - r0).max() / np.abs(r0).max()) <= 1e-4
+    # the runner
+    enc_cfg, _ = _cfgs()
+    enc_sd, tcn_sd = synth.fxencoder_state_dict(enc_cfg, seed=0), synth.tcn_state_dict(seed=0)
+    synth.save_reference_format_checkpoint(str(tmp_path / "enc.pt"), enc_sd)
+    synth.save_reference_format_checkpoint(str(tmp_path / "tcn.pt"), tcn_sd)
+    song = tmp_path / "data" / "song0" / "separated"
+    for kind, L in (("input", L_in), ("reference", L_ref)):
+        (song / kind).mkdir(parents=True)
+        for k, s in enumerate(stems):
+            _write_wav(song / kind / (s + ".wav"), 0.8 * stem(k, L).T if kind == "input" else synth.synth_music(2, L, seed=90 + k).numpy())
+    from music_mixing_style_transfer_amd.inference import style_transfer as st
+    args = st.build_parser().parse_args([
+        "--target_dir", str(tmp_path / "data") + "/", "--output_dir", str(tmp_path / "out") + "/", "--ckpt_path_enc", str(tmp_path / "enc.pt"),
+        "--ckpt_path_conv", str(tmp_path / "tcn.pt"), "--do_not_separate", "True", "--precomputed_normalization_feature",
+        str(tmp_path / "features.npy"), "--segment_length", str(seg_len), "--segment_length_ref", str(seg_len), "--batch_size", "2"])
+    assert args.normalize_input is True and args.normalization_order == order          # the reference's defaults
+    with open(os.path.join(REPO, "music_mixing_style_transfer_amd", "networks", "configs.yaml")) as f:
+        cfgs = yaml.full_load(f)
+    args.cfg_encoder, args.cfg_converter = cfgs["Effects_Encoder"]["default"], cfgs["TCN"]["default"]
+    st.Mixing_Style_Transfer_Inference(args).inference()
+    mix = load_wav_segment(os.path.join(str(tmp_path / "out"), "song0", "mixture_output.wav"), axis=0)
+    ref_mix = 0
+    for s in stems:
+        xin = load_wav_segment(str(song / "input" / (s + ".wav")), axis=0)
+        xin = N.normalize_audio(xin.transpose(), s, feats, order, compress_fn=cc).transpose()
+        xin = np.clip(xin, -1, 1).astype(np.float32)
+        xref = np.clip(load_wav_segment(str(song / "reference" / (s + ".wav")), axis=0), -1, 1).astype(np.float32)
+        embs = [R.fxencoder_forward(enc_sd, enc_cfg, torch.from_numpy(b)).numpy() for b in O.reference_batches(xref, seg_len, seg_len, 2)]
+        emb = torch.from_numpy(O.mean_embedding(embs))
+        ob = [R.tcn_forward(tcn_sd, torch.from_numpy(b), emb[None]).numpy() for b in O.input_batches(xin, seg_len, 2)]
+        ref_mix = ref_mix + O.reassemble(ob, L_in)
+    assert mix.shape == (2, L_in)
+    # normaliser tolerance (1e-4 relative on O(0.1) signals) carried through the converter, plus the PCM16 step
+    assert np.abs(mix - np.clip(ref_mix, -1, 1)).max() <= 2e-3

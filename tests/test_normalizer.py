@@ -1,0 +1,160 @@
+"""Row F - the input normaliser (Audio_Effects_Normalizer).
+
+CPU layer (`-m "not gpu"`): the oracle (oracle/normalizer_ref.py) against tests/golden/normalizer.npz (the reference's own
+imager normalisation; its EQ / compressor matching glue run with restated third-party stand-ins - see make_golden.py), and
+the product's host logic + kernels on the SIMT emulator against the oracle / the goldens.
+GPU layer: tests/test_gpu_parity.py::test_input_normalizer_*.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "normalizer.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+@pytest.fixture()
+def c_compress(oracle_fx_lib):
+    fp = C.POINTER(C.c_float)
+
+    def fn(x, sr, th, ratio, attack, release):
+        xx = np.ascontiguousarray(x, dtype=np.float32)
+        yy = np.empty_like(xx)
+        oracle_fx_lib.ref_compressor(xx.ctypes.data_as(fp), yy.ctypes.data_as(fp), C.c_long(xx.shape[0]), xx.shape[1], C.c_double(th),
+                                     C.c_double(attack), C.c_double(release), C.c_double(ratio), C.c_double(0.0), C.c_double(sr))
+        if np.max(np.abs(yy)) >= 1.0:
+            yy = np.clip(yy, -1.0, 1.0)
+        return yy
+    return fn
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(1e-12, np.abs(b).max()))
+
+
+# ---------------------------------------------------------------------------------------------- oracle vs goldens
+def test_oracle_imager_vs_reference(gold):
+    from oracle import normalizer_ref as N
+    for key, x, bal in (("imager_wide_bal0.3", "imager_x_wide", 0.3), ("imager_wide_bal0.8", "imager_x_wide", 0.8),
+                        ("imager_narrow_bal0.6", "imager_x_narrow", 0.6)):
+        assert _rel(N.normalize_imager(gold[x], bal, mono_threshold=2.0), gold[key]) <= 1e-6, key
+    b = N.process_balance(gold["imager_x_wide"][:, 0], gold["imager_x_wide"][:, 1], 0.35)
+    assert _rel(np.stack(b, 1), gold["balance_0.35"]) <= 1e-6
+
+
+def test_oracle_eq_and_comp_matching_vs_reference_glue(gold, c_compress):
+    from oracle import normalizer_ref as N
+    nfft, hop, ntaps = (int(v) for v in gold["eq_cfg"])
+    y = N.get_eq_matching(gold["eq_x"], gold["eq_ref_spec"], 44100, nfft, hop, -40, ntaps, -30)
+    assert _rel(y, gold["eq_y"]) <= 1e-6
+    assert np.array_equal(N.get_eq_matching((gold["eq_x"] * 1e-3).astype(np.float32), gold["eq_ref_spec"], 44100, nfft, hop, -40, ntaps, -30),
+                          gold["eq_quiet_y"])
+    x = gold["comp_x"]
+    g = np.float32(np.power(10.0, -10.0 / 20.0) / np.max(np.abs(x)))
+    pk = N.get_mean_peak(np.expand_dims(x * g, 1), 44100)
+    assert np.allclose(pk, gold["comp_mean_peak"], atol=1e-4)
+    for name in ("down", "inrange", "low"):
+        rp, rs = gold[f"comp_{name}_target"]
+        y = N.get_comp_matching(x, rp, rs, 4, 10.0, 180.0, 44100, -40, -10.0, -40, 20, 75, False, c_compress)
+        assert y.shape == gold[f"comp_{name}_y"].shape and _rel(y, gold[f"comp_{name}_y"]) <= 2e-6, name
+
+
+# ---------------------------------------------------------------------------------------------- product (emulated kernels)
+def test_product_imager_emulated(emu_default, gold):
+    from music_mixing_style_transfer_amd.mixing_manipulator.normalization_imager import normalize_imager, process_balance
+    for key, x, bal in (("imager_wide_bal0.3", "imager_x_wide", 0.3), ("imager_wide_bal0.8", "imager_x_wide", 0.8),
+                        ("imager_narrow_bal0.6", "imager_x_narrow", 0.6)):
+        y = normalize_imager(gold[x], target_side_mid_bal=bal, mono_threshold=2.0)
+        assert y.dtype == np.float32 and _rel(y, gold[key]) <= 1e-5, key
+    b = process_balance(gold["imager_x_wide"][:, 0], gold["imager_x_wide"][:, 1], 0.35)
+    assert _rel(np.stack(b, 1), gold["balance_0.35"]) <= 1e-6
+    # almost mono: the Haas effect (random parameters) widens the signal before balancing - the side share then meets the target
+    mono = np.stack([gold["imager_x_wide"][:, 0]] * 2, 1)
+    y = normalize_imager(mono, target_side_mid_bal=0.7, mono_threshold=0.975)
+    mid, side = y[:, 0] + y[:, 1], y[:, 0] - y[:, 1]
+    assert abs(float((mid ** 2).sum() / ((mid ** 2).sum() + (side ** 2).sum())) - 0.7) < 0.02
+
+
+def test_product_loudness_and_onset_kernels_emulated(emu_default, gold):
+    from music_mixing_style_transfer_amd.mixing_manipulator import _device_ops as D
+    from music_mixing_style_transfer_amd.mixing_manipulator import fx_utils
+    from music_mixing_style_transfer_amd.mixing_manipulator.onset import onset_times
+    from oracle import normalizer_ref as N
+    x = np.stack([gold["eq_x"], 0.5 * np.roll(gold["eq_x"], 999)], 1).astype(np.float32)
+    assert abs(fx_utils.Meter(44100).integrated_loudness(x) - N.integrated_loudness(x, 44100)) <= 1e-4
+    assert abs(fx_utils.Meter(44100).integrated_loudness(x[:, 0]) - N.integrated_loudness(x[:, 0], 44100)) <= 1e-4
+    assert _rel(fx_utils.lufs_normalize(x, 44100, -23.0, log=False), N.lufs_normalize(x, 44100, -23.0)) <= 1e-5
+    with pytest.raises(ValueError):
+        fx_utils.Meter(44100).integrated_loudness(x[:1000])
+    xc = gold["comp_x"]
+    od = D.onset_hfc(D.to_device(xc)[None], 1024, 0)[0]
+    hfc, ms = N._hfc_frames(xc, 1024)
+    assert od.shape == (len(xc) // 1024, 2)
+    assert _rel(od[:, 0], hfc) <= 1e-4 and _rel(od[:, 1], ms) <= 1e-5
+    assert onset_times(od[:, 0], od[:, 1], 1024, 44100) == N.onset_times(xc, 44100)
+    assert len(N.onset_times(xc, 44100)) >= 4
+
+
+def test_product_eq_matching_emulated(emu_default, gold):
+    from music_mixing_style_transfer_amd.mixing_manipulator.utils_data_normalization import get_eq_matching
+    nfft, hop, ntaps = (int(v) for v in gold["eq_cfg"])
+    y = get_eq_matching(gold["eq_x"], gold["eq_ref_spec"], sr=44100, n_fft=nfft, hop_length=hop, min_db=-40, ntaps=ntaps, lufs=-30)
+    assert y.shape == gold["eq_y"].shape
+    assert _rel(y, gold["eq_y"]) <= 2e-5              # float32 FFT convolutions against scipy's float64 filtfilt
+    q = (gold["eq_x"] * 1e-3).astype(np.float32)
+    assert np.array_equal(get_eq_matching(q, gold["eq_ref_spec"], sr=44100, n_fft=nfft, hop_length=hop, min_db=-40, ntaps=ntaps), q)
+
+
+def test_product_comp_matching_emulated(emu_default, gold):
+    from music_mixing_style_transfer_amd.mixing_manipulator.utils_data_normalization import get_comp_matching, get_mean_peak
+    x = gold["comp_x"]
+    g = np.float32(np.power(10.0, -10.0 / 20.0) / np.max(np.abs(x)))
+    assert np.allclose(get_mean_peak(np.expand_dims(x * g, 1), 44100), gold["comp_mean_peak"], atol=1e-3)
+    for name in ("down", "inrange", "low"):
+        rp, rs = gold[f"comp_{name}_target"]
+        y = get_comp_matching(x, rp, rs, 4, 10.0, 180.0, sr=44100, min_db=-40, comp_peak_norm=-10.0, min_th=-40, max_ratio=20,
+                              percentile=75, expander=False, batch=8)
+        assert y.shape == gold[f"comp_{name}_y"].shape and _rel(y, gold[f"comp_{name}_y"]) <= 5e-6, name
+
+
+def _features(seed=0):
+    k = np.arange(32769)
+    eq = lambda a, b: (a / (1.0 + (k / b) ** 1.3) + 0.02).astype(np.float64)
+    return {"eq": {"drums": eq(40.0, 900.0), "bass": eq(60.0, 150.0), "other": eq(30.0, 600.0), "vocals": eq(35.0, 700.0)},
+            "compression": {"drums": [-14.0, 2.0], "bass": [-12.0, 2.5], "other": [-15.0, 2.0], "vocals": [-13.0, 2.0]},
+            "imager": {"drums": 0.8, "bass": 0.95, "other": 0.7, "vocals": 0.85},
+            "loudness": {"drums": -20.0, "bass": -22.0, "other": -24.0, "vocals": -21.0}}
+
+
+def test_audio_effects_normalizer_emulated(emu_default, c_compress, tmp_path):
+    """The whole chain (default order of inference/style_transfer.py: loudness, eq, compression, imager, loudness) on a short stem
+    through the product (emulated kernels) against the oracle chain."""
+    import copy
+    from music_mixing_style_transfer_amd.mixing_manipulator.data_normalization import Audio_Effects_Normalizer
+    from music_mixing_style_transfer_amd.utils import synth
+    from oracle import normalizer_ref as N
+    order = ["loudness", "eq", "compression", "imager", "loudness"]
+    stems = ["drums", "bass", "other", "vocals"]
+    np.save(str(tmp_path / "features.npy"), _features())
+    norm = Audio_Effects_Normalizer(str(tmp_path / "features.npy"), STEMS=stems, EFFECTS=order)
+    assert norm.FFT_SIZE == 65536 and norm.NTAPS == 1001 and norm.comp_settings["bass"] == {"attack": 10.0, "release": 500.0, "ratio": 5, "n_mels": 16}
+    feats = N.smooth_features(copy.deepcopy(_features()), stems, order)
+    assert np.allclose(norm.features_mean["eq"]["vocals"], feats["eq"]["vocals"])
+    L = 30000
+    base = synth.synth_music(2, L, seed=21).numpy().T
+    t = np.arange(L)
+    burst = sum(a * np.exp(-np.maximum(0, t - n0) / 1500.0) * (t >= n0) * np.sin(2 * np.pi * 140.0 * t / 44100.0)
+                for n0, a in ((2000, 0.9), (9000, 0.6), (16000, 0.8), (23000, 0.5)))
+    x = (0.3 * base + np.stack([burst, 0.7 * burst], 1)).astype(np.float32)
+    y = norm.normalize_audio(x, "drums")
+    ref = N.normalize_audio(x, "drums", feats, order, compress_fn=c_compress)
+    assert y.shape == ref.shape == (L, 2) and y.dtype == np.float32
+    assert _rel(y, ref) <= 1e-4
+    with pytest.raises(AssertionError):
+        norm.normalize_audio(x, "piano")
