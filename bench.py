@@ -21,6 +21,7 @@ Prints ONE JSON line (rank 0).  Objects carried by the line:
                   ("t1_ms_same_job") so that T1 / (N * TN) can be read off one line;
   "parity_mode"   (N = 1) the same configs[1] step in the exact-fp32 mode that meets north_star's 1e-4 tolerance, its
                   dominant kernel against the fp32 MFMA peak, and the max-abs deviation of the HIP path from the oracle;
+  "bf16x3_mode"   (N = 1) the same step in the split-bf16 mode (three bf16 MFMAs per product): <= 1e-4 as well, at bf16-MFMA speed / 3;
   "fx_chain"      (N = 1) BASELINE configs[3]: EQ -> rms -> compressor -> rms -> imager -> rms -> gain on 64 segments;
   "cpu_baseline"  (N = 1) the oracle (torch-CPU restatement of the reference) on a bounded sample, all cores and 1 thread.
 With --workload track60 the track IS the headline ("scaling": "strong").
@@ -42,7 +43,8 @@ SEG_LEN = 131072
 BATCH = 32
 TRACK_SAMPLES = 60 * 60 * 44100                         # 158 760 000 -> 1211 full segments + a zero-padded tail
 TCN_FLOP_PER_SAMPLE_BLOCK = 2 * 128 * 128 * 15          # one dense TCN block, per output time step
-PEAK = {"bf16": 2500.0, "fp32": 157.3}                  # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+PEAK = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0}     # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+MFMA_PER_FLOP = {"bf16": 1, "fp32": 1, "bf16x3": 3}         # bf16x3 issues three bf16 MFMAs per algorithmic product
 HBM_PEAK_GBPS = 8000.0
 
 
@@ -124,11 +126,15 @@ def roofline(block_ms, nb, B, precision, traffic=None):
     avg_ms = sum(dense) / len(dense)
     flop = TCN_FLOP_PER_SAMPLE_BLOCK * B * SEG_LEN
     achieved = flop / (avg_ms * 1e-3) / 1e12
-    return {"kernel": "tcn_block_%s_kernel (dilated 128x128x15 conv + fused BN/LeakyReLU/FiLM/residual)" %
-                      ("bf16" if precision == "bf16" else "f32"),
-            "bound": "mfma", "achieved": achieved, "peak": PEAK[precision], "unit": "TFLOP/s",
-            "frac": achieved / PEAK[precision], "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": nb - 1,
-            "flop_per_launch": flop, "per_block_ms": block_ms}
+    out = {"kernel": "tcn_block_%s_kernel (dilated 128x128x15 conv + fused BN/LeakyReLU/FiLM/residual)" %
+                     {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3"}[precision],
+           "bound": "mfma", "achieved": achieved, "peak": PEAK[precision], "unit": "TFLOP/s",
+           "frac": achieved / PEAK[precision], "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": nb - 1,
+           "flop_per_launch": flop, "per_block_ms": block_ms}
+    if MFMA_PER_FLOP[precision] > 1:      # `achieved` / `frac` count ALGORITHMIC flops; the matrix pipe executes three times as many
+        out["mfma_flop_per_algorithmic_flop"] = MFMA_PER_FLOP[precision]
+        out["mfma_pipe_frac"] = MFMA_PER_FLOP[precision] * achieved / PEAK[precision]
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ 60-minute track
@@ -188,10 +194,10 @@ def bench_track60(enc, tcn, world, rank, dist, dev, steps, warmup, with_host=Tru
 
 
 # ------------------------------------------------------------------------------------------------ parity mode (fp32)
-def bench_parity_mode(engine, enc, tcn, lib, ref, inp, dev, enc_cfg, enc_sd, tcn_sd):
+def bench_parity_mode(engine, enc, tcn, lib, ref, inp, dev, enc_cfg, enc_sd, tcn_sd, precision="fp32"):
     from music_mixing_style_transfer_amd.utils import synth
     from oracle import networks_ref as R
-    enc.precision = tcn.precision = "fp32"
+    enc.precision = tcn.precision = precision
     try:
         dt, block_ms, _ = bench_configs1(engine, tcn, lib, ref, inp, 2, 1, 1, None, dev)
         L = 16384
@@ -201,8 +207,9 @@ def bench_parity_mode(engine, enc, tcn, lib, ref, inp, dev, enc_cfg, enc_sd, tcn
         err = float((y.cpu() - y_ref).abs().max())
     finally:
         enc.precision = tcn.precision = "bf16"
-    return {"dtype": "f32", "value": BATCH * 2 / dt, "unit": "segments/s", "ms_per_step": dt / 2 * 1e3,
-            "roofline": roofline(block_ms, tcn.hparams.nblocks, BATCH, "fp32"),
+    return {"dtype": "f32" if precision == "fp32" else "bf16x3 (fp32 operands split hi + lo, three bf16 MFMAs per product, fp32 accumulate)",
+            "value": BATCH * 2 / dt, "unit": "segments/s", "ms_per_step": dt / 2 * 1e3,
+            "roofline": roofline(block_ms, tcn.hparams.nblocks, BATCH, precision),
             "max_abs_vs_oracle": err, "probe": f"2 reference + 2 input segments of 2x{L} vs oracle/networks_ref.py", "tolerance": 1e-4}
 
 
@@ -266,7 +273,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--workload", default="all", choices=["all", "configs1", "track60"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -308,7 +315,7 @@ def main():
     tcn._ensure(lib)
     nb = tcn.hparams.nblocks
     B = args.batch
-    dtype = args.precision if args.precision == "bf16" else "f32"
+    dtype = {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3"}[args.precision]
     base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
             "dtype": dtype, "data": "synthetic"}
 
@@ -353,6 +360,7 @@ def main():
             out["track60"] = track
         if world == 1 and args.workload == "all" and args.precision == "bf16" and B == BATCH:
             out["parity_mode"] = bench_parity_mode(engine, enc, tcn, lib, ref, inp, dev, enc_cfg, enc_sd, tcn_sd)
+            out["bf16x3_mode"] = bench_parity_mode(engine, enc, tcn, lib, ref, inp, dev, enc_cfg, enc_sd, tcn_sd, "bf16x3")
             out["fx_chain"] = bench_fx_chain(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(enc_cfg, enc_sd, tcn_sd)

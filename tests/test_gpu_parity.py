@@ -4,7 +4,8 @@ tests/golden/make_golden.py generated from the REAL reference.  Nothing here rea
 
 Tolerances (stated per mode):
   fp32 mode  : max-abs <= 1e-4 on the output waveform (north_star), <= 2e-4 * max|ref| on activations
-  bf16 mode  : max-abs <= 5e-2 on the waveform (bf16 operands through 14 stacked K=1920 contractions)
+  bf16 mode  : max-abs <= 1e-2 on the waveform (bf16 operands through 14 stacked K=1920 contractions; measured 4e-3 .. 8.4e-3)
+  bf16x3 mode: max-abs <= 1e-4 on the waveform like fp32 (split-bf16 operands, measured ~5e-6)
   FX         : <= 2e-6 * max|ref| (float64 internals, float32 results; energy sums accumulate in f64 here)
 """
 import os
@@ -90,11 +91,11 @@ def test_tcn_bf16_vs_oracle(nets):
             err = float((a - col[n - 1]).abs().max())
             assert err <= 3e-2 * float(col[n - 1].abs().max()), f"block {n}: {err}"
         y = tcn(x.cuda(), cond.cuda()).cpu()
-        assert float((y - y_ref).abs().max()) <= 5e-2
+        assert float((y - y_ref).abs().max()) <= 1e-2
         # per-item condition rows (cond [B, 2048]): the block kernels pick the FiLM row of their tile's batch item
         condB = synth.synth_audio((2, 2048), seed=8, amp=0.5).abs()
         yB = tcn(x.cuda(), condB.cuda()).cpu()
-        assert float((yB - R.tcn_forward(nets["tcn_sd"], x, condB)).abs().max()) <= 5e-2
+        assert float((yB - R.tcn_forward(nets["tcn_sd"], x, condB)).abs().max()) <= 1e-2
         for i in range(2):      # ... and equals running that item alone with its own row, bit for bit
             assert torch.equal(tcn(x[i:i + 1].cuda(), condB[i:i + 1].cuda()).cpu()[0], yB[i])
     finally:
@@ -117,6 +118,33 @@ def test_encoder_vs_oracle(nets, B, L):
         assert err <= 2e-4 * max(1.0, float(col[n - 1].abs().max())), f"block {n}: {err}"
     e = enc(x.cuda()).cpu()
     assert float((e - e_ref).abs().max()) <= 1e-4 * max(1.0, float(e_ref.abs().max()))
+
+
+def test_tcn_bf16x3_vs_oracle(nets):
+    """Split-bf16 mode of the MixFXcloner: every block and the waveform within the fp32 tolerances (<= 1e-4 waveform,
+    <= 2e-4 * max|ref| activations), ragged length, per-item and per-block condition forms, bit-identical items."""
+    from music_mixing_style_transfer_amd.utils import synth
+    from oracle import networks_ref as R
+    tcn = nets["tcn"]
+    x = synth.synth_audio((3, 2, 20011), seed=12)
+    cond = synth.synth_audio((1, 2048), seed=7, amp=0.5).abs()
+    col = []
+    y_ref = R.tcn_forward(nets["tcn_sd"], x, cond, collect=col)
+    tcn.precision = "bf16x3"
+    try:
+        for n in (1, 2, 5, 10, 13, 14):
+            a = tcn.forward_blocks(x.cuda(), cond.cuda(), n).cpu()
+            err = float((a - col[n - 1]).abs().max())
+            assert err <= 2e-4 * float(col[n - 1].abs().max()), f"block {n}: {err}"
+        y = tcn(x.cuda(), cond.cuda()).cpu()
+        print(f"bf16x3 @ 3 x 2x20011: max|y - oracle| = {float((y - y_ref).abs().max()):.2e}")
+        assert float((y - y_ref).abs().max()) <= 1e-4
+        condB = synth.synth_audio((3, 2048), seed=8, amp=0.5).abs()
+        yB = tcn(x.cuda(), condB.cuda()).cpu()
+        assert float((yB - R.tcn_forward(nets["tcn_sd"], x, condB)).abs().max()) <= 1e-4
+        assert torch.equal(tcn(x[1:2].cuda(), condB[1:2].cuda()).cpu()[0], yB[1])
+    finally:
+        tcn.precision = "fp32"
 
 
 def test_encoder_bf16_vs_oracle(nets):
@@ -164,7 +192,15 @@ def test_full_size_against_reference_golden(nets):
     tcn.precision = "bf16"
     try:
         yb = tcn(x, torch.from_numpy(g["enc_emb"]).cuda()).cpu()
-        assert float((yb[0][:, idx] - torch.from_numpy(g["tcn_out_probe"])).abs().max()) <= 5e-2
+        assert float((yb[0][:, idx] - torch.from_numpy(g["tcn_out_probe"])).abs().max()) <= 1e-2
+        # split-bf16 mode (three bf16 MFMAs per product): the north_star tolerance at the full segment size, against the reference
+        tcn.precision = "bf16x3"
+        y3 = tcn(x, torch.from_numpy(g["enc_emb"]).cuda()).cpu()
+        e3 = float((y3[0][:, idx] - torch.from_numpy(g["tcn_out_probe"])).abs().max())
+        print(f"bf16x3 @ 2x131072 vs the reference golden: max-abs {e3:.2e}; vs the exact-fp32 mode {float((y3 - y).abs().max()):.2e}")
+        assert e3 <= 1e-4 and float((y3 - y).abs().max()) <= 1e-4
+        assert abs(float(y3.double().abs().sum()) - float(g["tcn_out_abs"])) <= 1e-5 * float(g["tcn_out_abs"])
+        assert abs(int((y3.abs() >= 1.0).sum()) - int(g["tcn_out_clamped"])) <= 2
     finally:
         tcn.precision = "fp32"
 
