@@ -135,6 +135,10 @@ int mst_enc_destroy(MstEnc *enc);
 int mst_enc_load_conv(MstEnc *enc, int block, int which, const float *w, const float *bias,
                       const float *bn_weight, const float *bn_bias, const float *bn_mean, const float *bn_var,
                       float bn_eps, void *stream);
+/* tuning (bf16 mode): a conv layer whose launch has at least rows_min_tiles tiles keeps its input rows resident in LDS
+ * (enc_conv_rows_kernel) instead of gathering an im2col slice per k-chunk; default 512, 0 = whenever the layer qualifies,
+ * negative = never.  Both forms produce identical bits. */
+int mst_enc_set_tuning(MstEnc *enc, long rows_min_tiles);
 size_t mst_enc_workspace_bytes(const MstEnc *enc, int B, int L);
 /* replaces FXencoder.forward (architectures.py:65-70): x_dev fp32 [B, 2, L] -> emb_dev fp32 [B, C_last].
  * precision: MST_PREC_F32 (exact fp32 MFMA, parity mode) or MST_PREC_BF16 (bf16 operands, fp32 accumulate;

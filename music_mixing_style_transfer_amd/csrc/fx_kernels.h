@@ -338,9 +338,9 @@ __global__ __launch_bounds__(64) void fx_comp_smooth_kernel(CompArgs a, double *
 // piecewise-linear map, and so is every composition F = f_xT o ... o f_x1 of a chunk - with at most T + 1 linear pieces
 // (aA > aR: the same with min / concave).  Three kernels replace the 131072 dependent steps per sequence:
 //   fx_comp_map_kernel    one lane per (sequence, chunk of T steps): the pieces (a_i, b_i) of the chunk's map F, F(y) = max_i
-//                         (a_i y + b_i).  Step x: pieces whose range of values lies below x take the attack transform, above x
-//                         the release transform, the piece that crosses x is split there (f_x(x) = x).  All in registers.
-//   fx_comp_chain_kernel  one WAVE per sequence walks the chunks: lanes = pieces, y <- max over lanes of a_i y + b_i.
+//                         (a_i y + b_i), sorted by value.  Step x: pieces whose range of values lies below x take the attack
+//                         transform, above x the release transform, the piece that crosses x is split there (f_x(x) = x).
+//   fx_comp_chain_kernel  one WAVE per sequence walks the chunks: lanes = pieces, y <- a_i y + b_i of the piece i that y falls in.
 //   fx_comp_fill_kernel   one lane per (sequence, chunk): the plain recursion inside the chunk from its true start value.
 // Exact arithmetic gives the serial result; in float64 the chunk start values differ from it by rounding (~1e-15 relative).
 // ------------------------------------------------------------------------------------------------
@@ -357,73 +357,75 @@ struct CompMapArgs {
     int use_min;          // aA > aR: concave maps, F = min over pieces
 };
 
-// grid (nchunks, ceil(n_seq / 64)), 64 threads: lanes = sequences of one chunk (coalesced time-major loads)
+// grid (nchunks, ceil(n_seq / 64)), 64 threads: lanes = sequences of one chunk (coalesced time-major loads).
+// The pieces are kept SORTED by value (= by input range, F is increasing): piece s covers the values [lb_s, lb_{s+1}).  A step x
+// splits exactly one piece (the one whose value range contains x; the outermost pieces are unbounded): slots below the split take
+// the attack transform in place, slots above move up by one and take the release transform, the new slot starts at value x
+// (f_x(x) = x).  Sorted pieces let the chain kernel FIND the piece that applies to y instead of maximising over all of them.
+// Dead slots (fewer than T steps in the last chunk) are stored with slope -1.
 __global__ __launch_bounds__(64) void fx_comp_map_kernel(CompMapArgs a) {
+    __shared__ double tr[64 * (MST_COMP_NP * 2 + 1)];               // [lane][66 + 1 pad]: rows leave as whole 528-byte records
     const int k = blockIdx.x;
     const int seq = blockIdx.y * 64 + threadIdx.x;
     const bool live = seq < a.n_seq;
     const size_t sq = live ? seq : a.n_seq - 1;
     const double cA = 1.0 - a.aA, cR = 1.0 - a.aR;
-    const double dead = a.use_min ? 1e300 : -1e300;
-    // piece i: F = pa y + pb on the part of the chunk's input range where its VALUE lies in [lo, hi]
-    double pa[MST_COMP_NP], pb[MST_COMP_NP], lo[MST_COMP_NP], hi[MST_COMP_NP];
-    pa[0] = 1.0; pb[0] = 0.0; lo[0] = -1e300; hi[0] = 1e300;         // the identity before the first step
+    double pa[MST_COMP_NP], pb[MST_COMP_NP], lb[MST_COMP_NP];
+#pragma unroll
+    for (int i = 0; i < MST_COMP_NP; ++i) { pa[i] = -1.0; pb[i] = 0.0; lb[i] = 1e300; }
+    pa[0] = 1.0; pb[0] = 0.0; lb[0] = -1e300;                         // the identity before the first step
 #pragma unroll
     for (int t = 0; t < MST_COMP_T; ++t) {
         const long n = (long)k * MST_COMP_T + t;
         if (n < a.L) {                                             // uniform over the wave
             const double x = a.xl[(size_t)n * a.n_seq + sq];
             const double oA = cA * x, oR = cR * x;
-            // the piece that crosses x (at most one) is remembered with selects and split after the loop: no divergent region
-            double ca = 0.0, cb = 0.0, chi = 0.0;
-            bool any = false;
 #pragma unroll
-            for (int i = 0; i <= t; ++i) {
-                const bool att = lo[i] < x;                         // values below x: the attack branch applies
-                const bool cross = att && x < hi[i];
-                const double coef = att ? a.aA : a.aR, off = att ? oA : oR;
-                ca = cross ? pa[i] : ca;
-                cb = cross ? pb[i] : cb;
-                chi = cross ? hi[i] : chi;
-                any = any || cross;
-                pa[i] = coef * pa[i];
-                pb[i] = coef * pb[i] + off;
-                lo[i] = coef * lo[i] + off;
-                hi[i] = cross ? x : coef * hi[i] + off;
+            for (int s = t + 1; s >= 0; --s) {                     // downwards: slot s reads the old slots s and s - 1
+                const bool low = lb[s] < x;                        // the slot stays and takes the attack branch
+                const bool fresh = !low && (s > 0 ? lb[s > 0 ? s - 1 : 0] < x : false);   // the upper half of the split piece
+                const double qa = low ? pa[s] : pa[s > 0 ? s - 1 : 0], qb = low ? pb[s] : pb[s > 0 ? s - 1 : 0];
+                const double ql = low ? lb[s] : lb[s > 0 ? s - 1 : 0];
+                const double coef = low ? a.aA : a.aR, off = low ? oA : oR;
+                pa[s] = coef * qa;
+                pb[s] = fma(coef, qb, off);
+                lb[s] = fresh ? x : fma(coef, ql, off);
             }
-            // its upper part takes the release transform and becomes piece t + 1 (a dead piece when nothing crossed)
-            pa[t + 1] = any ? a.aR * ca : 0.0;
-            pb[t + 1] = any ? a.aR * cb + oR : dead;
-            lo[t + 1] = any ? x : 1e300;
-            hi[t + 1] = any ? a.aR * chi + oR : 1e300;
-        } else {
-            pa[t + 1] = 0.0; pb[t + 1] = dead; lo[t + 1] = 1e300; hi[t + 1] = 1e300;
         }
     }
-    if (live) {
-        double *m = a.maps + ((size_t)seq * a.nchunks + k) * (MST_COMP_NP * 2);
+    double *row = tr + threadIdx.x * (MST_COMP_NP * 2 + 1);
 #pragma unroll
-        for (int i = 0; i < MST_COMP_NP; ++i) {
-            m[2 * i] = pa[i];
-            m[2 * i + 1] = pb[i];
-        }
+    for (int i = 0; i < MST_COMP_NP; ++i) {
+        row[2 * i] = pa[i];
+        row[2 * i + 1] = pb[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int nlive = a.n_seq - blockIdx.y * 64 < 64 ? a.n_seq - blockIdx.y * 64 : 64;
+    for (int r = 0; r < nlive; ++r) {                              // 66 doubles per record: two coalesced sweeps of the wave
+        double *m = a.maps + ((size_t)(blockIdx.y * 64 + r) * a.nchunks + k) * (MST_COMP_NP * 2);
+        const double *src = tr + r * (MST_COMP_NP * 2 + 1);
+        m[threadIdx.x] = src[threadIdx.x];
+        if (threadIdx.x < MST_COMP_NP * 2 - 64) m[64 + threadIdx.x] = src[64 + threadIdx.x];
     }
 }
 
 // grid n_seq, 64 threads: one wave per sequence, lanes = pieces.  The pieces of CB chunks at a time are staged through LDS
-// (one coalesced sweep per batch, the next batch's loads in flight during the current one): a chunk step then costs one
-// LDS read, one fma and the DPP reduction instead of a global-memory round trip (measured 1300 clocks per chunk without).
+// (one coalesced sweep per batch, the next batch's loads in flight during the current one).  A chunk step FINDS the piece that
+// applies to y: lane i holds the crossing test of pieces i - 1 and i, (a_i - a_{i-1}) y >= b_{i-1} - b_i (convex maps; <= for the
+// concave ones of aA > aR), the number of lanes that pass is the piece index (the pieces are sorted), and y becomes that
+// lane's a_i y + b_i: one fma + compare + popcount + readlane per chunk instead of a six-stage float64 wave reduction.  Near a
+// breakpoint the two neighbouring pieces agree to rounding, so a test decided by rounding picks an equally valid piece.
 template <bool USE_MIN>
 __global__ __launch_bounds__(64) void fx_comp_chain_kernel(CompMapArgs a) {
     constexpr int CB = 32, PER = MST_COMP_NP * 2, NLD = (CB * PER + 63) / 64;      // doubles per chunk / loads per lane per batch
     __shared__ double buf[2][CB * PER];
     __shared__ double ys[2][CB];
     const int seq = blockIdx.x, lane = threadIdx.x;
-    const double dead = USE_MIN ? 1e300 : -1e300;
     const double *m = a.maps + (size_t)seq * a.nchunks * PER;
     const size_t total = (size_t)a.nchunks * PER;
     const bool has = lane < MST_COMP_NP;
     const int nbatch = (a.nchunks + CB - 1) / CB;
+    const double never = USE_MIN ? -1e300 : 1e300, always = -never;       // db of a test that always fails / always passes
     double r[NLD];
     auto load = [&](int bt) {
 #pragma unroll
@@ -437,6 +439,20 @@ __global__ __launch_bounds__(64) void fx_comp_chain_kernel(CompMapArgs a) {
         for (int i = 0; i < NLD; ++i)
             if (i * 64 + lane < CB * PER) buf[b][i * 64 + lane] = r[i];
     };
+    struct Piece { double pa, pb, da, db; };
+    auto fetch = [&](int b, int c) {                                 // this lane's piece of chunk c and its crossing test
+        Piece p = {0.0, 0.0, 0.0, never};
+        if (has) {
+            p.pa = buf[b][c * PER + 2 * lane];
+            p.pb = buf[b][c * PER + 2 * lane + 1];
+            if (lane == 0) p.db = always;
+            else if (p.pa >= 0.0) {
+                p.da = p.pa - buf[b][c * PER + 2 * lane - 2];
+                p.db = buf[b][c * PER + 2 * lane - 1] - p.pb;
+            }
+        }
+        return p;
+    };
     load(0);
     put(0);
     __builtin_amdgcn_wave_barrier();
@@ -445,14 +461,14 @@ __global__ __launch_bounds__(64) void fx_comp_chain_kernel(CompMapArgs a) {
     for (int bt = 0; bt < nbatch; ++bt) {
         if (bt + 1 < nbatch) load(bt + 1);
         const int nc = a.nchunks - bt * CB < CB ? a.nchunks - bt * CB : CB;
-        double pa = has ? buf[cur][2 * lane] : 0.0, pb = has ? buf[cur][2 * lane + 1] : dead;
+        Piece p = fetch(cur, 0);
         for (int c = 0; c < nc; ++c) {
             if (lane == 0) ys[cur][c] = y;
-            const int cn = c + 1 < nc ? c + 1 : c;                // next chunk's pieces: LDS latency behind the reduction
-            const double na = has ? buf[cur][cn * PER + 2 * lane] : 0.0, nb = has ? buf[cur][cn * PER + 2 * lane + 1] : dead;
-            y = mst_wave_extreme_f64<USE_MIN>(pa * y + pb);
-            pa = na;
-            pb = nb;
+            const Piece nx = fetch(cur, c + 1 < nc ? c + 1 : c);   // next chunk's pieces: LDS latency behind the evaluation
+            const double t = fma(p.da, y, -p.db);
+            const int idx = mst_wave_count(USE_MIN ? t <= 0.0 : t >= 0.0) - 1;
+            y = mst_wave_read_f64(fma(p.pa, y, p.pb), idx);
+            p = nx;
         }
         __builtin_amdgcn_wave_barrier();
         if (lane < nc) a.ystart[(size_t)(bt * CB + lane) * a.n_seq + seq] = ys[cur][lane];

@@ -144,8 +144,7 @@ extern "C" int mst_tcn_create(const MstTcnDesc *desc, MstTcn **out) {
         return fail(MST_ERR_ARG, "mst_tcn_create: bad layer description");
     if (d.channels % d.ninputs != 0)
         return fail(MST_ERR_UNSUPPORTED, "mst_tcn_create: channel_width must be a multiple of ninputs (grouped 1x1 residual)");
-    const bool fast = d.channels == 128 && d.kernel_size == 15 && d.ninputs == 2 && d.noutputs <= 2 && d.dilations[0] == 1 &&
-                      !(getenv("MST_TCN_GENERIC") && atoi(getenv("MST_TCN_GENERIC")));
+    const bool fast = d.channels == 128 && d.kernel_size == 15 && d.ninputs == 2 && d.noutputs <= 2 && d.dilations[0] == 1;
     for (int n = 0; n < d.nblocks; ++n)
         if (d.dilations[n] < 1) return fail(MST_ERR_ARG, "mst_tcn_create: dilation < 1");
     MstTcn *t = new MstTcn();
@@ -357,38 +356,8 @@ int choose_phases(int d, int L, int precision) {
     return P;
 }
 
-int bf16_duo() {     // experimental two-set persistent kernel (MST_TCN_DUO=<workgroups>), off by default; read per launch
-    const char *e = getenv("MST_TCN_DUO");
-    return e ? atoi(e) : 0;
-}
-
-int bf16_solo() {    // experimental: MST_TCN_SOLO=<workgroups> (256 = one per CU), 512-time tiles, one wave per SIMD; read per launch
-    const char *e = getenv("MST_TCN_SOLO");
-    return e ? atoi(e) : 0;
-}
-
 template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream) {
     TcnBlockArgs a = a0;
-    if constexpr (P <= 4) {
-        if (precision == MST_PREC_BF16 && bf16_solo() > 0 && a.y_out == nullptr) {
-            // one 256-thread workgroup per CU on 512-time tiles: 16 accumulator tiles per wave (AGPRs), half the weight loads per MFMA
-            const long nsteps = ((long)a.L + a.d - 1) / a.d;
-            a.tiles_step = (int)((nsteps + 512 / P - 1) / (512 / P));
-            const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
-            const int pg = (int)(ntiles < bf16_solo() ? ntiles : bf16_solo());
-            MST_LAUNCH((tcn_block_bf16_duo_kernel<P, 16, 1>), dim3(pg), dim3(256), stream, a);
-            MST_CHECK_LAUNCH("tcn_block_bf16_duo_kernel<solo>");
-            return MST_OK;
-        }
-        if (precision == MST_PREC_BF16 && bf16_duo() > 0 && a.y_out == nullptr) {
-            const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;          // 256-time tiles, two per workgroup round
-            const long want = (ntiles + 1) / 2;
-            const int pg = (int)(want < bf16_duo() ? want : bf16_duo());
-            MST_LAUNCH((tcn_block_bf16_duo_kernel<P, 8, 2>), dim3(pg), dim3(512), stream, a);
-            MST_CHECK_LAUNCH("tcn_block_bf16_duo_kernel");
-            return MST_OK;
-        }
-    }
     if (precision == MST_PREC_BF16X3) {
         if constexpr (P <= 8) {
             constexpr int NQ = P == 8 ? 4 : 8;
@@ -404,8 +373,8 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
         }
     }
     if (precision == MST_PREC_BF16) {
-        // XCD-aware tile order (on unless MST_TCN_XCD=0): measured read traffic 1.38 -> 1.20 GB per launch at P = 4 (1.07 algorithmic)
-        static const int xcd_on = getenv("MST_TCN_XCD") ? atoi(getenv("MST_TCN_XCD")) : 1;
+        // XCD-aware tile order: measured read traffic 1.38 -> 1.20 GB per launch at P = 4 (1.07 algorithmic)
+        constexpr int xcd_on = 1;
         if constexpr (P == 8) {
             // P = 8 tiles of 256 times need 94 KB of LDS (one workgroup per CU); 128-time tiles (61 KB) keep two resident:
             // measured 1.98 -> 1.70 ms for the d = 4096 block at L = 131072
@@ -425,8 +394,7 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
                 MST_LAUNCH((tcn_block_bf16_kernel<P, 2, false, 8>), dim3(grid), dim3(256), stream, a);
         }
     } else {
-        static const int xcd_f32 = getenv("MST_TCN_XCD") ? atoi(getenv("MST_TCN_XCD")) : 1;
-        if (xcd_f32 && grid % 8 == 0) a.xcd_tiles = grid / 8;
+        if (grid % 8 == 0) a.xcd_tiles = grid / 8;
         MST_LAUNCH((tcn_block_f32_kernel<P>), dim3(grid), dim3(256), stream, a);
     }
     MST_CHECK_LAUNCH("tcn_block_kernel");
@@ -529,8 +497,7 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         a.Lp = Lp;
         const int grid = B * ((L + 511) / 512);      // 8 tiles of 64 steps per workgroup
         a.wpk16 = t->blk[0].w_bf16;
-        static const bool b0_valu = getenv("MST_TCN_BLOCK0_VALU") && atoi(getenv("MST_TCN_BLOCK0_VALU")) > 0;   // developer knob
-        if (precision == MST_PREC_BF16 && a.wpk16 && !b0_valu)
+        if (precision == MST_PREC_BF16 && a.wpk16)
             MST_LAUNCH(tcn_block0_mfma_kernel, dim3(B * ((L + 255) / 256)), dim3(256), stream, a);
         else if (precision == MST_PREC_BF16)
             MST_LAUNCH((tcn_block0_kernel<__bf16>), dim3(grid), dim3(256), stream, a);
@@ -565,20 +532,7 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         a.out_b = t->out_b;
         a.y_out = fuse_out ? y : nullptr;
         a.nout = t->d.noutputs;
-        a.prof = nullptr;
-        static const int stagger = getenv("MST_TCN_STAGGER") ? atoi(getenv("MST_TCN_STAGGER")) : 0;
-        static const int stagger2 = getenv("MST_TCN_STAGGER2") ? atoi(getenv("MST_TCN_STAGGER2")) : 0;
-        a.stagger = stagger;
-        a.stagger2 = stagger2;
         a.xcd_tiles = 0;
-        // developer hook: MST_TCN_PROF_BLOCK=n MST_TCN_PROF_FILE=path dumps per-workgroup phase clock stamps of block n
-        static const char *prof_file = getenv("MST_TCN_PROF_FILE");
-        static const int prof_block = getenv("MST_TCN_PROF_BLOCK") ? atoi(getenv("MST_TCN_PROF_BLOCK")) : -1;
-        long long *prof_dev = nullptr;
-        if (prof_file && prof_block == n && precision == MST_PREC_BF16) {
-            MST_HIP_TRY(hipMalloc((void **)&prof_dev, (size_t)grid * 10 * sizeof(long long)));
-            a.prof = prof_dev;
-        }
         if (grid > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_tcn_forward: grid too large");
         int rc;
         switch (P) {
@@ -589,16 +543,6 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
             default: rc = launch_block<16>(precision, a, (int)grid, stream); break;
         }
         if (rc) return rc;
-        if (prof_dev) {
-            std::vector<long long> hp((size_t)grid * 10);
-            MST_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-            MST_HIP_TRY(hipMemcpy(hp.data(), prof_dev, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
-            (void)hipFree(prof_dev);
-            if (FILE *f = fopen(prof_file, "wb")) {
-                fwrite(hp.data(), sizeof(long long), hp.size(), f);
-                fclose(f);
-            }
-        }
         if (ev) MST_HIP_TRY(hipEventRecord(ev[n + 1], (hipStream_t)stream));
         cur ^= 1;
     }
@@ -694,6 +638,7 @@ extern "C" int mst_tcn_forward_blocks(MstTcn *t, const float *x, float *act, int
 struct MstEnc {
     MstEncDesc d;
     std::vector<MstEncConv> conv;   // 2 per block
+    long rows_min_tiles = 512;      // bf16 mode: layers with at least this many tiles keep their input rows resident in LDS (mst_enc_set_tuning)
 };
 
 extern "C" int mst_enc_create(const MstEncDesc *desc, MstEnc **out) {
@@ -820,6 +765,12 @@ extern "C" int mst_enc_load_conv(MstEnc *e, int block, int which, const float *w
     return MST_OK;
 }
 
+extern "C" int mst_enc_set_tuning(MstEnc *e, long rows_min_tiles) {
+    if (!e) return fail(MST_ERR_ARG, "mst_enc_set_tuning: null handle");
+    e->rows_min_tiles = rows_min_tiles;
+    return MST_OK;
+}
+
 extern "C" int mst_enc_block_length(const MstEnc *e, int block, int L) {
     if (!e || block < 0 || block >= e->d.nblocks) return -1;
     for (int i = 0; i <= block; ++i) L = (L - 1) / e->d.strides[i] + 1;
@@ -893,8 +844,7 @@ bool enc_nlc_eligible(const MstEnc *e) {
     if (255 * d.strides[0] + (d.kernels[0] - 1) * d.dilations[0] + 1 > 256 * 8 + 64) return false;
     for (int i = 1; i <= d.nblocks; ++i)
         if (d.channels[i] % 8 != 0) return false;
-    const char *env = getenv("MST_ENC_NLC");
-    return !(env && atoi(env) == 0);
+    return true;
 }
 
 int enc_splitk(long tiles, int nchunks) {
@@ -966,7 +916,7 @@ int enc_launch_direct(const MstEncConv &c, const float *x, void *y, bool out_nlc
 }
 
 int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scratch, int B, int Lin, int Lout, int residual,
-                   void *stream) {
+                   long rows_min_tiles, void *stream) {
     if (Lin <= c.pad_l || Lin <= c.pad_r)
         return fail(MST_ERR_ARG, "mst_enc_forward: reflection padding needs the input to be longer than the padding");
     EncNlcArgs a;
@@ -989,13 +939,11 @@ int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scrat
     a.ksz = c.ksz;
     a.pad_l = c.pad_l;
     {
-        // long early layers: the tile's input rows resident in LDS instead of an im2col slice per k-chunk (MST_ENC_ROWS=0 disables)
-        const int rows_mode = getenv("MST_ENC_ROWS") ? atoi(getenv("MST_ENC_ROWS")) : 1;      // 0 off, 1 default, 2 also for small grids (tests)
-        const bool rows_on = rows_mode > 0;
+        // long early layers: the tile's input rows resident in LDS instead of an im2col slice per k-chunk
         const long tiles_item = (Lout + NT - 1) / NT;
         const long R = (long)(NT - 1) * c.stride + c.ksz, rpp = (R + c.stride - 1) / c.stride;
         const long lds = (long)c.stride * rpp * (c.cin * 2 + 16);
-        if (rows_on && c.dil == 1 && c.cin % 16 == 0 && Lout >= NT && lds <= 64 * 1024 && ((long)B * tiles_item * cotiles >= 512 || rows_mode > 1)) {
+        if (rows_min_tiles >= 0 && c.dil == 1 && c.cin % 16 == 0 && Lout >= NT && lds <= 64 * 1024 && (long)B * tiles_item * cotiles >= rows_min_tiles) {
             a.S = 1;
             a.part = nullptr;
             const dim3 grid((unsigned)(B * tiles_item), (unsigned)cotiles);
@@ -1040,8 +988,8 @@ int enc_run_nlc(MstEnc *e, const float *x, float *emb, float *blk_out, int B, in
             if ((rc = enc_launch_direct(e->conv[0], (const float *)cur, t1, false, B, len, len, 1, stream))) return rc;
             if ((rc = enc_launch_direct(e->conv[1], (const float *)t1, o[pp], true, B, len, lout, 0, stream))) return rc;
         } else {
-            if ((rc = enc_launch_nlc(e->conv[2 * i], (const __bf16 *)cur, (__bf16 *)t1, scratch, B, len, len, 1, stream))) return rc;
-            if ((rc = enc_launch_nlc(e->conv[2 * i + 1], (const __bf16 *)t1, (__bf16 *)o[pp], scratch, B, len, lout, 0, stream))) return rc;
+            if ((rc = enc_launch_nlc(e->conv[2 * i], (const __bf16 *)cur, (__bf16 *)t1, scratch, B, len, len, 1, e->rows_min_tiles, stream))) return rc;
+            if ((rc = enc_launch_nlc(e->conv[2 * i + 1], (const __bf16 *)t1, (__bf16 *)o[pp], scratch, B, len, lout, 0, e->rows_min_tiles, stream))) return rc;
         }
         cur = o[pp];
         pp ^= 1;
@@ -1259,9 +1207,8 @@ int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size
         const dim3 tiles((unsigned)((L + 63) / 64), (unsigned)((a.n_seq + 63) / 64));      // 64 x 64 (time x sequence) tiles
         MST_LAUNCH(fx_comp_gain_kernel, tiles, dim3(256), stream, a, scratch);
         MST_CHECK_LAUNCH("fx_comp_gain_kernel");
-        static const bool serial = getenv("MST_FX_COMP_SERIAL") && atoi(getenv("MST_FX_COMP_SERIAL")) > 0;   // developer knob
         const CompScratch cs = comp_scratch(n_items, L, C);
-        if (serial || cs.nchunks < 4) {
+        if (cs.nchunks < 4) {
             MST_LAUNCH(fx_comp_smooth_kernel, dim3((a.n_seq + 63) / 64), dim3(64), stream, a, scratch);
             MST_CHECK_LAUNCH("fx_comp_smooth_kernel");
         } else {       // the smoother parallel in time: chunk maps (convex piecewise-linear), a chain over chunks, a fill pass

@@ -79,3 +79,10 @@ __device__ __forceinline__ float mst_acc_read(float x) {
     asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(x));
     return r;
 }
+
+// number of lanes of the wave whose predicate holds (v_cmp -> s_bcnt1_i32_b64), and lane `src`'s double in every lane
+__device__ __forceinline__ int mst_wave_count(bool p) { return __builtin_popcountll(__ballot(p)); }
+__device__ __forceinline__ double mst_wave_read_f64(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}

@@ -41,8 +41,6 @@ struct TcnBlockArgs {
     const float *out_b;
     float *y_out;
     int nout;
-    long long *prof;      // developer hook: per-workgroup shader-clock stamps at phase boundaries (null = off)
-    int stagger, stagger2; // developer hook: first-generation start delays (clocks): spread over CUs / extra for the 2nd workgroup of a CU
     int xcd_tiles;        // > 0: tiles per XCD; workgroup i (dispatched to XCD i % 8) takes tile (i % 8) * xcd_tiles + i / 8, so that
                           // neighbouring time tiles (which share their halo rows) run on the same XCD and meet in its L2
 };
@@ -69,12 +67,6 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
     const int m0 = mg * MT, phi0 = pg * P;
     const __bf16 *xb = (const __bf16 *)a.x + (size_t)b * a.Lp * 128;
     __bf16 *yb = (__bf16 *)a.y + (size_t)b * a.Lp * 128;
-    if ((a.stagger | a.stagger2) && blockIdx.x < 512) {
-        const long long t0 = mst_clock();
-        const long long wait = (long long)(blockIdx.x % 256) * a.stagger / 256 + (blockIdx.x >= 256 ? a.stagger2 : 0);
-        while (mst_clock() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
-    if (a.prof && tid == 0) { a.prof[(size_t)blockIdx.x * 10 + 0] = mst_clock(); a.prof[(size_t)blockIdx.x * 10 + 4] = mst_hw_id(); a.prof[(size_t)blockIdx.x * 10 + 5] = mst_xcc_id(); }
     // per-channel epilogue parameters -> LDS while the tile is staged (one broadcast ds_read_b128 each in the epilogue
     // instead of four exposed L2 round trips)
     if (tid < 128) {
@@ -111,7 +103,6 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
             if (prow + 16 * i < R) *(bf16x8 *)(dst + i * 4096) = v[i];
     }
     __syncthreads();
-    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 1] = mst_clock();
 
     // the accumulators start from the BN shift of their channel (row (i&3) + 8 (i>>2) + 4 h of the wave's 32): no add later
     f32x16 acc[NQ];
@@ -202,7 +193,6 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
     }
 
     // ---- fused epilogue
-    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 2] = mst_clock();
     // residual inputs (centre tap rows) -> registers, then the input tile is dead and LDS is reused to transpose
     // the output tile so that global stores are whole 256-byte rows, 16 B per lane
     bf16x4 xin[4][NQ];
@@ -216,7 +206,6 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
         }
     }
     __syncthreads();
-    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 6] = mst_clock();
     float hs0[NQ], hs1[NQ];            // FUSE_OUT: this lane's partial sums of the 1x1 output head, per column tile
 #pragma unroll
     for (int q = 0; q < NQ; ++q) hs0[q] = hs1[q] = 0.0f;
@@ -273,7 +262,6 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
         }
     } else {
         __syncthreads();
-        if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 7] = mst_clock();
         const int slot = tid & 15, prow = tid >> 4;
         const long dt = (long)(16 / P) * a.d;
         long t = (long)(m0 + prow / P) * a.d + phi0 + (prow % P);
@@ -285,239 +273,6 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
             t += dt;
             dstp += dt * 128;
         }
-    }
-    if (a.prof && tid == 0) a.prof[(size_t)blockIdx.x * 10 + 3] = mst_clock();
-}
-
-// ------------------------------------------------------------------------------------------------
-// "Duo" form of the bf16 block kernel (MST_TCN_DUO=<workgroups>, experimental): ONE persistent 512-thread workgroup per CU
-// holds two wave sets (one wave of each set per SIMD), each with its own LDS tile buffer and its own stream of tiles.
-// What the micro-benchmarks (tools/micro) and the phase stamps of the kernel above say about gfx950:
-//   * two waves per SIMD that BOTH stream MFMAs share the matrix pipe at 24-28 clocks per MFMA; one wave alone gets 32-35;
-//   * VALU / LDS / VMEM instructions of a wave are starved (4-20x) while the other wave of its SIMD streams MFMAs, and even a
-//     wave's own VALU work does not hide behind its MFMAs beyond ~2 instructions per MFMA.  Non-MFMA work therefore cannot be
-//     overlapped with MFMA work on a SIMD by running the two waves in different phases (an anti-phase "ping-pong" variant of
-//     this kernel measured 1.75 ms against 1.66 ms); it can only be kept short, and memory LATENCY can be overlapped with it;
-//   * with two independent workgroups per CU the older one wins more MFMA slots, finishes its main loop ~20 k clocks early
-//     and then crawls through its epilogue beside the other's MFMA tail.
-// So here both sets run every phase together (one s_barrier per phase, optionally one per tap to keep the two MFMA streams
-// level), the rows of the NEXT tile are requested from HBM before the epilogue math of the current one and land in LDS after
-// it, parameters are read once, and nothing is re-dispatched.  Everything outside the main loop is wave-local (wave w stages,
-// transposes and stores only the 64-byte channel slice [32w, 32w+32) of each row, the slice its accumulators produce), so
-// the epilogue needs no barrier of its own.  Same arithmetic, tiling rule and weight packing as above.
-// ------------------------------------------------------------------------------------------------
-template <int P, int NQ, int NSETS>
-__global__ __launch_bounds__(256 * NSETS, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs a) {
-    static_assert(16 % P == 0, "row passes advance by a whole number of steps");
-    constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NPASS = (R + 15) / 16, NPART = (NPASS + 3) / 4, STEP = 16 / P;
-    constexpr int RP = NSETS == 1 ? NPASS * 16 : R;          // one set: room for whole passes, so that staging stores need no row predicate
-    __shared__ __attribute__((aligned(16))) unsigned char smem_all[NSETS * RP * 256];
-    __shared__ __attribute__((aligned(16))) float par_all[NSETS * 384];  // per set: FiLM r | FiLM b | res of its batch item
-    const int set = NSETS > 1 ? threadIdx.x >> 8 : 0, tid = threadIdx.x & 255;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);               // wave-uniform: lives in a scalar register
-    unsigned char *smem = smem_all + set * (RP * 256);
-    float *par = par_all + set * 384;
-    const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
-    const long per_round = (long)NSETS * gridDim.x, first = (long)NSETS * blockIdx.x;
-    if (first >= ntiles) return;
-    const int n_max = (int)((ntiles - first + per_round - 1) / per_round);                       // tiles of set 0 (>= set 1's)
-    const int n_mine = first + set < ntiles ? (int)((ntiles - first - set + per_round - 1) / per_round) : 0;
-    const bool stamp_wg = a.prof && tid == 0;
-
-    struct Coord { int b, m0, phi0; };
-    auto decode = [&](int k) {
-        long t = (long)k * per_round + first + set;
-        Coord c;
-        const int mg = (int)(t % a.tiles_step);
-        t /= a.tiles_step;
-        c.phi0 = (int)(t % a.tiles_phase) * P;
-        c.b = (int)(t / a.tiles_phase);
-        c.m0 = mg * MT;
-        return c;
-    };
-    int par_b = -1;
-    auto load_params = [&](int b) {             // visible to the set after the next workgroup barrier
-        if (tid < 128) {
-            const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
-            par[tid] = frow[tid];
-            par[128 + tid] = frow[128 + tid];
-            par[256 + tid] = a.res[tid];
-        }
-        par_b = b;
-    };
-
-    // Wave-local row pieces: pass i of a lane covers row prow + 16 i, 16-byte slot pslot = 4 w + lane % 4 (channels 8 pslot ..).
-    // Consecutive passes are STEP dilation steps apart in time, one 4096-byte stride apart in LDS (the XOR swizzle depends on
-    // row & 15 = prow only): running pointers instead of per-row address arithmetic.
-    // rows [i0, i1) of tile c -> v; zeros outside the segment / beyond the tile
-    auto stage_load = [&](const Coord &c, bool live, bf16x8 (&v)[NPASS], int lane_v, int i0, int i1) {
-        const int prow = lane_v >> 2, pslot = 4 * w + (lane_v & 3);
-        const long dt = (long)STEP * a.d;
-        long t = (long)(c.m0 + prow / P - 7) * a.d + c.phi0 + (prow % P) + i0 * dt;
-        const __bf16 *p = (const __bf16 *)a.x + ((size_t)c.b * a.Lp + t) * 128 + pslot * 8;
-        const __bf16 *safe = (const __bf16 *)a.x + pslot * 8;           // any valid address: rows outside the segment load it and are zeroed
-#pragma unroll
-        for (int i = i0; i < i1; ++i) {
-            if (i < NPASS) {
-                // never a predicated load: hipcc puts a branch and an s_waitcnt vmcnt(0) behind each one (measured: the
-                // prefetch of 36 rows cost ~18 k clocks that way); load from a clamped address, select afterwards
-                const bool ok = live && prow + 16 * i < R && t >= 0 && t < a.L;
-                const bf16x8 ld = *(const bf16x8 *)(ok ? p : safe);
-                v[i] = ok ? ld : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            }
-            t += dt;
-            p += dt * 128;
-        }
-    };
-    auto stage_store = [&](const bf16x8 (&v)[NPASS], int lane_v) {
-        const int prow = lane_v >> 2, pslot = 4 * w + (lane_v & 3);
-        unsigned char *q = smem + prow * 256 + ((pslot ^ (prow & 15)) << 4);
-#pragma unroll
-        for (int i = 0; i < NPASS; ++i)
-            if (RP > R || prow + 16 * i < R) *(bf16x8 *)(q + i * 4096) = v[i];
-    };
-
-    auto main_loop = [&](f32x16 (&acc)[NQ], int lane_v) {
-        const int ln = lane_v & 31, h = lane_v >> 5;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {           // accumulators start from the BN shift, like the default kernel
-            const f32x4 sh = *(const f32x4 *)(a.shift + 32 * w + 8 * g + 4 * h);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[q][4 * g + i] = sh[i];
-        }
-        const bf16x8 *wp = (const bf16x8 *)a.wpk + (w * 64 + lane_v);
-        bf16x8 af[8], bf[NQ];
-#pragma unroll
-        for (int kc = 0; kc < 8; ++kc) af[kc] = wp[kc * 256];
-        {
-            const unsigned char *rp0 = smem + ln * 256 + ((h ^ (ln & 15)) << 4);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 8192);
-        }
-        for (int j = 0; j < 15; ++j) {
-            const int jn = j < 14 ? j + 1 : 14;
-            const int rb0 = j * P + ln, rb1 = jn * P + ln;
-#pragma unroll
-            for (int kc = 0; kc < 8; ++kc) {
-                const int rbn = (kc == 7) ? rb1 : rb0;
-                const int kcn = (kc + 1) & 7;
-                const unsigned char *np = smem + rbn * 256 + (((2 * kcn + h) ^ (rbn & 15)) << 4);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kc], bf[q], acc[q], 0, 0, 0);
-                    bf[q] = *(const bf16x8 *)(np + q * 8192);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                af[kc] = wp[(jn * 8 + kc) * 256];
-            }
-            if (a.stagger2 & 2) __builtin_amdgcn_s_barrier();      // developer knob: keep the two MFMA streams of a SIMD level
-        }
-    };
-
-    // epilogue of tile c; the row loads of the next tile cn are issued in four parts, one per finished channel group, into the
-    // registers that group's accumulators just freed (no global load of the epilogue itself sits behind them: parameters come
-    // from LDS, so nothing waits on HBM until stage_store)
-    auto epilogue = [&](const f32x16 (&acc)[NQ], const Coord &c, bool live, const Coord &cn, bool next_live, bf16x8 (&vn)[NPASS], int lane_v) {
-        const int ln = lane_v & 31, h = lane_v >> 5;
-        const unsigned char *xr = smem + (ln + 7 * P) * 256 + 8 * h;      // residual rows (centre tap), + q * 8192
-        unsigned char *ow = smem + ln * 256 + 8 * h;                       // output rows, + q * 8192
-        const int sx = (ln + 7 * P) & 15, so = ln & 15;
-        f32x4 fr[4], fb[4], rs[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int co0 = 32 * w + 8 * g + 4 * h;
-            fr[g] = *(const f32x4 *)(par + co0);
-            fb[g] = *(const f32x4 *)(par + 128 + co0);
-            rs[g] = *(const f32x4 *)(par + 256 + co0);
-        }
-        // column tile by column tile, ascending: tile q reads its residual inputs from rows [32q + 7P, 32q + 7P + 32) and then
-        // overwrites rows [32q, 32q + 32) of the wave's slice - rows nobody reads any more (reads always run ahead of writes).
-        // Each finished tile frees its 16 accumulator registers; the next tile's row loads are issued into them.
-        bf16x4 xnext[4];                           // residual inputs are read one tile ahead (their rows lie above every row written so far)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) xnext[g] = *(const bf16x4 *)(xr + (((4 * w + g) ^ sx) << 4));
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (q > 0 && q % (NQ / 4) == 0) {                  // a quarter of the tiles finished: their registers take one part of the rows
-                __builtin_amdgcn_sched_barrier(0);
-                stage_load(cn, next_live, vn, lane_v, (q / (NQ / 4) - 1) * NPART, (q / (NQ / 4)) * NPART);
-            }
-            bf16x4 xin[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                xin[g] = xnext[g];
-                if (q + 1 < NQ) xnext[g] = *(const bf16x4 *)(xr + (q + 1) * 8192 + (((4 * w + g) ^ sx) << 4));
-            }
-            float va[16];                          // the tile's 16 accumulators: read out of their AGPRs back to back (NQ > 8), used below
-#pragma unroll
-            for (int e = 0; e < 16; ++e) va[e] = NQ > 8 ? mst_acc_read(acc[q][e]) : acc[q][e];
-            __builtin_amdgcn_wave_barrier();       // every lane's residual reads are issued before any lane overwrites rows of this tile
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                *(bf16x4 *)(ow + q * 8192 + (((4 * w + g) ^ so) << 4)) = tcn_epilogue4(va + 4 * g, fr[g], fb[g], rs[g], xin[g]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        stage_load(cn, next_live, vn, lane_v, 3 * NPART, 4 * NPART);      // the last part
-        __builtin_amdgcn_wave_barrier();           // the transposed slice of this wave is complete
-        {
-            const int prow = lane_v >> 2, pslot = 4 * w + (lane_v & 3);
-            const long dt = (long)STEP * a.d;
-            long t = (long)(c.m0 + prow / P) * a.d + c.phi0 + (prow % P);
-            __bf16 *yp = (__bf16 *)a.y + ((size_t)c.b * a.Lp + t) * 128 + pslot * 8;
-            const unsigned char *q = smem + prow * 256 + ((pslot ^ (prow & 15)) << 4);
-#pragma unroll
-            for (int i0 = 0; i0 < T / 16; i0 += 8) {          // eight rows out of LDS, then eight stores: one LDS latency per group
-                bf16x8 rows[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) rows[i] = *(const bf16x8 *)(q + (i0 + i) * 4096);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if (live && t < a.L) *(bf16x8 *)yp = rows[i];
-                    t += dt;
-                    yp += dt * 128;
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();           // ... and read back before this wave restages the buffer
-    };
-
-    {
-        const Coord c0 = decode(0);
-        if (n_mine > 0) load_params(c0.b);
-        bf16x8 v[NPASS];
-        stage_load(c0, n_mine > 0, v, (int)threadIdx.x & 63, 0, NPASS);
-        stage_store(v, (int)threadIdx.x & 63);
-    }
-    __syncthreads();
-#pragma nounroll
-    for (int k = 0; k < n_max; ++k) {
-        int lane_v = threadIdx.x & 63;
-        MST_LAUNDER(lane_v);               // per-lane index math is recomputed per tile instead of living (and spilling) across the loop
-        const bool mine = k < n_mine;
-        const bool stamp = stamp_wg && k == 2;
-        long long *pr = a.prof + ((size_t)blockIdx.x * NSETS + set) * 10;
-        const Coord c = decode(k);
-        // per-item FiLM rows: refresh when the batch item changes (nobody reads `par` during the main loop; the barrier
-        // behind it publishes the new values to the epilogue)
-        if (mine && a.film_rows > 1 && c.b != par_b) load_params(c.b);
-        if (stamp) pr[0] = pr[1] = mst_clock();
-        // a set without a tile in the last round (odd tile count) runs the same instruction stream on its stale buffer and
-        // stores nothing: no divergent control flow around the accumulators, whose registers the epilogue hands to the prefetch
-        f32x16 acc[NQ];
-        main_loop(acc, lane_v);
-        if (stamp) pr[2] = mst_clock();
-        __syncthreads();               // every wave's B-fragment reads of this tile are done: the buffers may be overwritten
-        if (stamp) pr[6] = mst_clock();
-        bf16x8 v[NPASS];                                   // the next tile's rows travel while the epilogue runs
-        const Coord cn = decode(k + 1);
-        epilogue(acc, c, mine, cn, k + 1 < n_mine, v, lane_v);
-        if (stamp) pr[7] = mst_clock();
-        stage_store(v, lane_v);
-        if (stamp) pr[3] = mst_clock();
-        __syncthreads();
     }
 }
 

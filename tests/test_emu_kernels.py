@@ -215,32 +215,10 @@ def test_haas_panner_emulated(emu_default):
         hp.process(np.zeros((16, 3), np.float32))
 
 
-def test_tcn_duo_kernel_matches_default_emulated(emu_default, monkeypatch):
-    """The experimental two-set persistent bf16 block kernel (MST_TCN_DUO) does the same arithmetic in the same order as the default
-    kernel: its activations must be bit-identical, for ragged tile counts, more workgroups than tiles and B > 1."""
+def test_tcn_bf16_per_item_rows_emulated(emu_default):
+    """bf16 mode, one FiLM row per batch item, against the oracle."""
     m, sd = _tcn(4)
     m.precision = "bf16"
-    cond = synth.synth_audio((1, 64), seed=2)
-    for shape, wgs in (((2, 2, 777), 2), ((1, 2, 300), 5), ((3, 2, 1100), 1)):
-        x = synth.synth_audio(shape, seed=shape[2])
-        for cnd in (cond, synth.synth_audio((shape[0], 64), seed=9)):          # broadcast row / one FiLM row per batch item
-            monkeypatch.delenv("MST_TCN_DUO", raising=False)
-            ref = [m.forward_blocks(x, cnd, n).clone() for n in (2, 3, 4)]
-            monkeypatch.setenv("MST_TCN_DUO", str(wgs))
-            for n, r in zip((2, 3, 4), ref):
-                assert torch.equal(m.forward_blocks(x, cnd, n), r), (shape, wgs, n)
-    monkeypatch.delenv("MST_TCN_DUO", raising=False)
-    # the one-set form on 512-time tiles (MST_TCN_SOLO): 16 accumulator tiles per wave, same arithmetic again
-    for shape, wgs in (((2, 2, 1500), 3), ((1, 2, 700), 1)):
-        x = synth.synth_audio(shape, seed=shape[2])
-        for cnd in (cond, synth.synth_audio((shape[0], 64), seed=9)):
-            monkeypatch.delenv("MST_TCN_SOLO", raising=False)
-            ref = [m.forward_blocks(x, cnd, n).clone() for n in (2, 3, 4)]
-            monkeypatch.setenv("MST_TCN_SOLO", str(wgs))
-            for n, r in zip((2, 3, 4), ref):
-                assert torch.equal(m.forward_blocks(x, cnd, n), r), (shape, wgs, n)
-    monkeypatch.delenv("MST_TCN_SOLO", raising=False)
-    # bf16, per-item rows vs the oracle (default kernel)
     x = synth.synth_audio((2, 2, 500), seed=3)
     cB = synth.synth_audio((2, 64), seed=10)
     assert float((m(x, cB) - R.tcn_forward(sd, x, cB, nblocks=4)).abs().max()) <= 4e-2
@@ -389,7 +367,7 @@ def test_time_parallel_fx_shapes_emulated(emu_default, L, n_items, C):
             assert np.abs(y[i] - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (L, bands, i)
 
 
-def test_encoder_rows_kernel_matches_im2col_emulated(emu_default, monkeypatch):
+def test_encoder_rows_kernel_matches_im2col_emulated(emu_default):
     """bf16 FXencoder: the LDS-resident-rows convolution kernel (long early layers) against the im2col kernel it replaces -
     same operands in the same k order, so bit-identical - over strides 1 / 2 / 4, even kernels, ragged last tiles."""
     from music_mixing_style_transfer_amd.networks import FXencoder
@@ -401,11 +379,12 @@ def test_encoder_rows_kernel_matches_im2col_emulated(emu_default, monkeypatch):
     enc.precision = "bf16"
     for shape in ((2, 2, 5000), (1, 2, 4097)):
         x = synth.synth_audio(shape, seed=shape[2])
-        monkeypatch.setenv("MST_ENC_ROWS", "0")
+        run = enc._get_runner()
+        run._ensure(emu_default)
+        emu_default.check(emu_default.mst_enc_set_tuning(run.handle, -1), "tuning")     # im2col form only
         ref = enc(x).clone()
-        monkeypatch.setenv("MST_ENC_ROWS", "2")
+        emu_default.check(emu_default.mst_enc_set_tuning(run.handle, 0), "tuning")      # rows form wherever it qualifies
         got = enc(x)
         assert torch.equal(got, ref), shape
         emb = R.fxencoder_forward(sd, cfg, x)
         assert float((got - emb).abs().max()) <= 3e-2 * float(emb.abs().max())
-    monkeypatch.delenv("MST_ENC_ROWS", raising=False)
