@@ -65,12 +65,16 @@ typedef struct {
     int kernel_size;               /*                                        default cfg: 15  */
     int cond_dim;                  /* FiLM condition length                  default cfg: 2048 */
     int dilations[MST_MAX_BLOCKS]; /* dilation_growth ** (n % stack_size), architectures.py:122 */
+    int causal;                    /* TCNBlock(causal=True): zero padding (k-1)*d on the left only - the reference pads both
+                                    * sides by (k-1)*d and drops the last (k-1)*d outputs (architectures.py:199,230-231) */
 } MstTcnDesc;
 
-/* replaces TCNModel.__init__ (architectures.py:93-133).  Non-causal, ungrouped, conditional blocks (what
- * inference/style_transfer.py:48-57 constructs).  The configs.yaml shape (channel_width 128, kernel_size 15,
- * ninputs 2, noutputs <= 2) runs on the specialised kernels in both precisions; any other channel width / kernel
- * size / dilation runs on a generic exact-fp32 implicit-GEMM path (the precision argument is then ignored). */
+/* replaces TCNModel.__init__ (architectures.py:93-133): conditional blocks of dense convolutions (a grouped conv1 is handed
+ * over as its block-diagonal dense weight).  The configs.yaml shape (channel_width 128, kernel_size 15, ninputs 2,
+ * noutputs <= 2, non-causal - what inference/style_transfer.py:48-57 constructs) runs on the specialised kernels in every
+ * precision; any other channel width / kernel size / input width / dilation / a causal net runs on a generic exact-fp32
+ * implicit-GEMM path (the precision argument is then ignored).  A single TCNBlock is a net of one block run through
+ * mst_tcn_forward_blocks. */
 int mst_tcn_create(const MstTcnDesc *desc, MstTcn **out);
 int mst_tcn_destroy(MstTcn *tcn);
 
@@ -126,6 +130,7 @@ typedef struct {
     int kernels[MST_MAX_BLOCKS];
     int strides[MST_MAX_BLOCKS];
     int dilations[MST_MAX_BLOCKS];
+    int valid_padding;                 /* Conv1d_layer(padding="VALID"): no reflection padding, L_out = (L - (k-1)d - 1)/s + 1   */
 } MstEncDesc;
 
 int mst_enc_create(const MstEncDesc *desc, MstEnc **out);
@@ -148,9 +153,20 @@ int mst_enc_forward(MstEnc *enc, const float *x_dev, float *emb_dev, int B, int 
 /* parity probe: run only the first n_run Res_ConvBlocks; out_dev fp32 [B, channels[n_run], L_out(n_run)] */
 int mst_enc_forward_blocks(MstEnc *enc, const float *x_dev, float *out_dev, int B, int L, int precision, int n_run,
                            void *workspace, size_t workspace_bytes, void *stream);
+/* Conv1d_layer.forward on its own (network_utils.py:86-89): ONE conv of the handle - which = 0: encoder.{block}.conv1
+ * (cin->cin, stride 1), 1: conv2 (cin->cout, stride s) - ReflectionPad1d -> Conv1d -> BatchNorm1d(eval) -> ReLU, exact fp32;
+ * x_dev [B, cin, L] -> y_dev [B, cout, mst_enc_conv_length(...)].  Only that conv needs to be loaded. */
+int mst_enc_conv_length(const MstEnc *enc, int block, int which, int L);
+int mst_enc_forward_conv(MstEnc *enc, int block, int which, const float *x_dev, float *y_dev, int B, int L, void *stream);
 /* output length of Res_ConvBlock `block` for input length L ("SAME" padding ignores the stride:
  * L_out = floor((L-1)/s)+1, network_utils.py:30-34,48-51) */
 int mst_enc_block_length(const MstEnc *enc, int block, int L);
+
+/* FiLM.forward on its own (network_utils.py:163-182): f = film_fc(cond) [rows, 2C]; y = f[:, :C] * x + f[:, C:] over x_dev
+ * [B, C, L] (NCL); rows = 1 (broadcast) or B.  w_dev [2C, cond_dim], b_dev [2C], cond_dev [rows, cond_dim] are device fp32
+ * (the module's parameters); table_dev: >= rows * 2C floats of caller scratch. */
+int mst_film_forward(const float *w_dev, const float *b_dev, const float *cond_dev, int rows, int cond_dim, int C,
+                     const float *x_dev, float *y_dev, int B, long L, float *table_dev, void *stream);
 
 /* replaces torch.stack/reshape/mean(axis=0) over segment embeddings (style_transfer.py:152-153):
  * out[d] = mean over rows of emb[n_rows, dim], summed in row order (so the result does not depend on

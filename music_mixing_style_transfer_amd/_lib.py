@@ -26,12 +26,12 @@ STATUS_NAMES = {0: "MST_OK", -1: "MST_ERR_ARG", -2: "MST_ERR_UNSUPPORTED", -3: "
 
 class MstTcnDesc(C.Structure):
     _fields_ = [("nblocks", C.c_int), ("ninputs", C.c_int), ("noutputs", C.c_int), ("channels", C.c_int),
-                ("kernel_size", C.c_int), ("cond_dim", C.c_int), ("dilations", C.c_int * MST_MAX_BLOCKS)]
+                ("kernel_size", C.c_int), ("cond_dim", C.c_int), ("dilations", C.c_int * MST_MAX_BLOCKS), ("causal", C.c_int)]
 
 
 class MstEncDesc(C.Structure):
     _fields_ = [("nblocks", C.c_int), ("channels", C.c_int * (MST_MAX_BLOCKS + 1)), ("kernels", C.c_int * MST_MAX_BLOCKS),
-                ("strides", C.c_int * MST_MAX_BLOCKS), ("dilations", C.c_int * MST_MAX_BLOCKS)]
+                ("strides", C.c_int * MST_MAX_BLOCKS), ("dilations", C.c_int * MST_MAX_BLOCKS), ("valid_padding", C.c_int)]
 
 
 _P = C.c_void_p
@@ -59,6 +59,9 @@ SIGNATURES = {
     "mst_enc_forward": (C.c_int, [_P, _F, _F, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "mst_enc_forward_blocks": (C.c_int, [_P, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "mst_enc_block_length": (C.c_int, [_P, C.c_int, C.c_int]),
+    "mst_enc_conv_length": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "mst_enc_forward_conv": (C.c_int, [_P, C.c_int, C.c_int, _F, _F, C.c_int, C.c_int, _P]),
+    "mst_film_forward": (C.c_int, [_F, _F, _F, C.c_int, C.c_int, C.c_int, _F, _F, C.c_int, C.c_long, _F, _P]),
     "mst_embedding_mean": (C.c_int, [_F, C.c_int, C.c_int, _F, _P]),
     "mst_fx_biquad_scratch_bytes": (C.c_size_t, [C.c_int, C.c_long, C.c_int, C.c_int]),
     "mst_fx_biquad_cascade": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.POINTER(C.c_double), C.c_int, _P, C.c_size_t, _P]),

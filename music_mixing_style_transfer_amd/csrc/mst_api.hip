@@ -144,7 +144,7 @@ extern "C" int mst_tcn_create(const MstTcnDesc *desc, MstTcn **out) {
         return fail(MST_ERR_ARG, "mst_tcn_create: bad layer description");
     if (d.channels % d.ninputs != 0)
         return fail(MST_ERR_UNSUPPORTED, "mst_tcn_create: channel_width must be a multiple of ninputs (grouped 1x1 residual)");
-    const bool fast = d.channels == 128 && d.kernel_size == 15 && d.ninputs == 2 && d.noutputs <= 2 && d.dilations[0] == 1;
+    const bool fast = d.channels == 128 && d.kernel_size == 15 && d.ninputs == 2 && d.noutputs <= 2 && d.dilations[0] == 1 && !d.causal;
     for (int n = 0; n < d.nblocks; ++n)
         if (d.dilations[n] < 1) return fail(MST_ERR_ARG, "mst_tcn_create: dilation < 1");
     MstTcn *t = new MstTcn();
@@ -154,8 +154,9 @@ extern "C" int mst_tcn_create(const MstTcnDesc *desc, MstTcn **out) {
     if (t->generic) {
         t->gconv.resize(d.nblocks + 1);
         for (int n = 0; n < d.nblocks; ++n) {
-            const int pad = ((d.kernel_size - 1) * d.dilations[n]) / 2;     // architectures.py:199 (non-causal)
-            conv_geometry(t->gconv[n], n == 0 ? d.ninputs : d.channels, d.channels, d.kernel_size, 1, d.dilations[n], pad, pad);
+            const int span = (d.kernel_size - 1) * d.dilations[n];          // architectures.py:199: span/2 each side, or all of it on the
+            const int pad_l = d.causal ? span : span / 2;                   // left for a causal block (pad both sides, drop the tail)
+            conv_geometry(t->gconv[n], n == 0 ? d.ninputs : d.channels, d.channels, d.kernel_size, 1, d.dilations[n], pad_l, span - pad_l);
         }
         conv_geometry(t->gconv[d.nblocks], d.channels, d.noutputs, 1, 1, 1, 0, 0);
     }
@@ -659,7 +660,7 @@ extern "C" int mst_enc_create(const MstEncDesc *desc, MstEnc **out) {
             c.ksz = desc->kernels[i];
             c.stride = which ? desc->strides[i] : 1;
             c.dil = desc->dilations[i];
-            const int pad = (c.ksz - 1) * c.dil;   // "SAME": total (k-1)*d, left = total//2 (network_utils.py:30-34)
+            const int pad = desc->valid_padding ? 0 : (c.ksz - 1) * c.dil;   // "SAME": total (k-1)*d, left = total//2 (network_utils.py:30-34)
             c.pad_l = pad / 2;
             c.pad_r = pad - c.pad_l;
             c.nchunks = (c.cin * c.ksz + 15) / 16;
@@ -771,10 +772,23 @@ extern "C" int mst_enc_set_tuning(MstEnc *e, long rows_min_tiles) {
     return MST_OK;
 }
 
+namespace {
+int conv_out_length(const MstEncConv &c, int L) {      // reflection-padded length, then the strided "valid" conv
+    const int span = (c.ksz - 1) * c.dil;
+    const int Lp = L + c.pad_l + c.pad_r;
+    return Lp > span ? (Lp - span - 1) / c.stride + 1 : 0;
+}
+}  // namespace
+
 extern "C" int mst_enc_block_length(const MstEnc *e, int block, int L) {
     if (!e || block < 0 || block >= e->d.nblocks) return -1;
-    for (int i = 0; i <= block; ++i) L = (L - 1) / e->d.strides[i] + 1;
+    for (int i = 0; i <= block; ++i) L = conv_out_length(e->conv[2 * i + 1], conv_out_length(e->conv[2 * i], L));
     return L;
+}
+
+extern "C" int mst_enc_conv_length(const MstEnc *e, int block, int which, int L) {
+    if (!e || block < 0 || block >= e->d.nblocks || which < 0 || which > 1) return -1;
+    return conv_out_length(e->conv[2 * block + which], L);
 }
 
 namespace {
@@ -1011,6 +1025,8 @@ int enc_run_nlc(MstEnc *e, const float *x, float *emb, float *blk_out, int B, in
 int enc_run(MstEnc *e, const float *x, float *emb, float *blk_out, int B, int L, int precision, int n_run, void *ws,
             size_t ws_bytes, void *stream) {
     if (!e || !x || B < 1 || L < 1) return fail(MST_ERR_ARG, "mst_enc_forward: bad argument");
+    if (e && e->d.valid_padding)
+        return fail(MST_ERR_UNSUPPORTED, "mst_enc_forward: a Res_ConvBlock needs 'SAME' padding (conv1(x) + x); VALID layers run through mst_enc_forward_conv");
     if (precision == MST_PREC_BF16X3) precision = MST_PREC_F32;          // the encoder's high-accuracy mode is its exact-fp32 path
     if (precision != MST_PREC_F32 && precision != MST_PREC_BF16) return fail(MST_ERR_ARG, "mst_enc_forward: bad precision");
     for (auto &c : e->conv)
@@ -1056,6 +1072,39 @@ extern "C" int mst_enc_forward_blocks(MstEnc *e, const float *x, float *out, int
                                       void *ws, size_t ws_bytes, void *stream) {
     if (!e || !out || n_run < 1 || n_run > e->d.nblocks) return fail(MST_ERR_ARG, "mst_enc_forward_blocks: bad argument");
     return enc_run(e, x, nullptr, out, B, L, precision, n_run, ws, ws_bytes, stream);
+}
+
+extern "C" int mst_enc_forward_conv(MstEnc *e, int block, int which, const float *x, float *y, int B, int L, void *stream) {
+    if (!e || !x || !y || B < 1 || L < 1 || block < 0 || block >= e->d.nblocks || which < 0 || which > 1)
+        return fail(MST_ERR_ARG, "mst_enc_forward_conv: bad argument");
+    const MstEncConv &c = e->conv[2 * block + which];
+    if (!c.loaded) return fail(MST_ERR_STATE, "mst_enc_forward_conv: conv weights not loaded");
+    const int lout = conv_out_length(c, L);
+    if (lout < 1) return fail(MST_ERR_ARG, "mst_enc_forward_conv: input shorter than the kernel");
+    return enc_launch(c, x, y, B, L, lout, 0, MST_PREC_F32, stream);
+}
+
+extern "C" int mst_film_forward(const float *w, const float *b, const float *cond, int rows, int cond_dim, int C, const float *x,
+                                float *y, int B, long L, float *table, void *stream) {
+    if (!w || !b || !cond || !x || !y || !table || rows < 1 || cond_dim < 1 || C < 1 || B < 1 || L < 1)
+        return fail(MST_ERR_ARG, "mst_film_forward: bad argument");
+    if (rows != 1 && rows != B) return fail(MST_ERR_ARG, "mst_film_forward: condition rows must be 1 or equal the batch size");
+    FilmArgs a;
+    a.fw = w;
+    a.fb = b;
+    a.cond = cond;
+    a.film = table;
+    a.nblocks = 1;
+    a.two_c = 2 * C;
+    a.D = cond_dim;
+    a.rows = rows;
+    a.block_stride = 0;
+    MST_LAUNCH(tcn_film_kernel, dim3((2 * C + 3) / 4), dim3(256), stream, a);
+    MST_CHECK_LAUNCH("tcn_film_kernel");
+    const long total = (long)B * C * L;
+    MST_LAUNCH(film_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, x, y, (const float *)table, rows, C, L, total);
+    MST_CHECK_LAUNCH("film_apply_kernel");
+    return MST_OK;
 }
 
 extern "C" int mst_embedding_mean(const float *emb, int n_rows, int dim, float *out, void *stream) {

@@ -817,6 +817,16 @@ __global__ __launch_bounds__(256) void tcn_film_kernel(FilmArgs a) {
     }
 }
 
+// FiLM.forward on its own (network_utils.py:181-182): y = r * x + b over NCL x [B][C][L], film[row][0..C) = r, [C..2C) = b
+__global__ __launch_bounds__(256) void film_apply_kernel(const float *x, float *y, const float *film, int rows, int C, long L, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long bc = i / L;
+    const int c = (int)(bc % C);
+    const float *f = film + (rows > 1 ? (size_t)(bc / C) * 2 * C : 0);
+    y[i] = f[c] * x[i] + f[C + c];
+}
+
 // NLC -> NCL fp32 copy of an intermediate activation (parity probe only, not on the hot path)
 template <typename InT>
 __global__ void tcn_unpack_kernel(const void *x, float *y, int B, int L, int Lp) {

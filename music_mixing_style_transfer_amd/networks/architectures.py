@@ -46,8 +46,7 @@ def _check_device(t, what):
     return b
 
 
-def _signature(module):
-    return tuple((p.data_ptr(), p._version, p.device) for p in list(module.parameters()) + list(module.buffers()))
+from .network_utils import _signature  # noqa: E402
 
 
 class _Workspace:
@@ -189,9 +188,34 @@ class FXencoder(_DeviceState, nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ TCN
-class TCNBlock(nn.Module):
-    """dilated conv -> BatchNorm -> LeakyReLU -> FiLM -> + grouped 1x1 residual.  Parameter container: the block
-    runs fused inside TCNModel.forward (one gfx950 kernel per block)."""
+def _dense_conv_weight(conv):
+    """conv.weight [out, in / groups, k] as the dense [out, in, k] weight of the same convolution (block diagonal for a grouped
+    conv1 - the kernels contract over all input channels; the zeros add nothing)."""
+    w = conv.weight.detach().to("cpu", torch.float32)
+    if conv.groups == 1:
+        return w.contiguous()
+    out_ch, per, k = w.shape
+    dense = torch.zeros(out_ch, conv.in_channels, k, dtype=torch.float32)
+    opg = out_ch // conv.groups
+    for o in range(out_ch):
+        g = o // opg
+        dense[o, g * per:(g + 1) * per] = w[o]
+    return dense
+
+
+def _load_tcn_block(b, h, n, blk):
+    f = lambda t: t.detach().to("cpu", torch.float32).contiguous()
+    arrs = [_dense_conv_weight(blk.conv1), f(blk.bn.weight), f(blk.bn.bias), f(blk.bn.running_mean), f(blk.bn.running_var),
+            f(blk.film.film_fc.weight), f(blk.film.film_fc.bias), f(blk.res.weight)]
+    b.check(b.mst_tcn_load_block(h, n, arrs[0].data_ptr(), arrs[1].data_ptr(), arrs[2].data_ptr(), arrs[3].data_ptr(),
+                                 arrs[4].data_ptr(), float(blk.bn.eps), arrs[5].data_ptr(), arrs[6].data_ptr(), arrs[7].data_ptr(),
+                                 None), "mst_tcn_load_block")
+
+
+class TCNBlock(_DeviceState, nn.Module):
+    """dilated conv -> BatchNorm -> LeakyReLU -> FiLM -> + grouped 1x1 residual.  Inside TCNModel.forward the block is one fused
+    gfx950 kernel; called on its own (reference :222-234) it runs as a one-block net through the same library."""
+    _DEVICE_STATE = (("_handle", None), ("_sig", None), ("_hlib", None), ("_ws", lambda: _Workspace()))
 
     def __init__(self, in_ch, out_ch, kernel_size=3, dilation=1, cond_dim=2048, grouped=False, causal=False,
                  conditional=False, **kwargs):
@@ -211,9 +235,58 @@ class TCNBlock(nn.Module):
         self.bn = nn.BatchNorm1d(out_ch)
         self.relu = nn.LeakyReLU()
         self.res = nn.Conv1d(in_ch, out_ch, kernel_size=1, groups=in_ch, bias=False)
+        self._handle = self._sig = self._hlib = None
+        self._ws = _Workspace()
 
-    def forward(self, x, p):  # pragma: no cover - guard
-        raise NotImplementedError("TCNBlock runs fused inside TCNModel.forward on MI355X; there is no torch fallback")
+    def _ensure(self, b):
+        sig = _signature(self)
+        if self._handle is not None and sig == self._sig and self._hlib is b:
+            return
+        self._close()
+        if not self.conditional:
+            raise AttributeError("'TCNBlock' object has no attribute 'film'")       # what the reference's forward raises
+        d = _lib.MstTcnDesc()
+        d.nblocks, d.ninputs, d.noutputs, d.channels = 1, self.in_ch, 1, self.out_ch
+        d.kernel_size, d.cond_dim, d.causal = self.kernel_size, self.film.film_fc.in_features, int(bool(self.causal))
+        d.dilations[0] = self.dilation
+        h = C.c_void_p()
+        b.check(b.mst_tcn_create(C.byref(d), C.byref(h)), "mst_tcn_create")
+        self._handle, self._hlib = h, b
+        _load_tcn_block(b, h, 0, self)
+        zero = torch.zeros(self.out_ch + 1, dtype=torch.float32)
+        b.check(b.mst_tcn_load_output(h, zero.data_ptr(), zero[self.out_ch:].data_ptr(), None), "mst_tcn_load_output")   # unused head
+        self._sig = sig
+
+    def _close(self):
+        if self._handle is not None:
+            self._hlib.mst_tcn_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._close()
+        except Exception:
+            pass
+
+    def forward(self, x, p):
+        b = _check_device(x, "TCNBlock.forward")
+        if x.dim() != 3 or x.shape[1] != self.in_ch:
+            raise ValueError(f"TCNBlock.forward: expected [B, {self.in_ch}, L], got {tuple(x.shape)}")
+        with b.device_ctx(x):
+            self._ensure(b)
+            x = x.contiguous()
+            B, _, L = x.shape
+            cond = p.to(x.device, torch.float32).contiguous()
+            if cond.shape[0] not in (1, B):
+                raise RuntimeError(f"The size of tensor a ({cond.shape[0]}) must match the size of tensor b ({B}) at non-singleton dimension 0")
+            st = _stream_ptr(x)
+            b.check(b.mst_tcn_set_cond(self._handle, cond.data_ptr(), cond.shape[0], 0, st), "mst_tcn_set_cond")
+            nbytes = b.mst_tcn_workspace_bytes(self._handle, B, L, _lib.MST_PREC_F32)
+            ws = self._ws.get(nbytes, x.device)
+            y = torch.empty(B, self.out_ch, L, dtype=torch.float32, device=x.device)
+            b.check(b.mst_tcn_forward_blocks(self._handle, x.data_ptr(), y.data_ptr(), B, L, _lib.MST_PREC_F32, 1, ws.data_ptr(), nbytes, st),
+                    "mst_tcn_forward_blocks")
+        return y
 
 
 class TCNModel(_DeviceState, nn.Module):
@@ -265,12 +338,13 @@ class TCNModel(_DeviceState, nn.Module):
             return
         self._close()
         hp = self.hparams
-        if hp.causal or hp.grouped or hp.channel_growth > 1 or not hp.nparams > 0:
-            raise NotImplementedError("TCNModel: only the non-causal, ungrouped, conditional configuration of "
-                                      "inference/style_transfer.py is implemented on gfx950")
-        d = _lib.MstTcnDesc()
+        if hp.channel_growth > 1:
+            raise NotImplementedError("TCNModel: channel_growth > 1 (a different width per block) is not implemented on gfx950")
+        if not hp.nparams > 0:
+            raise AttributeError("'TCNBlock' object has no attribute 'film'")       # nparams = 0 builds blocks without FiLM; the
+        d = _lib.MstTcnDesc()                                                          # reference's forward fails the same way
         d.nblocks, d.ninputs, d.noutputs = hp.nblocks, hp.ninputs, hp.noutputs
-        d.channels, d.kernel_size, d.cond_dim = hp.channel_width, hp.kernel_size, hp.cond_dim
+        d.channels, d.kernel_size, d.cond_dim, d.causal = hp.channel_width, hp.kernel_size, hp.cond_dim, int(bool(hp.causal))
         for n, blk in enumerate(self.blocks):
             d.dilations[n] = blk.dilation
         h = C.c_void_p()
@@ -278,11 +352,7 @@ class TCNModel(_DeviceState, nn.Module):
         self._handle, self._lib = h, b
         f = lambda t: t.detach().to("cpu", torch.float32).contiguous()
         for n, blk in enumerate(self.blocks):
-            arrs = [f(blk.conv1.weight), f(blk.bn.weight), f(blk.bn.bias), f(blk.bn.running_mean), f(blk.bn.running_var),
-                    f(blk.film.film_fc.weight), f(blk.film.film_fc.bias), f(blk.res.weight)]
-            b.check(b.mst_tcn_load_block(h, n, arrs[0].data_ptr(), arrs[1].data_ptr(), arrs[2].data_ptr(),
-                                         arrs[3].data_ptr(), arrs[4].data_ptr(), float(blk.bn.eps), arrs[5].data_ptr(),
-                                         arrs[6].data_ptr(), arrs[7].data_ptr(), None), "mst_tcn_load_block")
+            _load_tcn_block(b, h, n, blk)
         ow, ob = f(self.output.weight), f(self.output.bias)
         b.check(b.mst_tcn_load_output(h, ow.data_ptr(), ob.data_ptr(), None), "mst_tcn_load_output")
         self._sig = sig

@@ -10,8 +10,12 @@ networks/network_utils.py of the reference, so reference checkpoints load with s
     FiLM           :156-182 film_fc.{weight,bias}
 
 The torch.nn modules inside are parameter CONTAINERS only: arithmetic happens in the gfx950 library
-(csrc/), driven by FXencoder / TCNModel in architectures.py.  There is no torch fallback.
+(csrc/).  Every exported module runs on its own as well (Conv1d_layer / ConvBlock: mst_enc_forward_conv,
+FiLM: mst_film_forward, Res_ConvBlock: a one-block encoder handle); FXencoder / TCNModel in architectures.py
+drive whole stacks.  There is no torch fallback.
 """
+import ctypes as C
+
 import torch
 import torch.nn as nn
 
@@ -37,15 +41,21 @@ class _DeviceState:
         return state
 
 
-class _HipOnly(nn.Module):
-    def forward(self, *args, **kwargs):  # pragma: no cover - guard
-        raise NotImplementedError(
-            f"{type(self).__name__} is a parameter container; it runs on MI355X inside FXencoder / TCNModel / "
-            f"Res_ConvBlock.forward (libmst_hip.so).  There is no torch fallback.")
+def _signature(module):
+    return tuple((p.data_ptr(), p._version, p.device) for p in list(module.parameters()) + list(module.buffers()))
 
 
-class Conv1d_layer(_HipOnly):
+def _device_input(t, what):
+    b = _lib.lib()
+    b.require_device(t, what)
+    if t.dtype != torch.float32:
+        raise TypeError(f"{what}: float32 input expected, got {t.dtype}")
+    return b
+
+
+class Conv1d_layer(_DeviceState, nn.Module):
     """ReflectionPad1d -> Conv1d -> BatchNorm1d -> ReLU (reference order conv -> norm -> activation)."""
+    _DEVICE_STATE = (("_handle", None), ("_sig", None), ("_hlib", None))
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding="SAME", dilation=1, bias=True,
                  norm="batch", activation="relu", mode="conv"):
@@ -58,6 +68,7 @@ class Conv1d_layer(_HipOnly):
         self.kernel_size, self.stride, self.dilation = kernel_size, stride, dilation
         self.padding_area = same_padding(kernel_size, dilation) if padding == "SAME" else (0, 0)
         self.norm, self.activation = norm, activation
+        self._handle = self._sig = self._hlib = None
         self.conv1d = nn.Sequential()
         self.conv1d.add_module("conv1d_pad", nn.ReflectionPad1d(self.padding_area))
         self.conv1d.add_module("conv1d", nn.Conv1d(in_channels, out_channels, kernel_size, stride=stride, padding=0,
@@ -72,6 +83,54 @@ class Conv1d_layer(_HipOnly):
     def hip_supported(self):
         return self.norm == "batch" and self.activation == "relu" and self.padding_area == same_padding(
             self.kernel_size, self.dilation)
+
+    # ---- the layer on its own (reference :86-89) ------------------------------------------------
+    def _ensure(self, b):
+        sig = _signature(self)
+        if self._handle is not None and sig == self._sig and self._hlib is b:
+            return
+        self._close()
+        if self.norm != "batch" or self.activation != "relu":
+            raise NotImplementedError("Conv1d_layer: only norm='batch', activation='relu' layers are implemented on gfx950")
+        d = _lib.MstEncDesc()
+        d.nblocks = 1
+        d.channels[0], d.channels[1] = self.in_channels, self.out_channels
+        d.kernels[0], d.strides[0], d.dilations[0] = self.kernel_size, self.stride, self.dilation
+        d.valid_padding = 1 if self.padding_area == (0, 0) and self.kernel_size > 1 else 0
+        h = C.c_void_p()
+        b.check(b.mst_enc_create(C.byref(d), C.byref(h)), "mst_enc_create")
+        self._handle, self._hlib = h, b
+        a = self.export_arrays()
+        ptr = lambda t: None if t is None else t.data_ptr()
+        b.check(b.mst_enc_load_conv(h, 0, 1, ptr(a["w"]), ptr(a["bias"]), ptr(a["bn_w"]), ptr(a["bn_b"]), ptr(a["bn_mean"]),
+                                    ptr(a["bn_var"]), a["eps"], None), "mst_enc_load_conv")
+        self._sig = sig
+
+    def _close(self):
+        if self._handle is not None:
+            self._hlib.mst_enc_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._close()
+        except Exception:
+            pass
+
+    def forward(self, input):
+        b = _device_input(input, "Conv1d_layer.forward")
+        if input.dim() != 3 or input.shape[1] != self.in_channels:
+            raise ValueError(f"Conv1d_layer.forward: expected [B, {self.in_channels}, L], got {tuple(input.shape)}")
+        with b.device_ctx(input):
+            self._ensure(b)
+            x = input.contiguous()
+            B, _, L = x.shape
+            lout = b.mst_enc_conv_length(self._handle, 0, 1, L)
+            if lout < 1 or L <= max(self.padding_area):
+                raise RuntimeError("Conv1d_layer.forward: the input is too short for this kernel / reflection padding")
+            y = torch.empty(B, self.out_channels, lout, dtype=torch.float32, device=x.device)
+            b.check(b.mst_enc_forward_conv(self._handle, 0, 1, x.data_ptr(), y.data_ptr(), B, L, b.stream_ptr(x)), "mst_enc_forward_conv")
+        return y
 
     def export_arrays(self):
         """Host fp32 arrays in the reference's layouts for mst_enc_load_conv."""
@@ -104,9 +163,8 @@ class Res_ConvBlock(_DeviceState, nn.Module):
         return self._runner.run(input, pooled=False)
 
 
-class ConvBlock(_HipOnly):
-    """layer_num stacked Conv1d_layers; only the last one changes channels / strides (reference :126-151).
-    Constructible for state_dict compatibility; the default configs use conv_block='res'."""
+class ConvBlock(nn.Module):
+    """layer_num stacked Conv1d_layers; only the last one changes channels / strides (reference :126-151)."""
 
     def __init__(self, dimension, layer_num, in_channels, out_channels, kernel_size, stride=1, padding="SAME",
                  dilation=1, bias=True, norm="batch", activation="relu", last_activation="relu", mode="conv"):
@@ -119,13 +177,38 @@ class ConvBlock(_HipOnly):
                                    dilation=dilation, bias=bias, norm=norm, activation=last_activation, mode=mode))
         self.conv_block = nn.Sequential(*layers)
 
+    def forward(self, input):
+        return self.conv_block(input)
 
-class FiLM(_HipOnly):
+
+class FiLM(nn.Module):
     """Feature-wise linear modulation: film_fc(condition) -> split (scale r = first half, shift b = second
     half) -> r * feature + b.  Inside TCNModel the factors for all blocks are produced by mst_tcn_set_cond and
-    applied in the TCN block kernel's epilogue."""
+    applied in the TCN block kernel's epilogue; on its own the module runs mst_film_forward."""
 
     def __init__(self, condition_len=2048, feature_len=1024):
         super().__init__()
         self.film_fc = nn.Linear(condition_len, feature_len * 2)
         self.feat_len = feature_len
+
+    def forward(self, feature, condition):
+        """feature [B, feat_len, L] (a 1-d conv feature map) or [B, feat_len] (linear), condition [1|B, condition_len]."""
+        b = _device_input(feature, "FiLM.forward")
+        if feature.dim() not in (2, 3) or feature.shape[1] != self.feat_len:
+            raise ValueError(f"FiLM.forward: expected a [B, {self.feat_len}(, L)] feature, got {tuple(feature.shape)}")
+        x = feature.contiguous()
+        cond = condition.to(x.device, torch.float32).contiguous()
+        if cond.dim() != 2 or cond.shape[1] != self.film_fc.in_features:
+            raise ValueError(f"FiLM.forward: condition must be [rows, {self.film_fc.in_features}]")
+        B, L = x.shape[0], (x.shape[2] if x.dim() == 3 else 1)
+        if cond.shape[0] not in (1, B):
+            raise RuntimeError(f"The size of tensor a ({cond.shape[0]}) must match the size of tensor b ({B}) at non-singleton dimension 0")
+        w, bias = self.film_fc.weight.detach().contiguous(), self.film_fc.bias.detach().contiguous()
+        if w.device != x.device:
+            raise RuntimeError("FiLM.forward: the module's parameters and the feature live on different devices")
+        with b.device_ctx(x):
+            y = torch.empty_like(x)
+            table = torch.empty(cond.shape[0] * 2 * self.feat_len, dtype=torch.float32, device=x.device)
+            b.check(b.mst_film_forward(w.data_ptr(), bias.data_ptr(), cond.data_ptr(), cond.shape[0], cond.shape[1], self.feat_len,
+                                       x.data_ptr(), y.data_ptr(), B, L, table.data_ptr(), b.stream_ptr(x)), "mst_film_forward")
+        return y

@@ -16,6 +16,8 @@ Fixtures:
   fx.npz            compressor / imager / gain / haas / panner / rms-normalise vectors
   fx_reverb.npz     ConvolutionalReverb outputs (python tests/golden/make_golden.py reverb regenerates only this one)
   interp.npz        inference_interpolation orchestration with stand-in networks (... make_golden.py interp)
+  modules.npz       the exported building blocks on their own (Conv1d_layer, ConvBlock, FiLM, TCNBlock) and causal / grouped TCNModels
+                    (... make_golden.py modules)
   normalizer.npz    input normaliser: the reference's imager normalisation as is; its EQ / compressor matching glue run with
                     restated stand-ins for pyloudnorm / librosa / aubio (... make_golden.py normalizer)
 """
@@ -518,6 +520,65 @@ def normalizer_goldens():
     print("normalizer.npz", os.path.getsize(os.path.join(HERE, "normalizer.npz")), {k: (np.shape(v), np.asarray(v).dtype) for k, v in out.items()})
 
 
+def _hashed_state(module, seed):
+    """Deterministic values for every parameter / buffer of a reference module (BN running_var kept positive)."""
+    sd = module.state_dict()
+    out = {}
+    for k, v in sd.items():
+        if v.dtype == torch.int64:
+            out[k] = v.clone()
+            continue
+        n = v.numel()
+        lo, hi = (0.6, 1.4) if (k.endswith("running_var") or (k.endswith("weight") and v.dim() == 1)) else (-0.5, 0.5)
+        out[k] = torch.from_numpy(synth.hashed_uniform("mod/" + k, n, lo, hi, seed).reshape(v.shape).astype(np.float32))
+    return out
+
+
+def modules_goldens():
+    """modules.npz: the exported building blocks of networks/ run ON THEIR OWN by the reference (Conv1d_layer SAME / VALID,
+    ConvBlock, FiLM, TCNBlock) and the TCNModel variants the default config does not use (causal, grouped)."""
+    install_stubs()
+    sys.path.insert(0, os.path.join(REF, "mixing_style_transfer"))
+    from networks.architectures import TCNBlock, TCNModel  # the reference
+    from networks.network_utils import Conv1d_layer, ConvBlock, FiLM
+    torch.set_num_threads(8)
+    out = {}
+
+    def run(name, mod, seed, *inputs):
+        sd = _hashed_state(mod, seed)
+        mod.load_state_dict(sd)
+        mod.eval()
+        with torch.no_grad():
+            y = mod(*inputs)
+        for k, v in sd.items():
+            out[f"{name}/sd/{k}"] = v.numpy()
+        for i, t in enumerate(inputs):
+            out[f"{name}/in{i}"] = t.numpy()
+        out[f"{name}/out"] = y.numpy()
+
+    x = synth.synth_audio((2, 6, 301), seed=31)
+    run("conv_same_k4_s2", Conv1d_layer(6, 10, 4, stride=2, padding="SAME", dilation=1), 1, x)
+    run("conv_valid_k5_d2", Conv1d_layer(6, 7, 5, stride=1, padding="VALID", dilation=2), 2, x)
+    run("convblock_valid", ConvBlock(1, 2, 6, 9, 5, stride=2, padding="VALID", dilation=1), 3, x)
+    run("film_conv", FiLM(24, 6), 4, x, synth.synth_audio((2, 24), seed=32))
+    run("film_bcast", FiLM(24, 6), 5, x, synth.synth_audio((1, 24), seed=33))
+    xb = synth.synth_audio((2, 8, 211), seed=34)
+    run("tcnblock_8_8_d3", TCNBlock(8, 8, kernel_size=5, dilation=3, cond_dim=16, conditional=True), 6, xb, synth.synth_audio((1, 16), seed=35))
+    run("tcnblock_2_8", TCNBlock(2, 8, kernel_size=3, dilation=1, cond_dim=16, conditional=True), 7, synth.synth_audio((3, 2, 97), seed=36),
+        synth.synth_audio((3, 16), seed=37))
+    run("tcnblock_causal", TCNBlock(8, 8, kernel_size=5, dilation=2, cond_dim=16, causal=True, conditional=True), 8, xb,
+        synth.synth_audio((1, 16), seed=38))
+    run("tcnblock_grouped", TCNBlock(8, 8, kernel_size=5, dilation=2, cond_dim=16, grouped=True, conditional=True), 9, xb,
+        synth.synth_audio((1, 16), seed=39))
+    xt = synth.synth_audio((2, 2, 157), seed=12)
+    cond = synth.synth_audio((1, 16), seed=13)
+    for name, kw in (("tcn_causal", dict(causal=True)), ("tcn_grouped", dict(grouped=True)), ("tcn_causal_grouped", dict(causal=True, grouped=True))):
+        run(name, TCNModel(nparams=16, ninputs=2, noutputs=2, nblocks=4, dilation_growth=2, kernel_size=5, channel_width=8, stack_size=15,
+                           cond_dim=16, **kw), 10, xt, cond)
+    np.savez_compressed(os.path.join(HERE, "modules.npz"), **out)
+    print("modules.npz", os.path.getsize(os.path.join(HERE, "modules.npz")), len(out), "arrays")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "reverb":
         reverb_goldens()
@@ -525,8 +586,11 @@ if __name__ == "__main__":
         interpolation_goldens()
     elif len(sys.argv) > 1 and sys.argv[1] == "normalizer":
         normalizer_goldens()
+    elif len(sys.argv) > 1 and sys.argv[1] == "modules":
+        modules_goldens()
     else:
         main()
         reverb_goldens()
         interpolation_goldens()
         normalizer_goldens()
+        modules_goldens()

@@ -880,3 +880,14 @@ def test_input_normalizer_chain_and_cli_with_normalize_input(tmp_path, oracle_fx
     assert mix.shape == (2, L_in)
     # normaliser tolerance (1e-4 relative on O(0.1) signals) carried through the converter, plus the PCM16 step
     assert np.abs(mix - np.clip(ref_mix, -1, 1)).max() <= 2e-3
+
+
+@pytest.mark.parametrize("name", ["conv_same_k4_s2", "conv_valid_k5_d2", "convblock_valid", "film_conv", "film_bcast", "tcnblock_8_8_d3",
+                                  "tcnblock_2_8", "tcnblock_causal", "tcnblock_grouped", "tcn_causal", "tcn_grouped", "tcn_causal_grouped"])
+def test_standalone_modules_on_gpu(name):
+    """Conv1d_layer / ConvBlock / FiLM / TCNBlock on their own and causal / grouped TCNModels on the MI355X against the outputs of the
+    real reference modules (tests/golden/modules.npz)."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_modules_standalone import check
+    check(name, "cuda")

@@ -17,6 +17,8 @@ MST_BENCH_SHARE_GPU=1 MST_DIST_BACKEND=gloo timeout 900 python -m torch.distribu
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --steps 2 --warmup 1 --workload configs1 --no-cpu-baseline > gpurun_out/bench_torchrun1.json 2> gpurun_out/bench_torchrun1.err; echo "rc=$?" >> gpurun_out/bench_torchrun1.err
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_bf16" -o bench -- python "$R/bench.py" --steps 3 --warmup 1 --precision bf16 --workload configs1 --no-cpu-baseline > "$R/gpurun_out/prof_bf16.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_x3" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --precision bf16x3 --workload configs1 --no-cpu-baseline > "$R/gpurun_out/prof_x3.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_fx" -o bench -- python "$R/tools/bench_fx.py" > "$R/gpurun_out/prof_fx.log" 2>&1
 if [ -n "$WITH_FP32_PROF" ]; then
 timeout 900 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/prof_fp32" -o bench -- python "$R/bench.py" --steps 2 --warmup 1 --precision fp32 --workload configs1 --no-cpu-baseline > "$R/gpurun_out/prof_fp32.log" 2>&1
 fi
@@ -26,4 +28,5 @@ timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY -d $R/gpurun_out/pmc_sq -o pmc --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --precision bf16 --workload configs1 --no-cpu-baseline > $R/gpurun_out/pmc_sq.log 2>&1
 fi
 cd "$R"; DB=$(find gpurun_out/prof_bf16 -name "*.db" | head -1); python tools/rocprof_summary.py "$DB" "bench.py --workload configs1 --precision bf16 (3 steps + 1 warm-up)" > gpurun_out/prof_bf16_kernel_stats.txt 2>&1
+for k in x3 fx; do DB=$(find gpurun_out/prof_$k -name "*.db" | head -1); python tools/rocprof_summary.py "$DB" "prof_$k" > gpurun_out/prof_${k}_kernel_stats.txt 2>&1; done
 find gpurun_out -name "*.db" -size +20M -delete; ls gpurun_out | head -80
