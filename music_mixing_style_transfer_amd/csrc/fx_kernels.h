@@ -418,8 +418,10 @@ __global__ __launch_bounds__(64) void fx_comp_map_kernel(CompMapArgs a) {
 template <bool USE_MIN>
 __global__ __launch_bounds__(64) void fx_comp_chain_kernel(CompMapArgs a) {
     constexpr int CB = 32, PER = MST_COMP_NP * 2, NLD = (CB * PER + 63) / 64;      // doubles per chunk / loads per lane per batch
-    __shared__ double buf[2][CB * PER];
-    __shared__ double ys[2][CB];
+    constexpr int NE = CB * MST_COMP_NP, NEL = (NE + 63) / 64;                       // (chunk, piece) entries of a batch / per lane
+    __shared__ double raw[CB * PER];                                 // a batch of map records as stored: (a, b) per piece
+    __shared__ __attribute__((aligned(32))) double cooked[2][NE * 4];   // per (chunk, piece): a, b, da, db  (one 32-byte read per step)
+    __shared__ double ys[CB];
     const int seq = blockIdx.x, lane = threadIdx.x;
     const double *m = a.maps + (size_t)seq * a.nchunks * PER;
     const size_t total = (size_t)a.nchunks * PER;
@@ -434,45 +436,65 @@ __global__ __launch_bounds__(64) void fx_comp_chain_kernel(CompMapArgs a) {
             r[i] = m[e < total ? e : total - 1];
         }
     };
-    auto put = [&](int b) {
+    // registers -> raw records -> per-piece entries with the crossing test of pieces i - 1 and i (off the serial path:
+    // once per batch of CB chunks, 17 entries per lane)
+    auto cook = [&](int b) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-            if (i * 64 + lane < CB * PER) buf[b][i * 64 + lane] = r[i];
-    };
-    struct Piece { double pa, pb, da, db; };
-    auto fetch = [&](int b, int c) {                                 // this lane's piece of chunk c and its crossing test
-        Piece p = {0.0, 0.0, 0.0, never};
-        if (has) {
-            p.pa = buf[b][c * PER + 2 * lane];
-            p.pb = buf[b][c * PER + 2 * lane + 1];
-            if (lane == 0) p.db = always;
-            else if (p.pa >= 0.0) {
-                p.da = p.pa - buf[b][c * PER + 2 * lane - 2];
-                p.db = buf[b][c * PER + 2 * lane - 1] - p.pb;
+            if (i * 64 + lane < CB * PER) raw[i * 64 + lane] = r[i];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < NEL; ++i) {
+            const int e = i * 64 + lane;
+            if (e < NE) {
+                const int piece = e % MST_COMP_NP;
+                const double pa = raw[2 * e], pb = raw[2 * e + 1];
+                double da = 0.0, db = never;
+                if (piece == 0) db = always;
+                else if (pa >= 0.0) {                               // a live piece (dead slots carry slope -1)
+                    da = pa - raw[2 * e - 2];
+                    db = raw[2 * e - 1] - pb;
+                }
+                double *c = cooked[b] + 4 * e;
+                c[0] = pa; c[1] = pb; c[2] = da; c[3] = db;
             }
         }
-        return p;
+        __builtin_amdgcn_wave_barrier();
+    };
+    struct Piece { double pa, pb, da, db; };
+    const int pl = has ? lane : MST_COMP_NP - 1;                     // lanes without a piece shadow the last one; their test is masked
+    auto fetch = [&](int b, int c) {
+        const double *q = cooked[b] + 4 * (c * MST_COMP_NP + pl);
+        return Piece{q[0], q[1], q[2], q[3]};
     };
     load(0);
-    put(0);
-    __builtin_amdgcn_wave_barrier();
+    cook(0);
     double y = 0.0;                                              // yL_prev = 0 on entry (common_audioeffects.py:553)
     int cur = 0;
     for (int bt = 0; bt < nbatch; ++bt) {
         if (bt + 1 < nbatch) load(bt + 1);
         const int nc = a.nchunks - bt * CB < CB ? a.nchunks - bt * CB : CB;
-        Piece p = fetch(cur, 0);
-        for (int c = 0; c < nc; ++c) {
-            if (lane == 0) ys[cur][c] = y;
-            const Piece nx = fetch(cur, c + 1 < nc ? c + 1 : c);   // next chunk's pieces: LDS latency behind the evaluation
+        // three pieces in flight, rotated by unrolling (no register copies that would wait for the newest load): the entry of
+        // chunk c + 3 is requested when chunk c has been evaluated, so no LDS latency sits on the serial path
+        auto step = [&](const Piece &p, int c) {
+            if (lane == 0) ys[c] = y;
             const double t = fma(p.da, y, -p.db);
-            const int idx = mst_wave_count(USE_MIN ? t <= 0.0 : t >= 0.0) - 1;
+            const int idx = __builtin_popcountll(mst_wave_ballot(USE_MIN ? t <= 0.0 : t >= 0.0) & ((1ull << MST_COMP_NP) - 1)) - 1;
             y = mst_wave_read_f64(fma(p.pa, y, p.pb), idx);
-            p = nx;
+        };
+        auto clamp = [&](int c) { return c < nc ? c : nc - 1; };
+        Piece pA = fetch(cur, 0), pB = fetch(cur, clamp(1)), pC = fetch(cur, clamp(2));
+        for (int c = 0; c < nc; c += 3) {
+            step(pA, c);
+            pA = fetch(cur, clamp(c + 3));
+            if (c + 1 < nc) step(pB, c + 1);
+            pB = fetch(cur, clamp(c + 4));
+            if (c + 2 < nc) step(pC, c + 2);
+            pC = fetch(cur, clamp(c + 5));
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane < nc) a.ystart[(size_t)(bt * CB + lane) * a.n_seq + seq] = ys[cur][lane];
-        if (bt + 1 < nbatch) put(cur ^ 1);
+        if (lane < nc) a.ystart[(size_t)(bt * CB + lane) * a.n_seq + seq] = ys[lane];
+        if (bt + 1 < nbatch) cook(cur ^ 1);
         __builtin_amdgcn_wave_barrier();
         cur ^= 1;
     }

@@ -80,8 +80,8 @@ __device__ __forceinline__ float mst_acc_read(float x) {
     return r;
 }
 
-// number of lanes of the wave whose predicate holds (v_cmp -> s_bcnt1_i32_b64), and lane `src`'s double in every lane
-__device__ __forceinline__ int mst_wave_count(bool p) { return __builtin_popcountll(__ballot(p)); }
+// the wave's predicate mask (v_cmp writes it straight into an SGPR pair), and lane `src`'s double in every lane
+__device__ __forceinline__ unsigned long long mst_wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ double mst_wave_read_f64(double v, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);

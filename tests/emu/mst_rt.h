@@ -135,12 +135,12 @@ template <bool USE_MIN> static inline double mst_wave_extreme_f64(double v) {
     }
     return v;
 }
-static inline int mst_wave_count(bool p) {
-    int n = 0;
+static inline unsigned long long mst_wave_ballot(bool p) {
+    unsigned long long m = 0;
     const int mine = p ? 1 : 0;
     const unsigned char *base = emu::wave_publish(&mine, sizeof(int));
-    for (int l = 0; l < 64; ++l) { int v; memcpy(&v, base + 64 * l, sizeof(int)); n += v; }
-    return n;
+    for (int l = 0; l < 64; ++l) { int v; memcpy(&v, base + 64 * l, sizeof(int)); m |= (unsigned long long)(v & 1) << l; }
+    return m;
 }
 static inline double mst_wave_read_f64(double v, int src) { return emu_shfl(v, src); }
 template <typename T> static inline T __shfl_down(T v, int d, int = 64) {
