@@ -34,6 +34,10 @@ struct EncConvArgs {
     const float *film;   // epi 1: [film_rows][2*Cout]  (r | b)
     const float *res;    // epi 1: [Cout] grouped 1x1 residual scale; out-channel co reads in-channel co / res_div
     int film_rows, res_div;
+    // split-K (gridDim.z = S > 1, fp32 kernel): slice z contracts k-chunks [z * nchunks / S, (z + 1) * nchunks / S) and stores its
+    // raw partial sums to part[z][co][n]; enc_splitk_finalize_ncl_kernel adds the slices in order and applies the epilogue.
+    // Used for the short wide late layers, whose 128 tiles would otherwise leave half of the 256 CUs idle.
+    float *part = nullptr;
 };
 
 template <int MW>
@@ -103,9 +107,10 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
         }
     };
 
-    fetch(0);
-    for (int kc = 0; kc < a.nchunks; ++kc) {
-        if (kc) __syncthreads();
+    const int kc_lo = (int)((long)blockIdx.z * a.nchunks / gridDim.z), kc_hi = (int)((long)(blockIdx.z + 1) * a.nchunks / gridDim.z);
+    fetch(kc_lo);
+    for (int kc = kc_lo; kc < kc_hi; ++kc) {
+        if (kc > kc_lo) __syncthreads();
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int idx = tid + i * 256;
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
 #pragma unroll
         for (int e = 0; e < NB; ++e) Bs[tid + e * 256] = breg[e];
         __syncthreads();
-        if (kc + 1 < a.nchunks) fetch(kc + 1);
+        if (kc + 1 < kc_hi) fetch(kc + 1);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const float av = As[(2 * ks + h) * MT + 32 * mi + ln];
@@ -126,6 +131,20 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
         }
     }
 
+    if (a.part) {            // split-K slice: raw partial sums, consecutive lanes = consecutive columns
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long n = n0 + 128 * ni + 32 * q + ln;
+            if (n < a.Ntot) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cot * MT + 32 * mi + mfma32_row(r, lane);
+                    if (co < a.Cout) a.part[((size_t)blockIdx.z * a.Cout + co) * a.Ntot + n] = acc[q][r];
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const long n = n0 + 128 * ni + 32 * q + ln;
@@ -562,6 +581,22 @@ __global__ __launch_bounds__(256) void enc_splitk_finalize_kernel(const float *p
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = (__bf16)(fmaxf(s[k] + sh[k], 0.0f) + (float)r[k]);
     *(bf16x4 *)(y + (size_t)n * Cout + co0) = o;
+}
+
+// split-K finalize of the fp32 NCL kernel (encoder epilogue): y[b][co][to] = relu(sum_z part[z][co][n] + shift[co]) (+ x[b][co][to])
+__global__ __launch_bounds__(256) void enc_splitk_finalize_ncl_kernel(const float *part, int S, long Ntot, int Cout, int Lout,
+                                                                      const float *shift, const float *xres, float *y) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Ntot * Cout) return;
+    const int co = (int)(i / Ntot);
+    const long n = i % Ntot;
+    float s = 0.0f;
+    for (int z = 0; z < S; ++z) s += part[((size_t)z * Cout + co) * Ntot + n];
+    const long b = n / Lout, to = n % Lout;
+    const size_t o = ((size_t)b * Cout + co) * Lout + to;
+    float v = fmaxf(s + shift[co], 0.0f);
+    if (xres) v += xres[o];
+    y[o] = v;
 }
 
 // global average pool over time of an NLC bf16 activation -> fp32 [B][C]

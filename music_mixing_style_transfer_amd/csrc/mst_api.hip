@@ -804,8 +804,16 @@ size_t enc_buf_floats(const MstEnc *e, int B, int L) {
     return mx;
 }
 
+int enc_splitk_f32(long tiles, int nchunks) {        // slices of the fp32 NCL kernel: aim at >= 1024 workgroups, >= 8 k-chunks per slice
+    if (tiles >= 512) return 1;
+    int S = (int)((1024 + tiles - 1) / tiles);
+    if (S > 16) S = 16;
+    if (S > nchunks / 8) S = nchunks / 8;
+    return S < 1 ? 1 : S;
+}
+
 int enc_launch(const MstEncConv &c, const float *x, float *y, int B, int Lin, int Lout, int residual, int precision,
-               void *stream) {
+               void *stream, float *scratch = nullptr) {
     if (Lin <= c.pad_l || Lin <= c.pad_r)
         return fail(MST_ERR_ARG, "mst_enc_forward: reflection padding needs the input to be longer than the padding");
     EncConvArgs a;
@@ -832,7 +840,15 @@ int enc_launch(const MstEncConv &c, const float *x, float *y, int B, int Lin, in
     a.film_rows = 1;
     a.res_div = 1;
     const int MT = 32 * c.mw, NT = 128 * (4 / c.mw);
-    const dim3 grid((unsigned)((a.Ntot + NT - 1) / NT), (unsigned)((c.cout + MT - 1) / MT));
+    dim3 grid((unsigned)((a.Ntot + NT - 1) / NT), (unsigned)((c.cout + MT - 1) / MT));
+    int S = 1;
+    if (precision != MST_PREC_BF16 && scratch) {
+        S = enc_splitk_f32((long)grid.x * grid.y, c.nchunks);
+        if (S > 1) {
+            a.part = scratch;
+            grid.z = (unsigned)S;
+        }
+    }
     if (precision == MST_PREC_BF16) {
         switch (c.mw) {
             case 1: MST_LAUNCH((enc_conv_bf16_kernel<1>), grid, dim3(256), stream, a); break;
@@ -847,6 +863,12 @@ int enc_launch(const MstEncConv &c, const float *x, float *y, int B, int Lin, in
         }
     }
     MST_CHECK_LAUNCH("enc_conv_kernel");
+    if (S > 1) {
+        const long total = a.Ntot * c.cout;
+        MST_LAUNCH(enc_splitk_finalize_ncl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, (const float *)scratch, S, a.Ntot,
+                   c.cout, Lout, (const float *)c.shift, residual ? x : (const float *)nullptr, y);
+        MST_CHECK_LAUNCH("enc_splitk_finalize_ncl_kernel");
+    }
     return MST_OK;
 }
 
@@ -882,6 +904,8 @@ size_t enc_scratch_floats(const MstEnc *e, int B, int L) {
             const int nch = (c.cin * c.ksz + 63) / 64;
             const int S = enc_splitk(tiles, nch);
             if (S > 1) mx = std::max(mx, (size_t)S * ntot * c.cout);
+            const int Sf = enc_splitk_f32(tiles, c.nchunks);          // exact-fp32 mode slices
+            if (Sf > 1) mx = std::max(mx, (size_t)Sf * ntot * c.cout);
         }
         len = lout;
     }
@@ -1036,13 +1060,14 @@ int enc_run(MstEnc *e, const float *x, float *emb, float *blk_out, int B, int L,
     const size_t nb = align_up(enc_buf_floats(e, B, L) * sizeof(float), 256);
     float *t1 = (float *)ws;
     float *o[2] = {(float *)((unsigned char *)ws + nb), (float *)((unsigned char *)ws + 2 * nb)};
+    float *scratch = (float *)((unsigned char *)ws + 3 * nb);
     const float *cur = x;
     int len = L, rc, pp = 0;
     for (int i = 0; i < n_run; ++i) {
         const int lout = (len - 1) / e->d.strides[i] + 1;
-        if ((rc = enc_launch(e->conv[2 * i], cur, t1, B, len, len, 1, precision, stream))) return rc;
+        if ((rc = enc_launch(e->conv[2 * i], cur, t1, B, len, len, 1, precision, stream, scratch))) return rc;
         float *dst = (blk_out && i == n_run - 1) ? blk_out : o[pp];
-        if ((rc = enc_launch(e->conv[2 * i + 1], t1, dst, B, len, lout, 0, precision, stream))) return rc;
+        if ((rc = enc_launch(e->conv[2 * i + 1], t1, dst, B, len, lout, 0, precision, stream, scratch))) return rc;
         cur = dst;
         pp ^= 1;
         len = lout;
