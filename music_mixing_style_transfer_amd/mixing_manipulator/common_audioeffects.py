@@ -419,6 +419,16 @@ class Panner(Processor):
         self.update()
 
 
+_stream_pools = {}
+
+
+def _stream_pool(device, n):
+    pool = _stream_pools.setdefault(str(device), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device))
+    return pool
+
+
 class AugmentationChain:
     """Apply (processor, probability, rms_normalize) entries in order to every array of a list; optional shuffle
     and parallel dry/wet mix - the reference's chain semantics (:156-192)."""
@@ -441,23 +451,76 @@ class AugmentationChain:
         return [self.apply_processor(x, processor, rms_normalize) for x in x_list]
 
     def __call__(self, x_list):
+        x_list = list(x_list)
+        lanes = self._lanes(x_list)
         if self.shuffle:
             random.shuffle(self.fxs)
-        y_list = list(x_list)
-        for fx, p, rms in self.fxs:
-            if np.random.rand() < p:
-                if isinstance(fx, Processor):
+        if lanes > 1:
+            # every entry is a plain processor: their random draws do not depend on the audio, so the whole chain is drawn first
+            # (same order of draws as below) and then runs stripe by stripe with fixed settings
+            plan = []
+            for fx, p, rms in self.fxs:
+                if np.random.rand() < p:
                     if self.randomize_param_value:
                         fx.randomize()
                     else:
                         fx.update(None)
-                    y_list = self.apply_same_processor(y_list, fx, rms)
-                else:
-                    y_list = fx(y_list)
+                    plan.append((fx, rms))
+            y_list = [self._run_striped(plan, x_list[0], lanes)]
+        else:
+            y_list = list(x_list)
+            for fx, p, rms in self.fxs:
+                if np.random.rand() < p:
+                    if isinstance(fx, Processor):
+                        if self.randomize_param_value:
+                            fx.randomize()
+                        else:
+                            fx.update(None)
+                        y_list = self.apply_same_processor(y_list, fx, rms)
+                    else:
+                        y_list = fx(y_list)
         if self.parallel:
             w = self.parallel_weight_factor if self.parallel_weight_factor else np.random.rand() / 2.0
             y_list = [w * x + (1 - w) * y for x, y in zip(x_list, y_list)]
         return y_list
+
+    # ---- a large device batch [n_items, L, C]: the items are independent, and most FX kernels of a 64-item batch are too small
+    # to fill 256 CUs (the compressor's chunk walk is ONE wave per sequence), so the batch runs as `stripes` sub-batches on their
+    # own HIP streams - the latency-bound phases of one stripe overlap the bandwidth-bound phases of the others.
+    stripes = 4
+
+    def _lanes(self, x_list):
+        if len(x_list) != 1 or not isinstance(x_list[0], torch.Tensor) or not x_list[0].is_cuda or x_list[0].dim() != 3:
+            return 1
+        if not all(isinstance(fx, Processor) and type(fx).__name__ != "ConvolutionalReverb" for fx, _, _ in self.fxs):
+            return 1
+        same_settings = len({id(fx) for fx, _, _ in self.fxs}) == len(self.fxs)       # a processor listed twice keeps the plain loop
+        return min(self.stripes, x_list[0].shape[0] // 8) if same_settings else 1
+
+    def _run_striped(self, plan, x, lanes):
+        n = x.shape[0]
+        cur = torch.cuda.current_stream(x.device)
+        out = torch.empty((n,) + self._out_shape(plan, x), dtype=torch.float32, device=x.device)
+        bounds = [(k * n) // lanes for k in range(lanes + 1)]
+        pool = _stream_pool(x.device, lanes)
+        for k in range(lanes):
+            st = pool[k]
+            st.wait_stream(cur)
+            x.record_stream(st)
+            out.record_stream(st)
+            with torch.cuda.stream(st):
+                y = x[bounds[k]:bounds[k + 1]]
+                for fx, rms in plan:
+                    y = self.apply_processor(y, fx, rms)
+                out[bounds[k]:bounds[k + 1]] = y
+        for k in range(lanes):
+            cur.wait_stream(pool[k])
+        return out
+
+    @staticmethod
+    def _out_shape(plan, x):
+        stereo = any(type(fx).__name__ in ("Haas", "Panner") for fx, _ in plan)
+        return (x.shape[1], 2 if stereo else x.shape[2])
 
     def __repr__(self):
         return f"AugmentationChain(fxs={self.fxs!r}, shuffle={self.shuffle!r})"
