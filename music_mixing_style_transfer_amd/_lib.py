@@ -49,6 +49,7 @@ SIGNATURES = {
     "mst_tcn_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int, C.c_int]),
     "mst_tcn_forward": (C.c_int, [_P, _F, _F, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "mst_tcn_forward_blocks": (C.c_int, [_P, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "mst_tcn_set_tuning": (C.c_int, [_P, C.c_int]),
     "mst_tcn_timing_begin": (C.c_int, [_P, C.c_int]),
     "mst_tcn_timing_end": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "mst_enc_create": (C.c_int, [C.POINTER(MstEncDesc), C.POINTER(_P)]),

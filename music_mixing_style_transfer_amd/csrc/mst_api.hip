@@ -129,6 +129,7 @@ struct MstTcn {
     int film_rows = 0, film_cap = 0;
     float *out_w = nullptr, *out_b = nullptr;
     bool out_loaded = false;
+    int x3_small_tiles = 0;       // bf16x3 mode: 128-time tiles of <= 2 phases, two workgroups per CU (mst_tcn_set_tuning)
     std::vector<hipEvent_t> ev;   // timing hook: (nblocks + 2) events per recorded forward
     int ev_max = 0, ev_used = 0;
 };
@@ -348,6 +349,11 @@ int choose_phases(int d, int L, int precision) {
         if (P == 4 && d % 8 == 0 && 256 / P > nsteps) P = 8;
         return P;
     }
+    if (precision == MST_PREC_BF16X3 + 100) {   // bf16x3 with small tiles: 2 phases wherever 64 steps fit the segment
+        int Q = (d % 2 == 0) ? 2 : 1;
+        if (128 / Q <= nsteps) return Q;
+        return choose_phases(d, L, MST_PREC_BF16X3);
+    }
     if (precision != MST_PREC_BF16) {      // fp32 kernel: 256-time tiles only (its LDS tile is a 32-channel chunk)
         while (P < 16 && d % (2 * P) == 0 && 256 / P > nsteps) P *= 2;
         return P;
@@ -357,9 +363,20 @@ int choose_phases(int d, int L, int precision) {
     return P;
 }
 
-template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream) {
+template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream, int x3_small = 0) {
     TcnBlockArgs a = a0;
     if (precision == MST_PREC_BF16X3) {
+        if constexpr (P <= 2) {
+            if (x3_small) {          // 128-time tiles: 2 x 39 KB of LDS, two workgroups (8 waves) per CU
+                const long nsteps = ((long)a.L + a.d - 1) / a.d;
+                a.tiles_step = (int)((nsteps + 128 / P - 1) / (128 / P));
+                const long g2 = (long)a.B * a.tiles_phase * a.tiles_step;
+                if (g2 % 8 == 0) a.xcd_tiles = (int)(g2 / 8);
+                MST_LAUNCH((tcn_block_bf16x3_kernel<P, 4>), dim3((unsigned)g2), dim3(256), stream, a);
+                MST_CHECK_LAUNCH("tcn_block_bf16x3_kernel");
+                return MST_OK;
+            }
+        }
         if constexpr (P <= 8) {
             constexpr int NQ = P == 8 ? 4 : 8;
             const long nsteps = ((long)a.L + a.d - 1) / a.d;
@@ -510,7 +527,8 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
     int cur = 0;
     for (int n = 1; n < n_run; ++n) {
         const int d = t->d.dilations[n];
-        const int P = choose_phases(d, L, precision);
+        const int P = choose_phases(d, L, (precision == MST_PREC_BF16X3 && t->x3_small_tiles) ? MST_PREC_BF16X3 + 100 : precision);
+        const int x3_small = (precision == MST_PREC_BF16X3 && t->x3_small_tiles && P <= 2) ? 1 : 0;
         TcnBlockArgs a;
         a.x = buf[cur];
         a.y = buf[cur ^ 1];
@@ -537,10 +555,10 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         if (grid > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_tcn_forward: grid too large");
         int rc;
         switch (P) {
-            case 1: rc = launch_block<1>(precision, a, (int)grid, stream); break;
-            case 2: rc = launch_block<2>(precision, a, (int)grid, stream); break;
-            case 4: rc = launch_block<4>(precision, a, (int)grid, stream); break;
-            case 8: rc = launch_block<8>(precision, a, (int)grid, stream); break;
+            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small); break;
+            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small); break;
+            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small); break;
+            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small); break;
             default: rc = launch_block<16>(precision, a, (int)grid, stream); break;
         }
         if (rc) return rc;
@@ -583,6 +601,12 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
 }
 
 }  // namespace
+
+extern "C" int mst_tcn_set_tuning(MstTcn *t, int x3_small_tiles) {
+    if (!t) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: null handle");
+    t->x3_small_tiles = x3_small_tiles ? 1 : 0;
+    return MST_OK;
+}
 
 extern "C" int mst_tcn_timing_begin(MstTcn *t, int max_forwards) {
     if (!t || max_forwards < 1) return fail(MST_ERR_ARG, "mst_tcn_timing_begin: bad argument");

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
 // Same polyphase tiling, LDS swizzle and fragment order as tcn_block_bf16_kernel; one workgroup per CU (two 78 KB tiles).
 // ------------------------------------------------------------------------------------------------
 template <int P, int NQ>
-__global__ __launch_bounds__(256, 1) void tcn_block_bf16x3_kernel(TcnBlockArgs a) {
+__global__ __launch_bounds__(256, (NQ == 4 && P <= 2) ? 2 : 1) void tcn_block_bf16x3_kernel(TcnBlockArgs a) {
     constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * R * 256];      // [hi | lo] tiles
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

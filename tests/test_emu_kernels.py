@@ -49,7 +49,14 @@ def test_tcn_large_dilation_and_odd_growth_emulated(emu_default):
     m2.precision = "bf16"
     assert float((m2(x, cond) - y_ref).abs().max()) <= 4e-2
     m2.precision = "bf16x3"          # split-bf16 mode: 8-phase tiles of 128 times for the large dilations
-    assert float((m2(x, cond) - y_ref).abs().max()) <= 3e-5
+    y3 = m2(x, cond)
+    assert float((y3 - y_ref).abs().max()) <= 3e-5
+    emu_default.check(emu_default.mst_tcn_set_tuning(m2._handle, 1), "tuning")      # 128-time tiles of <= 2 phases: same bits
+    assert torch.equal(m2(x, cond), y3)
+    x5 = synth.synth_audio((2, 2, 700), seed=16)
+    y5 = m2(x5, cond)
+    emu_default.check(emu_default.mst_tcn_set_tuning(m2._handle, 0), "tuning")
+    assert torch.equal(m2(x5, cond), y5)
 
 
 def test_tcn_condition_forms_emulated(emu_default):
