@@ -268,6 +268,18 @@ int mst_fx_stft_mean_magnitude(MstStft *st, const float *x_dev, long L, int C, i
  * and y = M x per stereo sample, the composed re-mix (l', r') = (m00 l + m01 r, m10 l + m11 r). */
 int mst_fx_stereo_moments(const float *x_dev, int n_items, long L, double *out_dev, void *stream);
 int mst_fx_stereo_mix(const float *x_dev, float *y_dev, int n_items, long L, float m00, float m01, float m10, float m11, void *stream);
+/* AlgorithmicReverb.process (common_audioeffects.py:1447-1495): per side (left / right, the right delays longer by
+ * stereo_spread samples) the SUM of n_combs damped feedback comb filters on in_gain * x, then n_allpass all-pass sections in
+ * series, then out_L = wet1 xL + wet2 xR + dry x_L, out_R = wet1 xR + wet2 xL + dry x_R.  comb_delays [n_combs] and
+ * allpass_delays [n_allpass][2] (left, right) are host arrays; feedback of both filter kinds = room_size.  x_dev [n_items, L, C]
+ * (C = 1 or 2) -> y_dev [n_items, L, 2].  The caller resolves the reference's quirks (only combs 5..8 reach the output, the
+ * 255-sample right delay of the last all-pass).  Comb / all-pass arithmetic restated from the published Schroeder / Freeverb
+ * structure (pymixconsole.components, not vendored): parity unpinned. */
+size_t mst_fx_algorithmic_reverb_scratch_bytes(int n_items, long L, int n_combs);
+int mst_fx_algorithmic_reverb(const float *x_dev, float *y_dev, int n_items, long L, int C, const int *comb_delays, int n_combs,
+                              const int *allpass_delays, int n_allpass, int stereo_spread, double damping, double room_size,
+                              double in_gain, double wet1, double wet2, double dry, double *scratch_dev, size_t scratch_bytes,
+                              void *stream);
 
 #ifdef __cplusplus
 }

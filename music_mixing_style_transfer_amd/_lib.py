@@ -85,6 +85,9 @@ SIGNATURES = {
     "mst_fx_stft_destroy": (None, [_P]),
     "mst_fx_stft_workspace_bytes": (C.c_size_t, [_P]),
     "mst_fx_stft_mean_magnitude": (C.c_int, [_P, _F, C.c_long, C.c_int, C.c_int, _F, _P, C.c_size_t, _P]),
+    "mst_fx_algorithmic_reverb_scratch_bytes": (C.c_size_t, [C.c_int, C.c_long, C.c_int]),
+    "mst_fx_algorithmic_reverb": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_int,
+                                            C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _P, C.c_size_t, _P]),
     "mst_fx_stereo_moments": (C.c_int, [_F, C.c_int, C.c_long, _P, _P]),
     "mst_fx_stereo_mix": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "mst_fx_convolve": (C.c_int, [_P, _F, _F, C.c_long, _F, C.c_long, C.c_double, C.c_double, _P, C.c_size_t, _P]),

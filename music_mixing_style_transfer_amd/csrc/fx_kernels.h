@@ -861,3 +861,114 @@ __global__ __launch_bounds__(256) void fx_stereo_mix_kernel(const float *x, floa
     const f32x2 v = ((const f32x2 *)x)[i];
     ((f32x2 *)y)[i] = f32x2{m00 * v.x + m01 * v.y, m10 * v.x + m11 * v.y};
 }
+
+// =================================================================================================
+// AlgorithmicReverb (reference common_audioeffects.py:1429-1537): per channel, feedback comb filters with a damped feedback path
+// and four all-pass sections in series - the Schroeder / "Freeverb" structure of pymixconsole.components.comb / .allpass
+// (pymixconsole==0.0.1 is not vendored: restated from the published structure, parity unpinned):
+//   comb(D, damp, fb):  out_n = buf[n mod D];  store_n = out_n (1 - damp) + store_{n-1} damp;  buf[n mod D] = in_n + store_n fb;  y_n = out_n
+//   allpass(D, fb):     out_n = buf[n mod D];  y_n = out_n - in_n;  buf[n mod D] = in_n + out_n fb
+// float64 inside.  Time-parallel forms: the comb's feedback reaches back D samples, so inside a block of D samples out_n is known
+// from the previous block and store_n = damp store_{n-1} + u_n is a first-order linear scan (per-lane runs + a wave scan of the
+// carries); the all-pass couples only samples D apart: D independent recurrences.
+// =================================================================================================
+struct CombArgs {
+    const float *x;      // [n_items][L][C]
+    double *y;           // [n_combs][n_items * 2][L]   comb outputs per (item, side)
+    long L;
+    int C, n_items, n_combs;
+    int delay[8][2];     // [comb][side]
+    double damp, feedback, in_gain;
+};
+
+// grid (n_combs, n_items * 2), 64 threads: one wave per (comb, item, side)
+__global__ __launch_bounds__(64) void fx_comb_kernel(CombArgs a) {
+    constexpr int EMAX = 32;                                    // delay <= 64 * EMAX = 2048 samples
+    __shared__ double store_prev[64 * EMAX];                    // store values of the previous block
+    const int comb = blockIdx.x, sq = blockIdx.y, item = sq >> 1, side = sq & 1, lane = threadIdx.x;
+    const int D = a.delay[comb][side];
+    const int E = (D + 63) / 64;                                // consecutive elements per lane
+    const int i0 = lane * E;
+    const int cnt = D - i0 < 0 ? 0 : (D - i0 < E ? D - i0 : E); // this lane's share of the D samples of a block
+    const float *xp = a.x + (size_t)item * a.L * a.C + (a.C == 2 ? side : 0);
+    double *yp = a.y + ((size_t)comb * a.n_items * 2 + sq) * a.L;
+    const double d1 = a.damp, d2 = 1.0 - a.damp;
+    double dC = 1.0;                                            // damp^cnt: the decay a carry suffers across this lane's run
+    for (int i = 0; i < cnt; ++i) dC *= d1;
+    double carry_in = 0.0;                                      // store value just before the block
+    for (long n0 = 0; n0 < a.L; n0 += D) {
+        double run[EMAX], out[EMAX];
+        double s = 0.0;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            double o = 0.0;
+            if (e < cnt) {
+                const long n = n0 + i0 + e;
+                if (n0 > 0 && n < a.L) o = (double)xp[(n - D) * a.C] * a.in_gain + store_prev[i0 + e] * a.feedback;
+                s = d1 * s + d2 * o;                            // the run from a zero carry
+            }
+            out[e] = o;
+            run[e] = s;
+        }
+        // wave scan of the affine maps carry -> A carry + B of the lanes' runs (inclusive), then shifted by one lane
+        double A = dC, B = s;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const double Ap = __shfl_up(A, m), Bp = __shfl_up(B, m);
+            if (lane >= m) { B = A * Bp + B; A = A * Ap; }
+        }
+        double Ax = __shfl_up(A, 1), Bx = __shfl_up(B, 1);
+        if (lane == 0) { Ax = 1.0; Bx = 0.0; }
+        const double c = Ax * carry_in + Bx;                    // store value entering this lane's run
+        const double last = __shfl(A, 63) * carry_in + __shfl(B, 63);
+        __builtin_amdgcn_wave_barrier();
+        double p = d1;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e) {
+            if (e < cnt) {
+                const long n = n0 + i0 + e;
+                store_prev[i0 + e] = run[e] + p * c;
+                if (n < a.L) yp[n] = out[e];
+                p *= d1;
+            }
+        }
+        carry_in = last;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// one all-pass section in place over v[sq][L]: thread p of a workgroup owns the samples n = p, p + D, p + 2D, ...;
+// sum_combs > 0: the input is first formed as the sum of that many comb outputs (y layout of fx_comb_kernel)
+__global__ __launch_bounds__(1024) void fx_allpass_kernel(double *v, const double *combs, int sum_combs, int first_comb, long L, int n_seq,
+                                                          int delay_l, int delay_r, double feedback) {
+    const int sq = blockIdx.x, side = sq & 1;
+    const int D = side ? delay_r : delay_l;
+    double *vp = v + (size_t)sq * L;
+    for (int p = threadIdx.x; p < D; p += blockDim.x) {
+        double buf = 0.0;
+        for (long n = p; n < L; n += D) {
+            double in = vp[n];
+            if (sum_combs > 0) {
+                in = 0.0;
+                for (int k = 0; k < sum_combs; ++k) in += combs[((size_t)(first_comb + k) * n_seq + sq) * L + n];
+            }
+            const double out = buf;
+            vp[n] = out - in;
+            buf = in + out * feedback;
+        }
+    }
+}
+
+// output[:, 0] = wet1 xL + wet2 xR + dry dataL ; output[:, 1] = wet1 xR + wet2 xL + dry dataR  (:1462-1463)
+__global__ __launch_bounds__(256) void fx_reverb_mix_kernel(const float *x, const double *wet, float *y, long L, int C, double wet1, double wet2,
+                                                            double dry) {
+    const int item = blockIdx.y;
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= L) return;
+    const double xl = wet[((size_t)item * 2 + 0) * L + n], xr = wet[((size_t)item * 2 + 1) * L + n];
+    const float *xp = x + ((size_t)item * L + n) * C;
+    const double dl = (double)xp[0], dr = (double)xp[C == 2 ? 1 : 0];
+    float *yp = y + ((size_t)item * L + n) * 2;
+    yp[0] = (float)(wet1 * xl + wet2 * xr + dry * dl);
+    yp[1] = (float)(wet1 * xr + wet2 * xl + dry * dr);
+}

@@ -1673,3 +1673,51 @@ extern "C" int mst_fx_stereo_mix(const float *x, float *y, int n_items, long L, 
     MST_CHECK_LAUNCH("fx_stereo_mix_kernel");
     return MST_OK;
 }
+
+// ---- AlgorithmicReverb -------------------------------------------------------------------------------------------------
+extern "C" size_t mst_fx_algorithmic_reverb_scratch_bytes(int n_items, long L, int n_combs) {
+    if (n_items < 1 || L < 1 || n_combs < 1) return 0;
+    return ((size_t)n_combs + 1) * n_items * 2 * (size_t)L * sizeof(double);
+}
+
+extern "C" int mst_fx_algorithmic_reverb(const float *x, float *y, int n_items, long L, int C, const int *comb_delays, int n_combs,
+                                         const int *allpass_delays, int n_allpass, int stereo_spread, double damping, double room_size,
+                                         double in_gain, double wet1, double wet2, double dry, double *scratch, size_t scratch_bytes,
+                                         void *stream) {
+    if (!x || !y || !comb_delays || !allpass_delays || !scratch || n_items < 1 || L < 1 || (C != 1 && C != 2) || n_combs < 1 ||
+        n_combs > 8 || n_allpass < 1 || stereo_spread < 0)
+        return fail(MST_ERR_ARG, "mst_fx_algorithmic_reverb: bad argument");
+    if (scratch_bytes < mst_fx_algorithmic_reverb_scratch_bytes(n_items, L, n_combs))
+        return fail(MST_ERR_WORKSPACE, "mst_fx_algorithmic_reverb: scratch too small");
+    CombArgs a;
+    a.x = x;
+    a.y = scratch + (size_t)n_items * 2 * L;            // [n_combs][n_items * 2][L] behind the wet buffer
+    a.L = L;
+    a.C = C;
+    a.n_items = n_items;
+    a.n_combs = n_combs;
+    for (int k = 0; k < n_combs; ++k) {
+        if (comb_delays[k] < 1 || comb_delays[k] + stereo_spread > 2048)
+            return fail(MST_ERR_UNSUPPORTED, "mst_fx_algorithmic_reverb: comb delays up to 2048 samples");
+        a.delay[k][0] = comb_delays[k];
+        a.delay[k][1] = comb_delays[k] + stereo_spread;
+    }
+    a.damp = damping;
+    a.feedback = room_size;
+    a.in_gain = in_gain;
+    MST_LAUNCH(fx_comb_kernel, dim3(n_combs, n_items * 2), dim3(64), stream, a);
+    MST_CHECK_LAUNCH("fx_comb_kernel");
+    double *wet = scratch;                                // [n_items * 2][L]
+    for (int k = 0; k < n_allpass; ++k) {
+        const int dl = allpass_delays[2 * k], dr = allpass_delays[2 * k + 1];
+        if (dl < 1 || dr < 1) return fail(MST_ERR_ARG, "mst_fx_algorithmic_reverb: all-pass delay < 1");
+        const int threads = std::min(1024, std::max(64, ((std::max(dl, dr) + 63) / 64) * 64));
+        MST_LAUNCH(fx_allpass_kernel, dim3(n_items * 2), dim3(threads), stream, wet, (const double *)a.y, k == 0 ? n_combs : 0, 0, L,
+                   n_items * 2, dl, dr, room_size);
+        MST_CHECK_LAUNCH("fx_allpass_kernel");
+    }
+    MST_LAUNCH(fx_reverb_mix_kernel, dim3((unsigned)((L + 255) / 256), n_items), dim3(256), stream, x, (const double *)wet, y, L, C, wet1,
+               wet2, dry);
+    MST_CHECK_LAUNCH("fx_reverb_mix_kernel");
+    return MST_OK;
+}

@@ -3,16 +3,16 @@
 `common_audioeffects`.  Same effect names, probabilities, RMS-normalise rule (every effect except Gain and nested chains),
 shuffle / parallel semantics and the drums low/high split of the reverb branch.
 
-Not on the gfx950 path: `AlgorithmicReverb` (its comb/all-pass arithmetic lives in pymixconsole, which is neither vendored
-nor installable offline - "parity unpinned", so requesting it raises) and `Expander` (the reference names it but defines no
-such class: it raises NameError there)."""
+`AlgorithmicReverb` (requested by name, with `algorithmic=True`, or as the fallback when no impulse-response directory is given,
+like the reference :44-49) runs on the device too; its comb / all-pass arithmetic is pymixconsole's, restated from the published
+structure (parity unpinned).  `Expander`: the reference names it but defines no such class (NameError there); it raises here."""
 import glob
 import os
 
 import numpy as np
 
 from ..data_loader.loader_utils import load_wav_segment
-from .common_audioeffects import (AugmentationChain, Compressor, ConvolutionalReverb, Equaliser, Gain, MidSideImager, Panner,
+from .common_audioeffects import (AlgorithmicReverb, AugmentationChain, Compressor, ConvolutionalReverb, Equaliser, Gain, MidSideImager, Panner,
                                   Parameter, ParameterList, Processor)
 
 
@@ -54,8 +54,7 @@ def _make_processor(name, ir_dir_path, sample_rate):
     if "image" in key:
         return MidSideImager()
     if "algorithmic" in key or ("reverb" in key and ir_dir_path is None):
-        raise NotImplementedError("AlgorithmicReverb is not on the gfx950 path (pymixconsole arithmetic, parity unpinned); "
-                                  "pass ir_dir_path to use the convolution reverb")
+        return AlgorithmicReverb(sample_rate=sample_rate)
     if "reverb" in key:
         return ConvolutionalReverb(load_impulse_responses(ir_dir_path, sample_rate), sample_rate)
     raise ValueError(f"make sure the target effects are in the Augment FX chain : received fx called {name}")

@@ -419,6 +419,49 @@ class Panner(Processor):
         self.update()
 
 
+
+class AlgorithmicReverb(Processor):
+    """Schroeder / Freeverb-style algorithmic reverb (reference common_audioeffects.py:1429-1537): per side eight damped feedback
+    comb filters (the right side's delays are 23 samples longer) and four all-pass sections in series, then a width-dependent
+    wet cross-mix plus the dry signal.  Kept from the reference: the comb sum restarts at the fifth comb (`xL = combL5...`
+    overwrites the sum of the first four, :1467-1471), so only combs 5..8 reach the output; the fourth right all-pass is 255 + 23
+    samples long (:1512).  The filters start from silence on every call (the reference rebuilds them in update()).
+    The comb / all-pass arithmetic is pymixconsole's (not vendored): restated from the published structure, parity unpinned.
+    Output float32 [L, 2] (the reference returns float64)."""
+
+    COMB_DELAYS = (1116, 1188, 1277, 1356, 1422, 1491, 1557, 1617)
+    ALLPASS_DELAYS = ((556, 556), (441, 441), (341, 341), (225, 255))      # (left, right before the stereo spread)
+
+    def __init__(self, name="algoreverb", parameters=None, sample_rate=44100, **kwargs):
+        super().__init__(name=name, parameters=parameters, block_size=None, sample_rate=sample_rate)
+        if not parameters:
+            self.parameters = ParameterList()
+            self.parameters.add(Parameter("room_size", 0.5, "float", minimum=0.05, maximum=0.85))
+            self.parameters.add(Parameter("damping", 0.1, "float", minimum=0.0, maximum=1.0))
+            self.parameters.add(Parameter("dry_mix", 0.9, "float", minimum=0.0, maximum=1.0))
+            self.parameters.add(Parameter("wet_mix", 0.1, "float", minimum=0.0, maximum=1.0))
+            self.parameters.add(Parameter("width", 0.7, "float", minimum=0.0, maximum=1.0))
+        self.stereospread = 23
+        self.scalegain = 0.2
+
+    def process(self, data):
+        d = _Dev(data)
+        if d.C > 2:
+            raise ValueError("AlgorithmicReverb needs mono or stereo audio")
+        p = self.parameters
+        wet1 = p.wet_mix.value * ((p.width.value / 2) + 0.5)
+        wet2 = p.wet_mix.value * ((1 - p.width.value) / 2)
+        combs = (C.c_int * 4)(*self.COMB_DELAYS[4:])                         # combs 1..4 never reach the output (see above)
+        ap = (C.c_int * 8)(*[v + (self.stereospread if k % 2 else 0) for pair in self.ALLPASS_DELAYS for k, v in enumerate(pair)])
+        y = torch.empty(d.n, d.L, 2, dtype=torch.float32, device=d.x.device)
+        nbytes = d.lib.mst_fx_algorithmic_reverb_scratch_bytes(d.n, d.L, 4)
+        sc = d.scratch((nbytes + 7) // 8)
+        d.lib.check(d.lib.mst_fx_algorithmic_reverb(d.x.data_ptr(), y.data_ptr(), d.n, d.L, d.C, combs, 4, ap, 4, self.stereospread,
+                                                    float(p.damping.value), float(p.room_size.value), float(self.scalegain), float(wet1),
+                                                    float(wet2), float(p.dry_mix.value), sc.data_ptr(), nbytes, d.stream),
+                    "mst_fx_algorithmic_reverb")
+        return d.out(y)
+
 _stream_pools = {}
 
 

@@ -264,3 +264,49 @@ def fx_chain(x, cfg=CONFIG4, rate=44100, compressor_fn=None):
     w = rms_normalize(z, midside_imager(z, cfg["imager_bal"]))
     w = w.astype(np.float32)
     return gain(w, cfg["gain_db"]).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- algorithmic reverb
+def _comb(x, delay, damp, feedback):
+    """Freeverb feedback comb with a one-pole low-pass in the loop (pymixconsole.components.comb, restated; parity unpinned)."""
+    buf = np.zeros(delay)
+    y = np.empty(len(x))
+    store, idx = 0.0, 0
+    for n in range(len(x)):
+        out = buf[idx]
+        store = out * (1.0 - damp) + store * damp
+        buf[idx] = x[n] + store * feedback
+        idx = idx + 1 if idx + 1 < delay else 0
+        y[n] = out
+    return y
+
+
+def _allpass(x, delay, feedback):
+    """Schroeder all-pass section in Freeverb's form (pymixconsole.components.allpass, restated; parity unpinned)."""
+    buf = np.zeros(delay)
+    y = np.empty(len(x))
+    idx = 0
+    for n in range(len(x)):
+        out = buf[idx]
+        y[n] = out - x[n]
+        buf[idx] = x[n] + out * feedback
+        idx = idx + 1 if idx + 1 < delay else 0
+    return y
+
+
+def algorithmic_reverb(x, room_size=0.5, damping=0.1, dry_mix=0.9, wet_mix=0.1, width=0.7, stereospread=23, scalegain=0.2):
+    """AlgorithmicReverb.process (common_audioeffects.py:1447-1495) with the reference's quirks: the comb sum restarts at the fifth
+    comb (:1467-1471), the fourth right all-pass is 255 + spread long (:1512).  x [L] / [L, 1] / [L, 2] -> float64 [L, 2]."""
+    x = np.asarray(x)
+    if x.ndim == 1:
+        x = x[:, None]
+    dl, dr = x[:, 0].astype(np.float64), x[:, -1].astype(np.float64)
+    wet = []
+    for side, d in ((0, dl), (1, dr)):
+        ss = stereospread * side
+        v = sum(_comb(d * scalegain, D + ss, damping, room_size) for D in (1422, 1491, 1557, 1617))
+        for D in (556, 441, 341, (225, 255)[side]):
+            v = _allpass(v, D + ss, room_size)
+        wet.append(v)
+    wet1, wet2 = wet_mix * ((width / 2) + 0.5), wet_mix * ((1 - width) / 2)
+    return np.stack([wet1 * wet[0] + wet2 * wet[1] + dry_mix * dl, wet1 * wet[1] + wet2 * wet[0] + dry_mix * dr], 1)

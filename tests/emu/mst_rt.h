@@ -148,6 +148,10 @@ template <typename T> static inline T __shfl_down(T v, int d, int = 64) {
     return emu_shfl(v, l + d < 64 ? l + d : l);
 }
 template <typename T> static inline T __shfl(T v, int src, int = 64) { return emu_shfl(v, src); }
+template <typename T> static inline T __shfl_up(T v, int d, int = 64) {
+    const int l = emu::lane_id();
+    return emu_shfl(v, l - d >= 0 ? l - d : l);
+}
 #define __builtin_amdgcn_readfirstlane(v) emu_shfl((v), 0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)

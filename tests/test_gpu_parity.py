@@ -891,3 +891,25 @@ def test_standalone_modules_on_gpu(name):
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from test_modules_standalone import check
     check(name, "cuda")
+
+
+def test_fx_manipulator_chains_and_algorithmic_reverb_on_gpu(tmp_path):
+    """Row f-3 on the MI355X: the instrument FX chains (create_inst_effects_augmentation_chain: shuffled eq / comp, pan / imager,
+    low / high parallel convolution reverb, gain) against the oracle replay, and AlgorithmicReverb against the oracle - the bodies of the
+    emulator tests, here through libmst_hip.so - plus the reverb on a batch of full-size segments."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import test_emu_kernels as E
+    from music_mixing_style_transfer_amd import _lib
+    assert _lib.lib().path.endswith("libmst_hip.so")
+    E.test_fx_manipulator_chains_emulated(None, tmp_path)
+    E.test_algorithmic_reverb_emulated(None)
+    from music_mixing_style_transfer_amd.mixing_manipulator import AlgorithmicReverb
+    from oracle import fx_ref as F
+    n, L = 8, 131072
+    x = (0.1 * torch.randn(n, L, 2, generator=torch.Generator().manual_seed(4))).clamp_(-1, 1)
+    rv = AlgorithmicReverb()
+    rv.parameters.room_size.value, rv.parameters.wet_mix.value = 0.8, 0.5
+    y = rv.process(x.cuda()).cpu().numpy()
+    ref = F.algorithmic_reverb(x[5].numpy(), room_size=0.8, wet_mix=0.5)
+    assert np.abs(y[5] - ref).max() <= 2e-6 * np.abs(ref).max()
