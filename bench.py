@@ -277,7 +277,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--workload", default="all", choices=["all", "configs1", "track60"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--x3-small-tiles", action="store_true", help="bf16x3: 128-time tiles, two workgroups per CU (mst_tcn_set_tuning)")
+    ap.add_argument("--x3-large-tiles", action="store_true", help="bf16x3: 256-time tiles, one workgroup per CU (mst_tcn_set_tuning 0)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -314,8 +314,8 @@ def main():
     lib = _lib.lib()
     enc._get_runner()._ensure(lib)      # weight folding / packing is setup, not part of a step
     tcn._ensure(lib)
-    if args.x3_small_tiles:
-        lib.check(lib.mst_tcn_set_tuning(tcn._handle, 1), "mst_tcn_set_tuning")
+    if args.x3_large_tiles:
+        lib.check(lib.mst_tcn_set_tuning(tcn._handle, 0), "mst_tcn_set_tuning")
     nb = tcn.hparams.nblocks
     B = args.batch
     dtype = {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3"}[args.precision]

@@ -110,8 +110,9 @@ int mst_tcn_forward(MstTcn *tcn, const float *x_dev, float *y_dev, int B, int L,
 int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int B, int L, int precision, int n_run,
                            void *workspace, size_t workspace_bytes, void *stream);
 
-/* tuning (bf16x3 mode): x3_small_tiles = 1 runs the split-bf16 block kernel on 128-time tiles of <= 2 phases (two workgroups per CU)
- * wherever the dilation allows, instead of 256-time tiles (one workgroup per CU); identical results.  Default 0. */
+/* tuning (bf16x3 mode): x3_small_tiles = 1 (default; measured 5.13 instead of 5.45 ms per launch at 32 x 131072) runs the split-bf16
+ * block kernel on 128-time tiles of <= 2 phases (two workgroups per CU) wherever the segment has at least 64 steps per phase,
+ * 0 on 256-time tiles (one workgroup per CU); identical results. */
 int mst_tcn_set_tuning(MstTcn *tcn, int x3_small_tiles);
 
 /* measurement hook (bench.py's roofline leg): between _begin and _end every mst_tcn_forward records HIP events

@@ -129,7 +129,7 @@ struct MstTcn {
     int film_rows = 0, film_cap = 0;
     float *out_w = nullptr, *out_b = nullptr;
     bool out_loaded = false;
-    int x3_small_tiles = 0;       // bf16x3 mode: 128-time tiles of <= 2 phases, two workgroups per CU (mst_tcn_set_tuning)
+    int x3_small_tiles = 1;       // bf16x3 mode: 128-time tiles of <= 2 phases, two workgroups per CU (mst_tcn_set_tuning; measured 5.13 vs 5.45 ms)
     std::vector<hipEvent_t> ev;   // timing hook: (nblocks + 2) events per recorded forward
     int ev_max = 0, ev_used = 0;
 };

@@ -51,11 +51,11 @@ def test_tcn_large_dilation_and_odd_growth_emulated(emu_default):
     m2.precision = "bf16x3"          # split-bf16 mode: 8-phase tiles of 128 times for the large dilations
     y3 = m2(x, cond)
     assert float((y3 - y_ref).abs().max()) <= 3e-5
-    emu_default.check(emu_default.mst_tcn_set_tuning(m2._handle, 1), "tuning")      # 128-time tiles of <= 2 phases: same bits
+    emu_default.check(emu_default.mst_tcn_set_tuning(m2._handle, 0), "tuning")      # 256-time tiles instead of 128-time ones: same bits
     assert torch.equal(m2(x, cond), y3)
     x5 = synth.synth_audio((2, 2, 700), seed=16)
     y5 = m2(x5, cond)
-    emu_default.check(emu_default.mst_tcn_set_tuning(m2._handle, 0), "tuning")
+    emu_default.check(emu_default.mst_tcn_set_tuning(m2._handle, 1), "tuning")
     assert torch.equal(m2(x5, cond), y5)
 
 

@@ -11,7 +11,7 @@ fi
 timeout 300 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
 timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; echo "rc=$?" >> gpurun_out/bench_default.err
 timeout 600 python bench.py --precision bf16x3 --workload configs1 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_x3.json 2> gpurun_out/bench_x3.err
-timeout 600 python bench.py --precision bf16x3 --workload configs1 --steps 3 --warmup 1 --no-cpu-baseline --x3-small-tiles > gpurun_out/bench_x3_small.json 2> gpurun_out/bench_x3_small.err
+timeout 600 python bench.py --precision bf16x3 --workload configs1 --steps 3 --warmup 1 --no-cpu-baseline --x3-large-tiles > gpurun_out/bench_x3_large.json 2> gpurun_out/bench_x3_large.err
 timeout 900 python bench.py --workload track60 --steps 3 --warmup 1 > gpurun_out/bench_track60.json 2> gpurun_out/bench_track60.err; echo "rc=$?" >> gpurun_out/bench_track60.err
 # N > 1 code path on the single-GPU box: 2 ranks sharing cuda:0, gloo for the collective
 MST_BENCH_SHARE_GPU=1 MST_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 3 --warmup 1 > gpurun_out/bench_2rank_gloo.json 2> gpurun_out/bench_2rank_gloo.err; echo "rc=$?" >> gpurun_out/bench_2rank_gloo.err
