@@ -462,16 +462,6 @@ class AlgorithmicReverb(Processor):
                     "mst_fx_algorithmic_reverb")
         return d.out(y)
 
-_stream_pools = {}
-
-
-def _stream_pool(device, n):
-    pool = _stream_pools.setdefault(str(device), [])
-    while len(pool) < n:
-        pool.append(torch.cuda.Stream(device))
-    return pool
-
-
 class AugmentationChain:
     """Apply (processor, probability, rms_normalize) entries in order to every array of a list; optional shuffle
     and parallel dry/wet mix - the reference's chain semantics (:156-192)."""
@@ -494,102 +484,23 @@ class AugmentationChain:
         return [self.apply_processor(x, processor, rms_normalize) for x in x_list]
 
     def __call__(self, x_list):
-        x_list = list(x_list)
-        lanes = self._lanes(x_list)
         if self.shuffle:
             random.shuffle(self.fxs)
-        if lanes > 1:
-            # every entry is a plain processor: their random draws do not depend on the audio, so the whole chain is drawn first
-            # (same order of draws as below) and then runs stripe by stripe with fixed settings
-            plan = []
-            for fx, p, rms in self.fxs:
-                if np.random.rand() < p:
+        y_list = list(x_list)
+        for fx, p, rms in self.fxs:
+            if np.random.rand() < p:
+                if isinstance(fx, Processor):
                     if self.randomize_param_value:
                         fx.randomize()
                     else:
                         fx.update(None)
-                    plan.append((fx, rms))
-            y_list = [self._run_striped(plan, x_list[0], lanes)]
-        else:
-            y_list = list(x_list)
-            for fx, p, rms in self.fxs:
-                if np.random.rand() < p:
-                    if isinstance(fx, Processor):
-                        if self.randomize_param_value:
-                            fx.randomize()
-                        else:
-                            fx.update(None)
-                        y_list = self.apply_same_processor(y_list, fx, rms)
-                    else:
-                        y_list = fx(y_list)
+                    y_list = self.apply_same_processor(y_list, fx, rms)
+                else:
+                    y_list = fx(y_list)
         if self.parallel:
             w = self.parallel_weight_factor if self.parallel_weight_factor else np.random.rand() / 2.0
             y_list = [w * x + (1 - w) * y for x, y in zip(x_list, y_list)]
         return y_list
-
-    # ---- a large device batch [n_items, L, C] with FIXED processor settings: the items are independent, and most FX kernels of a
-    # 64-item batch are too small to fill 256 CUs (the compressor's chunk walk is ONE wave per sequence), so the batch runs as
-    # `stripes` sub-batches on their own HIP streams - the latency-bound phases of one stripe overlap the bandwidth-bound phases of
-    # the others.  The ~90 launches of such a pass are captured ONCE into a HIP graph (per settings and shape) and replayed:
-    # driven from Python launch by launch, the host cannot feed four streams fast enough (measured 3.3 ms instead of 2.0).
-    stripes = 4
-    _graphs = {}
-
-    def _lanes(self, x_list):
-        if self.randomize_param_value or self.shuffle or self.stripes < 2:
-            return 1
-        if len(x_list) != 1 or not isinstance(x_list[0], torch.Tensor) or not x_list[0].is_cuda or x_list[0].dim() != 3:
-            return 1
-        if not all(isinstance(fx, Processor) and type(fx).__name__ in ("Equaliser", "Compressor", "MidSideImager", "Gain", "Panner", "Haas")
-                   and p >= 1 for fx, p, _ in self.fxs):
-            return 1
-        same_settings = len({id(fx) for fx, _, _ in self.fxs}) == len(self.fxs)       # a processor listed twice keeps the plain loop
-        return min(self.stripes, x_list[0].shape[0] // 8) if same_settings else 1
-
-    def _run_striped(self, plan, x, lanes):
-        key = (tuple((type(fx).__name__, rms, tuple((p.name, p.value) for p in fx.parameters)) for fx, rms in plan), tuple(x.shape),
-               str(x.device), lanes)
-        entry = self._graphs.get(key)
-        if entry is None:
-            if len(self._graphs) > 8:
-                self._graphs.clear()
-            static_x = x.clone()
-            warm = torch.cuda.Stream(x.device)                       # one eager pass first (lazy initialisations stay out of the capture)
-            warm.wait_stream(torch.cuda.current_stream(x.device))
-            with torch.cuda.stream(warm):
-                self._striped_body(plan, static_x, lanes)
-            torch.cuda.current_stream(x.device).wait_stream(warm)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_out = self._striped_body(plan, static_x, lanes)
-            entry = self._graphs[key] = (graph, static_x, static_out)
-        graph, static_x, static_out = entry
-        static_x.copy_(x)
-        graph.replay()
-        return static_out.clone()
-
-    def _striped_body(self, plan, x, lanes):
-        n = x.shape[0]
-        cur = torch.cuda.current_stream(x.device)
-        out = torch.empty((n,) + self._out_shape(plan, x), dtype=torch.float32, device=x.device)
-        bounds = [(k * n) // lanes for k in range(lanes + 1)]
-        pool = _stream_pool(x.device, lanes)
-        for k in range(lanes):
-            st = pool[k]
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                y = x[bounds[k]:bounds[k + 1]]
-                for fx, rms in plan:
-                    y = self.apply_processor(y, fx, rms)
-                out[bounds[k]:bounds[k + 1]] = y
-        for k in range(lanes):
-            cur.wait_stream(pool[k])
-        return out
-
-    @staticmethod
-    def _out_shape(plan, x):
-        stereo = any(type(fx).__name__ in ("Haas", "Panner") for fx, _ in plan)
-        return (x.shape[1], 2 if stereo else x.shape[2])
 
     def __repr__(self):
         return f"AugmentationChain(fxs={self.fxs!r}, shuffle={self.shuffle!r})"
