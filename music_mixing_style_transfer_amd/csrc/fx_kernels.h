@@ -363,7 +363,7 @@ struct CompMapArgs {
 // the attack transform in place, slots above move up by one and take the release transform, the new slot starts at value x
 // (f_x(x) = x).  Sorted pieces let the chain kernel FIND the piece that applies to y instead of maximising over all of them.
 // Dead slots (fewer than T steps in the last chunk) are stored with slope -1.
-__global__ __launch_bounds__(64) void fx_comp_map_kernel(CompMapArgs a) {
+__global__ __launch_bounds__(64) MST_HEAVY_UNROLL void fx_comp_map_kernel(CompMapArgs a) {
     __shared__ double tr[64 * (MST_COMP_NP * 2 + 1)];               // [lane][66 + 1 pad]: rows leave as whole 528-byte records
     const int k = blockIdx.x;
     const int seq = blockIdx.y * 64 + threadIdx.x;
@@ -409,36 +409,34 @@ __global__ __launch_bounds__(64) void fx_comp_map_kernel(CompMapArgs a) {
     }
 }
 
-// grid n_seq, 64 threads: one wave per sequence, lanes = pieces.  The pieces of CB chunks at a time are staged through LDS
-// (one coalesced sweep per batch, the next batch's loads in flight during the current one).  A chunk step FINDS the piece that
-// applies to y: lane i holds the crossing test of pieces i - 1 and i, (a_i - a_{i-1}) y >= b_{i-1} - b_i (convex maps; <= for the
-// concave ones of aA > aR), the number of lanes that pass is the piece index (the pieces are sorted), and y becomes that
-// lane's a_i y + b_i: one fma + compare + popcount + readlane per chunk instead of a six-stage float64 wave reduction.  Near a
-// breakpoint the two neighbouring pieces agree to rounding, so a test decided by rounding picks an equally valid piece.
+// grid n_seq, 128 threads: two waves per sequence.  Wave 0 walks the chunks (lanes = pieces); wave 1 runs one batch of CB chunks ahead
+// of it and "cooks" the stored (a, b) records into per-piece entries (a, b, da, db) in LDS, where (da, db) is the crossing test of
+// pieces i - 1 and i: (a_i - a_{i-1}) y >= b_{i-1} - b_i (convex maps; <= for the concave ones of aA > aR).  A chunk step FINDS the
+// piece that applies to y: the pieces are sorted, so the number of lanes whose test passes IS the piece index, and y becomes that
+// lane's a_i y + b_i - one fma, one compare (straight into an SGPR pair), s_bcnt1, two v_readlane per chunk instead of a six-stage
+// float64 wave reduction.  Near a breakpoint the two neighbouring pieces agree to rounding, so a test decided by rounding picks an
+// equally valid piece.  The 32 steps of a batch are unrolled: entries are prefetched three chunks ahead with immediate offsets,
+// the chunk start values are parked in lane c of a register (v_writelane) and stored once per batch.
 template <bool USE_MIN>
-__global__ __launch_bounds__(64) void fx_comp_chain_kernel(CompMapArgs a) {
+__global__ __launch_bounds__(128) void fx_comp_chain_kernel(CompMapArgs a) {
     constexpr int CB = 32, PER = MST_COMP_NP * 2, NLD = (CB * PER + 63) / 64;      // doubles per chunk / loads per lane per batch
-    constexpr int NE = CB * MST_COMP_NP, NEL = (NE + 63) / 64;                       // (chunk, piece) entries of a batch / per lane
+    constexpr int NPE = MST_COMP_NP + 1;                                             // entries per chunk: the pieces + one "never" entry
+    constexpr int NE = CB * NPE, NEL = (NE + 63) / 64;
     __shared__ double raw[CB * PER];                                 // a batch of map records as stored: (a, b) per piece
-    __shared__ __attribute__((aligned(32))) double cooked[2][NE * 4];   // per (chunk, piece): a, b, da, db  (one 32-byte read per step)
-    __shared__ double ys[CB];
-    const int seq = blockIdx.x, lane = threadIdx.x;
+    __shared__ __attribute__((aligned(32))) double cooked[2][NE * 4];   // per (chunk, entry): a, b, da, db  (one 32-byte read per step)
+    const int seq = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double *m = a.maps + (size_t)seq * a.nchunks * PER;
     const size_t total = (size_t)a.nchunks * PER;
-    const bool has = lane < MST_COMP_NP;
     const int nbatch = (a.nchunks + CB - 1) / CB;
-    const double never = USE_MIN ? -1e300 : 1e300, always = -never;       // db of a test that always fails / always passes
-    double r[NLD];
-    auto load = [&](int bt) {
+    const double never = USE_MIN ? -1e300 : 1e300;                   // db of a test that always fails
+    // ---- wave 1: global -> registers -> raw records -> entries (17 entries per lane per batch)
+    auto cook = [&](int bt, int buf) {
+        double r[NLD];
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const size_t e = (size_t)bt * CB * PER + (size_t)i * 64 + lane;
             r[i] = m[e < total ? e : total - 1];
         }
-    };
-    // registers -> raw records -> per-piece entries with the crossing test of pieces i - 1 and i (off the serial path:
-    // once per batch of CB chunks, 17 entries per lane)
-    auto cook = [&](int b) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
             if (i * 64 + lane < CB * PER) raw[i * 64 + lane] = r[i];
@@ -447,56 +445,72 @@ __global__ __launch_bounds__(64) void fx_comp_chain_kernel(CompMapArgs a) {
         for (int i = 0; i < NEL; ++i) {
             const int e = i * 64 + lane;
             if (e < NE) {
-                const int piece = e % MST_COMP_NP;
-                const double pa = raw[2 * e], pb = raw[2 * e + 1];
-                double da = 0.0, db = never;
-                if (piece == 0) db = always;
-                else if (pa >= 0.0) {                               // a live piece (dead slots carry slope -1)
-                    da = pa - raw[2 * e - 2];
-                    db = raw[2 * e - 1] - pb;
+                const int c = e / NPE, piece = e % NPE;
+                double pa = 0.0, pb = 0.0, da = 0.0, db = never;   // entry NP and piece 0: the test never passes (no piece -> index 0)
+                if (piece < MST_COMP_NP) {
+                    const double *rec = raw + c * PER + 2 * piece;
+                    pa = rec[0];
+                    pb = rec[1];
+                    if (piece > 0 && pa >= 0.0) {                   // a live piece (dead slots carry slope -1)
+                        da = pa - rec[-2];
+                        db = rec[-1] - pb;
+                    }
                 }
-                double *c = cooked[b] + 4 * e;
-                c[0] = pa; c[1] = pb; c[2] = da; c[3] = db;
+                double *q = cooked[buf] + 4 * e;
+                q[0] = pa; q[1] = pb; q[2] = da; q[3] = db;
             }
         }
-        __builtin_amdgcn_wave_barrier();
     };
-    struct Piece { double pa, pb, da, db; };
-    const int pl = has ? lane : MST_COMP_NP - 1;                     // lanes without a piece shadow the last one; their test is masked
-    auto fetch = [&](int b, int c) {
-        const double *q = cooked[b] + 4 * (c * MST_COMP_NP + pl);
-        return Piece{q[0], q[1], q[2], q[3]};
-    };
-    load(0);
-    cook(0);
-    double y = 0.0;                                              // yL_prev = 0 on entry (common_audioeffects.py:553)
-    int cur = 0;
+    if (wave == 1) cook(0, 0);
+    __syncthreads();
+    MstUniformF64 yu = mst_wave_read_u64(0.0, 0);                   // yL_prev = 0 on entry (common_audioeffects.py:553)
+    const int pl = lane < MST_COMP_NP ? lane : MST_COMP_NP;          // lanes without a piece read the "never" entry
     for (int bt = 0; bt < nbatch; ++bt) {
-        if (bt + 1 < nbatch) load(bt + 1);
-        const int nc = a.nchunks - bt * CB < CB ? a.nchunks - bt * CB : CB;
-        // three pieces in flight, rotated by unrolling (no register copies that would wait for the newest load): the entry of
-        // chunk c + 3 is requested when chunk c has been evaluated, so no LDS latency sits on the serial path
-        auto step = [&](const Piece &p, int c) {
-            if (lane == 0) ys[c] = y;
-            const double t = fma(p.da, y, -p.db);
-            const int idx = __builtin_popcountll(mst_wave_ballot(USE_MIN ? t <= 0.0 : t >= 0.0) & ((1ull << MST_COMP_NP) - 1)) - 1;
-            y = mst_wave_read_f64(fma(p.pa, y, p.pb), idx);
-        };
-        auto clamp = [&](int c) { return c < nc ? c : nc - 1; };
-        Piece pA = fetch(cur, 0), pB = fetch(cur, clamp(1)), pC = fetch(cur, clamp(2));
-        for (int c = 0; c < nc; c += 3) {
-            step(pA, c);
-            pA = fetch(cur, clamp(c + 3));
-            if (c + 1 < nc) step(pB, c + 1);
-            pB = fetch(cur, clamp(c + 4));
-            if (c + 2 < nc) step(pC, c + 2);
-            pC = fetch(cur, clamp(c + 5));
+        const int cur = bt & 1;
+        if (wave == 1) {
+            if (bt + 1 < nbatch) cook(bt + 1, cur ^ 1);
+        } else {
+            const int nc = a.nchunks - bt * CB < CB ? a.nchunks - bt * CB : CB;
+            struct Piece { double pa, pb, da, db; };
+            const double *base = cooked[cur] + 4 * pl;
+            auto fetch = [&](int c) {
+                const double *q = base + 4 * NPE * (c < CB ? c : CB - 1);
+                return Piece{q[0], q[1], q[2], q[3]};
+            };
+            double keep = 0.0;                                      // lane c holds the start value of chunk c
+            if (nc == CB) {                                         // a whole batch: 32 steps in one basic block, y stays in SGPRs
+                Piece p[4];
+                p[0] = fetch(0); p[1] = fetch(1); p[2] = fetch(2);
+                yu = mst_wave_uniform(yu);
+#define MST_CHAIN_STEP(c)                                                                                              \
+    {                                                                                                                  \
+        p[((c) + 3) & 3] = fetch((c) + 3);                                                                             \
+        keep = mst_wave_park_f64<(c)>(keep, yu);                                                                       \
+        const Piece &q = p[(c) & 3];                                                                                   \
+        const double y = yu.value();                                                                                   \
+        const double t = fma(q.da, y, -q.db);                                                                          \
+        const int idx = __builtin_popcountll(mst_wave_ballot(USE_MIN ? t <= 0.0 : t >= 0.0));                          \
+        yu = mst_wave_read_u64(fma(q.pa, y, q.pb), idx);                                                               \
+    }
+#define MST_CHAIN_STEP8(c) MST_CHAIN_STEP(c) MST_CHAIN_STEP((c) + 1) MST_CHAIN_STEP((c) + 2) MST_CHAIN_STEP((c) + 3) \
+    MST_CHAIN_STEP((c) + 4) MST_CHAIN_STEP((c) + 5) MST_CHAIN_STEP((c) + 6) MST_CHAIN_STEP((c) + 7)
+                static_assert(CB == 32, "four groups of eight steps");
+                MST_CHAIN_STEP8(0) MST_CHAIN_STEP8(8) MST_CHAIN_STEP8(16) MST_CHAIN_STEP8(24)
+#undef MST_CHAIN_STEP8
+#undef MST_CHAIN_STEP
+            } else {                                                // the ragged last batch
+                for (int c = 0; c < nc; ++c) {
+                    const Piece q = fetch(c);
+                    const double y = yu.value();
+                    keep = lane == c ? y : keep;
+                    const double t = fma(q.da, y, -q.db);
+                    const int idx = __builtin_popcountll(mst_wave_ballot(USE_MIN ? t <= 0.0 : t >= 0.0));
+                    yu = mst_wave_read_u64(fma(q.pa, y, q.pb), idx);
+                }
+            }
+            if (lane < nc) a.ystart[(size_t)(bt * CB + lane) * a.n_seq + seq] = keep;
         }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < nc) a.ystart[(size_t)(bt * CB + lane) * a.n_seq + seq] = ys[lane];
-        if (bt + 1 < nbatch) cook(cur ^ 1);
-        __builtin_amdgcn_wave_barrier();
-        cur ^= 1;
+        __syncthreads();
     }
 }
 

@@ -1323,8 +1323,8 @@ int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size
             const dim3 cg((unsigned)cs.nchunks, (unsigned)((a.n_seq + 63) / 64));
             MST_LAUNCH(fx_comp_map_kernel, cg, dim3(64), stream, m);
             MST_CHECK_LAUNCH("fx_comp_map_kernel");
-            if (m.use_min) MST_LAUNCH((fx_comp_chain_kernel<true>), dim3(a.n_seq), dim3(64), stream, m);
-            else MST_LAUNCH((fx_comp_chain_kernel<false>), dim3(a.n_seq), dim3(64), stream, m);
+            if (m.use_min) MST_LAUNCH((fx_comp_chain_kernel<true>), dim3(a.n_seq), dim3(128), stream, m);
+            else MST_LAUNCH((fx_comp_chain_kernel<false>), dim3(a.n_seq), dim3(128), stream, m);
             MST_CHECK_LAUNCH("fx_comp_chain_kernel");
             MST_LAUNCH(fx_comp_fill_kernel, cg, dim3(64), stream, m, scratch);
             MST_CHECK_LAUNCH("fx_comp_fill_kernel");

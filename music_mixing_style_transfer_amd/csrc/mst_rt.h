@@ -9,6 +9,10 @@
 #include <cstdlib>
 #include <cstring>
 
+// marks a kernel whose fully unrolled body a HOST compiler cannot optimise in reasonable time (empty here; the emulator's mst_rt.h
+// turns it into an attribute for its own build)
+#define MST_HEAVY_UNROLL
+
 #define MST_LAUNCH(kern, grid, block, stream, ...) \
     hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__)
 
@@ -84,5 +88,23 @@ __device__ __forceinline__ float mst_acc_read(float x) {
 __device__ __forceinline__ unsigned long long mst_wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ double mst_wave_read_f64(double v, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+// a wave-uniform double as the two SGPR halves v_readlane returns (kept apart so that v_writelane can take them without a copy)
+struct MstUniformF64 {
+    int lo, hi;
+    __device__ __forceinline__ double value() const { return __hiloint2double(hi, lo); }
+};
+__device__ __forceinline__ MstUniformF64 mst_wave_uniform(MstUniformF64 y) {      // re-assert uniformity after divergent control flow
+    return MstUniformF64{__builtin_amdgcn_readfirstlane(y.lo), __builtin_amdgcn_readfirstlane(y.hi)};
+}
+__device__ __forceinline__ MstUniformF64 mst_wave_read_u64(double v, int src) {
+    return MstUniformF64{__builtin_amdgcn_readlane(__double2loint(v), src), __builtin_amdgcn_readlane(__double2hiint(v), src)};
+}
+// the wave-uniform y written into lane `dst` of keep (v_writelane_b32 x 2: no compare, no exec change)
+template <int DST> __device__ __forceinline__ double mst_wave_park_f64(double keep, MstUniformF64 y) {
+    int lo = __double2loint(keep), hi = __double2hiint(keep);      // the lane select is an inline constant: one SGPR per instruction
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"(y.lo), "n"(DST));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"(y.hi), "n"(DST));
     return __hiloint2double(hi, lo);
 }

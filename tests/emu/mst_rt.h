@@ -16,6 +16,7 @@
 #include <functional>
 
 #define MST_EMULATED 1
+#define MST_HEAVY_UNROLL __attribute__((optnone))      // host clang needs > 10 minutes at -O2 for the unrolled compressor map kernel
 #define __global__
 #define __device__
 #define __host__
@@ -143,6 +144,13 @@ static inline unsigned long long mst_wave_ballot(bool p) {
     return m;
 }
 static inline double mst_wave_read_f64(double v, int src) { return emu_shfl(v, src); }
+struct MstUniformF64 {
+    double v;
+    double value() const { return v; }
+};
+static inline MstUniformF64 mst_wave_read_u64(double v, int src) { return MstUniformF64{emu_shfl(v, src)}; }
+static inline MstUniformF64 mst_wave_uniform(MstUniformF64 y) { return y; }
+template <int DST> static inline double mst_wave_park_f64(double keep, MstUniformF64 y) { return emu::lane_id() == DST ? y.v : keep; }
 template <typename T> static inline T __shfl_down(T v, int d, int = 64) {
     const int l = emu::lane_id();
     return emu_shfl(v, l + d < 64 ? l + d : l);
