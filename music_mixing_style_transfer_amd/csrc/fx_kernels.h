@@ -138,51 +138,78 @@ __global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) 
     }
 }
 
-// s_0 = 0 ; s_k = A^M s_{k-1} + e_{k-1}.  One lane per sequence; AM is [S][S] row-major with S = 2*n_bands, state order
-// (z1, z2) per band.  ends / starts are laid out [chunk][state][sequence] so that the 64 lanes of this serial kernel move
-// contiguous rows; A^M arrives in the kernel arguments (no staging copy, no host synchronisation), sits in LDS (broadcast
-// reads), and the next chunk's end states are requested one chunk ahead.
-// (Sequence-major tables with A^M re-read from global memory: 1.02 ms for 128 sequences x 256 chunks.)
+// s_0 = 0 ; s_k = A^M s_{k-1} + e_{k-1}: a first-order linear recurrence over the chunks with a matrix coefficient - scanned in
+// parallel.  One workgroup of 256 threads per sequence; a block of 255 chunks at a time: element 0 is the carry (the start state of
+// the block's first chunk), element i > 0 the zero-state end state of chunk i - 1, and a Hillis-Steele scan
+//     t_i += (A^M)^(2^l) t_{i - 2^l}      l = 0 .. 7
+// leaves t_i = the true start state of chunk i (t_255 = the next block's carry).  The powers (A^M)^(2^l) are squared up in LDS by
+// the workgroup itself from A^M (kernel argument, float64).  128 sequences x 128 chunks: 8 matrix-vector products of depth per
+// sequence instead of 128 (round 1's kernel ran one LANE per sequence: 2 workgroups, 88 us); a 3-minute stem (7 752 chunks) is
+// 31 blocks instead of 7 752 serial steps.  AM is [S][S] row-major with S = 2 * n_bands, state order (z1, z2) per band; ends /
+// starts are laid out [chunk][state][sequence].
 struct BiquadPowArgs { double am[4 * MST_MAX_BANDS * MST_MAX_BANDS]; };      // A^M, [S][S] row-major, by value in the kernel arguments
 
 template <int NBANDS>
-__global__ __launch_bounds__(64) void fx_biquad_scan_kernel(const double *ends, double *starts, BiquadPowArgs pw, int n_seq,
-                                                           int nchunks) {
-    constexpr int SM = 2 * MST_MAX_BANDS, S = 2 * NBANDS;       // table row stride / live states
-    __shared__ double am[S * S];
-    for (int i = threadIdx.x; i < S * S; i += 64) am[i] = pw.am[i];
+__global__ __launch_bounds__(256) void fx_biquad_scan_kernel(const double *ends, double *starts, BiquadPowArgs pw, int n_seq,
+                                                            int nchunks) {
+    constexpr int SM = 2 * MST_MAX_BANDS, S = 2 * NBANDS, NL = 8, NB = 256;      // table row stride / live states / levels / elements
+    __shared__ double pm[NL][S * S];                 // (A^M)^(2^l)
+    __shared__ double st[2][NB][S];
+    const int seq = blockIdx.x, i = threadIdx.x;
+    for (int k = i; k < S * S; k += NB) pm[0][k] = pw.am[k];
     __syncthreads();
-    const int seq = blockIdx.x * 64 + threadIdx.x;
-    const bool live = seq < n_seq;
-    const size_t sq = live ? seq : n_seq - 1;                    // idle lanes of the last wave shadow a live one, store nothing
-    double s[S], e[S];
+    for (int l = 1; l < NL; ++l) {                   // squaring: pm[l] = pm[l-1] pm[l-1]
+        for (int k = i; k < S * S; k += NB) {
+            const int r = k / S, c = k % S;
+            double acc = 0.0;
 #pragma unroll
-    for (int i = 0; i < S; ++i) {
-        s[i] = 0.0;
-        e[i] = ends[(size_t)i * n_seq + sq];
+            for (int j = 0; j < S; ++j) acc += pm[l - 1][r * S + j] * pm[l - 1][j * S + c];
+            pm[l][k] = acc;
+        }
+        __syncthreads();
     }
-    for (int k = 0; k < nchunks; ++k) {
-        if (live) {
+    double carry[S];
 #pragma unroll
-            for (int i = 0; i < S; ++i) starts[((size_t)k * SM + i) * n_seq + sq] = s[i];
+    for (int j = 0; j < S; ++j) carry[j] = 0.0;
+    for (int k0 = 0; k0 < nchunks; k0 += NB - 1) {
+        // element i: the carry (i = 0) or the zero-state end state of chunk k0 + i - 1
+        double t[S];
+        const int kc = k0 + i - 1;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            t[j] = i == 0 ? carry[j] : (kc < nchunks ? ends[((size_t)kc * SM + j) * n_seq + seq] : 0.0);
+            st[0][i][j] = t[j];
         }
-        if (k + 1 == nchunks) break;
-        double en[S], nx[S];
-        const int kn = k + 2 < nchunks ? k + 1 : k;               // last useful chunk: harmless reload
+        __syncthreads();
+        int cur = 0;
 #pragma unroll
-        for (int i = 0; i < S; ++i) en[i] = ends[((size_t)kn * SM + i) * n_seq + sq];
+        for (int l = 0; l < NL; ++l) {
+            const int d = 1 << l;
+            if (i >= d) {
+                double u[S];
 #pragma unroll
-        for (int i = 0; i < S; ++i) {
-            double acc = e[i];
+                for (int j = 0; j < S; ++j) u[j] = st[cur][i - d][j];
 #pragma unroll
-            for (int j = 0; j < S; ++j) acc += am[i * S + j] * s[j];
-            nx[i] = acc;
+                for (int r = 0; r < S; ++r) {
+                    double acc = t[r];
+#pragma unroll
+                    for (int j = 0; j < S; ++j) acc += pm[l][r * S + j] * u[j];
+                    t[r] = acc;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < S; ++j) st[cur ^ 1][i][j] = t[j];
+            __syncthreads();
+            cur ^= 1;
+        }
+        // t = start state of chunk k0 + i (i < 255); element 255 is the next block's carry
+        if (i < NB - 1 && k0 + i < nchunks) {
+#pragma unroll
+            for (int j = 0; j < S; ++j) starts[((size_t)(k0 + i) * SM + j) * n_seq + seq] = t[j];
         }
 #pragma unroll
-        for (int i = 0; i < S; ++i) {
-            s[i] = nx[i];
-            e[i] = en[i];
-        }
+        for (int j = 0; j < S; ++j) carry[j] = st[cur][NB - 1][j];
+        __syncthreads();
     }
 }
 

@@ -1246,16 +1246,16 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         };
         launch_chunks(std::false_type{});
         MST_CHECK_LAUNCH("fx_biquad_chunk_kernel<state>");
-        const dim3 sg((a.n_seq + 63) / 64);
+        const dim3 sg((unsigned)a.n_seq);
         switch (n_bands) {
-            case 1: MST_LAUNCH((fx_biquad_scan_kernel<1>), sg, dim3(64), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
-            case 2: MST_LAUNCH((fx_biquad_scan_kernel<2>), sg, dim3(64), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
-            case 3: MST_LAUNCH((fx_biquad_scan_kernel<3>), sg, dim3(64), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
-            case 4: MST_LAUNCH((fx_biquad_scan_kernel<4>), sg, dim3(64), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
-            case 5: MST_LAUNCH((fx_biquad_scan_kernel<5>), sg, dim3(64), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
-            case 6: MST_LAUNCH((fx_biquad_scan_kernel<6>), sg, dim3(64), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
-            case 7: MST_LAUNCH((fx_biquad_scan_kernel<7>), sg, dim3(64), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
-            default: MST_LAUNCH((fx_biquad_scan_kernel<8>), sg, dim3(64), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
+            case 1: MST_LAUNCH((fx_biquad_scan_kernel<1>), sg, dim3(256), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
+            case 2: MST_LAUNCH((fx_biquad_scan_kernel<2>), sg, dim3(256), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
+            case 3: MST_LAUNCH((fx_biquad_scan_kernel<3>), sg, dim3(256), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
+            case 4: MST_LAUNCH((fx_biquad_scan_kernel<4>), sg, dim3(256), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
+            case 5: MST_LAUNCH((fx_biquad_scan_kernel<5>), sg, dim3(256), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
+            case 6: MST_LAUNCH((fx_biquad_scan_kernel<6>), sg, dim3(256), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
+            case 7: MST_LAUNCH((fx_biquad_scan_kernel<7>), sg, dim3(256), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
+            default: MST_LAUNCH((fx_biquad_scan_kernel<8>), sg, dim3(256), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
         }
         MST_CHECK_LAUNCH("fx_biquad_scan_kernel");
         launch_chunks(std::true_type{});

@@ -92,6 +92,12 @@ def test_product_loudness_and_onset_kernels_emulated(emu_default, gold):
     assert _rel(fx_utils.lufs_normalize(x, 44100, -23.0, log=False), N.lufs_normalize(x, 44100, -23.0)) <= 1e-5
     with pytest.raises(ValueError):
         fx_utils.Meter(44100).integrated_loudness(x[:1000])
+    # a long signal: 293 chunks of 1024 samples = two blocks of the parallel chunk-state scan (carry across blocks)
+    import scipy.signal
+    xl = np.tile(gold["eq_x"], 5)[:300000].astype(np.float32)
+    b, a = fx_utils.kweighting_coefficients(44100)[0]
+    yl = D.biquad(D.to_device(xl), b, a)[:, 0].cpu().numpy()
+    assert _rel(yl, scipy.signal.lfilter(b, a, xl.astype(np.float64))) <= 2e-7
     xc = gold["comp_x"]
     od = D.onset_hfc(D.to_device(xc)[None], 1024, 0)[0]
     hfc, ms = N._hfc_frames(xc, 1024)
