@@ -183,13 +183,29 @@ int mst_embedding_mean(const float *emb_dev, int n_rows, int dim, float *out_dev
  * reference processors: [n_items][L][C] time-major, interleaved channels, fp32.  One (item, channel)
  * sequence per lane for the serial recursions; float64 internal arithmetic like the reference.
  * ---------------------------------------------------------------------------------------------- */
+/* Chain fusion (AugmentationChain.apply_processor :115-148 without its extra passes).  A processor entry point that takes an
+ * MstFxFuse reads its input as x * (float)in_scale_dev[item] - the PENDING factor of the previous processor's rms-normalise,
+ * applied in float32 exactly like the separate scale pass would - and adds sum(y^2) of every item of its raw output to
+ * out_sumsq_dev[item] (float64; zeroed by the caller; the imager writes its closed form), so that an rms-normalise step costs
+ * one tiny mst_fx_rms_pending launch instead of two energy passes and a scale pass over the audio.  fuse = NULL or both
+ * members NULL: the plain processor.  mst_fx_scale_items applies a pending factor when a chain ends with one. */
+typedef struct {
+    const double *in_scale_dev;   /* [n_items] or NULL */
+    double *out_sumsq_dev;        /* [n_items] or NULL */
+} MstFxFuse;
+int mst_fx_sumsq(const float *x_dev, int n_items, long per_item, double *out_dev, void *stream);       /* out[item] = sum x^2 */
+/* scale_out[item] = float32(sqrt(mean(x_true^2) / max(1e-7, mean(y^2)))), mean(x_true^2) = scale_x^2 sumsq_x / per_x (scale_x NULL = 1) */
+int mst_fx_rms_pending(const double *scale_x_dev, const double *sumsq_x_dev, long per_x, const double *sumsq_y_dev, long per_y,
+                       double *scale_out_dev, int n_items, void *stream);
+int mst_fx_scale_items(const float *x_dev, float *y_dev, int n_items, long per_item, const double *scale_dev, void *stream);
+
 /* Equaliser.process (:500-525): cascade of n_bands biquads, zero initial state per band; coef host
  * float64 [n_bands][6] = (b0,b1,b2,a0,a1,a2) shared by all items.  With a scratch buffer of
  * mst_fx_biquad_scratch_bytes() the cascade runs parallel in time (chunked state-space scan, same float64
  * per-sample recursion); with scratch_dev = NULL it runs one lane per (item, channel) sequence. */
 size_t mst_fx_biquad_scratch_bytes(int n_items, long L, int C, int n_bands);
 int mst_fx_biquad_cascade(const float *x_dev, float *y_dev, int n_items, long L, int C, const double *coef_host,
-                          int n_bands, double *scratch_dev, size_t scratch_bytes, void *stream);
+                          int n_bands, double *scratch_dev, size_t scratch_bytes, const MstFxFuse *fuse, void *stream);
 /* Compressor.process / compressor_process (:529-587, :637-649), makeup gain 0.  With a scratch buffer of
  * mst_fx_compressor_scratch_bytes() (about 25 bytes per sample) the gain computer and the gain application run over all samples
  * in parallel and the attack/release smoother runs parallel in time (per-chunk convex piecewise-linear maps + one walk over the
@@ -197,10 +213,10 @@ int mst_fx_biquad_cascade(const float *x_dev, float *y_dev, int n_items, long L,
 size_t mst_fx_compressor_scratch_bytes(int n_items, long L, int C);
 int mst_fx_compressor(const float *x_dev, float *y_dev, int n_items, long L, int C, double threshold_db,
                       double attack_ms, double release_ms, double ratio, double sample_rate, double *scratch_dev,
-                      size_t scratch_bytes, void *stream);
+                      size_t scratch_bytes, const MstFxFuse *fuse, void *stream);
 /* MidSideImager.process (:964-1007), stereo only; scratch_dev: >= n_items*2 doubles */
 int mst_fx_midside_imager(const float *x_dev, float *y_dev, int n_items, long L, double bal, double *scratch_dev,
-                          void *stream);
+                          const MstFxFuse *fuse, void *stream);
 /* Haas.process / haas_process (:768-786, :826-843): y = x, y[:, wet] += feedback * np.roll(x[:, wet], delay) - the roll is
  * circular, delay may be negative; wet_channel 0 = 'left', 1 = 'right'.  c_in = 1 (mono, repeated to stereo) or 2;
  * y is always [n_items, L, 2]. */
@@ -224,7 +240,8 @@ size_t mst_fx_convolver_workspace_bytes(const MstConvolver *cv);
 int mst_fx_convolve(MstConvolver *cv, const float *x_dev, const float *h_dev, long Lh, float *y_dev, long offset, double dry,
                     double wet, void *workspace_dev, size_t workspace_bytes, void *stream);
 /* Gain.process (:1041-1051) */
-int mst_fx_gain(const float *x_dev, float *y_dev, int n_items, long L, int C, double gain_db, int invert, void *stream);
+int mst_fx_gain(const float *x_dev, float *y_dev, int n_items, long L, int C, double gain_db, int invert, const MstFxFuse *fuse,
+                void *stream);
 /* AugmentationChain.apply_processor rms_normalize branch (:143-146): y *= sqrt(mean(x^2)/max(1e-7, mean(y^2)))
  * per item; per_x / per_y = samples per item of x and of y (L * channels each: the means are scalars over each array, and a
  * processor such as Panner / Haas may turn mono into stereo); scratch_dev: >= n_items*4 doubles */

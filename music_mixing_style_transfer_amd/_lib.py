@@ -29,6 +29,10 @@ class MstTcnDesc(C.Structure):
                 ("kernel_size", C.c_int), ("cond_dim", C.c_int), ("dilations", C.c_int * MST_MAX_BLOCKS), ("causal", C.c_int)]
 
 
+class MstFxFuse(C.Structure):
+    _fields_ = [("in_scale_dev", C.c_void_p), ("out_sumsq_dev", C.c_void_p)]
+
+
 class MstEncDesc(C.Structure):
     _fields_ = [("nblocks", C.c_int), ("channels", C.c_int * (MST_MAX_BLOCKS + 1)), ("kernels", C.c_int * MST_MAX_BLOCKS),
                 ("strides", C.c_int * MST_MAX_BLOCKS), ("dilations", C.c_int * MST_MAX_BLOCKS), ("valid_padding", C.c_int)]
@@ -65,12 +69,15 @@ SIGNATURES = {
     "mst_film_forward": (C.c_int, [_F, _F, _F, C.c_int, C.c_int, C.c_int, _F, _F, C.c_int, C.c_long, _F, _P]),
     "mst_embedding_mean": (C.c_int, [_F, C.c_int, C.c_int, _F, _P]),
     "mst_fx_biquad_scratch_bytes": (C.c_size_t, [C.c_int, C.c_long, C.c_int, C.c_int]),
-    "mst_fx_biquad_cascade": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.POINTER(C.c_double), C.c_int, _P, C.c_size_t, _P]),
+    "mst_fx_biquad_cascade": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.POINTER(C.c_double), C.c_int, _P, C.c_size_t, _P, _P]),
+    "mst_fx_sumsq": (C.c_int, [_F, C.c_int, C.c_long, _P, _P]),
+    "mst_fx_rms_pending": (C.c_int, [_P, _P, C.c_long, _P, C.c_long, _P, C.c_int, _P]),
+    "mst_fx_scale_items": (C.c_int, [_F, _F, C.c_int, C.c_long, _P, _P]),
     "mst_fx_compressor_scratch_bytes": (C.c_size_t, [C.c_int, C.c_long, C.c_int]),
     "mst_fx_compressor": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
-                                    C.c_double, _P, C.c_size_t, _P]),
-    "mst_fx_midside_imager": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_double, _P, _P]),
-    "mst_fx_gain": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_double, C.c_int, _P]),
+                                    C.c_double, _P, C.c_size_t, _P, _P]),
+    "mst_fx_midside_imager": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_double, _P, _P, _P]),
+    "mst_fx_gain": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_double, C.c_int, _P, _P]),
     "mst_fx_haas": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_long, C.c_double, C.c_int, _P]),
     "mst_fx_panner": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_float, C.c_float, _P]),
     "mst_fx_rms_normalize": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_long, _P, _P]),

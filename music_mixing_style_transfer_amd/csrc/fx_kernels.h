@@ -72,6 +72,11 @@ struct BiquadChunkArgs {
     long L;
     int n_bands;
     double coef[MST_MAX_BANDS][5];
+    // chain fusion (AugmentationChain): the cascade reads x * (float)in_scale[item] - the pending rms-normalise factor of the previous
+    // processor, applied in float32 exactly like the separate scale pass would - and the apply pass adds sum(y^2) of every item
+    // to out_sumsq[item] (float64) so that the next rms-normalise needs no energy pass.  Both may be null.
+    const double *in_scale = nullptr;
+    double *out_sumsq = nullptr;
 };
 
 template <bool APPLY, int NBANDS>
@@ -92,8 +97,10 @@ __global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) 
         z1[b] = APPLY ? a.starts[((size_t)k * (2 * MST_MAX_BANDS) + 2 * b) * a.n_seq + seq] : 0.0;
         z2[b] = APPLY ? a.starts[((size_t)k * (2 * MST_MAX_BANDS) + 2 * b + 1) * a.n_seq + seq] : 0.0;
     }
+    const float sf = a.in_scale ? (float)a.in_scale[item] : 1.0f;
+    double ss = 0.0;
     auto step = [&](float xi) {
-        double v = (double)xi;
+        double v = (double)(xi * sf);
 #pragma unroll
         for (int b = 0; b < NBANDS; ++b) {
             const double yn = a.coef[b][0] * v + z1[b];
@@ -101,7 +108,9 @@ __global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) 
             z2[b] = a.coef[b][2] * v - a.coef[b][4] * yn;
             v = yn;
         }
-        return (float)v;
+        const float out = (float)v;
+        if (APPLY) ss += (double)out * (double)out;
+        return out;
     };
     // full batches of 16 steps without per-element predicates (predicated loads make hipcc drain vmcnt(0) per element), the
     // next batch's loads in flight behind the current one's arithmetic; the ragged tail of the last chunk step by step
@@ -135,6 +144,8 @@ __global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) 
             a.ends[((size_t)k * (2 * MST_MAX_BANDS) + 2 * b) * a.n_seq + seq] = z1[b];
             a.ends[((size_t)k * (2 * MST_MAX_BANDS) + 2 * b + 1) * a.n_seq + seq] = z2[b];
         }
+    } else if (a.out_sumsq) {
+        atomicAdd(&a.out_sumsq[item], ss);
     }
 }
 
@@ -229,6 +240,9 @@ struct CompArgs {
     // (thr_items[i], ratio_items[i]); with shared_x every item reads the SAME input signal (item 0 of x)
     const double *thr_items = nullptr, *ratio_items = nullptr;
     int shared_x = 0;
+    // chain fusion: x is read as x * (float)in_scale[item]; the apply pass adds sum(y^2) per item to out_sumsq (both may be null)
+    const double *in_scale = nullptr;
+    double *out_sumsq = nullptr;
 };
 
 __global__ __launch_bounds__(256) void fx_compressor_kernel(CompArgs a) {
@@ -300,8 +314,10 @@ __global__ __launch_bounds__(256) void fx_comp_gain_kernel(CompArgs a, double *x
         const int seq = s0 + sl;
         const long n = n0 + nl;
         double v = 0.0;
-        if (seq < a.n_seq && n < a.L)
-            v = fx_comp_level_diff(a, a.x[((size_t)(a.shared_x ? 0 : seq / a.C) * a.L + n) * a.C + seq % a.C], seq / a.C);
+        if (seq < a.n_seq && n < a.L) {
+            const float sf = a.in_scale ? (float)a.in_scale[seq / a.C] : 1.0f;
+            v = fx_comp_level_diff(a, a.x[((size_t)(a.shared_x ? 0 : seq / a.C) * a.L + n) * a.C + seq % a.C] * sf, seq / a.C);
+        }
         t[nl][sl] = v;
     }
     __syncthreads();
@@ -586,7 +602,21 @@ __global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const do
         if (seq < a.n_seq && n < a.L) {
             const size_t e = ((size_t)(seq / a.C) * a.L + n) * a.C + seq % a.C;
             const size_t ex = a.shared_x ? (size_t)n * a.C + seq % a.C : e;
-            a.y[e] = (float)((double)a.x[ex] * pow(10.0, (a.makeup - t[nl][sl]) / 20.0));
+            const float sf = a.in_scale ? (float)a.in_scale[seq / a.C] : 1.0f;
+            const float out = (float)((double)(a.x[ex] * sf) * pow(10.0, (a.makeup - t[nl][sl]) / 20.0));
+            a.y[e] = out;
+            if (a.out_sumsq) t[nl][sl] = (double)out * (double)out;          // this thread's own tile element: reused for the energy sum
+        } else if (a.out_sumsq) {
+            t[nl][sl] = 0.0;
+        }
+    }
+    if (a.out_sumsq) {             // column sums of the tile: one atomic per (tile, sequence)
+        __syncthreads();
+        if (threadIdx.x < 64 && s0 + (int)threadIdx.x < a.n_seq) {
+            double cs = 0.0;
+#pragma unroll 8
+            for (int nl = 0; nl < 64; ++nl) cs += t[nl][threadIdx.x];
+            atomicAdd(&a.out_sumsq[(s0 + threadIdx.x) / a.C], cs);
         }
     }
 }
@@ -631,20 +661,26 @@ __global__ __launch_bounds__(256) void fx_energy_kernel(const float *x, double *
 }
 
 // MidSideImager.process (:964-1007): gains from the two energies, applied in float32 like the reference
+// chain fusion: in_scale = the pending rms factor of the previous processor (the energies of the raw input scale with its square, the
+// samples are multiplied in float32 like the separate scale pass would); out_sumsq[item] = sum(y^2), here in closed form from the gains
 __global__ __launch_bounds__(256) void fx_imager_apply_kernel(const float *x, float *y, const double *acc, long L,
-                                                              double bal_rounded) {
+                                                              double bal_rounded, const double *in_scale, double *out_sumsq) {
     const int item = blockIdx.y;
-    const double mid_e = acc[item * 2], side_e = acc[item * 2 + 1];
+    const float sf = in_scale ? (float)in_scale[item] : 1.0f;
+    const double s2 = (double)sf * (double)sf;
+    const double mid_e = acc[item * 2] * s2, side_e = acc[item * 2 + 1] * s2;
     const double total_e = mid_e + side_e;
     const double max_side = sqrt(total_e / (side_e + 1e-3));
     const double side_gain = (bal_rounded <= 1.0) ? bal_rounded : max_side * (bal_rounded - 1.0);
     const double mid_gain = sqrt((total_e - side_e * side_gain * side_gain) / (mid_e + 1e-3));
     const float sg = (float)side_gain, mg = (float)mid_gain;
+    if (out_sumsq && blockIdx.x == 0 && threadIdx.x == 0)      // sum(l'^2 + r'^2) = (mg^2 sum(mid^2) + sg^2 sum(side^2)) / 2
+        out_sumsq[item] = ((double)mg * mg * mid_e + (double)sg * sg * side_e) / 2.0;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= L) return;
     const float *xp = x + ((size_t)item * L + i) * 2;
     float *yp = y + ((size_t)item * L + i) * 2;
-    const float l = xp[0], r = xp[1];
+    const float l = xp[0] * sf, r = xp[1] * sf;
     const float nm = (l + r) * mg, ns = (l - r) * sg;
     yp[0] = (nm + ns) / 2.0f;
     yp[1] = (nm - ns) / 2.0f;
@@ -652,9 +688,12 @@ __global__ __launch_bounds__(256) void fx_imager_apply_kernel(const float *x, fl
 
 // Gain.process (:1041-1051) and the final multiply of the rms normalise (:145-146)
 // mode 0: y = g * x ; mode 1: y *= sqrt(ex / max(1e-7, ey)) with ex = acc_x/per_item, ey = acc_y/per_item
+// in_scale (chain fusion, mode 0): y = (x * (float)in_scale[item]) * g - the pending rms factor first, like the separate pass would
 __global__ __launch_bounds__(256) void fx_scale_kernel(const float *x, float *y, long per_item, float g,
-                                                       const double *acc_x, const double *acc_y, int mode, long per_x) {
+                                                       const double *acc_x, const double *acc_y, int mode, long per_x,
+                                                       const double *in_scale) {
     const int item = blockIdx.y;
+    const float sf = in_scale ? (float)in_scale[item] : 1.0f;
     float scale = g;
     if (mode == 1) {        // mean(x^2) over x's own size, mean(y^2) over y's (a processor may change the channel count)
         const double ex = acc_x[item * 2] / (double)per_x, ey = acc_y[item * 2] / (double)per_item;
@@ -663,7 +702,7 @@ __global__ __launch_bounds__(256) void fx_scale_kernel(const float *x, float *y,
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= per_item) return;
     const size_t off = (size_t)item * per_item + i;
-    y[off] = (mode == 1 ? y[off] : x[off]) * scale;
+    y[off] = (mode == 1 ? y[off] : x[off] * sf) * scale;
 }
 
 // Haas effect, haas_process (:768-786): y = x; y[:, ch] += feedback * np.roll(x[:, ch], delay).  np.roll is circular:
@@ -1012,4 +1051,34 @@ __global__ __launch_bounds__(256) void fx_reverb_mix_kernel(const float *x, cons
     float *yp = y + ((size_t)item * L + n) * 2;
     yp[0] = (float)(wet1 * xl + wet2 * xr + dry * dl);
     yp[1] = (float)(wet1 * xr + wet2 * xl + dry * dr);
+}
+
+// chain fusion: the pending factor of an rms-normalise step (apply_processor :143-146) from the sums the producers left behind:
+// s_out = sqrt(mean(x_true^2) / max(1e-7, mean(y^2))), x_true = x_raw * s_x  =>  mean(x_true^2) = s_x^2 sumsq_x / per_x.
+// Rounded to float32 like the reference's scale factor.
+__global__ __launch_bounds__(64) void fx_rms_pending_kernel(const double *s_x, const double *sumsq_x, long per_x, const double *sumsq_y,
+                                                           long per_y, double *s_out, int n_items) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n_items) return;
+    const float sx = s_x ? (float)s_x[i] : 1.0f;
+    const double ex = (double)sx * (double)sx * sumsq_x[i] / (double)per_x, ey = sumsq_y[i] / (double)per_y;
+    s_out[i] = (double)(float)sqrt(ex / fmax(1e-7, ey));
+}
+
+// out[item] += sum of x^2 over the chunk-th part of the item (float64); grid n_items * chunks
+__global__ __launch_bounds__(256) void fx_sumsq_kernel(const float *x, double *out, long per_item, int chunks) {
+    __shared__ double red[4];
+    const int item = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const long per_chunk = (per_item + chunks - 1) / chunks;
+    const long lo = chunk * per_chunk, hi = (lo + per_chunk < per_item) ? lo + per_chunk : per_item;
+    const float *xp = x + (size_t)item * per_item;
+    double s = 0.0;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        const float v = xp[i];
+        s += (double)(v * v);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&out[item], (red[0] + red[1]) + (red[2] + red[3]));
 }

@@ -1190,7 +1190,7 @@ extern "C" size_t mst_fx_biquad_scratch_bytes(int n_items, long L, int C, int n_
 }
 
 extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long L, int C, const double *coef, int n_bands,
-                                     double *scratch, size_t scratch_bytes, void *stream) {
+                                     double *scratch, size_t scratch_bytes, const MstFxFuse *fuse, void *stream) {
     if (!x || !y || !coef || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_biquad_cascade: bad argument");
     if (n_bands < 0 || n_bands > MST_MAX_BANDS) return fail(MST_ERR_UNSUPPORTED, "mst_fx_biquad_cascade: at most 8 bands");
     const long nchunks = (L + BIQUAD_CHUNK - 1) / BIQUAD_CHUNK;
@@ -1206,6 +1206,8 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         a.M = BIQUAD_CHUNK;
         a.L = L;
         a.n_bands = n_bands;
+        a.in_scale = fuse ? fuse->in_scale_dev : nullptr;
+        a.out_sumsq = fuse ? fuse->out_sumsq_dev : nullptr;
         biquad_coefs(coef, n_bands, a.coef);
         const size_t states = (size_t)a.n_seq * nchunks * 2 * MST_MAX_BANDS;
         double *ends = scratch, *starts = scratch + states;
@@ -1262,6 +1264,8 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         MST_CHECK_LAUNCH("fx_biquad_chunk_kernel<apply>");
         return MST_OK;
     }
+    if (fuse && (fuse->in_scale_dev || fuse->out_sumsq_dev))
+        return fail(MST_ERR_UNSUPPORTED, "mst_fx_biquad_cascade: chain fusion needs the time-parallel path (scratch, more than one chunk, >= 1 band)");
     BiquadArgs a;
     a.x = x;
     a.y = y;
@@ -1341,9 +1345,12 @@ int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size
 
 extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, int C, double threshold_db,
                                  double attack_ms, double release_ms, double ratio, double sample_rate, double *scratch,
-                                 size_t scratch_bytes, void *stream) {
+                                 size_t scratch_bytes, const MstFxFuse *fuse, void *stream) {
     if (!x || !y || n_items < 1 || L < 1 || C < 1 || attack_ms <= 0 || release_ms <= 0 || ratio <= 0 || sample_rate <= 0)
         return fail(MST_ERR_ARG, "mst_fx_compressor: bad argument");
+    const bool fused = fuse && (fuse->in_scale_dev || fuse->out_sumsq_dev);
+    if (fused && (!scratch || (threshold_db == 0.0 && ratio == 1.0)))
+        return fail(MST_ERR_UNSUPPORTED, "mst_fx_compressor: chain fusion needs the scratch buffer and an active compressor");
     if (threshold_db == 0.0 && ratio == 1.0) {   // bypass (common_audioeffects.py:637)
         if (x != y) MST_HIP_TRY(hipMemcpyAsync(y, x, (size_t)n_items * L * C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
         return MST_OK;
@@ -1359,6 +1366,8 @@ extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, 
     a.alpha_att = std::exp(-1.0 / (0.001 * sample_rate * attack_ms));
     a.alpha_rel = std::exp(-1.0 / (0.001 * sample_rate * release_ms));
     a.makeup = 0.0;
+    a.in_scale = fuse ? fuse->in_scale_dev : nullptr;
+    a.out_sumsq = fuse ? fuse->out_sumsq_dev : nullptr;
     return compressor_run(a, n_items, L, C, scratch, scratch_bytes, stream);
 }
 
@@ -1433,24 +1442,27 @@ int energy(const float *x, double *acc, int n_items, long per_item, int mode, vo
 }
 }  // namespace
 
-extern "C" int mst_fx_midside_imager(const float *x, float *y, int n_items, long L, double bal, double *scratch, void *stream) {
+extern "C" int mst_fx_midside_imager(const float *x, float *y, int n_items, long L, double bal, double *scratch, const MstFxFuse *fuse,
+                                     void *stream) {
     if (!x || !y || !scratch || n_items < 1 || L < 1) return fail(MST_ERR_ARG, "mst_fx_midside_imager: bad argument");
     int rc;
     if ((rc = energy(x, scratch, n_items, 2 * L, 1, stream))) return rc;
     const double bal_r = std::round(bal * 1000.0) / 1000.0;   // round(bal, 3) (:980)
     MST_LAUNCH(fx_imager_apply_kernel, dim3((unsigned)((L + 255) / 256), n_items), dim3(256), stream, x, y,
-               (const double *)scratch, L, bal_r);
+               (const double *)scratch, L, bal_r, fuse ? fuse->in_scale_dev : (const double *)nullptr,
+               fuse ? fuse->out_sumsq_dev : (double *)nullptr);
     MST_CHECK_LAUNCH("fx_imager_apply_kernel");
     return MST_OK;
 }
 
-extern "C" int mst_fx_gain(const float *x, float *y, int n_items, long L, int C, double gain_db, int invert, void *stream) {
+extern "C" int mst_fx_gain(const float *x, float *y, int n_items, long L, int C, double gain_db, int invert, const MstFxFuse *fuse,
+                           void *stream) {
     if (!x || !y || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_gain: bad argument");
     double g = std::pow(10.0, gain_db / 20.0);
     if (invert) g = -g;
     const long per = L * C;
     MST_LAUNCH(fx_scale_kernel, dim3((unsigned)((per + 255) / 256), n_items), dim3(256), stream, x, y, per, (float)g,
-               (const double *)nullptr, (const double *)nullptr, 0, per);
+               (const double *)nullptr, (const double *)nullptr, 0, per, fuse ? fuse->in_scale_dev : (const double *)nullptr);
     MST_CHECK_LAUNCH("fx_scale_kernel");
     return MST_OK;
 }
@@ -1583,7 +1595,34 @@ extern "C" int mst_fx_rms_normalize(const float *x, float *y, int n_items, long 
     if ((rc = energy(x, scratch, n_items, per_x, 0, stream))) return rc;
     if ((rc = energy(y, scratch + 2 * n_items, n_items, per_y, 0, stream))) return rc;
     MST_LAUNCH(fx_scale_kernel, dim3((unsigned)((per_y + 255) / 256), n_items), dim3(256), stream, x, y, per_y, 1.0f,
-               (const double *)scratch, (const double *)(scratch + 2 * n_items), 1, per_x);
+               (const double *)scratch, (const double *)(scratch + 2 * n_items), 1, per_x, (const double *)nullptr);
+    MST_CHECK_LAUNCH("fx_scale_kernel");
+    return MST_OK;
+}
+
+// ---- chain fusion helpers -------------------------------------------------------------------------------------------------
+extern "C" int mst_fx_sumsq(const float *x, int n_items, long per_item, double *out, void *stream) {
+    if (!x || !out || n_items < 1 || per_item < 1) return fail(MST_ERR_ARG, "mst_fx_sumsq: bad argument");
+    MST_HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_items * sizeof(double), (hipStream_t)stream));
+    int chunks = (int)std::min<long>(64, (per_item + 8191) / 8192);
+    if (chunks < 1) chunks = 1;
+    MST_LAUNCH(fx_sumsq_kernel, dim3(n_items * chunks), dim3(256), stream, x, out, per_item, chunks);
+    MST_CHECK_LAUNCH("fx_sumsq_kernel");
+    return MST_OK;
+}
+
+extern "C" int mst_fx_rms_pending(const double *scale_x, const double *sumsq_x, long per_x, const double *sumsq_y, long per_y,
+                                  double *scale_out, int n_items, void *stream) {
+    if (!sumsq_x || !sumsq_y || !scale_out || n_items < 1 || per_x < 1 || per_y < 1) return fail(MST_ERR_ARG, "mst_fx_rms_pending: bad argument");
+    MST_LAUNCH(fx_rms_pending_kernel, dim3((n_items + 63) / 64), dim3(64), stream, scale_x, sumsq_x, per_x, sumsq_y, per_y, scale_out, n_items);
+    MST_CHECK_LAUNCH("fx_rms_pending_kernel");
+    return MST_OK;
+}
+
+extern "C" int mst_fx_scale_items(const float *x, float *y, int n_items, long per_item, const double *scale, void *stream) {
+    if (!x || !y || !scale || n_items < 1 || per_item < 1) return fail(MST_ERR_ARG, "mst_fx_scale_items: bad argument");
+    MST_LAUNCH(fx_scale_kernel, dim3((unsigned)((per_item + 255) / 256), n_items), dim3(256), stream, x, y, per_item, 1.0f,
+               (const double *)nullptr, (const double *)nullptr, 0, per_item, scale);
     MST_CHECK_LAUNCH("fx_scale_kernel");
     return MST_OK;
 }

@@ -32,7 +32,7 @@ def biquad(x, b, a):
         nbytes = lib.mst_fx_biquad_scratch_bytes(1, L, Cn, 1)
         sc = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=x.device)
         lib.check(lib.mst_fx_biquad_cascade(x.data_ptr(), y.data_ptr(), 1, L, Cn, coef.ctypes.data_as(C.POINTER(C.c_double)), 1,
-                                            sc.data_ptr(), nbytes, lib.stream_ptr(x)), "mst_fx_biquad_cascade")
+                                            sc.data_ptr(), nbytes, None, lib.stream_ptr(x)), "mst_fx_biquad_cascade")
     return y
 
 

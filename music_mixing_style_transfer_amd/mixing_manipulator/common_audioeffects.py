@@ -95,6 +95,15 @@ class _Dev:
     def scratch(self, n_doubles):
         return torch.empty(n_doubles, dtype=torch.float64, device=self.x.device)
 
+    def fuse(self, in_scale, want_sumsq):
+        """(MstFxFuse pointer or None, sumsq tensor or None) for a processor call inside a fused chain."""
+        if in_scale is None and not want_sumsq:
+            return None, None
+        sumsq = torch.zeros(self.n, dtype=torch.float64, device=self.x.device) if want_sumsq else None
+        f = _lib.MstFxFuse(in_scale.data_ptr() if in_scale is not None else None, sumsq.data_ptr() if want_sumsq else None)
+        self._keep = (f, in_scale, sumsq)              # alive until the launches are queued
+        return C.byref(f), sumsq
+
     def out(self, y):
         if not self.batched:
             y = y[0]
@@ -176,16 +185,24 @@ class Equaliser(Processor):
 
     def process(self, x):
         d = _Dev(x)
+        y, _ = self._run(d, None, False)
+        return d.out(y)
+
+    def fusable(self, d):
+        return not self.hard_clip and d.L > 1024 and len(self.bands) >= 1       # the time-parallel path, output left as filtered
+
+    def _run(self, d, in_scale, want_sumsq):
         coef = np.ascontiguousarray(self.coefficients())
         y = torch.empty_like(d.x)
         nbytes = d.lib.mst_fx_biquad_scratch_bytes(d.n, d.L, d.C, coef.shape[0])      # time-parallel (chunked scan) path
         sc = d.scratch((nbytes + 7) // 8)
+        fuse, sumsq = d.fuse(in_scale, want_sumsq)
         d.lib.check(d.lib.mst_fx_biquad_cascade(d.x.data_ptr(), y.data_ptr(), d.n, d.L, d.C,
                                                 coef.ctypes.data_as(C.POINTER(C.c_double)), coef.shape[0],
-                                                sc.data_ptr(), nbytes, d.stream), "mst_fx_biquad_cascade")
+                                                sc.data_ptr(), nbytes, fuse, d.stream), "mst_fx_biquad_cascade")
         if self.hard_clip:
             y = y.clamp_(-1.0, 1.0)
-        return d.out(y)
+        return y, sumsq
 
 
 class Compressor(Processor):
@@ -207,13 +224,23 @@ class Compressor(Processor):
         if p.threshold.value == 0.0 and p.ratio.value == 1.0:
             return x
         d = _Dev(x)
+        y, _ = self._run(d, None, False)
+        return d.out(y)
+
+    def fusable(self, d):
+        p = self.parameters
+        return not (p.threshold.value == 0.0 and p.ratio.value == 1.0)
+
+    def _run(self, d, in_scale, want_sumsq):
+        p = self.parameters
         y = torch.empty_like(d.x)
         nbytes = d.lib.mst_fx_compressor_scratch_bytes(d.n, d.L, d.C)
         sc = d.scratch((nbytes + 7) // 8)
+        fuse, sumsq = d.fuse(in_scale, want_sumsq)
         d.lib.check(d.lib.mst_fx_compressor(d.x.data_ptr(), y.data_ptr(), d.n, d.L, d.C, float(p.threshold.value),
                                             float(p.attack_time.value), float(p.release_time.value), float(p.ratio.value),
-                                            float(self.sample_rate), sc.data_ptr(), nbytes, d.stream), "mst_fx_compressor")
-        return d.out(y)
+                                            float(self.sample_rate), sc.data_ptr(), nbytes, fuse, d.stream), "mst_fx_compressor")
+        return y, sumsq
 
     def update(self, parameter_name=None):
         self.yL_prev = None
@@ -230,13 +257,21 @@ class MidSideImager(Processor):
 
     def process(self, data):
         d = _Dev(data)
+        y, _ = self._run(d, None, False)
+        return d.out(y)
+
+    def fusable(self, d):
+        return d.C == 2
+
+    def _run(self, d, in_scale, want_sumsq):
         if d.C != 2:
             raise ValueError("MidSideImager needs stereo audio [L, 2]")
         y = torch.empty_like(d.x)
         sc = d.scratch(2 * d.n)
+        fuse, sumsq = d.fuse(in_scale, want_sumsq)
         d.lib.check(d.lib.mst_fx_midside_imager(d.x.data_ptr(), y.data_ptr(), d.n, d.L, float(self.parameters.bal.value),
-                                                sc.data_ptr(), d.stream), "mst_fx_midside_imager")
-        return d.out(y)
+                                                sc.data_ptr(), fuse, d.stream), "mst_fx_midside_imager")
+        return y, sumsq
 
 
 class Gain(Processor):
@@ -251,10 +286,18 @@ class Gain(Processor):
 
     def process(self, x):
         d = _Dev(x)
-        y = torch.empty_like(d.x)
-        d.lib.check(d.lib.mst_fx_gain(d.x.data_ptr(), y.data_ptr(), d.n, d.L, d.C, float(self.parameters.gain.value),
-                                      int(bool(self.parameters.invert.value)), d.stream), "mst_fx_gain")
+        y, _ = self._run(d, None, False)
         return d.out(y)
+
+    def fusable(self, d):
+        return True
+
+    def _run(self, d, in_scale, want_sumsq):
+        y = torch.empty_like(d.x)
+        fuse, _ = d.fuse(in_scale, False)              # a gain leaves no energy sum behind (nothing downstream asks for one cheaply)
+        d.lib.check(d.lib.mst_fx_gain(d.x.data_ptr(), y.data_ptr(), d.n, d.L, d.C, float(self.parameters.gain.value),
+                                      int(bool(self.parameters.invert.value)), fuse, d.stream), "mst_fx_gain")
+        return y, None
 
 
 class ConvolutionalReverb(Processor):
@@ -462,6 +505,40 @@ class AlgorithmicReverb(Processor):
                     "mst_fx_algorithmic_reverb")
         return d.out(y)
 
+def _sumsq(d, t):
+    out = torch.empty(d.n, dtype=torch.float64, device=t.device)
+    d.lib.check(d.lib.mst_fx_sumsq(t.data_ptr(), d.n, t.shape[1] * t.shape[2], out.data_ptr(), d.stream), "mst_fx_sumsq")
+    return out
+
+
+class _Pending:
+    """An array on its way through an AugmentationChain: device batch t [n, L, C], the per-item factor still to be applied to it
+    (scale, float64 [n] or None) and sum(t^2) per item when its producer left it behind (sumsq, float64 [n] or None)."""
+    __slots__ = ("dev", "t", "scale", "sumsq")
+
+    def __init__(self, dev, t, scale, sumsq):
+        self.dev, self.t, self.scale, self.sumsq = dev, t, scale, sumsq
+
+    @staticmethod
+    def wrap(x):
+        d = _Dev(x)
+        return _Pending(d, d.x, None, None)
+
+    def materialize(self):
+        """The true batch [n, L, C] on the device."""
+        if self.scale is None:
+            return self.t
+        d = self.dev
+        y = torch.empty_like(self.t)
+        d.lib.check(d.lib.mst_fx_scale_items(self.t.data_ptr(), y.data_ptr(), d.n, self.t.shape[1] * self.t.shape[2],
+                                             self.scale.data_ptr(), d.stream), "mst_fx_scale_items")
+        return y
+
+    def result(self):
+        """In the caller's container type and rank."""
+        return self.dev.out(self.materialize())
+
+
 class AugmentationChain:
     """Apply (processor, probability, rms_normalize) entries in order to every array of a list; optional shuffle
     and parallel dry/wet mix - the reference's chain semantics (:156-192)."""
@@ -473,12 +550,36 @@ class AugmentationChain:
         self.randomize_param_value = randomize_param_value
 
     def apply_processor(self, x, processor, rms_normalize):
+        """x: an array / tensor, or a _Pending left by the previous processor of a fused chain.  Plain use (one processor,
+        array in -> array out) is the reference's apply_processor (:115-148)."""
         if processor.block_size is not None:
             raise NotImplementedError("block-wise processors are not on the gfx950 path")
-        y = processor.process(x)
+        if not isinstance(x, _Pending):
+            y = processor.process(x)
+            if rms_normalize:
+                y = rms_normalize_(x, y)
+            return y
+        d = x.dev
+        if hasattr(processor, "fusable") and processor.fusable(d):
+            # the pending rms factor of the previous step is folded into this processor's loads; its output leaves sum(y^2) behind
+            d.x = x.t
+            y, sumsq_y = processor._run(d, x.scale, rms_normalize)
+            if not rms_normalize:
+                return _Pending(d, y, None, sumsq_y)
+            sumsq_x = x.sumsq if x.sumsq is not None else _sumsq(d, x.t)
+            if sumsq_y is None:
+                sumsq_y = _sumsq(d, y)
+            scale = torch.empty(d.n, dtype=torch.float64, device=y.device)
+            d.lib.check(d.lib.mst_fx_rms_pending(x.scale.data_ptr() if x.scale is not None else None, sumsq_x.data_ptr(),
+                                                 x.t.shape[1] * x.t.shape[2], sumsq_y.data_ptr(), y.shape[1] * y.shape[2],
+                                                 scale.data_ptr(), d.n, d.stream), "mst_fx_rms_pending")
+            return _Pending(d, y, scale, sumsq_y)
+        xm = x.materialize()
+        y = processor.process(xm)
         if rms_normalize:
-            y = rms_normalize_(x, y)
-        return y
+            y = rms_normalize_(xm, y)
+        d.x = y if y.dim() == 3 else y[None]
+        return _Pending(d, d.x, None, None)
 
     def apply_same_processor(self, x_list, processor, rms_normalize):
         return [self.apply_processor(x, processor, rms_normalize) for x in x_list]
@@ -486,7 +587,9 @@ class AugmentationChain:
     def __call__(self, x_list):
         if self.shuffle:
             random.shuffle(self.fxs)
-        y_list = list(x_list)
+        # inside the chain every array travels as a _Pending: a device batch, the rms factor still to be applied to it and the
+        # sum of squares its producer left behind - a step then costs no extra pass over the audio (see MstFxFuse)
+        y_list = [_Pending.wrap(x) for x in x_list]
         for fx, p, rms in self.fxs:
             if np.random.rand() < p:
                 if isinstance(fx, Processor):
@@ -496,7 +599,8 @@ class AugmentationChain:
                         fx.update(None)
                     y_list = self.apply_same_processor(y_list, fx, rms)
                 else:
-                    y_list = fx(y_list)
+                    y_list = [_Pending.wrap(y) for y in fx([y.result() for y in y_list])]
+        y_list = [y.result() for y in y_list]
         if self.parallel:
             w = self.parallel_weight_factor if self.parallel_weight_factor else np.random.rand() / 2.0
             y_list = [w * x + (1 - w) * y for x, y in zip(x_list, y_list)]
