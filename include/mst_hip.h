@@ -189,12 +189,14 @@ int mst_embedding_mean(const float *emb_dev, int n_rows, int dim, float *out_dev
  * out_sumsq_dev[item] (float64; zeroed by the caller; the imager writes its closed form), so that an rms-normalise step costs
  * one tiny mst_fx_rms_pending launch instead of two energy passes and a scale pass over the audio.  fuse = NULL or both
  * members NULL: the plain processor.  mst_fx_scale_items applies a pending factor when a chain ends with one. */
+#define MST_SUMSQ_SLOTS 64     /* an energy sum is kept as 64 partial sums per item (producers spread their atomics over them) */
 typedef struct {
     const double *in_scale_dev;   /* [n_items] or NULL */
-    double *out_sumsq_dev;        /* [n_items] or NULL */
+    double *out_sumsq_dev;        /* [n_items][MST_SUMSQ_SLOTS] or NULL, zeroed by the caller */
 } MstFxFuse;
-int mst_fx_sumsq(const float *x_dev, int n_items, long per_item, double *out_dev, void *stream);       /* out[item] = sum x^2 */
-/* scale_out[item] = float32(sqrt(mean(x_true^2) / max(1e-7, mean(y^2)))), mean(x_true^2) = scale_x^2 sumsq_x / per_x (scale_x NULL = 1) */
+int mst_fx_sumsq(const float *x_dev, int n_items, long per_item, double *out_dev, void *stream);   /* out[item][slot]: partial sums of x^2 */
+/* scale_out[item] = float32(sqrt(mean(x_true^2) / max(1e-7, mean(y^2)))), mean(x_true^2) = scale_x^2 sum_slots(sumsq_x) / per_x
+ * (scale_x NULL = 1); sumsq_x / sumsq_y in the [n_items][MST_SUMSQ_SLOTS] form */
 int mst_fx_rms_pending(const double *scale_x_dev, const double *sumsq_x_dev, long per_x, const double *sumsq_y_dev, long per_y,
                        double *scale_out_dev, int n_items, void *stream);
 int mst_fx_scale_items(const float *x_dev, float *y_dev, int n_items, long per_item, const double *scale_dev, void *stream);

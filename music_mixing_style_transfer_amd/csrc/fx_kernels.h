@@ -63,6 +63,10 @@ __global__ __launch_bounds__(64) void fx_biquad_kernel(BiquadArgs a) {
 // Same float64 recursion per sample as the serial kernel; only the chunk-start states come through the scan
 // (float64, rounding-level differences).  One lane per (sequence, chunk): 16 384 lanes instead of 128.
 // ------------------------------------------------------------------------------------------------
+// energy sums of the chain fusion are kept as MST_SUMSQ_SLOTS partial sums per item (producers spread their atomics over the slots:
+// a 64-segment batch is 4096 tiles per kernel onto 64 items - one address per item serialises ~2000 atomics, measured +0.4 ms)
+#define MST_SUMSQ_SLOTS 64
+
 struct BiquadChunkArgs {
     const float *x;
     float *y;             // pass 2 only
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) 
             a.ends[((size_t)k * (2 * MST_MAX_BANDS) + 2 * b + 1) * a.n_seq + seq] = z2[b];
         }
     } else if (a.out_sumsq) {
-        atomicAdd(&a.out_sumsq[item], ss);
+        atomicAdd(&a.out_sumsq[item * MST_SUMSQ_SLOTS + (k & (MST_SUMSQ_SLOTS - 1))], ss);     // spread over the slots: few atomics per address
     }
 }
 
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const do
             double cs = 0.0;
 #pragma unroll 8
             for (int nl = 0; nl < 64; ++nl) cs += t[nl][threadIdx.x];
-            atomicAdd(&a.out_sumsq[(s0 + threadIdx.x) / a.C], cs);
+            atomicAdd(&a.out_sumsq[((s0 + threadIdx.x) / a.C) * MST_SUMSQ_SLOTS + (blockIdx.x & (MST_SUMSQ_SLOTS - 1))], cs);
         }
     }
 }
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(256) void fx_imager_apply_kernel(const float *x, fl
     const double mid_gain = sqrt((total_e - side_e * side_gain * side_gain) / (mid_e + 1e-3));
     const float sg = (float)side_gain, mg = (float)mid_gain;
     if (out_sumsq && blockIdx.x == 0 && threadIdx.x == 0)      // sum(l'^2 + r'^2) = (mg^2 sum(mid^2) + sg^2 sum(side^2)) / 2
-        out_sumsq[item] = ((double)mg * mg * mid_e + (double)sg * sg * side_e) / 2.0;
+        out_sumsq[item * MST_SUMSQ_SLOTS] = ((double)mg * mg * mid_e + (double)sg * sg * side_e) / 2.0;     // slot 0; the others stay zero
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= L) return;
     const float *xp = x + ((size_t)item * L + i) * 2;
@@ -1061,7 +1065,12 @@ __global__ __launch_bounds__(64) void fx_rms_pending_kernel(const double *s_x, c
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n_items) return;
     const float sx = s_x ? (float)s_x[i] : 1.0f;
-    const double ex = (double)sx * (double)sx * sumsq_x[i] / (double)per_x, ey = sumsq_y[i] / (double)per_y;
+    double qx = 0.0, qy = 0.0;
+    for (int k = 0; k < MST_SUMSQ_SLOTS; ++k) {
+        qx += sumsq_x[i * MST_SUMSQ_SLOTS + k];
+        qy += sumsq_y[i * MST_SUMSQ_SLOTS + k];
+    }
+    const double ex = (double)sx * (double)sx * qx / (double)per_x, ey = qy / (double)per_y;
     s_out[i] = (double)(float)sqrt(ex / fmax(1e-7, ey));
 }
 
@@ -1080,5 +1089,5 @@ __global__ __launch_bounds__(256) void fx_sumsq_kernel(const float *x, double *o
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&out[item], (red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) atomicAdd(&out[item * MST_SUMSQ_SLOTS + (chunk & (MST_SUMSQ_SLOTS - 1))], (red[0] + red[1]) + (red[2] + red[3]));
 }

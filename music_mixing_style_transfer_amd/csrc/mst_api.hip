@@ -1603,7 +1603,7 @@ extern "C" int mst_fx_rms_normalize(const float *x, float *y, int n_items, long 
 // ---- chain fusion helpers -------------------------------------------------------------------------------------------------
 extern "C" int mst_fx_sumsq(const float *x, int n_items, long per_item, double *out, void *stream) {
     if (!x || !out || n_items < 1 || per_item < 1) return fail(MST_ERR_ARG, "mst_fx_sumsq: bad argument");
-    MST_HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_items * sizeof(double), (hipStream_t)stream));
+    MST_HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_items * MST_SUMSQ_SLOTS * sizeof(double), (hipStream_t)stream));
     int chunks = (int)std::min<long>(64, (per_item + 8191) / 8192);
     if (chunks < 1) chunks = 1;
     MST_LAUNCH(fx_sumsq_kernel, dim3(n_items * chunks), dim3(256), stream, x, out, per_item, chunks);

@@ -20,6 +20,9 @@ import torch
 from .. import _lib
 
 
+SUMSQ_SLOTS = 64       # MST_SUMSQ_SLOTS of include/mst_hip.h: energy sums travel as 64 partial sums per item
+
+
 class Parameter:
     def __init__(self, name, value, kind, units=None, minimum=None, maximum=None, options=None, processor=None, **kw):
         self.name, self.value, self.kind, self.units = name, value, kind, units
@@ -99,7 +102,7 @@ class _Dev:
         """(MstFxFuse pointer or None, sumsq tensor or None) for a processor call inside a fused chain."""
         if in_scale is None and not want_sumsq:
             return None, None
-        sumsq = torch.zeros(self.n, dtype=torch.float64, device=self.x.device) if want_sumsq else None
+        sumsq = torch.zeros(self.n * SUMSQ_SLOTS, dtype=torch.float64, device=self.x.device) if want_sumsq else None
         f = _lib.MstFxFuse(in_scale.data_ptr() if in_scale is not None else None, sumsq.data_ptr() if want_sumsq else None)
         self._keep = (f, in_scale, sumsq)              # alive until the launches are queued
         return C.byref(f), sumsq
@@ -506,7 +509,7 @@ class AlgorithmicReverb(Processor):
         return d.out(y)
 
 def _sumsq(d, t):
-    out = torch.empty(d.n, dtype=torch.float64, device=t.device)
+    out = torch.empty(d.n * SUMSQ_SLOTS, dtype=torch.float64, device=t.device)
     d.lib.check(d.lib.mst_fx_sumsq(t.data_ptr(), d.n, t.shape[1] * t.shape[2], out.data_ptr(), d.stream), "mst_fx_sumsq")
     return out
 
