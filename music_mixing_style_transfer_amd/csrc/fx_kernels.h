@@ -476,14 +476,17 @@ __global__ __launch_bounds__(128) void fx_comp_chain_kernel(CompMapArgs a) {
     const size_t total = (size_t)a.nchunks * PER;
     const int nbatch = (a.nchunks + CB - 1) / CB;
     const double never = USE_MIN ? -1e300 : 1e300;                   // db of a test that always fails
-    // ---- wave 1: global -> registers -> raw records -> entries (17 entries per lane per batch)
-    auto cook = [&](int bt, int buf) {
-        double r[NLD];
+    // ---- wave 1: global -> registers (requested one batch EARLIER than they are cooked: the loads of batch bt + 2 fly while the
+    //      walker is on batch bt + 1) -> raw records -> entries (17 entries per lane per batch)
+    double r[NLD];
+    auto load = [&](int bt) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const size_t e = (size_t)bt * CB * PER + (size_t)i * 64 + lane;
+            const size_t e = (size_t)(bt < nbatch ? bt : nbatch - 1) * CB * PER + (size_t)i * 64 + lane;
             r[i] = m[e < total ? e : total - 1];
         }
+    };
+    auto cook = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
             if (i * 64 + lane < CB * PER) raw[i * 64 + lane] = r[i];
@@ -507,15 +510,23 @@ __global__ __launch_bounds__(128) void fx_comp_chain_kernel(CompMapArgs a) {
                 q[0] = pa; q[1] = pb; q[2] = da; q[3] = db;
             }
         }
+        __builtin_amdgcn_wave_barrier();
     };
-    if (wave == 1) cook(0, 0);
+    if (wave == 1) {
+        load(0);
+        cook(0);
+        load(1);
+    }
     __syncthreads();
     MstUniformF64 yu = mst_wave_read_u64(0.0, 0);                   // yL_prev = 0 on entry (common_audioeffects.py:553)
     const int pl = lane < MST_COMP_NP ? lane : MST_COMP_NP;          // lanes without a piece read the "never" entry
     for (int bt = 0; bt < nbatch; ++bt) {
         const int cur = bt & 1;
         if (wave == 1) {
-            if (bt + 1 < nbatch) cook(bt + 1, cur ^ 1);
+            if (bt + 1 < nbatch) {
+                cook(cur ^ 1);
+                load(bt + 2);
+            }
         } else {
             const int nc = a.nchunks - bt * CB < CB ? a.nchunks - bt * CB : CB;
             struct Piece { double pa, pb, da, db; };
