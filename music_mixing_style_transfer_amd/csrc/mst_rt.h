@@ -84,12 +84,8 @@ __device__ __forceinline__ float mst_acc_read(float x) {
     return r;
 }
 
-// the wave's predicate mask (v_cmp writes it straight into an SGPR pair), and lane `src`'s double in every lane
+// the wave's predicate mask (v_cmp writes it straight into an SGPR pair)
 __device__ __forceinline__ unsigned long long mst_wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-__device__ __forceinline__ double mst_wave_read_f64(double v, int src) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
 // a wave-uniform double as the two SGPR halves v_readlane returns (kept apart so that v_writelane can take them without a copy)
 struct MstUniformF64 {
     int lo, hi;

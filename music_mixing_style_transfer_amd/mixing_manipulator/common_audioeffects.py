@@ -95,6 +95,12 @@ class _Dev:
         self.n, self.L, self.C = self.x.shape
         self.stream = self.lib.stream_ptr(self.x)
 
+    def rebind(self, t):
+        """The batch this call works on changes along a chain (a processor may turn mono into stereo)."""
+        self.x = t
+        self.n, self.L, self.C = t.shape
+        return self
+
     def scratch(self, n_doubles):
         return torch.empty(n_doubles, dtype=torch.float64, device=self.x.device)
 
@@ -531,7 +537,7 @@ class _Pending:
         """The true batch [n, L, C] on the device."""
         if self.scale is None:
             return self.t
-        d = self.dev
+        d = self.dev.rebind(self.t)
         y = torch.empty_like(self.t)
         d.lib.check(d.lib.mst_fx_scale_items(self.t.data_ptr(), y.data_ptr(), d.n, self.t.shape[1] * self.t.shape[2],
                                              self.scale.data_ptr(), d.stream), "mst_fx_scale_items")
@@ -565,7 +571,7 @@ class AugmentationChain:
         d = x.dev
         if hasattr(processor, "fusable") and processor.fusable(d):
             # the pending rms factor of the previous step is folded into this processor's loads; its output leaves sum(y^2) behind
-            d.x = x.t
+            d.rebind(x.t)
             y, sumsq_y = processor._run(d, x.scale, rms_normalize)
             if not rms_normalize:
                 return _Pending(d, y, None, sumsq_y)
@@ -581,7 +587,7 @@ class AugmentationChain:
         y = processor.process(xm)
         if rms_normalize:
             y = rms_normalize_(xm, y)
-        d.x = y if y.dim() == 3 else y[None]
+        d.rebind(y if y.dim() == 3 else y[None])
         return _Pending(d, d.x, None, None)
 
     def apply_same_processor(self, x_list, processor, rms_normalize):

@@ -143,7 +143,6 @@ static inline unsigned long long mst_wave_ballot(bool p) {
     for (int l = 0; l < 64; ++l) { int v; memcpy(&v, base + 64 * l, sizeof(int)); m |= (unsigned long long)(v & 1) << l; }
     return m;
 }
-static inline double mst_wave_read_f64(double v, int src) { return emu_shfl(v, src); }
 struct MstUniformF64 {
     double v;
     double value() const { return v; }

@@ -4,7 +4,6 @@ embeddings, and the result equals the single-process run bit for bit (canonical-
 import os
 import sys
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -59,7 +58,6 @@ def _worker(rank, world, port, out_path):
 
 
 def test_two_ranks_equal_one(tmp_path, emu):
-    from music_mixing_style_transfer_amd.inference import segmentation as S
     from music_mixing_style_transfer_amd import _lib
     one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
     prev = _lib._default

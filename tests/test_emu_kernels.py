@@ -422,3 +422,21 @@ def test_algorithmic_reverb_emulated(emu_default):
     assert np.array_equal(yb[0], rv.process(x)) and np.abs(yb[1] - F.algorithmic_reverb(xb[1], **kw)).max() <= 2e-6
     chain = create_effects_augmentation_chain(["reverb"])            # no impulse-response directory: the algorithmic reverb
     assert type(chain.fxs[0][0]).__name__ == "AlgorithmicReverb" and chain.fxs[0][2] is True
+
+
+def test_advice_round1_regressions_emulated(emu_default):
+    """Round-1 advisor findings: (1) integer parameters draw with an exclusive upper bound - ConvolutionalReverb.randomize() never
+    indexes past its impulse-response list; (2) a MONO stem through a chain with a panner (mono -> stereo) and rms-normalise."""
+    from music_mixing_style_transfer_amd.mixing_manipulator import ConvolutionalReverb, create_effects_augmentation_chain
+    h = (np.exp(-np.arange(200) / 40.0)[:, None] * np.ones((1, 2))).astype(np.float32)
+    rv = ConvolutionalReverb([[{"impulse_response": (lambda: h)}], [{"impulse_response": (lambda: 0.5 * h)}]], 44100)
+    for _ in range(300):
+        rv.randomize()                                   # raised IndexError in a third of the calls before
+        assert 0 <= rv.parameters.index.value < 2
+    mono = synth.synth_music(1, 3000, seed=2).numpy().T.copy()          # [L, 1]
+    chain = create_effects_augmentation_chain(["pan", "gain"])
+    y = chain([mono])[0]
+    assert y.shape == (3000, 2) and np.isfinite(y).all()
+    # the panned stereo signal carries the mono input's mean square (rms-normalise across the channel change), up to the gain
+    g = 10.0 ** (chain.fxs[1][0].parameters.gain.value / 20.0)
+    assert abs(np.mean(y ** 2) / (g * g) - np.mean(mono ** 2)) <= 1e-5 * np.mean(mono ** 2) + 1e-9
