@@ -382,161 +382,186 @@ __global__ __launch_bounds__(64) void fx_comp_smooth_kernel(CompArgs a, double *
 // ------------------------------------------------------------------------------------------------
 // The smoother, parallel in time.  One step is y <- f_x(y) = (x > y) ? aA y + cA x : aR y + cR x.  With aA <= aR (attack faster
 // than release - every parameter range of the reference) f_x(y) = max(aA y + cA x, aR y + cR x): an increasing, convex,
-// piecewise-linear map, and so is every composition F = f_xT o ... o f_x1 of a chunk - with at most T + 1 linear pieces
-// (aA > aR: the same with min / concave).  Three kernels replace the 131072 dependent steps per sequence:
-//   fx_comp_map_kernel    one lane per (sequence, chunk of T steps): the pieces (a_i, b_i) of the chunk's map F, F(y) = max_i
-//                         (a_i y + b_i), sorted by value.  Step x: pieces whose range of values lies below x take the attack
-//                         transform, above x the release transform, the piece that crosses x is split there (f_x(x) = x).
+// piecewise-linear map, and so is every composition F = f_xT o ... o f_x1 of a chunk - with exactly T + 1 linear pieces
+// (aA > aR: the same with min / concave).  Two kernels replace the 131072 dependent steps per sequence, a third finishes:
+//   fx_comp_map_kernel    one lane per (sequence, chunk of T steps): the pieces of the chunk's map F, sorted by value.
 //   fx_comp_chain_kernel  one WAVE per sequence walks the chunks: lanes = pieces, y <- a_i y + b_i of the piece i that y falls in.
-//   fx_comp_fill_kernel   one lane per (sequence, chunk): the plain recursion inside the chunk from its true start value.
+//   fx_comp_apply_kernel<FILL>  one lane per (sequence, chunk): the plain recursion inside the chunk from its true start value, on the
+//                         way into the gain application.
 // Exact arithmetic gives the serial result; in float64 the chunk start values differ from it by rounding (~1e-15 relative).
+//
+// What a chunk's map needs to carry.  A step x splits exactly one piece - the one whose range of VALUES contains x (f_x(x) = x) -
+// sends the pieces below it through the attack branch and those above through the release branch.  So after n steps the piece at
+// sorted position p has been through n - p attack steps and p release steps whatever the signal was: its slope is aA^(n-p) aR^p, a
+// constant of the launch (CompMapArgs::slope).  F is continuous, so the pieces are fixed by the VALUES lb_p at which they meet plus the
+// intercept b_0 of the lowest piece: the kernel tracks only those (one float64 per piece) and rebuilds intercepts b_p and crossing
+// inputs u_p at the end:  u_1 = (lb_1 - b_0) / a_0,  u_(p+1) = u_p + (lb_(p+1) - lb_p) / a_p,  b_p = lb_p - a_p u_p.
+// A step on the sorted values is g_s = f_x(lb_s) (monotone: still sorted) followed by the insertion of x into the sorted list,
+// new_s = max(g_(s-1), min(g_s, x)): five float64 operations per piece and step, no compare, no select, no data-dependent move.
+// (Round 2's first version kept (a, b, lb) per piece and shifted them under exec masks: 4x the instructions, 2.5x the time.)
 // ------------------------------------------------------------------------------------------------
-#define MST_COMP_T 32                      // steps per chunk: T + 1 pieces of 4 doubles live in registers
+#define MST_COMP_T 32                      // steps per chunk: T + 1 pieces
 #define MST_COMP_NP (MST_COMP_T + 1)
+#define MST_COMP_REC (2 * (MST_COMP_NP + 1))   // doubles per stored record: (b_p, u_p) per piece + one entry that is never selected
+#define MST_COMP_NEVER 1e300
 
 struct CompMapArgs {
     const double *xl;     // [L][n_seq]  level differences (time-major)
-    double *maps;         // [n_seq][nchunks][MST_COMP_NP][2]  (a, b) per piece
+    double *maps;         // [n_seq][nchunks][MST_COMP_NP + 1][2]  (b, u) per piece, ascending
     double *ystart;       // [nchunks][n_seq]  smoother value at the start of each chunk
     int n_seq, nchunks;
     long L;
     double aA, aR;        // attack / release coefficients alpha
-    int use_min;          // aA > aR: concave maps, F = min over pieces
+    int use_min;          // aA > aR: concave maps
+    // slope of the piece at sorted position p and its reciprocal; [0]: a chunk of T steps, [1]: the last chunk when it is shorter
+    // (0 beyond its pieces)
+    double slope[2][MST_COMP_NP], inv_slope[2][MST_COMP_NP];
 };
 
-// grid (nchunks, ceil(n_seq / 64)), 64 threads: lanes = sequences of one chunk (coalesced time-major loads).
-// The pieces are kept SORTED by value (= by input range, F is increasing): piece s covers the values [lb_s, lb_{s+1}).  A step x
-// splits exactly one piece (the one whose value range contains x; the outermost pieces are unbounded): slots below the split take
-// the attack transform in place, slots above move up by one and take the release transform, the new slot starts at value x
-// (f_x(x) = x).  Sorted pieces let the chain kernel FIND the piece that applies to y instead of maximising over all of them.
-// Dead slots (fewer than T steps in the last chunk) are stored with slope -1.
-__global__ __launch_bounds__(64) MST_HEAVY_UNROLL void fx_comp_map_kernel(CompMapArgs a) {
-    __shared__ double tr[64 * (MST_COMP_NP * 2 + 1)];               // [lane][66 + 1 pad]: rows leave as whole 528-byte records
+// grid (nchunks, ceil(n_seq / 64)), 64 threads: lanes = sequences of one chunk (coalesced time-major loads).  Four waves per SIMD
+// (<= 128 registers, 8.5 KB of LDS): the early steps of a chunk have few pieces and little to overlap within one wave.
+template <bool USE_MIN>
+__global__ __launch_bounds__(64) MST_WAVES_PER_SIMD(4) MST_HEAVY_UNROLL void fx_comp_map_kernel(CompMapArgs a) {
+    constexpr int PASS = 16;                                        // doubles of every record that cross the LDS tile at a time (128 B)
+    __shared__ double tr[64 * (PASS + 1)];
     const int k = blockIdx.x;
     const int seq = blockIdx.y * 64 + threadIdx.x;
     const bool live = seq < a.n_seq;
     const size_t sq = live ? seq : a.n_seq - 1;
     const double cA = 1.0 - a.aA, cR = 1.0 - a.aR;
-    double pa[MST_COMP_NP], pb[MST_COMP_NP], lb[MST_COMP_NP];
-#pragma unroll
-    for (int i = 0; i < MST_COMP_NP; ++i) { pa[i] = -1.0; pb[i] = 0.0; lb[i] = 1e300; }
-    pa[0] = 1.0; pb[0] = 0.0; lb[0] = -1e300;                         // the identity before the first step
+    double lb[MST_COMP_NP + 1];                                     // lb[1 .. t]: the values at which the pieces meet after t steps
+    double b0 = 0.0;                                                // the lowest piece (always the attack branch); identity before step 1
 #pragma unroll
     for (int t = 0; t < MST_COMP_T; ++t) {
         const long n = (long)k * MST_COMP_T + t;
-        if (n < a.L) {                                             // uniform over the wave
+        if (n < a.L) {                                              // uniform over the wave
             const double x = a.xl[(size_t)n * a.n_seq + sq];
             const double oA = cA * x, oR = cR * x;
+            b0 = fma(a.aA, b0, oA);
+            // downwards, in place: slot s reads the old slots s and s - 1.  g = f_x(old value) = max (convex) / min (concave) of the branches
+            double m = x;                                           // min(g_s, x); above the top piece: x
 #pragma unroll
-            for (int s = t + 1; s >= 0; --s) {                     // downwards: slot s reads the old slots s and s - 1
-                const bool low = lb[s] < x;                        // the slot stays and takes the attack branch
-                const bool fresh = !low && (s > 0 ? lb[s > 0 ? s - 1 : 0] < x : false);   // the upper half of the split piece
-                const double qa = low ? pa[s] : pa[s > 0 ? s - 1 : 0], qb = low ? pb[s] : pb[s > 0 ? s - 1 : 0];
-                const double ql = low ? lb[s] : lb[s > 0 ? s - 1 : 0];
-                const double coef = low ? a.aA : a.aR, off = low ? oA : oR;
-                pa[s] = coef * qa;
-                pb[s] = fma(coef, qb, off);
-                lb[s] = fresh ? x : fma(coef, ql, off);
+            for (int s = t + 1; s >= 1; --s) {
+                if (s > 1) {
+                    const double v = lb[s - 1];
+                    const double gA = fma(a.aA, v, oA), gR = fma(a.aR, v, oR);
+                    const double g = USE_MIN ? fmin(gA, gR) : fmax(gA, gR);
+                    lb[s] = fmax(g, m);
+                    m = fmin(g, x);
+                } else {
+                    lb[1] = m;
+                }
             }
         }
     }
-    double *row = tr + threadIdx.x * (MST_COMP_NP * 2 + 1);
-#pragma unroll
-    for (int i = 0; i < MST_COMP_NP; ++i) {
-        row[2 * i] = pa[i];
-        row[2 * i + 1] = pb[i];
-    }
-    __builtin_amdgcn_wave_barrier();
+    const long left = a.L - (long)k * MST_COMP_T;
+    const int nsteps = left < MST_COMP_T ? (int)left : MST_COMP_T;  // uniform; >= 1
+    const bool shortc = nsteps < MST_COMP_T;                        // table [1]; selected element by element (scalar selects)
+    auto sl = [&](int p) { return shortc ? a.slope[1][p] : a.slope[0][p]; };
+    auto isl = [&](int p) { return shortc ? a.inv_slope[1][p] : a.inv_slope[0][p]; };
+    // the record (b_p, u_p), p = 0 .. NP (p = NP: the entry the lanes without a piece read), leaves in passes of 16 doubles through a
+    // [lane][16 + 1] tile: every store instruction of the wave writes 128 contiguous bytes of four records
     const int nlive = a.n_seq - blockIdx.y * 64 < 64 ? a.n_seq - blockIdx.y * 64 : 64;
-    for (int r = 0; r < nlive; ++r) {                              // 66 doubles per record: two coalesced sweeps of the wave
-        double *m = a.maps + ((size_t)(blockIdx.y * 64 + r) * a.nchunks + k) * (MST_COMP_NP * 2);
-        const double *src = tr + r * (MST_COMP_NP * 2 + 1);
-        m[threadIdx.x] = src[threadIdx.x];
-        if (threadIdx.x < MST_COMP_NP * 2 - 64) m[64 + threadIdx.x] = src[64 + threadIdx.x];
-    }
+    double *row = tr + threadIdx.x * (PASS + 1);
+    double *mbase = a.maps + ((size_t)(blockIdx.y * 64) * a.nchunks + k) * MST_COMP_REC;
+    double u = (lb[1] - b0) * isl(0);
+    auto pass = [&](auto J) {                                       // pieces 8 J .. 8 J + 7 (two flat loops: both unroll early, lb stays in registers)
+        constexpr int p0 = decltype(J)::value * (PASS / 2), p1 = p0 + PASS / 2 < MST_COMP_NP + 1 ? p0 + PASS / 2 : MST_COMP_NP + 1;
+        constexpr int cnt = 2 * (p1 - p0);                          // doubles in this pass
+#pragma unroll
+        for (int p = p0; p < p1; ++p) {
+            double pb, pu;
+            if (p == 0) {
+                pb = b0;
+                pu = -MST_COMP_NEVER;                               // the lowest piece: reached by every y
+            } else if (p <= nsteps && p < MST_COMP_NP) {            // uniform
+                if (p > 1) u = fma(lb[p] - lb[p - 1], isl(p - 1), u);
+                pb = fma(-sl(p), u, lb[p]);
+                pu = u;
+            } else {
+                pb = 0.0;
+                pu = MST_COMP_NEVER;
+            }
+            row[2 * (p - p0)] = pb;
+            row[2 * (p - p0) + 1] = pu;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < cnt; ++i) {                             // 64 records x cnt doubles, lane-linear over (record, double)
+            const int idx = i * 64 + threadIdx.x, r = idx / cnt, c = idx % cnt;
+            if (r < nlive) mbase[(size_t)r * a.nchunks * MST_COMP_REC + 2 * p0 + c] = tr[r * (PASS + 1) + c];
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    static_assert(MST_COMP_NP + 1 <= 5 * (PASS / 2), "five passes cover the record");
+    pass(std::integral_constant<int, 0>{});
+    pass(std::integral_constant<int, 1>{});
+    pass(std::integral_constant<int, 2>{});
+    pass(std::integral_constant<int, 3>{});
+    pass(std::integral_constant<int, 4>{});
 }
 
 // grid n_seq, 128 threads: two waves per sequence.  Wave 0 walks the chunks (lanes = pieces); wave 1 runs one batch of CB chunks ahead
-// of it and "cooks" the stored (a, b) records into per-piece entries (a, b, da, db) in LDS, where (da, db) is the crossing test of
-// pieces i - 1 and i: (a_i - a_{i-1}) y >= b_{i-1} - b_i (convex maps; <= for the concave ones of aA > aR).  A chunk step FINDS the
-// piece that applies to y: the pieces are sorted, so the number of lanes whose test passes IS the piece index, and y becomes that
-// lane's a_i y + b_i - one fma, one compare (straight into an SGPR pair), s_bcnt1, two v_readlane per chunk instead of a six-stage
-// float64 wave reduction.  Near a breakpoint the two neighbouring pieces agree to rounding, so a test decided by rounding picks an
-// equally valid piece.  The 32 steps of a batch are unrolled: entries are prefetched three chunks ahead with immediate offsets,
-// the chunk start values are parked in lane c of a register (v_writelane) and stored once per batch.
-template <bool USE_MIN>
+// of it and copies the stored records into LDS.  A chunk step FINDS the piece that applies to y: piece i applies from its crossing
+// input u_i on, and the pieces sit in the lanes in DESCENDING order, so the lowest lane with u <= y holds it - v_cmpx straight into
+// EXEC, v_readfirstlane of that lane's a_i y + b_i (mst_wave_first_ge): one float64 op and one lane read on the dependent chain per
+// chunk, instead of fma -> compare -> s_bcnt1 -> v_readlane (2.4x the latency) or a six-stage float64 wave reduction.  Near a
+// crossing the two neighbouring pieces agree to rounding, so a test decided by rounding picks an equally valid piece.  The slope is a
+// constant of the lane.  The 32 steps of a batch are unrolled: entries are prefetched three chunks ahead with immediate offsets, the
+// chunk start values are parked in lane c of a register (v_writelane) and stored once per batch.
+#ifndef MST_CHAIN_PROBE
+#define MST_CHAIN_PROBE 0      // tools/micro/fx_chain_variants.hip: 1 = the copy wave alone, 2 = the walker alone (timing probes)
+#endif
 __global__ __launch_bounds__(128) void fx_comp_chain_kernel(CompMapArgs a) {
-    constexpr int CB = 32, PER = MST_COMP_NP * 2, NLD = (CB * PER + 63) / 64;      // doubles per chunk / loads per lane per batch
-    constexpr int NPE = MST_COMP_NP + 1;                                             // entries per chunk: the pieces + one "never" entry
-    constexpr int NE = CB * NPE, NEL = (NE + 63) / 64;
-    __shared__ double raw[CB * PER];                                 // a batch of map records as stored: (a, b) per piece
-    __shared__ __attribute__((aligned(32))) double cooked[2][NE * 4];   // per (chunk, entry): a, b, da, db  (one 32-byte read per step)
+    constexpr int CB = 32, PER = MST_COMP_REC;                        // chunks per batch, doubles per record
+    constexpr int NLD = (CB * PER / 2 + 63) / 64;                     // 16-byte loads per copy lane per batch
+    __shared__ __attribute__((aligned(16))) double cooked[2][CB * PER];
     const int seq = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double *m = a.maps + (size_t)seq * a.nchunks * PER;
-    const size_t total = (size_t)a.nchunks * PER;
+    const double2 *m = (const double2 *)(a.maps + (size_t)seq * a.nchunks * PER);
+    const size_t total = (size_t)a.nchunks * PER / 2;
     const int nbatch = (a.nchunks + CB - 1) / CB;
-    const double never = USE_MIN ? -1e300 : 1e300;                   // db of a test that always fails
-    // ---- wave 1: global -> registers (requested one batch EARLIER than they are cooked: the loads of batch bt + 2 fly while the
-    //      walker is on batch bt + 1) -> raw records -> entries (17 entries per lane per batch)
-    double r[NLD];
+    // ---- wave 1: global -> registers (requested one batch EARLIER than they are written: the loads of batch bt + 2 fly while the
+    //      walker is on batch bt + 1) -> LDS
+    double2 r[NLD];
     auto load = [&](int bt) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const size_t e = (size_t)(bt < nbatch ? bt : nbatch - 1) * CB * PER + (size_t)i * 64 + lane;
+            const size_t e = (size_t)(bt < nbatch ? bt : nbatch - 1) * (CB * PER / 2) + (size_t)i * 64 + lane;
             r[i] = m[e < total ? e : total - 1];
         }
     };
     auto cook = [&](int buf) {
+        double2 *dst = (double2 *)cooked[buf];
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-            if (i * 64 + lane < CB * PER) raw[i * 64 + lane] = r[i];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < NEL; ++i) {
-            const int e = i * 64 + lane;
-            if (e < NE) {
-                const int c = e / NPE, piece = e % NPE;
-                double pa = 0.0, pb = 0.0, da = 0.0, db = never;   // entry NP and piece 0: the test never passes (no piece -> index 0)
-                if (piece < MST_COMP_NP) {
-                    const double *rec = raw + c * PER + 2 * piece;
-                    pa = rec[0];
-                    pb = rec[1];
-                    if (piece > 0 && pa >= 0.0) {                   // a live piece (dead slots carry slope -1)
-                        da = pa - rec[-2];
-                        db = rec[-1] - pb;
-                    }
-                }
-                double *q = cooked[buf] + 4 * e;
-                q[0] = pa; q[1] = pb; q[2] = da; q[3] = db;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
+            if (i * 64 + lane < CB * PER / 2) dst[i * 64 + lane] = r[i];
     };
-    if (wave == 1) {
+    if (wave != 0) {
         load(0);
         cook(0);
         load(1);
     }
     __syncthreads();
     MstUniformF64 yu = mst_wave_read_u64(0.0, 0);                   // yL_prev = 0 on entry (common_audioeffects.py:553)
-    const int pl = lane < MST_COMP_NP ? lane : MST_COMP_NP;          // lanes without a piece read the "never" entry
+    const int pl = lane < MST_COMP_NP ? MST_COMP_NP - 1 - lane : MST_COMP_NP;   // descending; lanes without a piece read the "never" entry
+    const double a_full = pl < MST_COMP_NP ? a.slope[0][pl] : 0.0, a_last = pl < MST_COMP_NP ? a.slope[1][pl] : 0.0;
     for (int bt = 0; bt < nbatch; ++bt) {
         const int cur = bt & 1;
-        if (wave == 1) {
-            if (bt + 1 < nbatch) {
+        if (wave != 0) {
+            if (bt + 1 < nbatch && (MST_CHAIN_PROBE != 2 || bt == 0)) {
                 cook(cur ^ 1);
                 load(bt + 2);
             }
-        } else {
+        } else if (MST_CHAIN_PROBE != 1) {
             const int nc = a.nchunks - bt * CB < CB ? a.nchunks - bt * CB : CB;
-            struct Piece { double pa, pb, da, db; };
-            const double *base = cooked[cur] + 4 * pl;
+            struct Piece { double pb, u; };
+            const double *base = cooked[cur] + 2 * pl;
             auto fetch = [&](int c) {
-                const double *q = base + 4 * NPE * (c < CB ? c : CB - 1);
-                return Piece{q[0], q[1], q[2], q[3]};
+                const double2 q = *(const double2 *)(base + PER * (c < CB ? c : CB - 1));
+                return Piece{q.x, q.y};
             };
             double keep = 0.0;                                      // lane c holds the start value of chunk c
-            if (nc == CB) {                                         // a whole batch: 32 steps in one basic block, y stays in SGPRs
+            if ((long)(bt + 1) * CB * MST_COMP_T <= a.L) {          // a whole batch of whole chunks: 32 steps in one basic block, y stays in SGPRs
                 Piece p[4];
                 p[0] = fetch(0); p[1] = fetch(1); p[2] = fetch(2);
                 yu = mst_wave_uniform(yu);
@@ -545,10 +570,7 @@ __global__ __launch_bounds__(128) void fx_comp_chain_kernel(CompMapArgs a) {
         p[((c) + 3) & 3] = fetch((c) + 3);                                                                             \
         keep = mst_wave_park_f64<(c)>(keep, yu);                                                                       \
         const Piece &q = p[(c) & 3];                                                                                   \
-        const double y = yu.value();                                                                                   \
-        const double t = fma(q.da, y, -q.db);                                                                          \
-        const int idx = __builtin_popcountll(mst_wave_ballot(USE_MIN ? t <= 0.0 : t >= 0.0));                          \
-        yu = mst_wave_read_u64(fma(q.pa, y, q.pb), idx);                                                               \
+        yu = mst_wave_first_ge(yu, q.u, fma(a_full, yu.value(), q.pb));                                                \
     }
 #define MST_CHAIN_STEP8(c) MST_CHAIN_STEP(c) MST_CHAIN_STEP((c) + 1) MST_CHAIN_STEP((c) + 2) MST_CHAIN_STEP((c) + 3) \
     MST_CHAIN_STEP((c) + 4) MST_CHAIN_STEP((c) + 5) MST_CHAIN_STEP((c) + 6) MST_CHAIN_STEP((c) + 7)
@@ -556,14 +578,13 @@ __global__ __launch_bounds__(128) void fx_comp_chain_kernel(CompMapArgs a) {
                 MST_CHAIN_STEP8(0) MST_CHAIN_STEP8(8) MST_CHAIN_STEP8(16) MST_CHAIN_STEP8(24)
 #undef MST_CHAIN_STEP8
 #undef MST_CHAIN_STEP
-            } else {                                                // the ragged last batch
+            } else {                                                // the last batch: ragged, or its last chunk is short
                 for (int c = 0; c < nc; ++c) {
                     const Piece q = fetch(c);
                     const double y = yu.value();
                     keep = lane == c ? y : keep;
-                    const double t = fma(q.da, y, -q.db);
-                    const int idx = __builtin_popcountll(mst_wave_ballot(USE_MIN ? t <= 0.0 : t >= 0.0));
-                    yu = mst_wave_read_u64(fma(q.pa, y, q.pb), idx);
+                    const double sa = (long)(bt * CB + c + 1) * MST_COMP_T > a.L ? a_last : a_full;
+                    yu = mst_wave_first_ge(yu, q.u, fma(sa, y, q.pb));
                 }
             }
             if (lane < nc) a.ystart[(size_t)(bt * CB + lane) * a.n_seq + seq] = keep;
@@ -572,41 +593,40 @@ __global__ __launch_bounds__(128) void fx_comp_chain_kernel(CompMapArgs a) {
     }
 }
 
-// grid (nchunks, ceil(n_seq / 64)), 64 threads: the recursion inside each chunk, y_l written over x_l
-__global__ __launch_bounds__(64) void fx_comp_fill_kernel(CompMapArgs a, double *xl) {
-    const int k = blockIdx.x;
-    const int seq = blockIdx.y * 64 + threadIdx.x;
-    if (seq >= a.n_seq) return;
-    const double cA = 1.0 - a.aA, cR = 1.0 - a.aR;
-    double prev = a.ystart[(size_t)k * a.n_seq + seq];
-    double v[MST_COMP_T];
-#pragma unroll
-    for (int t = 0; t < MST_COMP_T; ++t) {
-        const long n = (long)k * MST_COMP_T + t;
-        v[t] = xl[(size_t)(n < a.L ? n : a.L - 1) * a.n_seq + seq];
-    }
-#pragma unroll
-    for (int t = 0; t < MST_COMP_T; ++t) {
-        const double d = v[t] - prev;
-        prev = fma(d > 0.0 ? cA : cR, d, prev);
-        v[t] = prev;
-    }
-#pragma unroll
-    for (int t = 0; t < MST_COMP_T; ++t) {
-        const long n = (long)k * MST_COMP_T + t;
-        if (n < a.L) xl[(size_t)n * a.n_seq + seq] = v[t];
-    }
-}
-
-// grid (ceil(L / 64), ceil(n_seq / 64)), 256 threads
-__global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const double *yl) {
+// grid (ceil(L / 64), ceil(n_seq / 64)), 256 threads.  FILL: yl holds the level differences x_l and the smoother runs here, inside each
+// chunk from its true start value (two chunks per tile, one (chunk, sequence) per thread of the
+// first two waves) - the smoothed levels never travel to HBM and back.
+template <bool FILL>
+__global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const double *yl, const double *ystart, int nchunks) {
     __shared__ double t[64][65];
     const long n0 = (long)blockIdx.x * 64;
     const int s0 = blockIdx.y * 64;
+    if constexpr (FILL) {
+        static_assert(MST_COMP_T == 32, "two chunks per 64-step tile");
+        const int sl = threadIdx.x & 63, hh = threadIdx.x >> 6;
+        const long k = (long)blockIdx.x * 2 + hh;
+        if (hh < 2 && s0 + sl < a.n_seq && k < nchunks) {
+            const double cA = 1.0 - a.alpha_att, cR = 1.0 - a.alpha_rel;
+            double prev = ystart[(size_t)k * a.n_seq + s0 + sl];
+            double v[MST_COMP_T];
+#pragma unroll
+            for (int i = 0; i < MST_COMP_T; ++i) {
+                const long n = k * MST_COMP_T + i;
+                v[i] = yl[(size_t)(n < a.L ? n : a.L - 1) * a.n_seq + s0 + sl];
+            }
+#pragma unroll
+            for (int i = 0; i < MST_COMP_T; ++i) {
+                const double d = v[i] - prev;
+                prev = fma(d > 0.0 ? cA : cR, d, prev);
+                t[hh * MST_COMP_T + i][sl] = prev;
+            }
+        }
+    } else {
 #pragma unroll 4
-    for (int k = 0; k < 16; ++k) {
-        const int idx = k * 256 + threadIdx.x, nl = idx >> 6, sl = idx & 63;
-        t[nl][sl] = (s0 + sl < a.n_seq && n0 + nl < a.L) ? yl[(size_t)(n0 + nl) * a.n_seq + s0 + sl] : 0.0;
+        for (int k = 0; k < 16; ++k) {
+            const int idx = k * 256 + threadIdx.x, nl = idx >> 6, sl = idx & 63;
+            t[nl][sl] = (s0 + sl < a.n_seq && n0 + nl < a.L) ? yl[(size_t)(n0 + nl) * a.n_seq + s0 + sl] : 0.0;
+        }
     }
     __syncthreads();
 #pragma unroll 4
@@ -618,7 +638,8 @@ __global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const do
             const size_t e = ((size_t)(seq / a.C) * a.L + n) * a.C + seq % a.C;
             const size_t ex = a.shared_x ? (size_t)n * a.C + seq % a.C : e;
             const float sf = a.in_scale ? (float)a.in_scale[seq / a.C] : 1.0f;
-            const float out = (float)((double)(a.x[ex] * sf) * pow(10.0, (a.makeup - t[nl][sl]) / 20.0));
+            // 10^(v / 20) as exp(v ln10 / 20): the general pow() is five times the instructions for the same value to 1e-15 relative
+            const float out = (float)((double)(a.x[ex] * sf) * exp((a.makeup - t[nl][sl]) * 0.11512925464970228420));
             a.y[e] = out;
             if (a.out_sumsq) t[nl][sl] = (double)out * (double)out;          // this thread's own tile element: reused for the energy sum
         } else if (a.out_sumsq) {

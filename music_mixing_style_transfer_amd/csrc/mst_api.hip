@@ -1280,14 +1280,14 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
 }
 
 namespace {
-// scratch = level differences [L][n_seq] | chunk maps [n_seq][nchunks][NP][2] | chunk start values [nchunks][n_seq]
+// scratch = level differences [L][n_seq] | chunk maps [n_seq][nchunks][NP + 1][2] | chunk start values [nchunks][n_seq]
 struct CompScratch { size_t xl, maps, ystart, total; long nchunks; };
 CompScratch comp_scratch(int n_items, long L, int C) {
     CompScratch c;
     const size_t n_seq = (size_t)n_items * C;
     c.nchunks = (L + MST_COMP_T - 1) / MST_COMP_T;
     c.xl = n_seq * (size_t)L * sizeof(double);
-    c.maps = n_seq * (size_t)c.nchunks * MST_COMP_NP * 2 * sizeof(double);
+    c.maps = n_seq * (size_t)c.nchunks * MST_COMP_REC * sizeof(double);
     c.ystart = n_seq * (size_t)c.nchunks * sizeof(double);
     c.total = c.xl + c.maps + c.ystart;
     return c;
@@ -1324,16 +1324,26 @@ int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size
             m.aA = a.alpha_att;
             m.aR = a.alpha_rel;
             m.use_min = a.alpha_att > a.alpha_rel ? 1 : 0;
+            // the piece at sorted position p of a chunk of n steps has been through n - p attack and p release steps
+            const int n_last = (int)(L - (cs.nchunks - 1) * MST_COMP_T);
+            for (int which = 0; which < 2; ++which) {
+                const int n = which ? n_last : MST_COMP_T;
+                for (int p = 0; p < MST_COMP_NP; ++p) {
+                    m.slope[which][p] = p <= n ? std::pow(m.aA, n - p) * std::pow(m.aR, p) : 0.0;
+                    m.inv_slope[which][p] = p <= n ? 1.0 / m.slope[which][p] : 0.0;
+                }
+            }
             const dim3 cg((unsigned)cs.nchunks, (unsigned)((a.n_seq + 63) / 64));
-            MST_LAUNCH(fx_comp_map_kernel, cg, dim3(64), stream, m);
+            if (m.use_min) MST_LAUNCH(fx_comp_map_kernel<true>, cg, dim3(64), stream, m);
+            else MST_LAUNCH(fx_comp_map_kernel<false>, cg, dim3(64), stream, m);
             MST_CHECK_LAUNCH("fx_comp_map_kernel");
-            if (m.use_min) MST_LAUNCH((fx_comp_chain_kernel<true>), dim3(a.n_seq), dim3(128), stream, m);
-            else MST_LAUNCH((fx_comp_chain_kernel<false>), dim3(a.n_seq), dim3(128), stream, m);
+            MST_LAUNCH(fx_comp_chain_kernel, dim3(a.n_seq), dim3(128), stream, m);
             MST_CHECK_LAUNCH("fx_comp_chain_kernel");
-            MST_LAUNCH(fx_comp_fill_kernel, cg, dim3(64), stream, m, scratch);
-            MST_CHECK_LAUNCH("fx_comp_fill_kernel");
+            MST_LAUNCH((fx_comp_apply_kernel<true>), tiles, dim3(256), stream, a, (const double *)scratch, (const double *)m.ystart, m.nchunks);
+            MST_CHECK_LAUNCH("fx_comp_apply_kernel");
+            return MST_OK;
         }
-        MST_LAUNCH(fx_comp_apply_kernel, tiles, dim3(256), stream, a, (const double *)scratch);
+        MST_LAUNCH((fx_comp_apply_kernel<false>), tiles, dim3(256), stream, a, (const double *)scratch, (const double *)nullptr, 0);
         MST_CHECK_LAUNCH("fx_comp_apply_kernel");
         return MST_OK;
     }

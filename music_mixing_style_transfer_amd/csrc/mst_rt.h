@@ -12,6 +12,8 @@
 // marks a kernel whose fully unrolled body a HOST compiler cannot optimise in reasonable time (empty here; the emulator's mst_rt.h
 // turns it into an attribute for its own build)
 #define MST_HEAVY_UNROLL
+// register budget of a kernel: exactly n waves per SIMD (empty in the emulator)
+#define MST_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 
 #define MST_LAUNCH(kern, grid, block, stream, ...) \
     hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__)
@@ -96,6 +98,27 @@ __device__ __forceinline__ MstUniformF64 mst_wave_uniform(MstUniformF64 y) {    
 }
 __device__ __forceinline__ MstUniformF64 mst_wave_read_u64(double v, int src) {
     return MstUniformF64{__builtin_amdgcn_readlane(__double2loint(v), src), __builtin_amdgcn_readlane(__double2hiint(v), src)};
+}
+// r of the LOWEST lane whose u <= y (y wave-uniform; at least one lane must pass): v_cmpx writes the compare straight into EXEC and
+// v_readfirstlane picks the first lane left - no trip through the scalar unit (v_cmp -> s_bcnt1 -> v_readlane) on a dependent chain.
+// Wait states by hand (the hazard recogniser does not look inside): VALU-written SGPR -> VALU read 2, VALU-written EXEC -> readfirstlane 4.
+__device__ __forceinline__ MstUniformF64 mst_wave_first_ge(MstUniformF64 y, double u, double r) {
+    MstUniformF64 o;
+    unsigned long long save;
+    const double yd = y.value();
+    const int rlo = __double2loint(r), rhi = __double2hiint(r);
+    asm volatile("s_mov_b64 %[save], exec\n\t"
+                 "s_nop 0\n\t"
+                 "v_cmpx_ge_f64_e32 vcc, %[y], %[u]\n\t"
+                 "s_nop 3\n\t"
+                 "v_readfirstlane_b32 %[olo], %[rlo]\n\t"
+                 "v_readfirstlane_b32 %[ohi], %[rhi]\n\t"
+                 "s_mov_b64 exec, %[save]\n\t"
+                 "s_nop 0"
+                 : [olo] "=&s"(o.lo), [ohi] "=&s"(o.hi), [save] "=&s"(save)
+                 : [y] "s"(yd), [u] "v"(u), [rlo] "v"(rlo), [rhi] "v"(rhi)
+                 : "vcc");
+    return o;
 }
 // the wave-uniform y written into lane `dst` of keep (v_writelane_b32 x 2: no compare, no exec change)
 template <int DST> __device__ __forceinline__ double mst_wave_park_f64(double keep, MstUniformF64 y) {

@@ -17,6 +17,7 @@
 
 #define MST_EMULATED 1
 #define MST_HEAVY_UNROLL __attribute__((optnone))      // host clang needs > 10 minutes at -O2 for the unrolled compressor map kernel
+#define MST_WAVES_PER_SIMD(n)
 #define __global__
 #define __device__
 #define __host__
@@ -57,6 +58,7 @@ static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return 0; }
 
 struct float2 { float x, y; };
+struct double2 { double x, y; };
 struct float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return {x, y}; }
@@ -149,6 +151,10 @@ struct MstUniformF64 {
 };
 static inline MstUniformF64 mst_wave_read_u64(double v, int src) { return MstUniformF64{emu_shfl(v, src)}; }
 static inline MstUniformF64 mst_wave_uniform(MstUniformF64 y) { return y; }
+static inline MstUniformF64 mst_wave_first_ge(MstUniformF64 y, double u, double r) {
+    const unsigned long long m = mst_wave_ballot(y.v >= u);
+    return MstUniformF64{emu_shfl(r, m ? __builtin_ctzll(m) : 0)};
+}
 template <int DST> static inline double mst_wave_park_f64(double keep, MstUniformF64 y) { return emu::lane_id() == DST ? y.v : keep; }
 template <typename T> static inline T __shfl_down(T v, int d, int = 64) {
     const int l = emu::lane_id();
