@@ -154,20 +154,21 @@ __global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) 
 }
 
 // s_0 = 0 ; s_k = A^M s_{k-1} + e_{k-1}: a first-order linear recurrence over the chunks with a matrix coefficient - scanned in
-// parallel.  One workgroup of 256 threads per sequence; a block of 255 chunks at a time: element 0 is the carry (the start state of
-// the block's first chunk), element i > 0 the zero-state end state of chunk i - 1, and a Hillis-Steele scan
-//     t_i += (A^M)^(2^l) t_{i - 2^l}      l = 0 .. 7
-// leaves t_i = the true start state of chunk i (t_255 = the next block's carry).  The powers (A^M)^(2^l) are squared up in LDS by
+// parallel.  One workgroup of NB = 256 or 512 threads per sequence; a block of NB - 1 chunks at a time: element 0 is the carry (the
+// start state of the block's first chunk), element i > 0 the zero-state end state of chunk i - 1, and a Hillis-Steele scan
+//     t_i += (A^M)^(2^l) t_{i - 2^l}      l = 0 .. log2(NB) - 1
+// leaves t_i = the true start state of chunk i (t_(NB-1) = the next block's carry).  The powers (A^M)^(2^l) are squared up in LDS by
 // the workgroup itself from A^M (kernel argument, float64).  128 sequences x 128 chunks: 8 matrix-vector products of depth per
 // sequence instead of 128 (round 1's kernel ran one LANE per sequence: 2 workgroups, 88 us); a 3-minute stem (7 752 chunks) is
 // 31 blocks instead of 7 752 serial steps.  AM is [S][S] row-major with S = 2 * n_bands, state order (z1, z2) per band; ends /
 // starts are laid out [chunk][state][sequence].
 struct BiquadPowArgs { double am[4 * MST_MAX_BANDS * MST_MAX_BANDS]; };      // A^M, [S][S] row-major, by value in the kernel arguments
 
-template <int NBANDS>
-__global__ __launch_bounds__(256) void fx_biquad_scan_kernel(const double *ends, double *starts, BiquadPowArgs pw, int n_seq,
-                                                            int nchunks) {
-    constexpr int SM = 2 * MST_MAX_BANDS, S = 2 * NBANDS, NL = 8, NB = 256;      // table row stride / live states / levels / elements
+template <int NBANDS, int NB>
+__global__ __launch_bounds__(NB) void fx_biquad_scan_kernel(const double *ends, double *starts, BiquadPowArgs pw, int n_seq,
+                                                           int nchunks) {
+    constexpr int SM = 2 * MST_MAX_BANDS, S = 2 * NBANDS, NL = NB == 512 ? 9 : 8;      // table row stride / live states / levels
+    static_assert(NB == 256 || NB == 512, "elements per block");
     __shared__ double pm[NL][S * S];                 // (A^M)^(2^l)
     __shared__ double st[2][NB][S];
     const int seq = blockIdx.x, i = threadIdx.x;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void fx_biquad_scan_kernel(const double *ends,
             __syncthreads();
             cur ^= 1;
         }
-        // t = start state of chunk k0 + i (i < 255); element 255 is the next block's carry
+        // t = start state of chunk k0 + i (i < NB - 1); the last element is the next block's carry
         if (i < NB - 1 && k0 + i < nchunks) {
 #pragma unroll
             for (int j = 0; j < S; ++j) starts[((size_t)(k0 + i) * SM + j) * n_seq + seq] = t[j];

@@ -1167,7 +1167,16 @@ extern "C" int mst_embedding_mean(const float *emb, int n_rows, int dim, float *
 // FX processors
 // =================================================================================================
 namespace {
-constexpr int BIQUAD_CHUNK = 1024;
+// Steps per chunk of the time-parallel biquad cascade.  Two chunk passes cost ~0.19 us per step of a chunk (one lane walks it), the
+// scan over the chunk states ~25 us per block of 511 chunks: short segments get one scan block (a 131072-sample segment: 272 steps,
+// 482 chunks - with 128 sequences that is one wave per SIMD), long stems the chunk length that balances the two, sqrt(L / 4).
+int biquad_chunk(long L) {
+    auto up16 = [](long v) { return (int)((v + 15) / 16 * 16); };
+    const int one_block = up16((L + 510) / 511);
+    if (one_block <= 1024) return one_block < 64 ? 64 : one_block;
+    const int bal = up16((long)std::sqrt((double)L / 4.0));
+    return bal < 1024 ? 1024 : (bal > 4096 ? 4096 : bal);
+}
 void biquad_coefs(const double *coef, int n_bands, double (*out)[5]) {
     for (int k = 0; k < MST_MAX_BANDS; ++k)
         for (int i = 0; i < 5; ++i) out[k][i] = 0.0;
@@ -1184,7 +1193,8 @@ void biquad_coefs(const double *coef, int n_bands, double (*out)[5]) {
 
 extern "C" size_t mst_fx_biquad_scratch_bytes(int n_items, long L, int C, int n_bands) {
     if (n_items < 1 || L < 1 || C < 1 || n_bands < 1) return 0;
-    const long nchunks = (L + BIQUAD_CHUNK - 1) / BIQUAD_CHUNK;
+    const int M = biquad_chunk(L);
+    const long nchunks = (L + M - 1) / M;
     const size_t states = (size_t)n_items * C * nchunks * 2 * MST_MAX_BANDS;
     return (2 * states + (size_t)4 * MST_MAX_BANDS * MST_MAX_BANDS) * sizeof(double);
 }
@@ -1193,7 +1203,8 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
                                      double *scratch, size_t scratch_bytes, const MstFxFuse *fuse, void *stream) {
     if (!x || !y || !coef || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_biquad_cascade: bad argument");
     if (n_bands < 0 || n_bands > MST_MAX_BANDS) return fail(MST_ERR_UNSUPPORTED, "mst_fx_biquad_cascade: at most 8 bands");
-    const long nchunks = (L + BIQUAD_CHUNK - 1) / BIQUAD_CHUNK;
+    const int M = biquad_chunk(L);
+    const long nchunks = (L + M - 1) / M;
     if (scratch && nchunks > 1 && n_bands > 0) {
         if (scratch_bytes < mst_fx_biquad_scratch_bytes(n_items, L, C, n_bands))
             return fail(MST_ERR_WORKSPACE, "mst_fx_biquad_cascade: scratch too small");
@@ -1203,7 +1214,7 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         a.n_seq = n_items * C;
         a.C = C;
         a.nchunks = (int)nchunks;
-        a.M = BIQUAD_CHUNK;
+        a.M = M;
         a.L = L;
         a.n_bands = n_bands;
         a.in_scale = fuse ? fuse->in_scale_dev : nullptr;
@@ -1220,7 +1231,7 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         for (int col = 0; col < S; ++col) {
             std::vector<double> z(S, 0.0);
             z[col] = 1.0;
-            for (int n = 0; n < BIQUAD_CHUNK; ++n) {
+            for (int n = 0; n < M; ++n) {
                 double v = 0.0;
                 for (int b = 0; b < n_bands; ++b) {
                     const double yn = a.coef[b][0] * v + z[2 * b];
@@ -1249,16 +1260,22 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         launch_chunks(std::false_type{});
         MST_CHECK_LAUNCH("fx_biquad_chunk_kernel<state>");
         const dim3 sg((unsigned)a.n_seq);
-        switch (n_bands) {
-            case 1: MST_LAUNCH((fx_biquad_scan_kernel<1>), sg, dim3(256), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
-            case 2: MST_LAUNCH((fx_biquad_scan_kernel<2>), sg, dim3(256), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
-            case 3: MST_LAUNCH((fx_biquad_scan_kernel<3>), sg, dim3(256), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
-            case 4: MST_LAUNCH((fx_biquad_scan_kernel<4>), sg, dim3(256), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
-            case 5: MST_LAUNCH((fx_biquad_scan_kernel<5>), sg, dim3(256), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
-            case 6: MST_LAUNCH((fx_biquad_scan_kernel<6>), sg, dim3(256), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
-            case 7: MST_LAUNCH((fx_biquad_scan_kernel<7>), sg, dim3(256), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
-            default: MST_LAUNCH((fx_biquad_scan_kernel<8>), sg, dim3(256), stream, (const double *)ends, starts, pw, a.n_seq, (int)nchunks); break;
-        }
+        auto launch_scan = [&](auto NBv) {
+            constexpr int nb = decltype(NBv)::value;
+            const double *e = ends;
+            switch (n_bands) {
+                case 1: MST_LAUNCH((fx_biquad_scan_kernel<1, nb>), sg, dim3(nb), stream, e, starts, pw, a.n_seq, (int)nchunks); break;
+                case 2: MST_LAUNCH((fx_biquad_scan_kernel<2, nb>), sg, dim3(nb), stream, e, starts, pw, a.n_seq, (int)nchunks); break;
+                case 3: MST_LAUNCH((fx_biquad_scan_kernel<3, nb>), sg, dim3(nb), stream, e, starts, pw, a.n_seq, (int)nchunks); break;
+                case 4: MST_LAUNCH((fx_biquad_scan_kernel<4, nb>), sg, dim3(nb), stream, e, starts, pw, a.n_seq, (int)nchunks); break;
+                case 5: MST_LAUNCH((fx_biquad_scan_kernel<5, nb>), sg, dim3(nb), stream, e, starts, pw, a.n_seq, (int)nchunks); break;
+                case 6: MST_LAUNCH((fx_biquad_scan_kernel<6, nb>), sg, dim3(nb), stream, e, starts, pw, a.n_seq, (int)nchunks); break;
+                case 7: MST_LAUNCH((fx_biquad_scan_kernel<7, nb>), sg, dim3(nb), stream, e, starts, pw, a.n_seq, (int)nchunks); break;
+                default: MST_LAUNCH((fx_biquad_scan_kernel<8, nb>), sg, dim3(nb), stream, e, starts, pw, a.n_seq, (int)nchunks); break;
+            }
+        };
+        if (nchunks > 255) launch_scan(std::integral_constant<int, 512>{});
+        else launch_scan(std::integral_constant<int, 256>{});
         MST_CHECK_LAUNCH("fx_biquad_scan_kernel");
         launch_chunks(std::true_type{});
         MST_CHECK_LAUNCH("fx_biquad_chunk_kernel<apply>");

@@ -99,23 +99,22 @@ __device__ __forceinline__ MstUniformF64 mst_wave_uniform(MstUniformF64 y) {    
 __device__ __forceinline__ MstUniformF64 mst_wave_read_u64(double v, int src) {
     return MstUniformF64{__builtin_amdgcn_readlane(__double2loint(v), src), __builtin_amdgcn_readlane(__double2hiint(v), src)};
 }
-// r of the LOWEST lane whose u <= y (y wave-uniform; at least one lane must pass): v_cmpx writes the compare straight into EXEC and
-// v_readfirstlane picks the first lane left - no trip through the scalar unit (v_cmp -> s_bcnt1 -> v_readlane) on a dependent chain.
-// Wait states by hand (the hazard recogniser does not look inside): VALU-written SGPR -> VALU read 2, VALU-written EXEC -> readfirstlane 4.
+// r of the LOWEST lane whose u <= y (y wave-uniform; at least one lane must pass; ALL 64 lanes of the calling wave must be active - EXEC
+// is put back to all ones): v_cmpx writes the compare straight into EXEC and v_readfirstlane picks the first lane left - no trip through
+// the scalar unit (v_cmp -> s_bcnt1 -> v_readlane) on a dependent chain.  Wait states by hand (the hazard recogniser does not look
+// inside): VALU-written EXEC -> v_readfirstlane 4; VALU-written SGPR -> VALU read 2 (the trailing s_nop; callers keep two instructions
+// between two calls of a chain, which the fma that produces r and the bookkeeping around it always are).
 __device__ __forceinline__ MstUniformF64 mst_wave_first_ge(MstUniformF64 y, double u, double r) {
     MstUniformF64 o;
-    unsigned long long save;
     const double yd = y.value();
     const int rlo = __double2loint(r), rhi = __double2hiint(r);
-    asm volatile("s_mov_b64 %[save], exec\n\t"
-                 "s_nop 0\n\t"
-                 "v_cmpx_ge_f64_e32 vcc, %[y], %[u]\n\t"
+    asm volatile("v_cmpx_ge_f64_e32 vcc, %[y], %[u]\n\t"
                  "s_nop 3\n\t"
                  "v_readfirstlane_b32 %[olo], %[rlo]\n\t"
                  "v_readfirstlane_b32 %[ohi], %[rhi]\n\t"
-                 "s_mov_b64 exec, %[save]\n\t"
+                 "s_mov_b64 exec, -1\n\t"
                  "s_nop 0"
-                 : [olo] "=&s"(o.lo), [ohi] "=&s"(o.hi), [save] "=&s"(save)
+                 : [olo] "=&s"(o.lo), [ohi] "=&s"(o.hi)
                  : [y] "s"(yd), [u] "v"(u), [rlo] "v"(rlo), [rhi] "v"(rhi)
                  : "vcc");
     return o;

@@ -172,6 +172,9 @@ def test_fx_emulated(emu_default):
     for band, (gg, fc, q) in F.CONFIG4["eq"].items():
         getattr(eq.parameters, band + "_gain").value = gg
     assert np.abs(eq.process(x.copy()) - F.equaliser(x.copy(), F.CONFIG4["eq"])).max() <= 1e-7
+    # more than 255 chunks: the 512-element scan over the chunk states (20000 samples -> 313 chunks of 64), ragged last chunk
+    xl = (0.1 * np.random.default_rng(5).standard_normal((20000, 2))).astype(np.float32)
+    assert np.abs(eq.process(xl.copy()) - F.equaliser(xl.copy(), F.CONFIG4["eq"])).max() <= 1e-7
     im = MidSideImager()
     for bal in (0.0, 0.4567, 1.5, 2.0):
         im.parameters.bal.value = bal
