@@ -214,6 +214,17 @@ def bench_parity_mode(engine, enc, tcn, lib, ref, inp, dev, enc_cfg, enc_sd, tcn
 
 
 # ------------------------------------------------------------------------------------------------ FX chain (config 4)
+def bench_input_normalizer():
+    """Row F: Audio_Effects_Normalizer (the reference CLI's default --normalize_input True) on two 3-minute stereo stems, the oracle
+    chain on a 6 s excerpt beside it (tools/bench_normalizer.py)."""
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import bench_normalizer
+    r = bench_normalizer.run(180.0, 6.0, "drums,other")
+    return {"workload": "loudness -> eq -> compression -> imager -> loudness on 2 stems of [7938000, 2] (host in, host out)",
+            "value": r["value"], "unit": r["unit"], "s_per_stem": r["s_per_stem"], "s_per_effect": r["s_per_effect"],
+            "rel_dev_vs_oracle_on_excerpt": r["rel_dev_vs_oracle_on_excerpt"], "cpu_baseline": r["cpu_baseline"]}
+
+
 def bench_fx_chain(dev, steps=5):
     import numpy as np
     from music_mixing_style_transfer_amd.mixing_manipulator import (AugmentationChain, Compressor, Equaliser, Gain,
@@ -365,6 +376,7 @@ def main():
             out["parity_mode"] = bench_parity_mode(engine, enc, tcn, lib, ref, inp, dev, enc_cfg, enc_sd, tcn_sd)
             out["bf16x3_mode"] = bench_parity_mode(engine, enc, tcn, lib, ref, inp, dev, enc_cfg, enc_sd, tcn_sd, "bf16x3")
             out["fx_chain"] = bench_fx_chain(dev)
+            out["input_normalizer"] = bench_input_normalizer()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(enc_cfg, enc_sd, tcn_sd)
         print(json.dumps(out), flush=True)

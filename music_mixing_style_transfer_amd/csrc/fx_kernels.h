@@ -773,34 +773,38 @@ __global__ __launch_bounds__(256) void fx_panner_kernel(const float *x, float *y
     yp[1] = xp[c_in - 1] * g1;
 }
 
-// ---- FFT convolution reverb (ConvolutionalReverb.process, common_audioeffects.py:727-764) -------------------------
-// The two FFTs and the inverse run in hipFFT (plain library transforms); everything around them is here.
-// pack: interleaved [n_items][L][C] -> one zero-padded real sequence of n_fft samples per (item, channel)
-__global__ __launch_bounds__(256) void fx_conv_pack_kernel(const float *x, float *seq, long L, int C, long n_fft) {
-    const int sq = blockIdx.y, item = sq / C, c = sq % C;
+// ---- FFT convolution (ConvolutionalReverb.process, common_audioeffects.py:727-764; the normaliser's 1001-tap FIR) ----------------
+// The two FFTs and the inverse run in hipFFT (plain library transforms); everything around them is here.  A signal that is long
+// against the impulse response is cut into nb overlapping blocks (overlap-save): block b holds the samples b * step - shift + i,
+// i in [0, n_fft), its circular convolution with the zero-padded response is the linear convolution at the outputs b * step + j,
+// j in [0, step), found at position shift + j.  A short signal is one block with step = n_fft, shift = 0.
+// pack: interleaved [n_items][L][C] -> nb zero-padded real blocks of n_fft samples per (item, channel)
+__global__ __launch_bounds__(256) void fx_conv_pack_kernel(const float *x, float *seq, long L, int C, long n_fft, int nb, long step, long shift) {
+    const int blk = blockIdx.y, sq = blk / nb, b = blk % nb, item = sq / C, c = sq % C;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_fft) return;
-    seq[(size_t)sq * n_fft + i] = i < L ? x[((size_t)item * L + i) * C + c] : 0.0f;
+    const long n = (long)b * step - shift + i;
+    seq[(size_t)blk * n_fft + i] = (n >= 0 && n < L) ? x[((size_t)item * L + n) * C + c] : 0.0f;
 }
 
-// spectrum product X[s][k] *= H[s % C][k] / n_fft (hipFFT's inverse is unnormalised)
-__global__ __launch_bounds__(256) void fx_conv_mul_kernel(float2 *X, const float2 *H, long nbin, int C, float scale) {
-    const int sq = blockIdx.y;
+// spectrum product X[block of sequence s][k] *= H[s % C][k] / n_fft (hipFFT's inverse is unnormalised)
+__global__ __launch_bounds__(256) void fx_conv_mul_kernel(float2 *X, const float2 *H, long nbin, int C, int nb, float scale) {
+    const int blk = blockIdx.y, sq = blk / nb;
     const long k = (long)blockIdx.x * 256 + threadIdx.x;
     if (k >= nbin) return;
-    const float2 a = X[(size_t)sq * nbin + k], b = H[(size_t)(sq % C) * nbin + k];
-    X[(size_t)sq * nbin + k] = make_float2((a.x * b.x - a.y * b.y) * scale, (a.x * b.y + a.y * b.x) * scale);
+    const float2 a = X[(size_t)blk * nbin + k], b = H[(size_t)(sq % C) * nbin + k];
+    X[(size_t)blk * nbin + k] = make_float2((a.x * b.x - a.y * b.y) * scale, (a.x * b.y + a.y * b.x) * scale);
 }
 
 // y[item][t][c] = dry * x[item][t][c] + wet * conv[item, c][offset + t]   (the reference cuts y[idx : idx + len(x)], :754-761)
-__global__ __launch_bounds__(256) void fx_conv_mix_kernel(const float *x, const float *seq, float *y, long L, int C, long n_fft,
-                                                          long offset, float dry, float wet) {
+__global__ __launch_bounds__(256) void fx_conv_mix_kernel(const float *x, const float *seq, float *y, long L, int C, long n_fft, int nb,
+                                                          long step, long shift, long offset, float dry, float wet) {
     const int item = blockIdx.y;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;          // element of the [L][C] item
     if (e >= L * C) return;
-    const long t = e / C;
+    const long t = e / C, m = offset + t, b = m / step;
     const int c = (int)(e % C);
-    const float v = seq[((size_t)item * C + c) * n_fft + offset + t];
+    const float v = seq[(((size_t)item * C + c) * nb + b) * n_fft + shift + (m - b * step)];
     y[(size_t)item * L * C + e] = dry * x[(size_t)item * L * C + e] + wet * v;
 }
 

@@ -1520,6 +1520,8 @@ extern "C" int mst_fx_panner(const float *x, float *y, int n_items, long L, int 
 // ---- FFT convolution (ConvolutionalReverb) ---------------------------------------------------------------------------
 struct MstConvolver {
     long L = 0, Lh_max = 0, n_fft = 0;
+    long step = 0, shift = 0;       // overlap-save: block b holds the samples b * step - shift + i; one block: step = n_fft, shift = 0
+    int nb = 1;                     // blocks per (item, channel)
     int n_items = 0, C = 0;
     void *plan_x = nullptr, *plan_h = nullptr, *plan_inv = nullptr;       // hipfftHandle: R2C batch n_items*C, R2C batch C, C2R
 };
@@ -1554,13 +1556,30 @@ extern "C" int mst_fx_convolver_create(long L, long Lh_max, int n_items, int C, 
     if (!f.ok) return fail(MST_ERR_HIP, "mst_fx_convolver_create: cannot load hipFFT (libhipfft.so)");
     long n = 1;
     while (n < L + Lh_max - 1) n <<= 1;
+    long step = n, shift = 0;
+    int nb = 1;
+    if (n > (1L << 18)) {
+        // a long signal: overlap-save blocks of max(2^16, 4 x the response rounded up to a power of two) samples - one plan (and one
+        // set of run-time-compiled transform kernels) for every signal length, float32 rounding of a 2^16..2^19-point transform
+        long nh = 1;
+        while (nh < Lh_max) nh <<= 1;
+        const long nblk = 4 * nh > (1L << 16) ? 4 * nh : (1L << 16);
+        if (nblk < n) {
+            n = nblk;
+            shift = Lh_max - 1;
+            step = n - shift;
+            nb = (int)((L + Lh_max - 1 + step - 1) / step);
+        }
+    }
     if (n > (1L << 30)) return fail(MST_ERR_UNSUPPORTED, "mst_fx_convolver_create: transform longer than 2^30 samples");
+    if ((long)n_items * C * nb > 65535) return fail(MST_ERR_UNSUPPORTED, "mst_fx_convolver_create: more than 65535 transform blocks (split the batch)");
     auto *cv = new MstConvolver;
     cv->L = L; cv->Lh_max = Lh_max; cv->n_fft = n; cv->n_items = n_items; cv->C = C;
+    cv->step = step; cv->shift = shift; cv->nb = nb;
     int nn = (int)n;
-    if (f.plan_many(&cv->plan_x, 1, &nn, nullptr, 1, 0, nullptr, 1, 0, kFftR2C, n_items * C) ||
+    if (f.plan_many(&cv->plan_x, 1, &nn, nullptr, 1, 0, nullptr, 1, 0, kFftR2C, n_items * C * nb) ||
         f.plan_many(&cv->plan_h, 1, &nn, nullptr, 1, 0, nullptr, 1, 0, kFftR2C, C) ||
-        f.plan_many(&cv->plan_inv, 1, &nn, nullptr, 1, 0, nullptr, 1, 0, kFftC2R, n_items * C)) {
+        f.plan_many(&cv->plan_inv, 1, &nn, nullptr, 1, 0, nullptr, 1, 0, kFftC2R, n_items * C * nb)) {
         mst_fx_convolver_destroy(cv);
         return fail(MST_ERR_HIP, "mst_fx_convolver_create: hipfftPlanMany failed");
     }
@@ -1581,7 +1600,7 @@ extern "C" void mst_fx_convolver_destroy(MstConvolver *cv) {
 
 extern "C" size_t mst_fx_convolver_workspace_bytes(const MstConvolver *cv) {
     if (!cv) return 0;
-    const size_t nbin = (size_t)cv->n_fft / 2 + 1, seqs = (size_t)cv->n_items * cv->C + cv->C;
+    const size_t nbin = (size_t)cv->n_fft / 2 + 1, seqs = (size_t)cv->n_items * cv->C * cv->nb + cv->C;
     return seqs * (size_t)cv->n_fft * sizeof(float) + seqs * nbin * sizeof(float2) + 256;
 }
 
@@ -1593,25 +1612,25 @@ extern "C" int mst_fx_convolve(MstConvolver *cv, const float *x, const float *h,
     if (ws_bytes < mst_fx_convolver_workspace_bytes(cv)) return fail(MST_ERR_WORKSPACE, "mst_fx_convolve: workspace too small");
     const FftApi &f = fft_api();
     const long n = cv->n_fft, nbin = n / 2 + 1;
-    const int nseq = cv->n_items * cv->C, C = cv->C;
-    float *rx = (float *)ws, *rh = rx + (size_t)nseq * n;
-    float2 *cx = (float2 *)(((uintptr_t)(rh + (size_t)C * n) + 255) & ~(uintptr_t)255), *ch = cx + (size_t)nseq * nbin;
+    const int nseq = cv->n_items * cv->C, C = cv->C, nb = cv->nb, nblk = nseq * nb;
+    float *rx = (float *)ws, *rh = rx + (size_t)nblk * n;
+    float2 *cx = (float2 *)(((uintptr_t)(rh + (size_t)C * n) + 255) & ~(uintptr_t)255), *ch = cx + (size_t)nblk * nbin;
     const unsigned gb = (unsigned)((n + 255) / 256);
-    MST_LAUNCH(fx_conv_pack_kernel, dim3(gb, nseq), dim3(256), stream, x, rx, cv->L, C, n);
+    MST_LAUNCH(fx_conv_pack_kernel, dim3(gb, nblk), dim3(256), stream, x, rx, cv->L, C, n, nb, cv->step, cv->shift);
     MST_CHECK_LAUNCH("fx_conv_pack_kernel");
-    MST_LAUNCH(fx_conv_pack_kernel, dim3(gb, C), dim3(256), stream, h, rh, Lh, C, n);       // the IR is one [Lh][C] "item"
+    MST_LAUNCH(fx_conv_pack_kernel, dim3(gb, C), dim3(256), stream, h, rh, Lh, C, n, 1, n, 0L);       // the IR is one [Lh][C] "item"
     MST_CHECK_LAUNCH("fx_conv_pack_kernel");
     if (f.set_stream(cv->plan_x, (hipStream_t)stream) || f.set_stream(cv->plan_h, (hipStream_t)stream) ||
         f.set_stream(cv->plan_inv, (hipStream_t)stream))
         return fail(MST_ERR_HIP, "mst_fx_convolve: hipfftSetStream failed");
     if (f.exec_r2c(cv->plan_x, rx, cx) || f.exec_r2c(cv->plan_h, rh, ch)) return fail(MST_ERR_HIP, "mst_fx_convolve: hipfftExecR2C failed");
-    MST_LAUNCH(fx_conv_mul_kernel, dim3((unsigned)((nbin + 255) / 256), nseq), dim3(256), stream, cx, (const float2 *)ch, nbin, C,
+    MST_LAUNCH(fx_conv_mul_kernel, dim3((unsigned)((nbin + 255) / 256), nblk), dim3(256), stream, cx, (const float2 *)ch, nbin, C, nb,
                1.0f / (float)n);
     MST_CHECK_LAUNCH("fx_conv_mul_kernel");
     if (f.exec_c2r(cv->plan_inv, cx, rx)) return fail(MST_ERR_HIP, "mst_fx_convolve: hipfftExecC2R failed");
     const long per = cv->L * C;
     MST_LAUNCH(fx_conv_mix_kernel, dim3((unsigned)((per + 255) / 256), cv->n_items), dim3(256), stream, x, (const float *)rx, y, cv->L,
-               C, n, offset, (float)dry, (float)wet);
+               C, n, nb, cv->step, cv->shift, offset, (float)dry, (float)wet);
     MST_CHECK_LAUNCH("fx_conv_mix_kernel");
     return MST_OK;
 }

@@ -819,6 +819,19 @@ def test_input_normalizer_pieces_vs_reference_goldens(oracle_fx_lib):
     assert rel(od[:, 0], hfc) <= 1e-4 and rel(od[:, 1], ms) <= 1e-5
 
 
+def test_fir_overlap_save_long_signal():
+    """The normaliser's 1001-tap zero-phase FIR on a stem-sized signal (2 M samples: 32 overlap-save blocks of 2^16) against
+    scipy.signal.lfilter started from the steady state of the first sample (what filtfilt's two passes are made of)."""
+    import scipy.signal as sps
+    from music_mixing_style_transfer_amd.mixing_manipulator import _device_ops as D
+    rng = np.random.default_rng(3)
+    x = (0.3 * rng.standard_normal(2_000_000) + 0.1).astype(np.float32)
+    taps = sps.firwin2(1001, [0, 0.1, 0.3, 1.0], [1.0, 0.8, 0.2, 0.05], window="hamming")
+    y = D.fir_causal(D.to_device(torch.from_numpy(x[:, None])), taps).cpu().numpy()[:, 0]
+    ref = sps.lfilter(taps, 1.0, x.astype(np.float64), zi=sps.lfilter_zi(taps, 1.0) * float(x[0]))[0]
+    assert y.shape == ref.shape and np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
 def test_input_normalizer_chain_and_cli_with_normalize_input(tmp_path, oracle_fx_lib):
     """`--normalize_input True` (the reference CLI's default) end to end on the MI355X: the normaliser chain on one stem against the
     oracle chain, then the runner on a 4-stem song with a features file against oracle normaliser + oracle networks."""
