@@ -296,33 +296,75 @@ __global__ __launch_bounds__(256) void fx_compressor_kernel(CompArgs a) {
 // The two parallel kernels move 64 x 64 (time x sequence) tiles through LDS so that both their audio side
 // ([item][n][c], time-contiguous) and their scratch side (sequence-contiguous) are coalesced.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double fx_comp_level_diff(const CompArgs &a, float x, int item) {
-    const double threshold = a.thr_items ? a.thr_items[item] : a.threshold, ratio = a.ratio_items ? a.ratio_items[item] : a.ratio;
-    const double ax = fabs((double)x);
-    const double xg = (ax < 0.000001) ? -120.0 : 20.0 * log10(ax);
+// log10 of a positive normal float32 value as a float64 (error ~1e-16 relative, like the library's log10 of the converted value, at
+// a sixth of its instructions: the library routine carries double-double arithmetic for arguments it cannot know are float32).
+// |x| = 2^e * m, m in [1, 2) with 23 mantissa bits; m_hi = the top 7 of them; r = (m - m_hi) / m_hi in [0, 2^-7) (m - m_hi is exact):
+//     log10 |x| = e log10(2) + log10(m_hi) + log10(e) * log1p(r),   log1p(r) = r - r^2/2 + ... + r^7/7   (next term < 2e-18)
+// tab[i] = log10(1 + i/128), tab[128 + i] = 1 / (1 + i/128): 2 KB of LDS filled by the workgroup with the library functions.
+__device__ __forceinline__ void fx_log10_table_fill(double *tab, int tid, int nthreads) {
+    for (int i = tid; i < 128; i += nthreads) {
+        const double mh = 1.0 + (double)i * (1.0 / 128.0);
+        tab[i] = log10(mh);
+        tab[128 + i] = 1.0 / mh;
+    }
+}
+__device__ __forceinline__ double fx_log10_f32(float ax, const double *tab) {
+    const unsigned bits = __float_as_uint(ax);
+    const int e = (int)(bits >> 23) - 127;
+    const unsigned i = (bits >> 16) & 127u;
+    const double m = (double)__uint_as_float((bits & 0x007fffffu) | 0x3f800000u);
+    const double mh = (double)__uint_as_float((bits & 0x007f0000u) | 0x3f800000u);
+    const double r = (m - mh) * tab[128 + i];
+    double p = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+    p = fma(r, p, 1.0 / 5.0);
+    p = fma(r, p, -1.0 / 4.0);
+    p = fma(r, p, 1.0 / 3.0);
+    p = fma(r, p, -0.5);
+    const double l1p = fma(r * r, p, r);
+    return fma(l1p, 0.43429448190325182765, fma((double)e, 0.30102999566398119521, tab[i]));
+}
+
+// x_l = x_g - y_g of one sample (:556-575).  thr / mul / mode are per sequence: mode 1 = compressor (ratio > 1, mul = 1 / ratio),
+// 2 = expander (ratio < 1, mul = ratio: the reference divides by 1 / ratio), 0 = ratio == 1 (neither branch assigns y_g: it stays 0)
+__device__ __forceinline__ double fx_comp_level_diff(float x, double thr, double mul, int mode, const double *tab) {
+    const float axf = fabsf(x);
+    const double xg = ((double)axf < 0.000001) ? -120.0 : 20.0 * fx_log10_f32(axf, tab);
     double yg = 0.0;
-    if (ratio > 1.0)
-        yg = (xg >= threshold) ? threshold + (xg - threshold) / ratio : xg;
-    else if (ratio < 1.0)
-        yg = (xg <= threshold) ? threshold + (xg - threshold) / (1.0 / ratio) : xg;
+    if (mode == 1)
+        yg = (xg >= thr) ? fma(xg - thr, mul, thr) : xg;
+    else if (mode == 2)
+        yg = (xg <= thr) ? fma(xg - thr, mul, thr) : xg;
     return xg - yg;
 }
 
 // grid (ceil(L / 64), ceil(n_seq / 64)), 256 threads
 __global__ __launch_bounds__(256) void fx_comp_gain_kernel(CompArgs a, double *xl) {
     __shared__ double t[64][65];
+    __shared__ double tab[256];
+    __shared__ double sthr[64], smul[64];
+    __shared__ int smode[64];
+    __shared__ float ssf[64];
     const long n0 = (long)blockIdx.x * 64;
     const int s0 = blockIdx.y * 64;
+    fx_log10_table_fill(tab, threadIdx.x, 256);
+    if (threadIdx.x < 64) {                               // the static curve of every sequence of the tile
+        const int seq = s0 + threadIdx.x < a.n_seq ? s0 + threadIdx.x : a.n_seq - 1, item = seq / a.C;
+        const double ratio = a.ratio_items ? a.ratio_items[item] : a.ratio;
+        sthr[threadIdx.x] = a.thr_items ? a.thr_items[item] : a.threshold;
+        smode[threadIdx.x] = ratio > 1.0 ? 1 : (ratio < 1.0 ? 2 : 0);
+        smul[threadIdx.x] = ratio > 1.0 ? 1.0 / ratio : ratio;
+        ssf[threadIdx.x] = a.in_scale ? (float)a.in_scale[item] : 1.0f;
+    }
+    __syncthreads();
 #pragma unroll 4
     for (int k = 0; k < 16; ++k) {                       // audio side: lanes run along time within one sequence
         const int idx = k * 256 + threadIdx.x, sl = idx >> 6, nl = idx & 63;
         const int seq = s0 + sl;
         const long n = n0 + nl;
         double v = 0.0;
-        if (seq < a.n_seq && n < a.L) {
-            const float sf = a.in_scale ? (float)a.in_scale[seq / a.C] : 1.0f;
-            v = fx_comp_level_diff(a, a.x[((size_t)(a.shared_x ? 0 : seq / a.C) * a.L + n) * a.C + seq % a.C] * sf, seq / a.C);
-        }
+        if (seq < a.n_seq && n < a.L)
+            v = fx_comp_level_diff(a.x[((size_t)(a.shared_x ? 0 : seq / a.C) * a.L + n) * a.C + seq % a.C] * ssf[sl], sthr[sl], smul[sl],
+                                   smode[sl], tab);
         t[nl][sl] = v;
     }
     __syncthreads();

@@ -57,6 +57,8 @@ static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu_
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return 0; }
 
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 struct float2 { float x, y; };
 struct double2 { double x, y; };
 struct float4 { float x, y, z, w; };
