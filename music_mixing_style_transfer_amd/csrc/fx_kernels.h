@@ -337,6 +337,21 @@ __device__ __forceinline__ double fx_comp_level_diff(float x, double thr, double
     return xg - yg;
 }
 
+// the log10 table once per launch sequence (256 doubles in the caller's scratch): the time-parallel kernels copy it into LDS
+__global__ __launch_bounds__(128) void fx_log10_table_kernel(double *tab) { fx_log10_table_fill(tab, threadIdx.x, 128); }
+
+// the static curve of one sequence as fx_comp_level_diff takes it
+struct FxCompCurve { double thr, mul; int mode; float sf; };
+__device__ __forceinline__ FxCompCurve fx_comp_curve(const CompArgs &a, int item) {
+    const double ratio = a.ratio_items ? a.ratio_items[item] : a.ratio;
+    FxCompCurve c;
+    c.thr = a.thr_items ? a.thr_items[item] : a.threshold;
+    c.mode = ratio > 1.0 ? 1 : (ratio < 1.0 ? 2 : 0);
+    c.mul = ratio > 1.0 ? 1.0 / ratio : ratio;
+    c.sf = a.in_scale ? (float)a.in_scale[item] : 1.0f;
+    return c;
+}
+
 // grid (ceil(L / 64), ceil(n_seq / 64)), 256 threads
 __global__ __launch_bounds__(256) void fx_comp_gain_kernel(CompArgs a, double *xl) {
     __shared__ double t[64][65];
@@ -348,12 +363,9 @@ __global__ __launch_bounds__(256) void fx_comp_gain_kernel(CompArgs a, double *x
     const int s0 = blockIdx.y * 64;
     fx_log10_table_fill(tab, threadIdx.x, 256);
     if (threadIdx.x < 64) {                               // the static curve of every sequence of the tile
-        const int seq = s0 + threadIdx.x < a.n_seq ? s0 + threadIdx.x : a.n_seq - 1, item = seq / a.C;
-        const double ratio = a.ratio_items ? a.ratio_items[item] : a.ratio;
-        sthr[threadIdx.x] = a.thr_items ? a.thr_items[item] : a.threshold;
-        smode[threadIdx.x] = ratio > 1.0 ? 1 : (ratio < 1.0 ? 2 : 0);
-        smul[threadIdx.x] = ratio > 1.0 ? 1.0 / ratio : ratio;
-        ssf[threadIdx.x] = a.in_scale ? (float)a.in_scale[item] : 1.0f;
+        const int seq = s0 + threadIdx.x < a.n_seq ? s0 + threadIdx.x : a.n_seq - 1;
+        const FxCompCurve c = fx_comp_curve(a, seq / a.C);
+        sthr[threadIdx.x] = c.thr; smul[threadIdx.x] = c.mul; smode[threadIdx.x] = c.mode; ssf[threadIdx.x] = c.sf;
     }
     __syncthreads();
 #pragma unroll 4
@@ -449,7 +461,7 @@ __global__ __launch_bounds__(64) void fx_comp_smooth_kernel(CompArgs a, double *
 #define MST_COMP_NEVER 1e300
 
 struct CompMapArgs {
-    const double *xl;     // [L][n_seq]  level differences (time-major)
+    const double *log_tab; // fx_log10_table_kernel's 256 doubles
     double *maps;         // [n_seq][nchunks][MST_COMP_NP + 1][2]  (b, u) per piece, ascending
     double *ystart;       // [nchunks][n_seq]  smoother value at the start of each chunk
     int n_seq, nchunks;
@@ -464,21 +476,29 @@ struct CompMapArgs {
 // grid (nchunks, ceil(n_seq / 64)), 64 threads: lanes = sequences of one chunk (coalesced time-major loads).  Four waves per SIMD
 // (<= 128 registers, 8.5 KB of LDS): the early steps of a chunk have few pieces and little to overlap within one wave.
 template <bool USE_MIN>
-__global__ __launch_bounds__(64) MST_WAVES_PER_SIMD(4) MST_HEAVY_UNROLL void fx_comp_map_kernel(CompMapArgs a) {
+__global__ __launch_bounds__(64) MST_WAVES_PER_SIMD(4) MST_HEAVY_UNROLL void fx_comp_map_kernel(CompMapArgs a, CompArgs ca) {
     constexpr int PASS = 16;                                        // doubles of every record that cross the LDS tile at a time (128 B)
     __shared__ double tr[64 * (PASS + 1)];
+    __shared__ double tab[256];
     const int k = blockIdx.x;
     const int seq = blockIdx.y * 64 + threadIdx.x;
     const bool live = seq < a.n_seq;
     const size_t sq = live ? seq : a.n_seq - 1;
     const double cA = 1.0 - a.aA, cR = 1.0 - a.aR;
+    // the level differences x_l are computed here from the audio (a lane walks its own sequence: 32 frames = 256 contiguous bytes that
+    // it shares with the lane of the other channel), not read from a float64 scratch that a separate pass would have to write
+    for (int i = threadIdx.x; i < 256; i += 64) tab[i] = a.log_tab[i];
+    const int item = (int)(sq / ca.C);
+    const FxCompCurve cv = fx_comp_curve(ca, item);
+    const float *xp = ca.x + ((size_t)(ca.shared_x ? 0 : item) * ca.L) * ca.C + sq % ca.C;
+    __builtin_amdgcn_wave_barrier();
     double lb[MST_COMP_NP + 1];                                     // lb[1 .. t]: the values at which the pieces meet after t steps
     double b0 = 0.0;                                                // the lowest piece (always the attack branch); identity before step 1
 #pragma unroll
     for (int t = 0; t < MST_COMP_T; ++t) {
         const long n = (long)k * MST_COMP_T + t;
         if (n < a.L) {                                              // uniform over the wave
-            const double x = a.xl[(size_t)n * a.n_seq + sq];
+            const double x = fx_comp_level_diff(xp[(size_t)n * ca.C] * cv.sf, cv.thr, cv.mul, cv.mode, tab);
             const double oA = cA * x, oR = cR * x;
             b0 = fma(a.aA, b0, oA);
             // downwards, in place: slot s reads the old slots s and s - 1.  g = f_x(old value) = max (convex) / min (concave) of the branches
@@ -636,9 +656,9 @@ __global__ __launch_bounds__(128) void fx_comp_chain_kernel(CompMapArgs a) {
     }
 }
 
-// grid (ceil(L / 64), ceil(n_seq / 64)), 256 threads.  FILL: yl holds the level differences x_l and the smoother runs here, inside each
-// chunk from its true start value (two chunks per tile, one (chunk, sequence) per thread of the
-// first two waves) - the smoothed levels never travel to HBM and back.
+// grid (ceil(L / 64), ceil(n_seq / 64)), 256 threads.  FILL: the whole tail of the compressor on a 64 x 64 (time x sequence) tile - level
+// differences from the audio (yl = the log10 table), the smoother inside each chunk from its true start value (two chunks per tile, one
+// (chunk, sequence) per thread of the first two waves), the gain application: neither x_l nor y_l ever travels to HBM.
 template <bool FILL>
 __global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const double *yl, const double *ystart, int nchunks) {
     __shared__ double t[64][65];
@@ -646,20 +666,39 @@ __global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const do
     const int s0 = blockIdx.y * 64;
     if constexpr (FILL) {
         static_assert(MST_COMP_T == 32, "two chunks per 64-step tile");
+        // yl = the log10 table: the level differences are recomputed from the audio (audio side: lanes along time), the smoother runs
+        // along time in LDS (sequence side), the result stays in the tile for the gain application below
+        __shared__ double tab[256];
+        __shared__ double sthr[64], smul[64];
+        __shared__ int smode[64];
+        __shared__ float ssf[64];
+        tab[threadIdx.x] = yl[threadIdx.x];
+        if (threadIdx.x < 64) {
+            const int seq = s0 + threadIdx.x < a.n_seq ? s0 + threadIdx.x : a.n_seq - 1;
+            const FxCompCurve c = fx_comp_curve(a, seq / a.C);
+            sthr[threadIdx.x] = c.thr; smul[threadIdx.x] = c.mul; smode[threadIdx.x] = c.mode; ssf[threadIdx.x] = c.sf;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const int idx = k * 256 + threadIdx.x, sl = idx >> 6, nl = idx & 63;
+            const int seq = s0 + sl;
+            const long n = n0 + nl;
+            double v = 0.0;
+            if (seq < a.n_seq && n < a.L)
+                v = fx_comp_level_diff(a.x[((size_t)(a.shared_x ? 0 : seq / a.C) * a.L + n) * a.C + seq % a.C] * ssf[sl], sthr[sl], smul[sl],
+                                       smode[sl], tab);
+            t[nl][sl] = v;
+        }
+        __syncthreads();
         const int sl = threadIdx.x & 63, hh = threadIdx.x >> 6;
         const long k = (long)blockIdx.x * 2 + hh;
         if (hh < 2 && s0 + sl < a.n_seq && k < nchunks) {
             const double cA = 1.0 - a.alpha_att, cR = 1.0 - a.alpha_rel;
             double prev = ystart[(size_t)k * a.n_seq + s0 + sl];
-            double v[MST_COMP_T];
 #pragma unroll
             for (int i = 0; i < MST_COMP_T; ++i) {
-                const long n = k * MST_COMP_T + i;
-                v[i] = yl[(size_t)(n < a.L ? n : a.L - 1) * a.n_seq + s0 + sl];
-            }
-#pragma unroll
-            for (int i = 0; i < MST_COMP_T; ++i) {
-                const double d = v[i] - prev;
+                const double d = t[hh * MST_COMP_T + i][sl] - prev;
                 prev = fma(d > 0.0 ? cA : cR, d, prev);
                 t[hh * MST_COMP_T + i][sl] = prev;
             }

@@ -1297,16 +1297,18 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
 }
 
 namespace {
-// scratch = level differences [L][n_seq] | chunk maps [n_seq][nchunks][NP + 1][2] | chunk start values [nchunks][n_seq]
-struct CompScratch { size_t xl, maps, ystart, total; long nchunks; };
+// scratch = level differences [L][n_seq] (serial fallback only) | chunk maps [n_seq][nchunks][NP + 1][2] | chunk start values
+// [nchunks][n_seq] | log10 table [256]
+struct CompScratch { size_t xl, maps, ystart, tab, total; long nchunks; };
 CompScratch comp_scratch(int n_items, long L, int C) {
     CompScratch c;
     const size_t n_seq = (size_t)n_items * C;
     c.nchunks = (L + MST_COMP_T - 1) / MST_COMP_T;
-    c.xl = n_seq * (size_t)L * sizeof(double);
+    c.xl = c.nchunks < 4 ? n_seq * (size_t)L * sizeof(double) : 0;      // only the serial form of very short signals stores them
     c.maps = n_seq * (size_t)c.nchunks * MST_COMP_REC * sizeof(double);
     c.ystart = n_seq * (size_t)c.nchunks * sizeof(double);
-    c.total = c.xl + c.maps + c.ystart;
+    c.tab = 256 * sizeof(double);
+    c.total = c.xl + c.maps + c.ystart + c.tab;
     return c;
 }
 }  // namespace
@@ -1321,18 +1323,19 @@ int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size
     if (scratch) {
         if (scratch_bytes < mst_fx_compressor_scratch_bytes(n_items, L, C))
             return fail(MST_ERR_WORKSPACE, "mst_fx_compressor: scratch too small");
-        if ((size_t)a.n_seq * (size_t)L * sizeof(double) >= (1ull << 32))      // the serial kernel addresses the scratch with 32-bit offsets
-            return fail(MST_ERR_UNSUPPORTED, "mst_fx_compressor: more than 2^29 samples per call (split the batch)");
         const dim3 tiles((unsigned)((L + 63) / 64), (unsigned)((a.n_seq + 63) / 64));      // 64 x 64 (time x sequence) tiles
-        MST_LAUNCH(fx_comp_gain_kernel, tiles, dim3(256), stream, a, scratch);
-        MST_CHECK_LAUNCH("fx_comp_gain_kernel");
         const CompScratch cs = comp_scratch(n_items, L, C);
         if (cs.nchunks < 4) {
+            MST_LAUNCH(fx_comp_gain_kernel, tiles, dim3(256), stream, a, scratch);
+            MST_CHECK_LAUNCH("fx_comp_gain_kernel");
             MST_LAUNCH(fx_comp_smooth_kernel, dim3((a.n_seq + 63) / 64), dim3(64), stream, a, scratch);
             MST_CHECK_LAUNCH("fx_comp_smooth_kernel");
-        } else {       // the smoother parallel in time: chunk maps (convex piecewise-linear), a chain over chunks, a fill pass
+        } else {       // the smoother parallel in time: chunk maps (convex piecewise-linear), a chain over chunks, the rest in one pass
             CompMapArgs m;
-            m.xl = scratch;
+            double *tab = (double *)((unsigned char *)scratch + cs.xl + cs.maps + cs.ystart);
+            MST_LAUNCH(fx_log10_table_kernel, dim3(1), dim3(128), stream, tab);
+            MST_CHECK_LAUNCH("fx_log10_table_kernel");
+            m.log_tab = tab;
             m.maps = (double *)((unsigned char *)scratch + cs.xl);
             m.ystart = (double *)((unsigned char *)scratch + cs.xl + cs.maps);
             m.n_seq = a.n_seq;
@@ -1351,12 +1354,12 @@ int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size
                 }
             }
             const dim3 cg((unsigned)cs.nchunks, (unsigned)((a.n_seq + 63) / 64));
-            if (m.use_min) MST_LAUNCH(fx_comp_map_kernel<true>, cg, dim3(64), stream, m);
-            else MST_LAUNCH(fx_comp_map_kernel<false>, cg, dim3(64), stream, m);
+            if (m.use_min) MST_LAUNCH(fx_comp_map_kernel<true>, cg, dim3(64), stream, m, a);
+            else MST_LAUNCH(fx_comp_map_kernel<false>, cg, dim3(64), stream, m, a);
             MST_CHECK_LAUNCH("fx_comp_map_kernel");
             MST_LAUNCH(fx_comp_chain_kernel, dim3(a.n_seq), dim3(128), stream, m);
             MST_CHECK_LAUNCH("fx_comp_chain_kernel");
-            MST_LAUNCH((fx_comp_apply_kernel<true>), tiles, dim3(256), stream, a, (const double *)scratch, (const double *)m.ystart, m.nchunks);
+            MST_LAUNCH((fx_comp_apply_kernel<true>), tiles, dim3(256), stream, a, (const double *)tab, (const double *)m.ystart, m.nchunks);
             MST_CHECK_LAUNCH("fx_comp_apply_kernel");
             return MST_OK;
         }
