@@ -209,7 +209,7 @@ size_t mst_fx_biquad_scratch_bytes(int n_items, long L, int C, int n_bands);
 int mst_fx_biquad_cascade(const float *x_dev, float *y_dev, int n_items, long L, int C, const double *coef_host,
                           int n_bands, double *scratch_dev, size_t scratch_bytes, const MstFxFuse *fuse, void *stream);
 /* Compressor.process / compressor_process (:529-587, :637-649), makeup gain 0.  With a scratch buffer of
- * mst_fx_compressor_scratch_bytes() (about 17 bytes per sample) the gain computer and the gain application run over all samples
+ * mst_fx_compressor_scratch_bytes() (about 9 bytes per sample) the gain computer and the gain application run over all samples
  * in parallel and the attack/release smoother runs parallel in time (per-chunk convex piecewise-linear maps + one walk over the
  * chunk summaries of each sequence); scratch_dev = NULL runs the serial form, one wave per sequence. */
 size_t mst_fx_compressor_scratch_bytes(int n_items, long L, int C);

@@ -449,20 +449,21 @@ __global__ __launch_bounds__(64) void fx_comp_smooth_kernel(CompArgs a, double *
 // sends the pieces below it through the attack branch and those above through the release branch.  So after n steps the piece at
 // sorted position p has been through n - p attack steps and p release steps whatever the signal was: its slope is aA^(n-p) aR^p, a
 // constant of the launch (CompMapArgs::slope).  F is continuous, so the pieces are fixed by the VALUES lb_p at which they meet plus the
-// intercept b_0 of the lowest piece: the kernel tracks only those (one float64 per piece) and rebuilds intercepts b_p and crossing
-// inputs u_p at the end:  u_1 = (lb_1 - b_0) / a_0,  u_(p+1) = u_p + (lb_(p+1) - lb_p) / a_p,  b_p = lb_p - a_p u_p.
+// intercept b_0 of the lowest piece: the map kernel tracks and STORES only those (one float64 per piece: 272 bytes per chunk - the
+// kernel is bound by writing its records); the chain kernel's helper waves rebuild intercepts b_p and crossing inputs u_p while the
+// walker is busy:  u_1 = (lb_1 - b_0) / a_0,  u_(p+1) = u_p + (lb_(p+1) - lb_p) / a_p  (a prefix sum over the pieces),  b_p = lb_p - a_p u_p.
 // A step on the sorted values is g_s = f_x(lb_s) (monotone: still sorted) followed by the insertion of x into the sorted list,
 // new_s = max(g_(s-1), min(g_s, x)): five float64 operations per piece and step, no compare, no select, no data-dependent move.
 // (Round 2's first version kept (a, b, lb) per piece and shifted them under exec masks: 4x the instructions, 2.5x the time.)
 // ------------------------------------------------------------------------------------------------
 #define MST_COMP_T 32                      // steps per chunk: T + 1 pieces
 #define MST_COMP_NP (MST_COMP_T + 1)
-#define MST_COMP_REC (2 * (MST_COMP_NP + 1))   // doubles per stored record: (b_p, u_p) per piece + one entry that is never selected
+#define MST_COMP_REC (MST_COMP_NP + 1)   // doubles per stored record: b_0, lb_1 .. lb_T (NEVER beyond the chunk's pieces), one pad
 #define MST_COMP_NEVER 1e300
 
 struct CompMapArgs {
     const double *log_tab; // fx_log10_table_kernel's 256 doubles
-    double *maps;         // [n_seq][nchunks][MST_COMP_NP + 1][2]  (b, u) per piece, ascending
+    double *maps;         // [n_seq][nchunks][MST_COMP_REC]  b_0, lb_1 .. lb_T per chunk
     double *ystart;       // [nchunks][n_seq]  smoother value at the start of each chunk
     int n_seq, nchunks;
     long L;
@@ -519,90 +520,108 @@ __global__ __launch_bounds__(64) MST_WAVES_PER_SIMD(4) MST_HEAVY_UNROLL void fx_
     }
     const long left = a.L - (long)k * MST_COMP_T;
     const int nsteps = left < MST_COMP_T ? (int)left : MST_COMP_T;  // uniform; >= 1
-    const bool shortc = nsteps < MST_COMP_T;                        // table [1]; selected element by element (scalar selects)
-    auto sl = [&](int p) { return shortc ? a.slope[1][p] : a.slope[0][p]; };
-    auto isl = [&](int p) { return shortc ? a.inv_slope[1][p] : a.inv_slope[0][p]; };
-    // the record (b_p, u_p), p = 0 .. NP (p = NP: the entry the lanes without a piece read), leaves in passes of 16 doubles through a
-    // [lane][16 + 1] tile: every store instruction of the wave writes 128 contiguous bytes of four records
+    // the record (b_0, lb_1 .. lb_T, pad) leaves in passes of 16 doubles through a [lane][16 + 1] tile: every store instruction of the
+    // wave writes 128 contiguous bytes of four records
     const int nlive = a.n_seq - blockIdx.y * 64 < 64 ? a.n_seq - blockIdx.y * 64 : 64;
     double *row = tr + threadIdx.x * (PASS + 1);
     double *mbase = a.maps + ((size_t)(blockIdx.y * 64) * a.nchunks + k) * MST_COMP_REC;
-    double u = (lb[1] - b0) * isl(0);
-    auto pass = [&](auto J) {                                       // pieces 8 J .. 8 J + 7 (two flat loops: both unroll early, lb stays in registers)
-        constexpr int p0 = decltype(J)::value * (PASS / 2), p1 = p0 + PASS / 2 < MST_COMP_NP + 1 ? p0 + PASS / 2 : MST_COMP_NP + 1;
-        constexpr int cnt = 2 * (p1 - p0);                          // doubles in this pass
+    auto pass = [&](auto J) {                                       // two flat loops: both unroll early, lb stays in registers
+        constexpr int p0 = decltype(J)::value * PASS, p1 = p0 + PASS < MST_COMP_REC ? p0 + PASS : MST_COMP_REC;
+        constexpr int cnt = p1 - p0;                                // doubles in this pass
 #pragma unroll
-        for (int p = p0; p < p1; ++p) {
-            double pb, pu;
-            if (p == 0) {
-                pb = b0;
-                pu = -MST_COMP_NEVER;                               // the lowest piece: reached by every y
-            } else if (p <= nsteps && p < MST_COMP_NP) {            // uniform
-                if (p > 1) u = fma(lb[p] - lb[p - 1], isl(p - 1), u);
-                pb = fma(-sl(p), u, lb[p]);
-                pu = u;
-            } else {
-                pb = 0.0;
-                pu = MST_COMP_NEVER;
-            }
-            row[2 * (p - p0)] = pb;
-            row[2 * (p - p0) + 1] = pu;
-        }
+        for (int p = p0; p < p1; ++p) row[p - p0] = p == 0 ? b0 : ((p <= nsteps && p <= MST_COMP_T) ? lb[p <= MST_COMP_T ? p : 0] : MST_COMP_NEVER);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < cnt; ++i) {                             // 64 records x cnt doubles, lane-linear over (record, double)
             const int idx = i * 64 + threadIdx.x, r = idx / cnt, c = idx % cnt;
-            if (r < nlive) mbase[(size_t)r * a.nchunks * MST_COMP_REC + 2 * p0 + c] = tr[r * (PASS + 1) + c];
+            if (r < nlive) mbase[(size_t)r * a.nchunks * MST_COMP_REC + p0 + c] = tr[r * (PASS + 1) + c];
         }
         __builtin_amdgcn_wave_barrier();
     };
-    static_assert(MST_COMP_NP + 1 <= 5 * (PASS / 2), "five passes cover the record");
+    static_assert(MST_COMP_REC <= 3 * PASS, "three passes cover the record");
     pass(std::integral_constant<int, 0>{});
     pass(std::integral_constant<int, 1>{});
     pass(std::integral_constant<int, 2>{});
-    pass(std::integral_constant<int, 3>{});
-    pass(std::integral_constant<int, 4>{});
 }
 
-// grid n_seq, 128 threads: two waves per sequence.  Wave 0 walks the chunks (lanes = pieces); wave 1 runs one batch of CB chunks ahead
-// of it and copies the stored records into LDS.  A chunk step FINDS the piece that applies to y: piece i applies from its crossing
-// input u_i on, and the pieces sit in the lanes in DESCENDING order, so the lowest lane with u <= y holds it - v_cmpx straight into
-// EXEC, v_readfirstlane of that lane's a_i y + b_i (mst_wave_first_ge): one float64 op and one lane read on the dependent chain per
-// chunk, instead of fma -> compare -> s_bcnt1 -> v_readlane (2.4x the latency) or a six-stage float64 wave reduction.  Near a
-// crossing the two neighbouring pieces agree to rounding, so a test decided by rounding picks an equally valid piece.  The slope is a
-// constant of the lane.  The 32 steps of a batch are unrolled: entries are prefetched three chunks ahead with immediate offsets, the
-// chunk start values are parked in lane c of a register (v_writelane) and stored once per batch.
+// grid n_seq, 384 threads: six waves per sequence.  Wave 0 walks the chunks (lanes = pieces); waves 1, 2, 3 and 5 run one batch of CB
+// chunks ahead of it (a quarter of a batch each; with two of them the walker waited for its entries: 202 us against 153 alone; wave 4
+// would share the walker's SIMD and only keeps the barriers company) and turn the stored records (b_0, lb_1 .. lb_T) into per-piece entries (b_p, u_p) in LDS: two chunks at
+// a time, one per half-wave, lane = piece, the crossing inputs by a 32-lane DPP prefix sum (mst_half_prefix_sum_f64).  A chunk step FINDS
+// the piece that applies to y: piece i applies from its crossing input u_i on, and the pieces sit in the walker's lanes in DESCENDING
+// order, so the lowest lane with u <= y holds it - v_cmpx straight into EXEC, v_readfirstlane of that lane's a_i y + b_i
+// (mst_wave_first_ge): one float64 op and one lane read on the dependent chain per chunk, instead of fma -> compare -> s_bcnt1 ->
+// v_readlane (2.4x the latency) or a six-stage float64 wave reduction.  Near a crossing the two neighbouring pieces agree to rounding,
+// so a test decided by rounding picks an equally valid piece.  The slope is a constant of the lane.  The 32 steps of a batch are
+// unrolled: entries are prefetched three chunks ahead with immediate offsets, the chunk start values are parked in lane c of a
+// register (v_writelane) and stored once per batch.
 #ifndef MST_CHAIN_PROBE
-#define MST_CHAIN_PROBE 0      // tools/micro/fx_chain_variants.hip: 1 = the copy wave alone, 2 = the walker alone (timing probes)
+#define MST_CHAIN_PROBE 0      // tools/micro/fx_chain_variants.hip: 1 = the helper waves alone, 2 = the walker alone (timing probes)
 #endif
-__global__ __launch_bounds__(128) void fx_comp_chain_kernel(CompMapArgs a) {
-    constexpr int CB = 32, PER = MST_COMP_REC;                        // chunks per batch, doubles per record
-    constexpr int NLD = (CB * PER / 2 + 63) / 64;                     // 16-byte loads per copy lane per batch
-    __shared__ __attribute__((aligned(16))) double cooked[2][CB * PER];
-    const int seq = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const double2 *m = (const double2 *)(a.maps + (size_t)seq * a.nchunks * PER);
-    const size_t total = (size_t)a.nchunks * PER / 2;
+#define MST_CHAIN_HELPERS 4
+#define MST_CHAIN_THREADS 384
+__global__ __launch_bounds__(MST_CHAIN_THREADS) void fx_comp_chain_kernel(CompMapArgs a) {
+    constexpr int CB = 32, REC = MST_COMP_REC, NPE = MST_COMP_NP + 1, ENT = 2 * NPE;      // chunks per batch, doubles per record / per chunk of entries
+    constexpr int NH = MST_CHAIN_HELPERS, HB = CB / NH;               // helper waves; chunks per helper wave and batch
+    constexpr int NLD = (HB * REC / 2 + 63) / 64;                     // 16-byte loads per helper lane per batch
+    static_assert(REC % 2 == 0 && HB % 2 == 0, "records are whole 16-byte units; a helper takes its chunks two at a time");
+    __shared__ __attribute__((aligned(16))) double raw[NH][HB * REC];
+    __shared__ __attribute__((aligned(16))) double cooked[2][CB * ENT];      // per (chunk, piece): b, u; entry NP is never selected
+    static_assert(NH == 4, "helper waves 1, 2, 3, 5");
+    const int seq = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hw = wave == 5 ? 3 : (wave > 0 ? wave - 1 : 0);
+    const bool helper = wave != 0 && wave != 4;
+    const double2 *m = (const double2 *)(a.maps + (size_t)seq * a.nchunks * REC);
+    const size_t total = (size_t)a.nchunks * REC / 2;
     const int nbatch = (a.nchunks + CB - 1) / CB;
-    // ---- wave 1: global -> registers (requested one batch EARLIER than they are written: the loads of batch bt + 2 fly while the
-    //      walker is on batch bt + 1) -> LDS
-    double2 r[NLD];
+    // ---- waves 1, 2: global -> registers -> raw records in LDS -> entries
+    const int hp = (lane & 31) + 1;                                   // the piece this helper lane rebuilds (1 .. T)
+    const double sl_full = a.slope[0][hp], isl_full = a.inv_slope[0][hp - 1], sl_last = a.slope[1][hp], isl_last = a.inv_slope[1][hp - 1];
+    double rx[NLD], ry[NLD];                                          // (plain doubles: an array of double2 stays in scratch memory)
     auto load = [&](int bt) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const size_t e = (size_t)(bt < nbatch ? bt : nbatch - 1) * (CB * PER / 2) + (size_t)i * 64 + lane;
-            r[i] = m[e < total ? e : total - 1];
+            const size_t e = ((size_t)(bt < nbatch ? bt : nbatch - 1) * CB + hw * HB) * (REC / 2) + (size_t)i * 64 + lane;
+            const double2 v = m[e < total ? e : total - 1];
+            rx[i] = v.x;
+            ry[i] = v.y;
         }
     };
-    auto cook = [&](int buf) {
-        double2 *dst = (double2 *)cooked[buf];
+    // the records of batch bt leave the registers for LDS, the loads of batch bt + 1 are issued at once (a whole batch of walking and
+    // rebuilding covers their latency), then the entries of batch bt are rebuilt
+    auto cook = [&](int buf, int bt) {
+        double2 *dst = (double2 *)raw[hw];
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-            if (i * 64 + lane < CB * PER / 2) dst[i * 64 + lane] = r[i];
+            if (i * 64 + lane < HB * REC / 2) dst[i * 64 + lane] = double2{rx[i], ry[i]};
+        load(bt + 1);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < HB / 2; ++it) {
+            const int c = 2 * it + (lane >> 5);                       // chunk of this half-wave within the helper's share
+            const double *rec = raw[hw] + c * REC;
+            const double lbp = rec[hp], lbm = rec[hp - 1];            // rec[0] = b_0
+            const bool valid = lbp < 0.5 * MST_COMP_NEVER;            // the piece exists (the last chunk may be short)
+            const bool shortc = (long)(bt * CB + hw * HB + c + 1) * MST_COMP_T > a.L;
+            const double d = valid ? (lbp - lbm) * (shortc ? isl_last : isl_full) : 0.0;
+            const double u = mst_half_prefix_sum_f64(d);
+            double *q = cooked[buf] + ((hw * HB + c) * NPE + hp) * 2;
+            q[0] = valid ? fma(-(shortc ? sl_last : sl_full), u, lbp) : 0.0;
+            q[1] = valid ? u : MST_COMP_NEVER;
+            if (hp == 1) {                                            // the lowest piece: reached by every y
+                q[-2] = lbm;
+                q[-1] = -MST_COMP_NEVER;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     };
-    if (wave != 0) {
+    if (helper) {
+        for (int i = lane; i < 2 * HB; i += 64) {                     // the entry the lanes without a piece read: written once
+            double *q = &cooked[i / HB][((hw * HB + i % HB) * NPE + MST_COMP_NP) * 2];
+            q[0] = 0.0;
+            q[1] = MST_COMP_NEVER;
+        }
         load(0);
-        cook(0);
-        load(1);
+        cook(0, 0);
     }
     __syncthreads();
     MstUniformF64 yu = mst_wave_read_u64(0.0, 0);                   // yL_prev = 0 on entry (common_audioeffects.py:553)
@@ -610,17 +629,16 @@ __global__ __launch_bounds__(128) void fx_comp_chain_kernel(CompMapArgs a) {
     const double a_full = pl < MST_COMP_NP ? a.slope[0][pl] : 0.0, a_last = pl < MST_COMP_NP ? a.slope[1][pl] : 0.0;
     for (int bt = 0; bt < nbatch; ++bt) {
         const int cur = bt & 1;
-        if (wave != 0) {
+        if (helper) {
             if (bt + 1 < nbatch && (MST_CHAIN_PROBE != 2 || bt == 0)) {
-                cook(cur ^ 1);
-                load(bt + 2);
+                cook(cur ^ 1, bt + 1);
             }
-        } else if (MST_CHAIN_PROBE != 1) {
+        } else if (wave == 0 && MST_CHAIN_PROBE != 1) {
             const int nc = a.nchunks - bt * CB < CB ? a.nchunks - bt * CB : CB;
             struct Piece { double pb, u; };
             const double *base = cooked[cur] + 2 * pl;
             auto fetch = [&](int c) {
-                const double2 q = *(const double2 *)(base + PER * (c < CB ? c : CB - 1));
+                const double2 q = *(const double2 *)(base + ENT * (c < CB ? c : CB - 1));
                 return Piece{q.x, q.y};
             };
             double keep = 0.0;                                      // lane c holds the start value of chunk c

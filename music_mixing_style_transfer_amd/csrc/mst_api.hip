@@ -1297,7 +1297,7 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
 }
 
 namespace {
-// scratch = level differences [L][n_seq] (serial fallback only) | chunk maps [n_seq][nchunks][NP + 1][2] | chunk start values
+// scratch = level differences [L][n_seq] (serial fallback only) | chunk maps [n_seq][nchunks][NP + 1] | chunk start values
 // [nchunks][n_seq] | log10 table [256]
 struct CompScratch { size_t xl, maps, ystart, tab, total; long nchunks; };
 CompScratch comp_scratch(int n_items, long L, int C) {
@@ -1357,7 +1357,7 @@ int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size
             if (m.use_min) MST_LAUNCH(fx_comp_map_kernel<true>, cg, dim3(64), stream, m, a);
             else MST_LAUNCH(fx_comp_map_kernel<false>, cg, dim3(64), stream, m, a);
             MST_CHECK_LAUNCH("fx_comp_map_kernel");
-            MST_LAUNCH(fx_comp_chain_kernel, dim3(a.n_seq), dim3(128), stream, m);
+            MST_LAUNCH(fx_comp_chain_kernel, dim3(a.n_seq), dim3(MST_CHAIN_THREADS), stream, m);
             MST_CHECK_LAUNCH("fx_comp_chain_kernel");
             MST_LAUNCH((fx_comp_apply_kernel<true>), tiles, dim3(256), stream, a, (const double *)tab, (const double *)m.ystart, m.nchunks);
             MST_CHECK_LAUNCH("fx_comp_apply_kernel");

@@ -99,6 +99,23 @@ __device__ __forceinline__ MstUniformF64 mst_wave_uniform(MstUniformF64 y) {    
 __device__ __forceinline__ MstUniformF64 mst_wave_read_u64(double v, int src) {
     return MstUniformF64{__builtin_amdgcn_readlane(__double2loint(v), src), __builtin_amdgcn_readlane(__double2hiint(v), src)};
 }
+// inclusive prefix sum over each 32-lane half of the wave (lanes 0..31 and 32..63 separately): four row_shr steps inside the 16-lane
+// rows, then row_bcast:15 carries the first row's total into the second row of each half.  DPP moves: VALU speed, no LDS crossbar.
+__device__ __forceinline__ double mst_half_prefix_sum_f64(double v) {
+#define MST_SCAN_STEP(CTRL, ROWS)                                                                          \
+    {                                                                                                      \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xf, false);          \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xf, false);          \
+        v += __hiloint2double(hi, lo);                       /* lanes without a source add 0 */           \
+    }
+    MST_SCAN_STEP(0x111, 0xf)      // row_shr:1
+    MST_SCAN_STEP(0x112, 0xf)      // row_shr:2
+    MST_SCAN_STEP(0x114, 0xf)      // row_shr:4
+    MST_SCAN_STEP(0x118, 0xf)      // row_shr:8
+    MST_SCAN_STEP(0x142, 0xa)      // row_bcast:15 into rows 1 and 3
+#undef MST_SCAN_STEP
+    return v;
+}
 // r of the LOWEST lane whose u <= y (y wave-uniform; at least one lane must pass; ALL 64 lanes of the calling wave must be active - EXEC
 // is put back to all ones): v_cmpx writes the compare straight into EXEC and v_readfirstlane picks the first lane left - no trip through
 // the scalar unit (v_cmp -> s_bcnt1 -> v_readlane) on a dependent chain.  Wait states by hand (the hazard recogniser does not look

@@ -153,6 +153,13 @@ struct MstUniformF64 {
 };
 static inline MstUniformF64 mst_wave_read_u64(double v, int src) { return MstUniformF64{emu_shfl(v, src)}; }
 static inline MstUniformF64 mst_wave_uniform(MstUniformF64 y) { return y; }
+static inline double mst_half_prefix_sum_f64(double v) {
+    const int l = emu::lane_id();
+    const unsigned char *base = emu::wave_publish(&v, sizeof(double));      // one rendezvous, then every lane sums its own prefix
+    double s = 0.0;
+    for (int j = l & 32; j <= l; ++j) { double t; memcpy(&t, base + 64 * j, sizeof(double)); s += t; }
+    return s;
+}
 static inline MstUniformF64 mst_wave_first_ge(MstUniformF64 y, double u, double r) {
     const unsigned long long m = mst_wave_ballot(y.v >= u);
     return MstUniformF64{emu_shfl(r, m ? __builtin_ctzll(m) : 0)};

@@ -2,7 +2,7 @@
 // that brings the records into LDS.  Runs the product's own map kernel on 128 sequences x 131072 samples of noise whose level
 // wanders around the threshold, then times the map kernel and the chain kernel.  Compile three times:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../music_mixing_style_transfer_amd/csrc -DMST_CHAIN_PROBE=0 -o fx_chain_p0 fx_chain_variants.hip
-//   ... -DMST_CHAIN_PROBE=1 (copy wave alone) ... -DMST_CHAIN_PROBE=2 (walker alone, on the first two batches' entries)
+//   ... -DMST_CHAIN_PROBE=1 (helper waves alone) ... -DMST_CHAIN_PROBE=2 (walker alone, on the first two batches' entries)
 #include "fx_kernels.h"
 
 #include <vector>
@@ -52,8 +52,8 @@ int main() {
     }
     const dim3 cg((unsigned)nchunks, (n_seq + 63) / 64);
     const float t_map = time_us([&] { hipLaunchKernelGGL(fx_comp_map_kernel<false>, cg, dim3(64), 0, 0, m, ca); }, 5);
-    const float t_chain = time_us([&] { hipLaunchKernelGGL(fx_comp_chain_kernel, dim3(n_seq), dim3(128), 0, 0, m); }, 5);
-    printf("probe %d  (0 = product, 1 = copy wave alone, 2 = walker alone), 128 sequences x %ld chunks: map kernel %.1f us, chain kernel %.1f us\n",
+    const float t_chain = time_us([&] { hipLaunchKernelGGL(fx_comp_chain_kernel, dim3(n_seq), dim3(MST_CHAIN_THREADS), 0, 0, m); }, 5);
+    printf("probe %d  (0 = product, 1 = helper waves alone, 2 = walker alone), 128 sequences x %ld chunks: map kernel %.1f us, chain kernel %.1f us\n",
            MST_CHAIN_PROBE, nchunks, t_map, t_chain);
     std::vector<double> ys(8);
     hipMemcpy(ys.data(), dys + (size_t)(nchunks - 1) * n_seq, 64, hipMemcpyDeviceToHost);
