@@ -132,10 +132,26 @@ __global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) 
         const long nn = n_lo + ((bt + 1 < nfull) ? (bt + 1) * NB : bt * NB);      // last batch: harmless reload
 #pragma unroll
         for (int i = 0; i < NB; ++i) nx[i] = xp[(nn + i) * a.C];
+        float o[NB];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const float out = step(xin[i]);
-            if (APPLY) yp[(n_lo + bt * NB + i) * a.C] = out;
+        for (int i = 0; i < NB; ++i) o[i] = step(xin[i]);
+        if (APPLY) {
+            if (a.C == 2) {
+                // stereo: the two channels of a chunk are neighbouring lanes in lock-step.  They trade halves so that each owns two whole
+                // frames of every four (even lane: frames f, f + 1; odd lane: f + 2, f + 3) and stores them as one 16-byte piece - the
+                // pair writes 32 contiguous bytes per instruction instead of 8: a quarter of the L2 write transactions
+                const bool odd = c != 0;
+                float *fp = a.y + ((size_t)item * a.L + n_lo + bt * NB) * 2;
+#pragma unroll
+                for (int f = 0; f < NB; f += 4) {
+                    const float ta = mst_lane_swap(odd ? o[f] : o[f + 2]), tb = mst_lane_swap(odd ? o[f + 1] : o[f + 3]);
+                    const float4 v = odd ? make_float4(ta, o[f + 2], tb, o[f + 3]) : make_float4(o[f], ta, o[f + 1], tb);
+                    *(float4 *)(fp + (f + (odd ? 2 : 0)) * 2) = v;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) yp[(n_lo + bt * NB + i) * a.C] = o[i];
+            }
         }
     }
     for (long n = n_lo + nfull * NB; n < n_hi; ++n) {

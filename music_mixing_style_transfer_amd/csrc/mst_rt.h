@@ -99,6 +99,10 @@ __device__ __forceinline__ MstUniformF64 mst_wave_uniform(MstUniformF64 y) {    
 __device__ __forceinline__ MstUniformF64 mst_wave_read_u64(double v, int src) {
     return MstUniformF64{__builtin_amdgcn_readlane(__double2loint(v), src), __builtin_amdgcn_readlane(__double2hiint(v), src)};
 }
+// the value of the neighbouring lane (lane ^ 1): one DPP move (quad_perm [1, 0, 3, 2])
+__device__ __forceinline__ float mst_lane_swap(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+}
 // inclusive prefix sum over each 32-lane half of the wave (lanes 0..31 and 32..63 separately): four row_shr steps inside the 16-lane
 // rows, then row_bcast:15 carries the first row's total into the second row of each half.  DPP moves: VALU speed, no LDS crossbar.
 __device__ __forceinline__ double mst_half_prefix_sum_f64(double v) {

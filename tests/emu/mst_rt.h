@@ -153,6 +153,7 @@ struct MstUniformF64 {
 };
 static inline MstUniformF64 mst_wave_read_u64(double v, int src) { return MstUniformF64{emu_shfl(v, src)}; }
 static inline MstUniformF64 mst_wave_uniform(MstUniformF64 y) { return y; }
+static inline float mst_lane_swap(float v) { return emu_shfl(v, emu::lane_id() ^ 1); }
 static inline double mst_half_prefix_sum_f64(double v) {
     const int l = emu::lane_id();
     const unsigned char *base = emu::wave_publish(&v, sizeof(double));      // one rendezvous, then every lane sums its own prefix
