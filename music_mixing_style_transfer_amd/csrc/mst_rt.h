@@ -18,11 +18,6 @@
 #define MST_LAUNCH(kern, grid, block, stream, ...) \
     hipLaunchKernelGGL(kern, (grid), (block), 0, (hipStream_t)(stream), __VA_ARGS__)
 
-// hardware wave slot of the calling wave (s_getreg_b32 hwreg(HW_REG_HW_ID, 0, 4)) and a 127*64-clock sleep
-__device__ __forceinline__ unsigned mst_wave_slot() { return __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)); }
-__device__ __forceinline__ unsigned mst_hw_id() { return __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); }
-__device__ __forceinline__ unsigned mst_xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); }
-
 // value barrier: the compiler may not fuse the operation that produced `v` with the one that consumes it (fp contraction)
 #define MST_NO_CONTRACT(v) asm volatile("" : "+v"(v))
 
@@ -32,9 +27,6 @@ __device__ __forceinline__ float mst_fmax(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-
-// opaque identity on an integer in a vector register: values derived from it are recomputed rather than kept live
-#define MST_LAUNDER(v) asm volatile("" : "+v"(v))
 
 // hipFFT entry points bound at first use (no link-time dependency); returns false when the library cannot be loaded
 #include <dlfcn.h>
@@ -51,43 +43,6 @@ static inline bool mst_fft_bind(void **plan_many, void **set_stream, void **exec
     return *plan_many && *set_stream && *exec_r2c && *exec_c2r && *destroy;
 }
 
-// wave-wide max (or min) of a double, returned in every lane.  DPP row shifts / row broadcasts (VALU speed) instead of
-// ds_bpermute shuffles: a 64-bit __shfl_xor is two LDS-crossbar round trips per level, ~1.6 k clocks for six levels.
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ double mst_dpp_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);      // lanes without a source keep their own value
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-template <bool USE_MIN> __device__ __forceinline__ double mst_wave_extreme_f64(double v) {
-    // plain v_max_f64 / v_min_f64: fmax()/fmin() cost an extra canonicalising v_max per operand
-#define MST_RED_STEP(CTRL, MASK)                                                    \
-    {                                                                               \
-        const double o = mst_dpp_f64<CTRL, MASK>(v);                                \
-        if (USE_MIN) asm("v_min_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o));        \
-        else asm("v_max_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o));                \
-    }
-    MST_RED_STEP(0x111, 0xf)      // row_shr:1
-    MST_RED_STEP(0x112, 0xf)      // row_shr:2
-    MST_RED_STEP(0x114, 0xf)      // row_shr:4
-    MST_RED_STEP(0x118, 0xf)      // row_shr:8   -> lane 15 of every row holds its row's extreme
-    MST_RED_STEP(0x142, 0xa)      // row_bcast:15 into rows 1 and 3
-    MST_RED_STEP(0x143, 0xc)      // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's extreme
-#undef MST_RED_STEP
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
-
-// read one accumulator element out of its AGPR exactly here (256-accumulator kernels: hipcc otherwise copies every
-// accumulator to VGPRs right after the main loop and spills most of them)
-__device__ __forceinline__ float mst_acc_read(float x) {
-    float r;
-    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(x));
-    return r;
-}
-
-// the wave's predicate mask (v_cmp writes it straight into an SGPR pair)
-__device__ __forceinline__ unsigned long long mst_wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // a wave-uniform double as the two SGPR halves v_readlane returns (kept apart so that v_writelane can take them without a copy)
 struct MstUniformF64 {
     int lo, hi;

@@ -65,8 +65,6 @@ struct float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 static inline float2 make_float2(float x, float y) { return {x, y}; }
 static inline float mst_fmax(float a, float b) { return fmaxf(a, b); }
-static inline float mst_acc_read(float x) { return x; }
-#define MST_LAUNDER(v) asm volatile("" : "+r"(v))
 #define MST_NO_CONTRACT(v) asm volatile("" : "+x"(v))      // value barrier: no fp contraction across it
 
 namespace emu {
@@ -133,13 +131,6 @@ template <typename T> static inline T emu_shfl(T v, int src) {
     return out;
 }
 template <typename T> static inline T __shfl_xor(T v, int mask, int = 64) { return emu_shfl(v, emu::lane_id() ^ mask); }
-template <bool USE_MIN> static inline double mst_wave_extreme_f64(double v) {
-    for (int m = 32; m >= 1; m >>= 1) {
-        const double o = __shfl_xor(v, m);
-        v = USE_MIN ? fmin(v, o) : fmax(v, o);
-    }
-    return v;
-}
 static inline unsigned long long mst_wave_ballot(bool p) {
     unsigned long long m = 0;
     const int mine = p ? 1 : 0;
@@ -207,9 +198,6 @@ static inline unsigned __brev(unsigned v) { unsigned r = 0; for (int i = 0; i < 
 static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
-static inline unsigned mst_wave_slot() { return 0; }
-static inline unsigned mst_hw_id() { return 0; }
-static inline unsigned mst_xcc_id() { return 0; }
 
 // ---- host stand-ins for the five hipFFT entry points the library binds (power-of-two lengths, double precision inside)
 #include <complex>
