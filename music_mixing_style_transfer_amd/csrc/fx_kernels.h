@@ -698,6 +698,7 @@ __global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const do
     __shared__ double t[64][65];
     const long n0 = (long)blockIdx.x * 64;
     const int s0 = blockIdx.y * 64;
+    float xv[16];
     if constexpr (FILL) {
         static_assert(MST_COMP_T == 32, "two chunks per 64-step tile");
         // yl = the log10 table: the level differences are recomputed from the audio (audio side: lanes along time), the smoother runs
@@ -712,17 +713,21 @@ __global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const do
             const FxCompCurve c = fx_comp_curve(a, seq / a.C);
             sthr[threadIdx.x] = c.thr; smul[threadIdx.x] = c.mul; smode[threadIdx.x] = c.mode; ssf[threadIdx.x] = c.sf;
         }
-        __syncthreads();
-#pragma unroll 4
+        // this thread's 16 samples (scaled), all loads in flight before the first use; kept in registers for the gain application
+#pragma unroll
         for (int k = 0; k < 16; ++k) {
+            const int idx = k * 256 + threadIdx.x, sq = s0 + (idx >> 6);
+            const long n = n0 + (idx & 63);
+            const bool ok = sq < a.n_seq && n < a.L;
+            const int sc = ok ? sq : 0;
+            xv[k] = a.x[((size_t)(a.shared_x ? 0 : sc / a.C) * a.L + (ok ? n : 0)) * a.C + sc % a.C];      // never a predicated load
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {                               // (full unroll: xv stays in registers)
             const int idx = k * 256 + threadIdx.x, sl = idx >> 6, nl = idx & 63;
-            const int seq = s0 + sl;
-            const long n = n0 + nl;
-            double v = 0.0;
-            if (seq < a.n_seq && n < a.L)
-                v = fx_comp_level_diff(a.x[((size_t)(a.shared_x ? 0 : seq / a.C) * a.L + n) * a.C + seq % a.C] * ssf[sl], sthr[sl], smul[sl],
-                                       smode[sl], tab);
-            t[nl][sl] = v;
+            xv[k] *= ssf[sl];
+            t[nl][sl] = (s0 + sl < a.n_seq && n0 + nl < a.L) ? fx_comp_level_diff(xv[k], sthr[sl], smul[sl], smode[sl], tab) : 0.0;
         }
         __syncthreads();
         const int sl = threadIdx.x & 63, hh = threadIdx.x >> 6;
@@ -745,7 +750,7 @@ __global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const do
         }
     }
     __syncthreads();
-#pragma unroll 4
+#pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int idx = k * 256 + threadIdx.x, sl = idx >> 6, nl = idx & 63;
         const int seq = s0 + sl;
@@ -753,9 +758,9 @@ __global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const do
         if (seq < a.n_seq && n < a.L) {
             const size_t e = ((size_t)(seq / a.C) * a.L + n) * a.C + seq % a.C;
             const size_t ex = a.shared_x ? (size_t)n * a.C + seq % a.C : e;
-            const float sf = a.in_scale ? (float)a.in_scale[seq / a.C] : 1.0f;
+            const float xs = FILL ? xv[k] : a.x[ex] * (a.in_scale ? (float)a.in_scale[seq / a.C] : 1.0f);
             // 10^(v / 20) as exp(v ln10 / 20): the general pow() is five times the instructions for the same value to 1e-15 relative
-            const float out = (float)((double)(a.x[ex] * sf) * exp((a.makeup - t[nl][sl]) * 0.11512925464970228420));
+            const float out = (float)((double)xs * exp((a.makeup - t[nl][sl]) * 0.11512925464970228420));
             a.y[e] = out;
             if (a.out_sumsq) t[nl][sl] = (double)out * (double)out;          // this thread's own tile element: reused for the energy sum
         } else if (a.out_sumsq) {
