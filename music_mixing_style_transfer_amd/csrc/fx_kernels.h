@@ -70,8 +70,8 @@ __global__ __launch_bounds__(64) void fx_biquad_kernel(BiquadArgs a) {
 struct BiquadChunkArgs {
     const float *x;
     float *y;             // pass 2 only
-    double *ends;         // [nchunks][2*MST_MAX_BANDS][n_seq]  zero-state end states (pass 1 out)
-    const double *starts; // [nchunks][2*MST_MAX_BANDS][n_seq]  true start states (pass 2 in)
+    double *ends;         // [n_seq][nchunks][2*MST_MAX_BANDS]  zero-state end states (pass 1 out): one 128-byte record per chunk
+    const double *starts; // [n_seq][nchunks][2*MST_MAX_BANDS]  true start states (pass 2 in)
     int n_seq, C, nchunks, M;
     long L;
     int n_bands;
@@ -98,8 +98,9 @@ __global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) 
     double z1[NBANDS], z2[NBANDS];
 #pragma unroll
     for (int b = 0; b < NBANDS; ++b) {
-        z1[b] = APPLY ? a.starts[((size_t)k * (2 * MST_MAX_BANDS) + 2 * b) * a.n_seq + seq] : 0.0;
-        z2[b] = APPLY ? a.starts[((size_t)k * (2 * MST_MAX_BANDS) + 2 * b + 1) * a.n_seq + seq] : 0.0;
+        const double2 zz = APPLY ? *(const double2 *)(a.starts + ((size_t)seq * a.nchunks + k) * (2 * MST_MAX_BANDS) + 2 * b) : double2{0.0, 0.0};
+        z1[b] = zz.x;
+        z2[b] = zz.y;
     }
     const float sf = a.in_scale ? (float)a.in_scale[item] : 1.0f;
     double ss = 0.0;
@@ -161,8 +162,7 @@ __global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) 
     if (!APPLY) {
 #pragma unroll
         for (int b = 0; b < NBANDS; ++b) {
-            a.ends[((size_t)k * (2 * MST_MAX_BANDS) + 2 * b) * a.n_seq + seq] = z1[b];
-            a.ends[((size_t)k * (2 * MST_MAX_BANDS) + 2 * b + 1) * a.n_seq + seq] = z2[b];
+            *(double2 *)(a.ends + ((size_t)seq * a.nchunks + k) * (2 * MST_MAX_BANDS) + 2 * b) = double2{z1[b], z2[b]};
         }
     } else if (a.out_sumsq) {
         atomicAdd(&a.out_sumsq[item * MST_SUMSQ_SLOTS + (k & (MST_SUMSQ_SLOTS - 1))], ss);     // spread over the slots: few atomics per address
@@ -173,32 +173,59 @@ __global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) 
 // parallel.  One workgroup of NB = 256 or 512 threads per sequence; a block of NB - 1 chunks at a time: element 0 is the carry (the
 // start state of the block's first chunk), element i > 0 the zero-state end state of chunk i - 1, and a Hillis-Steele scan
 //     t_i += (A^M)^(2^l) t_{i - 2^l}      l = 0 .. log2(NB) - 1
-// leaves t_i = the true start state of chunk i (t_(NB-1) = the next block's carry).  The powers (A^M)^(2^l) are squared up in LDS by
-// the workgroup itself from A^M (kernel argument, float64).  128 sequences x 128 chunks: 8 matrix-vector products of depth per
+// leaves t_i = the true start state of chunk i (t_(NB-1) = the next block's carry).  The powers (A^M)^(2^l) come from
+// fx_biquad_pow_kernel (squared up from the host's A^M, float64).  128 sequences x 128 chunks: 8 matrix-vector products of depth per
 // sequence instead of 128 (round 1's kernel ran one LANE per sequence: 2 workgroups, 88 us); a 3-minute stem (7 752 chunks) is
 // 31 blocks instead of 7 752 serial steps.  AM is [S][S] row-major with S = 2 * n_bands, state order (z1, z2) per band; ends /
-// starts are laid out [chunk][state][sequence].
+// starts are laid out [sequence][chunk][16 states]: one 128-byte record per chunk, so that the scan's element i reads / writes
+// record i (the first layout, [chunk][state][sequence], cost the scan 19 of its 39 us in 8-byte accesses 16 KB apart).
 struct BiquadPowArgs { double am[4 * MST_MAX_BANDS * MST_MAX_BANDS]; };      // A^M, [S][S] row-major, by value in the kernel arguments
+#define MST_BIQUAD_LEVELS 9                                                   // log2 of the largest scan block
+
+// pm[l] = (A^M)^(2^l), l = 0 .. 8, squared up by one workgroup into the caller's scratch: the scan kernel reads the matrix elements
+// with scalar loads (uniform addresses) and feeds them to v_fma_f64 as SGPR operands - its first version kept them in LDS and spent
+// its time on 100 broadcast ds_read_b64 per thread and level (40 us for 482 chunks of 128 sequences)
+template <int NBANDS>
+__global__ __launch_bounds__(256) void fx_biquad_pow_kernel(BiquadPowArgs pw, double *pm) {
+    constexpr int S = 2 * NBANDS;
+    __shared__ double cur[S * S];
+    const int i = threadIdx.x;
+    if (i < S * S) {
+        cur[i] = pw.am[i];
+        pm[i] = pw.am[i];
+    }
+    __syncthreads();
+    for (int l = 1; l < MST_BIQUAD_LEVELS; ++l) {
+        double acc = 0.0;
+        if (i < S * S) {
+            const int r = i / S, c = i % S;
+#pragma unroll
+            for (int j = 0; j < S; ++j) acc += cur[r * S + j] * cur[j * S + c];
+        }
+        __syncthreads();
+        if (i < S * S) {
+            cur[i] = acc;
+            pm[l * S * S + i] = acc;
+        }
+        __syncthreads();
+    }
+}
 
 template <int NBANDS, int NB>
-__global__ __launch_bounds__(NB) void fx_biquad_scan_kernel(const double *ends, double *starts, BiquadPowArgs pw, int n_seq,
+__global__ __launch_bounds__(NB) void fx_biquad_scan_kernel(const double *ends, double *starts, const double *__restrict__ pm, int n_seq,
                                                            int nchunks) {
     constexpr int SM = 2 * MST_MAX_BANDS, S = 2 * NBANDS, NL = NB == 512 ? 9 : 8;      // table row stride / live states / levels
     static_assert(NB == 256 || NB == 512, "elements per block");
-    __shared__ double pm[NL][S * S];                 // (A^M)^(2^l)
-    __shared__ double st[2][NB][S];
+    static_assert(NL <= MST_BIQUAD_LEVELS, "powers available");
+    __shared__ double st[2][S][NB];                  // state-major: neighbouring elements are neighbouring doubles
     const int seq = blockIdx.x, i = threadIdx.x;
-    for (int k = i; k < S * S; k += NB) pm[0][k] = pw.am[k];
-    __syncthreads();
-    for (int l = 1; l < NL; ++l) {                   // squaring: pm[l] = pm[l-1] pm[l-1]
-        for (int k = i; k < S * S; k += NB) {
-            const int r = k / S, c = k % S;
-            double acc = 0.0;
+    // every level reads its own 100 matrix elements with scalar loads exactly once: all of them cold misses (5 k clocks of waiting per
+    // level).  Touch the whole table first - one line of 64 bytes per load, all in flight together - so that the levels hit the scalar cache.
+    {
+        double warm = 0.0;
 #pragma unroll
-            for (int j = 0; j < S; ++j) acc += pm[l - 1][r * S + j] * pm[l - 1][j * S + c];
-            pm[l][k] = acc;
-        }
-        __syncthreads();
+        for (int k = 0; k < NL * S * S; k += 8) warm += pm[k];
+        if (warm == 1.2345e301) starts[0] = warm;      // never true; keeps the loads
     }
     double carry[S];
 #pragma unroll
@@ -207,40 +234,53 @@ __global__ __launch_bounds__(NB) void fx_biquad_scan_kernel(const double *ends, 
         // element i: the carry (i = 0) or the zero-state end state of chunk k0 + i - 1
         double t[S];
         const int kc = k0 + i - 1;
+        const bool have = i > 0 && kc < nchunks;
+        // never a predicated load (hipcc branches around it and drains vmcnt(0) behind each: ten serial memory latencies per block)
+        const double2 *rec = (const double2 *)(ends + ((size_t)seq * nchunks + (have ? kc : 0)) * SM);
+#pragma unroll
+        for (int j = 0; j < S; j += 2) {
+            const double2 v = rec[j / 2];
+            t[j] = v.x;
+            t[j + 1] = v.y;
+        }
 #pragma unroll
         for (int j = 0; j < S; ++j) {
-            t[j] = i == 0 ? carry[j] : (kc < nchunks ? ends[((size_t)kc * SM + j) * n_seq + seq] : 0.0);
-            st[0][i][j] = t[j];
+            t[j] = i == 0 ? carry[j] : (have ? t[j] : 0.0);
+            st[0][j][i] = t[j];
         }
         __syncthreads();
         int cur = 0;
+#ifdef MST_SCAN_PROBE
+        if (nchunks < 0)                 // tools/micro/fx_scan_probe.hip: the load / store shell alone
+#endif
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const int d = 1 << l;
             if (i >= d) {
                 double u[S];
 #pragma unroll
-                for (int j = 0; j < S; ++j) u[j] = st[cur][i - d][j];
+                for (int j = 0; j < S; ++j) u[j] = st[cur][j][i - d];
 #pragma unroll
                 for (int r = 0; r < S; ++r) {
                     double acc = t[r];
 #pragma unroll
-                    for (int j = 0; j < S; ++j) acc += pm[l][r * S + j] * u[j];
+                    for (int j = 0; j < S; ++j) acc = fma(pm[(l * S + r) * S + j], u[j], acc);      // uniform address: a scalar load
                     t[r] = acc;
                 }
             }
 #pragma unroll
-            for (int j = 0; j < S; ++j) st[cur ^ 1][i][j] = t[j];
+            for (int j = 0; j < S; ++j) st[cur ^ 1][j][i] = t[j];
             __syncthreads();
             cur ^= 1;
         }
         // t = start state of chunk k0 + i (i < NB - 1); the last element is the next block's carry
         if (i < NB - 1 && k0 + i < nchunks) {
+            double2 *out = (double2 *)(starts + ((size_t)seq * nchunks + k0 + i) * SM);
 #pragma unroll
-            for (int j = 0; j < S; ++j) starts[((size_t)(k0 + i) * SM + j) * n_seq + seq] = t[j];
+            for (int j = 0; j < S; j += 2) out[j / 2] = double2{t[j], t[j + 1]};
         }
 #pragma unroll
-        for (int j = 0; j < S; ++j) carry[j] = st[cur][NB - 1][j];
+        for (int j = 0; j < S; ++j) carry[j] = st[cur][j][NB - 1];
         __syncthreads();
     }
 }

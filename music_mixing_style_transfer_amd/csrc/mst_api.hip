@@ -1167,15 +1167,28 @@ extern "C" int mst_embedding_mean(const float *emb, int n_rows, int dim, float *
 // FX processors
 // =================================================================================================
 namespace {
-// Steps per chunk of the time-parallel biquad cascade.  Two chunk passes cost ~0.19 us per step of a chunk (one lane walks it), the
-// scan over the chunk states ~25 us per block of 511 chunks: short segments get one scan block (a 131072-sample segment: 272 steps,
-// 482 chunks - with 128 sequences that is one wave per SIMD), long stems the chunk length that balances the two, sqrt(L / 4).
-int biquad_chunk(long L) {
+// Steps per chunk of the time-parallel biquad cascade: the number of 511-chunk scan blocks that minimises
+//     16 us per scan block + two chunk passes at 0.19 us per step of a chunk
+// (measured on an MI355X; a pass is one lane per chunk and its time falls with the chunk length until every SIMD holds a wave = 65536
+// lanes, after which it is the total work that counts: 144-step chunks at 116 k lanes take the same 105 us as 272-step chunks at 62 k).
+// A 131072-sample segment x 128 sequences: 1 block, 272 steps, 482 chunks; a 3-minute stem x 2: ~16 blocks, ~976 steps.
+int biquad_chunk(long L, long n_seq) {
     auto up16 = [](long v) { return (int)((v + 15) / 16 * 16); };
-    const int one_block = up16((L + 510) / 511);
-    if (one_block <= 1024) return one_block < 64 ? 64 : one_block;
-    const int bal = up16((long)std::sqrt((double)L / 4.0));
-    return bal < 1024 ? 1024 : (bal > 4096 ? 4096 : bal);
+    int best_m = 64;
+    double best = 1e300;
+    for (int B = 1; B <= 64; ++B) {
+        int m = up16((L + 511L * B - 1) / (511L * B));
+        if (m < 64) m = 64;
+        const long nchunks = (L + m - 1) / m;
+        const double lanes = (double)n_seq * (double)nchunks;
+        const double cost = 16.0 * (double)((nchunks + 510) / 511) + 0.39 * m * (lanes > 65536.0 ? lanes / 65536.0 : 1.0);
+        if (cost < best) {
+            best = cost;
+            best_m = m;
+        }
+        if (m == 64) break;
+    }
+    return best_m;
 }
 void biquad_coefs(const double *coef, int n_bands, double (*out)[5]) {
     for (int k = 0; k < MST_MAX_BANDS; ++k)
@@ -1193,17 +1206,17 @@ void biquad_coefs(const double *coef, int n_bands, double (*out)[5]) {
 
 extern "C" size_t mst_fx_biquad_scratch_bytes(int n_items, long L, int C, int n_bands) {
     if (n_items < 1 || L < 1 || C < 1 || n_bands < 1) return 0;
-    const int M = biquad_chunk(L);
+    const int M = biquad_chunk(L, (long)n_items * C);
     const long nchunks = (L + M - 1) / M;
     const size_t states = (size_t)n_items * C * nchunks * 2 * MST_MAX_BANDS;
-    return (2 * states + (size_t)4 * MST_MAX_BANDS * MST_MAX_BANDS) * sizeof(double);
+    return (2 * states + (size_t)MST_BIQUAD_LEVELS * 4 * MST_MAX_BANDS * MST_MAX_BANDS) * sizeof(double);      // ends | starts | (A^M)^(2^l)
 }
 
 extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long L, int C, const double *coef, int n_bands,
                                      double *scratch, size_t scratch_bytes, const MstFxFuse *fuse, void *stream) {
     if (!x || !y || !coef || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_biquad_cascade: bad argument");
     if (n_bands < 0 || n_bands > MST_MAX_BANDS) return fail(MST_ERR_UNSUPPORTED, "mst_fx_biquad_cascade: at most 8 bands");
-    const int M = biquad_chunk(L);
+    const int M = biquad_chunk(L, (long)n_items * C);
     const long nchunks = (L + M - 1) / M;
     if (scratch && nchunks > 1 && n_bands > 0) {
         if (scratch_bytes < mst_fx_biquad_scratch_bytes(n_items, L, C, n_bands))
@@ -1260,18 +1273,30 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         launch_chunks(std::false_type{});
         MST_CHECK_LAUNCH("fx_biquad_chunk_kernel<state>");
         const dim3 sg((unsigned)a.n_seq);
+        double *pmat = scratch + 2 * states;          // (A^M)^(2^l), l = 0 .. 8
+        switch (n_bands) {
+            case 1: MST_LAUNCH(fx_biquad_pow_kernel<1>, dim3(1), dim3(256), stream, pw, pmat); break;
+            case 2: MST_LAUNCH(fx_biquad_pow_kernel<2>, dim3(1), dim3(256), stream, pw, pmat); break;
+            case 3: MST_LAUNCH(fx_biquad_pow_kernel<3>, dim3(1), dim3(256), stream, pw, pmat); break;
+            case 4: MST_LAUNCH(fx_biquad_pow_kernel<4>, dim3(1), dim3(256), stream, pw, pmat); break;
+            case 5: MST_LAUNCH(fx_biquad_pow_kernel<5>, dim3(1), dim3(256), stream, pw, pmat); break;
+            case 6: MST_LAUNCH(fx_biquad_pow_kernel<6>, dim3(1), dim3(256), stream, pw, pmat); break;
+            case 7: MST_LAUNCH(fx_biquad_pow_kernel<7>, dim3(1), dim3(256), stream, pw, pmat); break;
+            default: MST_LAUNCH(fx_biquad_pow_kernel<8>, dim3(1), dim3(256), stream, pw, pmat); break;
+        }
+        MST_CHECK_LAUNCH("fx_biquad_pow_kernel");
         auto launch_scan = [&](auto NBv) {
             constexpr int nb = decltype(NBv)::value;
-            const double *e = ends;
+            const double *e = ends, *pmc = pmat;
             switch (n_bands) {
-                case 1: MST_LAUNCH((fx_biquad_scan_kernel<1, nb>), sg, dim3(nb), stream, e, starts, pw, a.n_seq, (int)nchunks); break;
-                case 2: MST_LAUNCH((fx_biquad_scan_kernel<2, nb>), sg, dim3(nb), stream, e, starts, pw, a.n_seq, (int)nchunks); break;
-                case 3: MST_LAUNCH((fx_biquad_scan_kernel<3, nb>), sg, dim3(nb), stream, e, starts, pw, a.n_seq, (int)nchunks); break;
-                case 4: MST_LAUNCH((fx_biquad_scan_kernel<4, nb>), sg, dim3(nb), stream, e, starts, pw, a.n_seq, (int)nchunks); break;
-                case 5: MST_LAUNCH((fx_biquad_scan_kernel<5, nb>), sg, dim3(nb), stream, e, starts, pw, a.n_seq, (int)nchunks); break;
-                case 6: MST_LAUNCH((fx_biquad_scan_kernel<6, nb>), sg, dim3(nb), stream, e, starts, pw, a.n_seq, (int)nchunks); break;
-                case 7: MST_LAUNCH((fx_biquad_scan_kernel<7, nb>), sg, dim3(nb), stream, e, starts, pw, a.n_seq, (int)nchunks); break;
-                default: MST_LAUNCH((fx_biquad_scan_kernel<8, nb>), sg, dim3(nb), stream, e, starts, pw, a.n_seq, (int)nchunks); break;
+                case 1: MST_LAUNCH((fx_biquad_scan_kernel<1, nb>), sg, dim3(nb), stream, e, starts, pmc, a.n_seq, (int)nchunks); break;
+                case 2: MST_LAUNCH((fx_biquad_scan_kernel<2, nb>), sg, dim3(nb), stream, e, starts, pmc, a.n_seq, (int)nchunks); break;
+                case 3: MST_LAUNCH((fx_biquad_scan_kernel<3, nb>), sg, dim3(nb), stream, e, starts, pmc, a.n_seq, (int)nchunks); break;
+                case 4: MST_LAUNCH((fx_biquad_scan_kernel<4, nb>), sg, dim3(nb), stream, e, starts, pmc, a.n_seq, (int)nchunks); break;
+                case 5: MST_LAUNCH((fx_biquad_scan_kernel<5, nb>), sg, dim3(nb), stream, e, starts, pmc, a.n_seq, (int)nchunks); break;
+                case 6: MST_LAUNCH((fx_biquad_scan_kernel<6, nb>), sg, dim3(nb), stream, e, starts, pmc, a.n_seq, (int)nchunks); break;
+                case 7: MST_LAUNCH((fx_biquad_scan_kernel<7, nb>), sg, dim3(nb), stream, e, starts, pmc, a.n_seq, (int)nchunks); break;
+                default: MST_LAUNCH((fx_biquad_scan_kernel<8, nb>), sg, dim3(nb), stream, e, starts, pmc, a.n_seq, (int)nchunks); break;
             }
         };
         if (nchunks > 255) launch_scan(std::integral_constant<int, 512>{});
