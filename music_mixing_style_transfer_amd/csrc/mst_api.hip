@@ -129,6 +129,7 @@ struct MstTcn {
     int film_rows = 0, film_cap = 0;
     float *out_w = nullptr, *out_b = nullptr;
     bool out_loaded = false;
+    void *zero_row = nullptr;     // 1 KB of zeros: what the block kernels stage for time steps outside the segment
     int x3_small_tiles = 1;       // bf16x3 mode: 128-time tiles of <= 2 phases, two workgroups per CU (mst_tcn_set_tuning; measured 5.13 vs 5.45 ms)
     std::vector<hipEvent_t> ev;   // timing hook: (nblocks + 2) events per recorded forward
     int ev_max = 0, ev_used = 0;
@@ -163,7 +164,11 @@ extern "C" int mst_tcn_create(const MstTcnDesc *desc, MstTcn **out) {
     }
     const size_t fw = (size_t)d.nblocks * 2 * d.channels * d.cond_dim;
     if (hipMalloc((void **)&t->film_w, fw * sizeof(float)) != hipSuccess ||
-        hipMalloc((void **)&t->film_b, (size_t)d.nblocks * 2 * d.channels * sizeof(float)) != hipSuccess) {
+        hipMalloc((void **)&t->film_b, (size_t)d.nblocks * 2 * d.channels * sizeof(float)) != hipSuccess ||
+        hipMalloc(&t->zero_row, 1024) != hipSuccess || hipMemset(t->zero_row, 0, 1024) != hipSuccess) {
+        (void)hipFree(t->film_w);
+        (void)hipFree(t->film_b);
+        (void)hipFree(t->zero_row);
         delete t;
         return fail(MST_ERR_HIP, "mst_tcn_create: hipMalloc failed");
     }
@@ -185,6 +190,7 @@ extern "C" int mst_tcn_destroy(MstTcn *t) {
     (void)hipFree(t->film);
     (void)hipFree(t->out_w);
     (void)hipFree(t->out_b);
+    (void)hipFree(t->zero_row);
     for (auto &c : t->gconv) {
         (void)hipFree(c.wpk);
         (void)hipFree(c.ktab);
@@ -552,6 +558,7 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         a.y_out = fuse_out ? y : nullptr;
         a.nout = t->d.noutputs;
         a.xcd_tiles = 0;
+        a.zeros = t->zero_row;
         if (grid > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_tcn_forward: grid too large");
         int rc;
         switch (P) {

@@ -41,6 +41,7 @@ struct TcnBlockArgs {
     const float *out_b;
     float *y_out;
     int nout;
+    const void *zeros;    // >= 256 bytes of zeros in device memory: the row staged for time steps outside the segment
     int xcd_tiles;        // > 0: tiles per XCD; workgroup i (dispatched to XCD i % 8) takes tile (i % 8) * xcd_tiles + i / 8, so that
                           // neighbouring time tiles (which share their halo rows) run on the same XCD and meet in its L2
 };
@@ -67,40 +68,51 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
     const int m0 = mg * MT, phi0 = pg * P;
     const __bf16 *xb = (const __bf16 *)a.x + (size_t)b * a.Lp * 128;
     __bf16 *yb = (__bf16 *)a.y + (size_t)b * a.Lp * 128;
-    // per-channel epilogue parameters -> LDS while the tile is staged (one broadcast ds_read_b128 each in the epilogue
-    // instead of four exposed L2 round trips)
-    if (tid < 128) {
-        const float *frow0 = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
-        par[tid] = a.shift[tid];
-        par[128 + tid] = frow0[tid];
-        par[256 + tid] = frow0[128 + tid];
-        par[384 + tid] = a.res[tid];
-    }
     // ---- stage the (256 + 14P) input rows: 16 lanes x 16 B per row, XOR-swizzled 16-B slots so that the
     //      32 consecutive rows of one B-fragment read hit 16 distinct slots per ds_read_b128 lane group
     {
         // all (R+15)/16 row loads of a thread are issued back to back (one exposed memory latency per tile;
         // the accumulators are not live yet, so the registers are free), then written to LDS
         // consecutive passes of a thread are 16 / P dilation steps apart in time and 4096 bytes apart in LDS (the XOR
-        // swizzle depends on row & 15 = the thread's first row only): running pointers, no per-row address arithmetic
+        // swizzle depends on row & 15 = the thread's first row only): running pointers, no per-row address arithmetic.
+        // NEVER a predicated load: hipcc branches around each and, here, drained vmcnt(0) behind the second one (a register-tuple
+        // copy) - a second exposed latency per tile.  Rows outside the segment read a row of zeros instead.
         static_assert(16 % P == 0, "row passes advance by a whole number of steps");
         const int slot = tid & 15, prow = tid >> 4;
         constexpr int NPASS = (R + 15) / 16;
         const long dt = (long)(16 / P) * a.d;
         long t = (long)(m0 + prow / P - 7) * a.d + phi0 + (prow % P);
         const __bf16 *src = xb + t * 128 + slot * 8;
+        const __bf16 *zsrc = (const __bf16 *)a.zeros + slot * 8;
         bf16x8 v[NPASS];
 #pragma unroll
         for (int i = 0; i < NPASS; ++i) {
-            v[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (prow + 16 * i < R && t >= 0 && t < a.L) v[i] = *(const bf16x8 *)src;
+            const bool ok = prow + 16 * i < R && t >= 0 && t < a.L;
+            v[i] = *(const bf16x8 *)(ok ? src : zsrc);
             t += dt;
             src += dt * 128;
+        }
+        // per-channel epilogue parameters -> LDS (one broadcast ds_read_b128 each in the epilogue instead of four exposed L2 round
+        // trips); requested BEHIND the row loads, so that their latency is not a third one in front of the tile's
+        float pv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        {
+            const int pc = tid & 127;
+            const float *frow0 = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+            pv[0] = a.shift[pc];
+            pv[1] = frow0[pc];
+            pv[2] = frow0[128 + pc];
+            pv[3] = a.res[pc];
         }
         unsigned char *dst = smem + prow * 256 + ((slot ^ (prow & 15)) << 4);
 #pragma unroll
         for (int i = 0; i < NPASS; ++i)
             if (prow + 16 * i < R) *(bf16x8 *)(dst + i * 4096) = v[i];
+        if (tid < 128) {
+            par[tid] = pv[0];
+            par[128 + tid] = pv[1];
+            par[256 + tid] = pv[2];
+            par[384 + tid] = pv[3];
+        }
     }
     __syncthreads();
 
