@@ -340,11 +340,12 @@ __global__ __launch_bounds__(256) void fx_compressor_kernel(CompArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same compressor split by dependency structure (needs 8 bytes of scratch per sample):
+// The same compressor split by dependency structure, for signals too short for the time-parallel form below (fewer than four
+// 32-step chunks; 8 bytes of scratch per sample):
 //   fx_comp_gain_kernel    every sample in parallel: x_l = x_g - y_g (log10 + static curve), float64
 //   fx_comp_smooth_kernel  one lane per sequence: ONLY the branchy one-pole recursion (2 FMAs + compare + select per
 //                          sample), y_l written over x_l
-//   fx_comp_apply_kernel   every sample in parallel: y = x * 10^((makeup - y_l) / 20)
+//   fx_comp_apply_kernel<false>  every sample in parallel: y = x * 10^((makeup - y_l) / 20)
 // Same float64 arithmetic per sample; the serial part shrinks to the recursion itself.
 // Scratch layout: xl[n][seq] (TIME-major): the 64 lanes of the serial kernel - one sequence each - read and write 512
 // contiguous bytes per step.  (Sequence-major, every lane touched its own cache line: 2 x 64 addresses per step through
