@@ -110,7 +110,7 @@ void conv_geometry(MstEncConv &c, int cin, int cout, int ksz, int stride, int di
 // TCN
 // =================================================================================================
 struct MstTcnBlock {
-    void *w_bf16 = nullptr;   // blocks >= 1: [120][4][64][8] bf16
+    void *w_bf16 = nullptr;   // blocks >= 1: [60][2][4][64][8] bf16 (A fragments of v_mfma_f32_16x16x32_bf16)
     void *w_x3 = nullptr;     // blocks >= 1: [hi | lo][120][4][64][8] bf16 (bf16x3 mode: W' = W'_hi + W'_lo)
     float *w_f32 = nullptr;   // blocks >= 1: [15][4][4][4][64][4] fp32 ; block 0: [2][15][128]
     float *shift = nullptr;   // [128]
@@ -247,15 +247,16 @@ extern "C" int mst_tcn_load_block(MstTcn *t, int n, const float *conv_w, const f
             if ((rc = upload((__bf16 **)&b.w_bf16, wb))) return rc;
         }
     } else {
-        // bf16 A fragments of v_mfma_f32_32x32x16_bf16: [ks = j*8 + kc][wave][lane][e]
+        // bf16 A fragments of v_mfma_f32_16x16x32_bf16: [ks = j*4 + kk][row tile m][wave][lane][e]
         std::vector<__bf16> wb((size_t)120 * 4 * 64 * 8);
         for (int j = 0; j < K; ++j)
-            for (int kc = 0; kc < 8; ++kc)
-                for (int w = 0; w < 4; ++w)
-                    for (int l = 0; l < 64; ++l)
-                        for (int e = 0; e < 8; ++e)
-                            wb[((((size_t)(j * 8 + kc) * 4 + w) * 64 + l) * 8) + e] =
-                                (__bf16)W(32 * w + (l & 31), 16 * kc + 8 * (l >> 5) + e, j);
+            for (int kk = 0; kk < 4; ++kk)
+                for (int m = 0; m < 2; ++m)
+                    for (int w = 0; w < 4; ++w)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 8; ++e)
+                                wb[(((((size_t)(j * 4 + kk) * 2 + m) * 4 + w) * 64 + l) * 8) + e] =
+                                    (__bf16)W(32 * w + 16 * m + (l & 15), 32 * kk + 8 * (l >> 4) + e, j);
         if ((rc = upload((__bf16 **)&b.w_bf16, wb))) return rc;
         // bf16x3 mode: the same fragment image twice, W'_hi = bf16(W') and W'_lo = bf16(W' - W'_hi)
         std::vector<__bf16> wx((size_t)2 * 120 * 4 * 64 * 8);
@@ -407,15 +408,15 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
             const long g2 = (long)a.B * a.tiles_phase * a.tiles_step;
             if (xcd_on && g2 % 8 == 0) a.xcd_tiles = (int)(g2 / 8);
             if (a.y_out)
-                MST_LAUNCH((tcn_block_bf16_kernel<P, 2, true, 4>), dim3((unsigned)g2), dim3(256), stream, a);
+                MST_LAUNCH((tcn_block_bf16_kernel<P, true, 4>), dim3((unsigned)g2), dim3(256), stream, a);
             else
-                MST_LAUNCH((tcn_block_bf16_kernel<P, 2, false, 4>), dim3((unsigned)g2), dim3(256), stream, a);
+                MST_LAUNCH((tcn_block_bf16_kernel<P, false, 4>), dim3((unsigned)g2), dim3(256), stream, a);
         } else {
             if (xcd_on && grid % 8 == 0) a.xcd_tiles = grid / 8;
             if (a.y_out)
-                MST_LAUNCH((tcn_block_bf16_kernel<P, 2, true, 8>), dim3(grid), dim3(256), stream, a);
+                MST_LAUNCH((tcn_block_bf16_kernel<P, true, 8>), dim3(grid), dim3(256), stream, a);
             else
-                MST_LAUNCH((tcn_block_bf16_kernel<P, 2, false, 8>), dim3(grid), dim3(256), stream, a);
+                MST_LAUNCH((tcn_block_bf16_kernel<P, false, 8>), dim3(grid), dim3(256), stream, a);
         }
     } else {
         if (grid % 8 == 0) a.xcd_tiles = grid / 8;

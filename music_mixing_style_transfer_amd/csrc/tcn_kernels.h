@@ -50,15 +50,20 @@ struct TcnBlockArgs {
 // blocks 1..n-1, bf16 MFMA (v_mfma_f32_32x32x16_bf16), bf16 activations.  MFMA-bound:
 // 2*128*1920 = 491 520 FLOP per output time step against 512 B of HBM traffic.
 // ------------------------------------------------------------------------------------------------
-// NQ = column tiles (of 32 output times) per wave: 8 -> 256-time tiles (2 workgroups per CU at P <= 4), 4 -> 128-time tiles
+// NQ = groups of 32 output times per wave: 8 -> 256-time tiles (2 workgroups per CU at P <= 4), 4 -> 128-time tiles
 // (half the accumulators and LDS: 3 workgroups per CU, A fragments re-streamed twice as often).
-template <int P, int PIPE, bool FUSE_OUT, int NQ>
+// The matrix instruction is v_mfma_f32_16x16x32_bf16 (round 2): the wave's 32 channels are two row tiles of 16, its times 2 NQ column
+// tiles of 16, a k-step is 32 input channels of one tap.  Per FLOP it moves exactly the operands the 32 x 32 x 16 form moved (every
+// B fragment feeds two MFMAs) - and under the chip's power limit it runs 15 % faster: on realistic operands the bare instruction
+// stream sustains 1934-1982 TFLOP/s against 1666-1685, the whole main loop 1570-1585 against 1367-1377
+// (tools/micro/tcn_mainloop_variants.hip, profiles/r02_micro_tcn_mainloop_variants.txt).
+template <int P, bool FUSE_OUT, int NQ>
 __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1))) void tcn_block_bf16_kernel(TcnBlockArgs a) {
-    constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P;
+    constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NC = 2 * NQ;
     __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
     __shared__ __attribute__((aligned(16))) float par[4 * 128];     // shift | FiLM r | FiLM b | res of this block / batch item
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int ln = lane & 31, h = lane >> 5;
+    const int l16 = lane & 15, g = lane >> 4;
 
     int tile = a.xcd_tiles > 0 ? (int)(blockIdx.x & 7) * a.xcd_tiles + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int mg = tile % a.tiles_step;
@@ -116,114 +121,93 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
     }
     __syncthreads();
 
-    // the accumulators start from the BN shift of their channel (row (i&3) + 8 (i>>2) + 4 h of the wave's 32): no add later
-    f32x16 acc[NQ];
+    // the accumulators start from the BN shift of their channel (row 4 g + i of the row tile's 16): no add later
+    f32x4 acc[2][NC];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 sh = *(const f32x4 *)(par + 32 * w + 8 * g + 4 * h);
+    for (int m = 0; m < 2; ++m) {
+        const f32x4 sh = *(const f32x4 *)(par + 32 * w + 16 * m + 4 * g);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[q][4 * g + i] = sh[i];
+        for (int q = 0; q < NC; ++q) acc[m][q] = sh;
     }
 
-    // A fragments: wpk[ks = j*8 + kc][wave][lane] = 8 bf16 = W'[32w + ln][16kc + 8h + e][j]
-    const bf16x8 *wp = (const bf16x8 *)a.wpk + (w * 64 + lane);
-    if constexpr (PIPE == 0) {
-        bf16x8 acur[8], anxt[8];
-#pragma unroll
-        for (int kc = 0; kc < 8; ++kc) anxt[kc] = acur[kc] = wp[kc * 256];
-        for (int j = 0; j < 15; ++j) {
-            if (j < 14) {
-#pragma unroll
-                for (int kc = 0; kc < 8; ++kc) anxt[kc] = wp[((j + 1) * 8 + kc) * 256];
-            }
-            const int rowbase = j * P + ln;
-            const int sw = rowbase & 15;
-            const unsigned char *rp = smem + rowbase * 256;
-#pragma unroll
-            for (int kc = 0; kc < 8; ++kc) {
-                const int off = ((2 * kc + h) ^ sw) << 4;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const bf16x8 bfr = *(const bf16x8 *)(rp + q * 8192 + off);
-                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[kc], bfr, acc[q], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int kc = 0; kc < 8; ++kc) acur[kc] = anxt[kc];
-        }
-    } else {
-        // software pipeline: the B fragments of k-step ks+1 are requested from LDS right behind the MFMAs of
-        // k-step ks that free their registers (ring of 8 fragments, one full k-step = 8 MFMAs of latency cover);
-        // the A fragment of (j+1, kc) is requested from L2 as soon as (j, kc) has been consumed.
+    // A fragments: wpk[ks = j*4 + kk][row tile m][wave][lane] = 8 bf16 = W'[32w + 16m + (lane & 15)][32kk + 8 (lane >> 4) + e][j]
+    {
+        // software pipeline: a ring of 8 B fragments - the fragment eight column tiles ahead (of this k-step, or of the next one) is
+        // requested from LDS right behind the two MFMAs that free its register: 16 MFMAs = 256 clocks of latency cover; the A fragments
+        // of (j+1, kk) are requested from L2 as soon as (j, kk) has been consumed.
         // A fragment addresses = uniform (scalar) base of the k-step + a fixed 32-bit lane offset: no per-load vector address math
         const unsigned char *wbase = (const unsigned char *)a.wpk;
         const unsigned aoff = (unsigned)(w * 64 + lane) * 16u;
-        bf16x8 af[8], bf[NQ];
+        constexpr int RB = 8;
+        static_assert(NC % RB == 0, "the ring divides the column tiles");
+        bf16x8 af[2][4], bf[RB];
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc) af[kc] = *(const bf16x8 *)(wbase + (size_t)kc * 4096 + aoff);
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) af[m][kk] = *(const bf16x8 *)(wbase + (size_t)(kk * 2 + m) * 4096 + aoff);
         {
-            const unsigned char *rp0 = smem + ln * 256 + ((h ^ (ln & 15)) << 4);
+            const unsigned char *rp0 = smem + l16 * 256 + ((g ^ l16) << 4);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 8192);
+            for (int q = 0; q < RB; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 4096);
         }
         // P = 16 tiles (largest dilation on a short segment) cover steps far outside the segment: a (column tile q, tap j)
-        // pair whose 32 input rows are all zero padding contributes nothing and its MFMAs are skipped (wave-uniform;
-        // 20 % of the MFMAs at d = 8192, L = 131072.  At P = 8 only 7 % are skippable and the branches cost more).
+        // pair whose 16 input rows are all zero padding contributes nothing and its MFMAs are skipped (wave-uniform).
         const int nsteps = (int)(((long)a.L + a.d - 1) / a.d);
         for (int j = 0; j < 15; ++j) {
             const int jn = j < 14 ? j + 1 : 14;
-            const int rb0 = j * P + ln, rb1 = jn * P + ln;
-            unsigned live = 0xffu;
+            const int rb0 = j * P + l16, rb1 = jn * P + l16;
+            unsigned live = 0xffffu;
             if constexpr (P >= 16) {
                 live = 0;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const int s_lo = m0 + (32 * q) / P + j - 7, s_hi = m0 + (32 * q + 31) / P + j - 7;
+                for (int q = 0; q < NC; ++q) {
+                    const int s_lo = m0 + (16 * q) / P + j - 7, s_hi = m0 + (16 * q + 15) / P + j - 7;
                     if (!(s_hi < 0 || s_lo >= nsteps)) live |= 1u << q;
                 }
             }
 #pragma unroll
-            for (int kc = 0; kc < 8; ++kc) {
-                const int rbn = (kc == 7) ? rb1 : rb0;
-                const int kcn = (kc + 1) & 7;
-                const unsigned char *np = smem + rbn * 256 + (((2 * kcn + h) ^ (rbn & 15)) << 4);
+            for (int kk = 0; kk < 4; ++kk) {
+                const int rbn = (kk == 3) ? rb1 : rb0;
+                const int kn = (kk + 1) & 3;
+                const unsigned char *cp = smem + rb0 * 256 + (((4 * kk + g) ^ (rb0 & 15)) << 4);
+                const unsigned char *np = smem + rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    if (P < 16 || ((live >> q) & 1u))
-                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kc], bf[q], acc[q], 0, 0, 0);
-                    bf[q] = *(const bf16x8 *)(np + q * 8192);
-                    if constexpr (PIPE == 2) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                for (int q = 0; q < NC; ++q) {
+                    if (P < 16 || ((live >> q) & 1u)) {
+                        acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][kk], bf[q % RB], acc[0][q], 0, 0, 0);
+                        acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][kk], bf[q % RB], acc[1][q], 0, 0, 0);
                     }
+                    bf[q % RB] = (q + RB < NC) ? *(const bf16x8 *)(cp + (q + RB) * 4096) : *(const bf16x8 *)(np + (q + RB - NC) * 4096);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-                af[kc] = *(const bf16x8 *)(wbase + (size_t)(jn * 8 + kc) * 4096 + aoff);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) af[m][kk] = *(const bf16x8 *)(wbase + (size_t)((jn * 4 + kk) * 2 + m) * 4096 + aoff);
             }
         }
     }
 
     // ---- fused epilogue
     // residual inputs (centre tap rows) -> registers, then the input tile is dead and LDS is reused to transpose
-    // the output tile so that global stores are whole 256-byte rows, 16 B per lane
-    bf16x4 xin[4][NQ];
+    // the output tile so that global stores are whole 256-byte rows, 16 B per lane.  A lane's four accumulator rows of a tile are four
+    // consecutive channels co0 .. co0 + 3 of output time 16 q + l16.
+    bf16x4 xin[2][NC];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int co0 = 32 * w + 8 * g + 4 * h;
+    for (int m = 0; m < 2; ++m) {
+        const int co0 = 32 * w + 16 * m + 4 * g;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int row = 32 * q + ln + 7 * P;
-            xin[g][q] = *(const bf16x4 *)(smem + row * 256 + (((co0 >> 3) ^ (row & 15)) << 4) + 8 * h);
+        for (int q = 0; q < NC; ++q) {
+            const int row = 16 * q + l16 + 7 * P;
+            xin[m][q] = *(const bf16x4 *)(smem + row * 256 + (((co0 >> 3) ^ (row & 15)) << 4) + 2 * (co0 & 7));
         }
     }
     __syncthreads();
-    float hs0[NQ], hs1[NQ];            // FUSE_OUT: this lane's partial sums of the 1x1 output head, per column tile
+    float hs0[NC], hs1[NC];            // FUSE_OUT: this lane's partial sums of the 1x1 output head, per column tile
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) hs0[q] = hs1[q] = 0.0f;
+    for (int q = 0; q < NC; ++q) hs0[q] = hs1[q] = 0.0f;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int co0 = 32 * w + 8 * g + 4 * h;
+    for (int m = 0; m < 2; ++m) {
+        const int co0 = 32 * w + 16 * m + 4 * g;
         const f32x4 fr = *(const f32x4 *)(par + 128 + co0);
         const f32x4 fb = *(const f32x4 *)(par + 256 + co0);
         const f32x4 rs = *(const f32x4 *)(par + 384 + co0);
@@ -233,10 +217,10 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
             if (a.nout > 1) ow1 = *(const f32x4 *)(a.out_w + 128 + co0);
         }
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int o = 32 * q + ln;
-            const float v4[4] = {acc[q][4 * g], acc[q][4 * g + 1], acc[q][4 * g + 2], acc[q][4 * g + 3]};
-            const bf16x4 out = tcn_epilogue4(v4, fr, fb, rs, xin[g][q]);
+        for (int q = 0; q < NC; ++q) {
+            const int o = 16 * q + l16;
+            const float v4[4] = {acc[m][q][0], acc[m][q][1], acc[m][q][2], acc[m][q][3]};
+            const bf16x4 out = tcn_epilogue4(v4, fr, fb, rs, xin[m][q]);
             if constexpr (FUSE_OUT) {          // the head reads the bf16-rounded activation, like the separate output kernel
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -244,21 +228,23 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
                     hs1[q] = fmaf(ow1[i], (float)out[i], hs1[q]);
                 }
             }
-            if constexpr (!FUSE_OUT) *(bf16x4 *)(smem + o * 256 + (((co0 >> 3) ^ (o & 15)) << 4) + 8 * h) = out;
+            if constexpr (!FUSE_OUT) *(bf16x4 *)(smem + o * 256 + (((co0 >> 3) ^ (o & 15)) << 4) + 2 * (co0 & 7)) = out;
         }
     }
     if constexpr (FUSE_OUT) {
         // last block: 1x1 output conv + bias + clamp(-1, 1) (reference architectures.py:133,145) straight from the
-        // registers - the last activation never travels to HBM.  Lane pairs (l, l+32) hold the two channel halves of a
-        // column, the four waves the four channel quarters: one shuffle, then a 4-way sum through LDS.
+        // registers - the last activation never travels to HBM.  The four lanes l16 + 16 g hold the four channel groups of a
+        // column tile, the four waves the four channel quarters: two shuffles, then a 4-way sum through LDS.
         float *part = (float *)smem;                 // [4 waves][2 outputs][T columns]
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
+        for (int q = 0; q < NC; ++q) {
+            hs0[q] += __shfl_xor(hs0[q], 16);
+            hs1[q] += __shfl_xor(hs1[q], 16);
             hs0[q] += __shfl_xor(hs0[q], 32);
             hs1[q] += __shfl_xor(hs1[q], 32);
-            if (h == 0) {
-                part[(w * 2 + 0) * T + 32 * q + ln] = hs0[q];
-                part[(w * 2 + 1) * T + 32 * q + ln] = hs1[q];
+            if (g == 0) {
+                part[(w * 2 + 0) * T + 16 * q + l16] = hs0[q];
+                part[(w * 2 + 1) * T + 16 * q + l16] = hs1[q];
             }
         }
         __syncthreads();

@@ -122,6 +122,26 @@ static inline emu_f32x16 emu_mfma_f32_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, 
     }
     return c;
 }
+// v_mfma_f32_16x16x32_bf16: lane l holds 8 consecutive k of A row (l&15) / B column (l&15), k group = l>>4;
+// D: col = l&15, row = 4*(l>>4) + reg; fp32 accumulate.
+typedef __attribute__((ext_vector_type(4))) float emu_f32x4;
+static inline emu_f32x4 emu_mfma_f32_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c) {
+    struct AB { emu_bf16x8 a, b; } me = {a, b};
+    const unsigned char *base = emu::wave_publish(&me, sizeof(me));
+    const int l = emu::lane_id(), col = l & 15, hi = l >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * hi + r;
+        double acc = 0.0;
+        for (int kg = 0; kg < 4; ++kg) {
+            const AB *pa = (const AB *)(base + 64 * (row + 16 * kg));
+            const AB *pb = (const AB *)(base + 64 * (col + 16 * kg));
+            for (int e = 0; e < 8; ++e) acc += (double)(float)pa->a[e] * (double)(float)pb->b[e];
+        }
+        c[r] = (float)((double)c[r] + acc);
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_f32_16x16x32_bf16((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_f32_32x32x2f32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_f32_32x32x16_bf16((a), (b), (c))
 

@@ -6,6 +6,8 @@
 //   noB       the same with the B fragments loaded once per tile (as if the LDS reads were free)
 //   noAB      bare MFMAs on these operands
 //   w64x128   64 channels x 128 times per wave: per k-step 2 A fragments, 4 B fragments (each used twice), 8 MFMAs
+//   bare16x16 bare v_mfma_f32_16x16x32_bf16 on these operands (the same FLOPs per wave in twice the instructions)
+//   base16x16 the product loop's operand traffic with that shape (2 A fragments + 16 B fragments per 32 MFMAs)
 // Two 256-thread workgroups per CU, REP tiles per workgroup, no staging, no epilogue.
 //   hipcc --offload-arch=gfx950 -O3 -o tcn_mainloop_variants tcn_mainloop_variants.hip
 #include <hip/hip_runtime.h>
@@ -124,6 +126,94 @@ __global__ __launch_bounds__(256, 2) void k_w64(const bf16x8 *wpk, float *out, i
     out[(size_t)blockIdx.x * 256 + tid] = s;
 }
 
+// bare MFMAs of the other bf16 shape, v_mfma_f32_16x16x32_bf16 (same FLOPs per wave: 1920 instructions of 16384 FLOP on 32 accumulator
+// tiles of 16 x 16): does the shape change what the power limit lets through?
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+__global__ __launch_bounds__(256, 2) void k_bare16(const bf16x8 *wpk, float *out, int rep) {
+    constexpr int P = 4, T = 256, R = T + 14 * P;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    fill_lds(smem, R * 256, tid);
+    __syncthreads();
+    f32x4 acc[2][16];
+    for (int m = 0; m < 2; ++m)
+        for (int q = 0; q < 16; ++q)
+            for (int i = 0; i < 4; ++i) acc[m][q][i] = 0.0f;
+    bf16x8 af[2][4], bf[16];
+    for (int m = 0; m < 2; ++m)
+        for (int k = 0; k < 4; ++k) af[m][k] = wpk[(k * 2 + m) * 256 + w * 64 + lane];
+    for (int q = 0; q < 16; ++q) bf[q] = *(const bf16x8 *)(smem + (16 * q + (lane & 15)) * 256 + ((lane >> 4) << 4));
+    for (int r = 0; r < rep; ++r)
+        for (int j = 0; j < 15; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][k], bf[q], acc[0][q], 0, 0, 0);
+                    acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][k], bf[q], acc[1][q], 0, 0, 0);
+                }
+    float s = 0.0f;
+    for (int m = 0; m < 2; ++m)
+        for (int q = 0; q < 16; ++q)
+            for (int i = 0; i < 4; ++i) s += acc[m][q][i];
+    out[(size_t)blockIdx.x * 256 + tid] = s;
+}
+
+// the product loop's operand traffic with the 16 x 16 x 32 shape: per k-step of 32 two A fragments from L2 (row tiles of 16 channels),
+// sixteen B fragments from LDS (16 rows x 4 consecutive 16-byte slots, the same swizzle), 32 MFMAs - every B fragment feeds two
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_base16(const bf16x8 *wpk, float *out, int rep) {
+    constexpr int P = 4, T = 256, R = T + 14 * P;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    fill_lds(smem, R * 256, tid);
+    __syncthreads();
+    f32x4 acc[2][16];
+    for (int m = 0; m < 2; ++m)
+        for (int q = 0; q < 16; ++q)
+            for (int i = 0; i < 4; ++i) acc[m][q][i] = 0.0f;
+    const bf16x8 *wp = wpk + (w * 64 + lane);                     // [k32-step (4 per tap)][row tile][wave][lane]
+    for (int r = 0; r < rep; ++r) {
+        bf16x8 af[2][4], bf[16];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { af[0][kk] = wp[(kk * 2) * 256]; af[1][kk] = wp[(kk * 2 + 1) * 256]; }
+        {
+            const unsigned char *rp0 = smem + l16 * 256 + ((g ^ l16) << 4);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 4096);
+        }
+        for (int j = 0; j < 15; ++j) {
+            const int jn = j < 14 ? j + 1 : 14;
+            const int rb0 = j * P + l16, rb1 = jn * P + l16;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int rbn = (kk == 3) ? rb1 : rb0;
+                const int kn = (kk + 1) & 3;
+                const unsigned char *np = smem + rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][kk], bf[q], acc[0][q], 0, 0, 0);
+                    acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][kk], bf[q], acc[1][q], 0, 0, 0);
+                    if (MODE == 0) {
+                        bf[q] = *(const bf16x8 *)(np + q * 4096);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                if (MODE == 0) {
+                    af[0][kk] = wp[((jn * 4 + kk) * 2) * 256];
+                    af[1][kk] = wp[((jn * 4 + kk) * 2 + 1) * 256];
+                }
+            }
+        }
+    }
+    float s = 0.0f;
+    for (int m = 0; m < 2; ++m)
+        for (int q = 0; q < 16; ++q)
+            for (int i = 0; i < 4; ++i) s += acc[m][q][i];
+    out[(size_t)blockIdx.x * 256 + tid] = s;
+}
+
 // sustained rate: NL launches back to back (~0.15 s), the second half timed - the chip's power controller needs tens of milliseconds
 // to settle, a pair of launches measures the transient (1277 vs 1480 TFLOP/s for the same kernel in two consecutive pairs)
 template <typename F> static void run(const char *name, F launch, int rep) {
@@ -164,6 +254,8 @@ int main() {
         run("noB", [&] { k_base<2><<<512, 256>>>(wa, out, rep); }, rep);
         run("noAB", [&] { k_base<3><<<512, 256>>>(wa, out, rep); }, rep);
         run("w64x128", [&] { k_w64<<<512, 256>>>(wa, out, rep); }, rep);
+        run("bare16x16", [&] { k_bare16<<<512, 256>>>(wa, out, rep); }, rep);
+        run("base16x16", [&] { k_base16<0><<<512, 256>>>(wa, out, rep); }, rep);
     }
     return 0;
 }
