@@ -261,16 +261,17 @@ extern "C" int mst_tcn_load_block(MstTcn *t, int n, const float *conv_w, const f
         // bf16x3 mode: the same fragment image twice, W'_hi = bf16(W') and W'_lo = bf16(W' - W'_hi)
         std::vector<__bf16> wx((size_t)2 * 120 * 4 * 64 * 8);
         for (int j = 0; j < K; ++j)
-            for (int kc = 0; kc < 8; ++kc)
-                for (int w = 0; w < 4; ++w)
-                    for (int l = 0; l < 64; ++l)
-                        for (int e = 0; e < 8; ++e) {
-                            const float v = W(32 * w + (l & 31), 16 * kc + 8 * (l >> 5) + e, j);
-                            const __bf16 hi = (__bf16)v;
-                            const size_t idx = ((((size_t)(j * 8 + kc) * 4 + w) * 64 + l) * 8) + e;
-                            wx[idx] = hi;
-                            wx[(size_t)120 * 4 * 64 * 8 + idx] = (__bf16)(v - (float)hi);
-                        }
+            for (int kk = 0; kk < 4; ++kk)
+                for (int m = 0; m < 2; ++m)
+                    for (int w = 0; w < 4; ++w)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 8; ++e) {
+                                const float v = W(32 * w + 16 * m + (l & 15), 32 * kk + 8 * (l >> 4) + e, j);
+                                const __bf16 hi = (__bf16)v;
+                                const size_t idx = (((((size_t)(j * 4 + kk) * 2 + m) * 4 + w) * 64 + l) * 8) + e;
+                                wx[idx] = hi;
+                                wx[(size_t)120 * 4 * 64 * 8 + idx] = (__bf16)(v - (float)hi);
+                            }
         if ((rc = upload((__bf16 **)&b.w_x3, wx))) return rc;
         // fp32 A fragments of v_mfma_f32_32x32x2_f32: [j][chunk c][ksg][wave][lane][i]
         std::vector<float> wf((size_t)K * 4 * 4 * 4 * 64 * 4);

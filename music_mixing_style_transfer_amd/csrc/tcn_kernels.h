@@ -291,7 +291,6 @@ __global__ __launch_bounds__(256, (NQ == 4 && P <= 2) ? 2 : 1) void tcn_block_bf
     constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * R * 256];      // [hi | lo] tiles
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int ln = lane & 31, h = lane >> 5;
     unsigned char *const sm_hi = smem, *const sm_lo = smem + R * 256;
 
     int tile = a.xcd_tiles > 0 ? (int)(blockIdx.x & 7) * a.xcd_tiles + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -344,83 +343,96 @@ __global__ __launch_bounds__(256, (NQ == 4 && P <= 2) ? 2 : 1) void tcn_block_bf
     }
     __syncthreads();
 
-    f32x16 acc[NQ];
+    // v_mfma_f32_16x16x32_bf16 like the bf16 kernel (same operand traffic per FLOP as the 32 x 32 x 16 form, more throughput under the
+    // power limit): two row tiles of 16 channels x NC column tiles of 16 times per wave
+    constexpr int NC = 2 * NQ;
+    const int l16 = lane & 15, g = lane >> 4;
+    f32x4 acc[2][NC];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {          // accumulators start from the BN shift of their channel
-        const f32x4 sh = *(const f32x4 *)(a.shift + 32 * w + 8 * g + 4 * h);
+    for (int m = 0; m < 2; ++m) {          // accumulators start from the BN shift of their channel
+        const f32x4 sh = *(const f32x4 *)(a.shift + 32 * w + 16 * m + 4 * g);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[q][4 * g + i] = sh[i];
+        for (int q = 0; q < NC; ++q) acc[m][q] = sh;
     }
 
-    // A fragments: wpk[part][ks = j*8 + kc][wave][lane] = 8 bf16, part 0 = hi, 1 = lo (each image 120 * 4096 bytes)
+    // A fragments: wpk[part][ks = j*4 + kk][row tile m][wave][lane] = 8 bf16, part 0 = hi, 1 = lo (each image 120 * 4096 bytes)
     const unsigned char *wbase = (const unsigned char *)a.wpk;
     const unsigned aoff = (unsigned)(w * 64 + lane) * 16u;
     constexpr size_t LO_IMG = (size_t)120 * 4096;
-    // ring of 4 k-steps of A fragments (hi and lo): the pair of k-step ks + 4 is requested from L2 when ks has been consumed
-    bf16x8 ah[4], al[4], bh[NQ], bl[NQ];
+    // ring of 2 k-steps of A fragments (hi and lo, two row tiles): the set of k-step ks + 2 is requested from L2 when ks has been consumed;
+    // ring of 8 column tiles of B fragments (hi and lo)
+    constexpr int RB = 8;
+    static_assert(NC % RB == 0, "the ring divides the column tiles");
+    bf16x8 ah[2][2], al[2][2], bh[RB], bl[RB];
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-        ah[kc] = *(const bf16x8 *)(wbase + (size_t)kc * 4096 + aoff);
-        al[kc] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)kc * 4096 + aoff);
-    }
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            ah[kk][m] = *(const bf16x8 *)(wbase + (size_t)(kk * 2 + m) * 4096 + aoff);
+            al[kk][m] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)(kk * 2 + m) * 4096 + aoff);
+        }
     {
-        const int o0 = ln * 256 + ((h ^ (ln & 15)) << 4);
+        const int o0 = l16 * 256 + ((g ^ l16) << 4);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            bh[q] = *(const bf16x8 *)(sm_hi + o0 + q * 8192);
-            bl[q] = *(const bf16x8 *)(sm_lo + o0 + q * 8192);
+        for (int q = 0; q < RB; ++q) {
+            bh[q] = *(const bf16x8 *)(sm_hi + o0 + q * 4096);
+            bl[q] = *(const bf16x8 *)(sm_lo + o0 + q * 4096);
         }
     }
     for (int j = 0; j < 15; ++j) {
         const int jn = j < 14 ? j + 1 : 14;
-        const int rb0 = j * P + ln, rb1 = jn * P + ln;
+        const int rb0 = j * P + l16, rb1 = jn * P + l16;
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc) {
-            const int rbn = (kc == 7) ? rb1 : rb0;
-            const int kcn = (kc + 1) & 7;
-            const int on = rbn * 256 + (((2 * kcn + h) ^ (rbn & 15)) << 4);
-            const int s = kc & 3;
-            // three sweeps over the column tiles: consecutive MFMAs go to different accumulators (no dependent issue stalls);
-            // the small terms first
+        for (int kk = 0; kk < 4; ++kk) {
+            const int rbn = (kk == 3) ? rb1 : rb0;
+            const int kn = (kk + 1) & 3;
+            const int oc = rb0 * 256 + (((4 * kk + g) ^ (rb0 & 15)) << 4);
+            const int on = rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
+            const int s = kk & 1;
+            // per column tile six MFMAs (two row tiles x three terms, the small terms first): consecutive MFMAs alternate between the two
+            // accumulators; the fragment pair eight column tiles ahead is requested behind them
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh[q], acc[q], 0, 0, 0);
+            for (int q = 0; q < NC; ++q) {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl[q], acc[q], 0, 0, 0);
+                for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s][m], bh[q % RB], acc[m][q], 0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh[q], acc[q], 0, 0, 0);
-                bh[q] = *(const bf16x8 *)(sm_hi + on + q * 8192);
-                bl[q] = *(const bf16x8 *)(sm_lo + on + q * 8192);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][m], bl[q % RB], acc[m][q], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][m], bh[q % RB], acc[m][q], 0, 0, 0);
+                const int ofs = (q + RB < NC) ? oc + (q + RB) * 4096 : on + (q + RB - NC) * 4096;
+                bh[q % RB] = *(const bf16x8 *)(sm_hi + ofs);
+                bl[q % RB] = *(const bf16x8 *)(sm_lo + ofs);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
-            int ksn = j * 8 + kc + 4;
-            ksn = ksn < 120 ? ksn : 119;
-            ah[s] = *(const bf16x8 *)(wbase + (size_t)ksn * 4096 + aoff);
-            al[s] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)ksn * 4096 + aoff);
+            int ksn = j * 4 + kk + 2;
+            ksn = ksn < 60 ? ksn : 59;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ah[s][m] = *(const bf16x8 *)(wbase + (size_t)(ksn * 2 + m) * 4096 + aoff);
+                al[s][m] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)(ksn * 2 + m) * 4096 + aoff);
+            }
         }
     }
 
     // ---- exact fp32 epilogue: LeakyReLU -> FiLM -> + res * x_in (x_in re-read in fp32 from global memory)
     const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int co0 = 32 * w + 8 * g + 4 * h;
+    for (int m = 0; m < 2; ++m) {
+        const int co0 = 32 * w + 16 * m + 4 * g;
         const f32x4 fr = *(const f32x4 *)(frow + co0);
         const f32x4 fb = *(const f32x4 *)(frow + 128 + co0);
         const f32x4 rs = *(const f32x4 *)(a.res + co0);
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int o = 32 * q + ln;
+        for (int q = 0; q < NC; ++q) {
+            const int o = 16 * q + l16;
             const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
             if (t < a.L) {
                 const f32x4 xin = *(const f32x4 *)(xb + t * 128 + co0);
                 f32x4 out;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float v = leaky_relu(acc[q][4 * g + i]);
+                    float v = leaky_relu(acc[m][q][i]);
                     v = fr[i] * v + fb[i];
                     out[i] = v + rs[i] * xin[i];
                 }
