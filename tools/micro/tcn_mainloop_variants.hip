@@ -8,6 +8,8 @@
 //   w64x128   64 channels x 128 times per wave: per k-step 2 A fragments, 4 B fragments (each used twice), 8 MFMAs
 //   bare16x16 bare v_mfma_f32_16x16x32_bf16 on these operands (the same FLOPs per wave in twice the instructions)
 //   base16x16 the product loop's operand traffic with that shape (2 A fragments + 16 B fragments per 32 MFMAs)
+//   noA16x16 / noB16x16  the same without the weight stream / without the LDS reads
+//   w64_16x16 64 channels x 128 times per wave in that shape (4 A fragments + 8 B fragments per 32 MFMAs)
 // Two 256-thread workgroups per CU, REP tiles per workgroup, no staging, no epilogue.
 //   hipcc --offload-arch=gfx950 -O3 -o tcn_mainloop_variants tcn_mainloop_variants.hip
 #include <hip/hip_runtime.h>
@@ -194,13 +196,13 @@ __global__ __launch_bounds__(256, 2) void k_base16(const bf16x8 *wpk, float *out
                 for (int q = 0; q < 16; ++q) {
                     acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][kk], bf[q], acc[0][q], 0, 0, 0);
                     acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][kk], bf[q], acc[1][q], 0, 0, 0);
-                    if (MODE == 0) {
+                    if (MODE == 0 || MODE == 1) {
                         bf[q] = *(const bf16x8 *)(np + q * 4096);
                         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                 }
-                if (MODE == 0) {
+                if (MODE == 0 || MODE == 2) {
                     af[0][kk] = wp[((jn * 4 + kk) * 2) * 256];
                     af[1][kk] = wp[((jn * 4 + kk) * 2 + 1) * 256];
                 }
@@ -210,6 +212,59 @@ __global__ __launch_bounds__(256, 2) void k_base16(const bf16x8 *wpk, float *out
     float s = 0.0f;
     for (int m = 0; m < 2; ++m)
         for (int q = 0; q < 16; ++q)
+            for (int i = 0; i < 4; ++i) s += acc[m][q][i];
+    out[(size_t)blockIdx.x * 256 + tid] = s;
+}
+
+// 64 channels x 128 times per wave with the 16 x 16 x 32 shape: per k-step of 32 four A fragments, eight B fragments, 32 MFMAs
+__global__ __launch_bounds__(256, 2) void k_w64_16(const bf16x8 *wpk, float *out, int rep) {
+    constexpr int P = 4, T = 256, R = T + 14 * P;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    const int ch = w & 1, th = w >> 1;
+    fill_lds(smem, R * 256, tid);
+    __syncthreads();
+    f32x4 acc[4][8];
+    for (int m = 0; m < 4; ++m)
+        for (int q = 0; q < 8; ++q)
+            for (int i = 0; i < 4; ++i) acc[m][q][i] = 0.0f;
+    const bf16x8 *wp = wpk + (ch * 128 + lane);                   // row tiles 4 ch .. 4 ch + 3 of every k-step (synthetic addressing)
+    const unsigned char *tbase = smem + th * 8 * 4096;            // this wave's eight column tiles
+    for (int r = 0; r < rep; ++r) {
+        bf16x8 af[4][4], bf[8];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) af[m][kk] = wp[(kk * 2) * 256 + m * 32];
+        {
+            const unsigned char *rp0 = tbase + l16 * 256 + ((g ^ l16) << 4);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 4096);
+        }
+        for (int j = 0; j < 15; ++j) {
+            const int jn = j < 14 ? j + 1 : 14;
+            const int rb0 = j * P + l16, rb1 = jn * P + l16;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int rbn = (kk == 3) ? rb1 : rb0;
+                const int kn = (kk + 1) & 3;
+                const unsigned char *np = tbase + rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m][kk], bf[q], acc[m][q], 0, 0, 0);
+                    bf[q] = *(const bf16x8 *)(np + q * 4096);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[m][kk] = wp[((jn * 4 + kk) * 2) * 256 + m * 32];
+            }
+        }
+    }
+    float s = 0.0f;
+    for (int m = 0; m < 4; ++m)
+        for (int q = 0; q < 8; ++q)
             for (int i = 0; i < 4; ++i) s += acc[m][q][i];
     out[(size_t)blockIdx.x * 256 + tid] = s;
 }
@@ -256,6 +311,9 @@ int main() {
         run("w64x128", [&] { k_w64<<<512, 256>>>(wa, out, rep); }, rep);
         run("bare16x16", [&] { k_bare16<<<512, 256>>>(wa, out, rep); }, rep);
         run("base16x16", [&] { k_base16<0><<<512, 256>>>(wa, out, rep); }, rep);
+        run("noA16x16", [&] { k_base16<1><<<512, 256>>>(wa, out, rep); }, rep);
+        run("noB16x16", [&] { k_base16<2><<<512, 256>>>(wa, out, rep); }, rep);
+        run("w64_16x16", [&] { k_w64_16<<<512, 256>>>(wa, out, rep); }, rep);
     }
     return 0;
 }
