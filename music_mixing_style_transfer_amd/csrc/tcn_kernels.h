@@ -17,8 +17,8 @@
 // weights, pre-packed in fragment order) stream from L2 straight into registers.
 //
 // MFMA orientation: D[co][t] = sum_k W'[co][k] * X[k][t]; wave w owns output channels 32w..32w+31 and all
-// 256 time steps of the tile (8 accumulator tiles of 32x32).  A lane's 4 consecutive accumulator rows are
-// 4 consecutive channels -> one 8-byte (bf16) / 16-byte (fp32) store per time step.
+// 256 time steps of the tile (bf16 / bf16x3: 2 x 16 accumulator tiles of 16x16; fp32: 8 tiles of 32x32).  A lane's 4 consecutive
+// accumulator rows are 4 consecutive channels -> one 8-byte (bf16) / 16-byte (fp32) store per time step.
 //
 // Epilogue (fused): + BN shift -> LeakyReLU(0.01) -> FiLM r*y+b -> + res_scale * x_in  -> store.
 #pragma once
@@ -47,7 +47,7 @@ struct TcnBlockArgs {
 };
 
 // ------------------------------------------------------------------------------------------------
-// blocks 1..n-1, bf16 MFMA (v_mfma_f32_32x32x16_bf16), bf16 activations.  MFMA-bound:
+// blocks 1..n-1, bf16 MFMA (v_mfma_f32_16x16x32_bf16), bf16 activations.  MFMA-bound:
 // 2*128*1920 = 491 520 FLOP per output time step against 512 B of HBM traffic.
 // ------------------------------------------------------------------------------------------------
 // NQ = groups of 32 output times per wave: 8 -> 256-time tiles (2 workgroups per CU at P <= 4), 4 -> 128-time tiles
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
 // for the activations (while the tile is staged into LDS: two tiles, hi and lo) and for the BN-folded weights (on the host,
 // two fragment images), and the contraction keeps the three leading terms
 //     W x ~= W_hi x_hi + W_hi x_lo + W_lo x_hi                          (the dropped W_lo x_lo term is ~2^-16 of the result)
-// as three v_mfma_f32_32x32x16_bf16 into the same fp32 accumulator.  Activations stay fp32 in HBM (1024 B of traffic per
+// as three v_mfma_f32_16x16x32_bf16 into the same fp32 accumulator.  Activations stay fp32 in HBM (1024 B of traffic per
 // time step against 3 * 491 520 FLOP: compute bound), the epilogue is the exact fp32 one of the parity kernel and reads the
 // residual input from global memory (L2-hot: the tile's centre rows were just staged).  Measured against the oracle: 5e-6
 // max-abs on the output waveform (exact-fp32 mode: 9e-7; plain bf16 mode: 4e-3) at three MFMAs per bf16-mode MFMA.
