@@ -289,6 +289,7 @@ def main():
     ap.add_argument("--workload", default="all", choices=["all", "configs1", "track60"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--x3-large-tiles", action="store_true", help="bf16x3: 256-time tiles, one workgroup per CU (mst_tcn_set_tuning 0)")
+    ap.add_argument("--tcn-tuning", type=int, default=None, help="mst_tcn_set_tuning flags (bit 0: bf16x3 small tiles, bit 1: persistent LDS-DMA bf16 block kernel)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -327,6 +328,8 @@ def main():
     tcn._ensure(lib)
     if args.x3_large_tiles:
         lib.check(lib.mst_tcn_set_tuning(tcn._handle, 0), "mst_tcn_set_tuning")
+    if args.tcn_tuning is not None:
+        lib.check(lib.mst_tcn_set_tuning(tcn._handle, args.tcn_tuning), "mst_tcn_set_tuning")
     nb = tcn.hparams.nblocks
     B = args.batch
     dtype = {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3"}[args.precision]

@@ -110,10 +110,14 @@ int mst_tcn_forward(MstTcn *tcn, const float *x_dev, float *y_dev, int B, int L,
 int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int B, int L, int precision, int n_run,
                            void *workspace, size_t workspace_bytes, void *stream);
 
-/* tuning (bf16x3 mode): x3_small_tiles = 1 (default; measured 5.13 instead of 5.45 ms per launch at 32 x 131072) runs the split-bf16
- * block kernel on 128-time tiles of <= 2 phases (two workgroups per CU) wherever the segment has at least 64 steps per phase,
- * 0 on 256-time tiles (one workgroup per CU); identical results. */
-int mst_tcn_set_tuning(MstTcn *tcn, int x3_small_tiles);
+/* tuning flags (choose between forms of the block kernels):
+ * bit 0 (bf16x3 mode; default 1, measured 5.13 instead of 5.45 ms per launch at 32 x 131072): the split-bf16 block kernel on 128-time
+ *   tiles of <= 2 phases (two workgroups per CU) wherever the segment has at least 64 steps per phase, 0 = 256-time tiles (one
+ *   workgroup per CU); identical results.
+ * bit 1 (bf16 mode): the persistent block kernel whose input rows arrive by LDS-DMA one 32-channel chunk ahead of the matrix cores
+ *   (tcn_block_bf16_stream_kernel) instead of the one-tile-per-workgroup kernel; same arithmetic, the fp32 accumulation runs
+ *   chunk-major instead of tap-major (results agree to accumulation rounding). */
+int mst_tcn_set_tuning(MstTcn *tcn, int flags);
 
 /* measurement hook (bench.py's roofline leg): between _begin and _end every mst_tcn_forward records HIP events
  * on its stream around each kernel; _end synchronises, writes the AVERAGE milliseconds per forward of

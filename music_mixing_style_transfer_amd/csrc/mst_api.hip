@@ -131,6 +131,7 @@ struct MstTcn {
     bool out_loaded = false;
     void *zero_row = nullptr;     // 1 KB of zeros: what the block kernels stage for time steps outside the segment
     int x3_small_tiles = 1;       // bf16x3 mode: 128-time tiles of <= 2 phases, two workgroups per CU (mst_tcn_set_tuning; measured 5.13 vs 5.45 ms)
+    int bf16_stream = 0;          // bf16 mode: the persistent LDS-DMA-streamed block kernel (mst_tcn_set_tuning bit 1)
     std::vector<hipEvent_t> ev;   // timing hook: (nblocks + 2) events per recorded forward
     int ev_max = 0, ev_used = 0;
 };
@@ -371,8 +372,29 @@ int choose_phases(int d, int L, int precision) {
     return P;
 }
 
-template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream, int x3_small = 0) {
+// the persistent bf16 kernel: two workgroups per CU, workgroup i walks tiles of XCD i % 8's contiguous range
+template <int P, int NQ> int launch_block_stream(TcnBlockArgs a, void *stream) {
+    const long nsteps = ((long)a.L + a.d - 1) / a.d;
+    a.tiles_step = (int)((nsteps + (32 * NQ) / P - 1) / ((32 * NQ) / P));
+    const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
+    long grid = 2L * mst_num_cus();
+    if (grid > ntiles) grid = ntiles;
+    a.xcd_tiles = 0;
+    if (grid >= 8) {
+        grid -= grid % 8;
+        a.xcd_tiles = (int)((ntiles + 7) / 8);
+    }
+    if (a.y_out)
+        MST_LAUNCH((tcn_block_bf16_stream_kernel<P, true, NQ>), dim3((unsigned)grid), dim3(256), stream, a);
+    else
+        MST_LAUNCH((tcn_block_bf16_stream_kernel<P, false, NQ>), dim3((unsigned)grid), dim3(256), stream, a);
+    MST_CHECK_LAUNCH("tcn_block_bf16_stream_kernel");
+    return MST_OK;
+}
+
+template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream, int x3_small = 0, int bf16_stream = 0) {
     TcnBlockArgs a = a0;
+    if (precision == MST_PREC_BF16 && bf16_stream) return launch_block_stream<P, (P == 8 ? 4 : 8)>(a, stream);
     if (precision == MST_PREC_BF16X3) {
         if constexpr (P <= 2) {
             if (x3_small) {          // 128-time tiles: 2 x 39 KB of LDS, two workgroups (8 waves) per CU
@@ -564,11 +586,11 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         if (grid > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_tcn_forward: grid too large");
         int rc;
         switch (P) {
-            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small); break;
-            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small); break;
-            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small); break;
-            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small); break;
-            default: rc = launch_block<16>(precision, a, (int)grid, stream); break;
+            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small, t->bf16_stream); break;
+            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_stream); break;
+            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_stream); break;
+            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_stream); break;
+            default: rc = launch_block<16>(precision, a, (int)grid, stream, 0, t->bf16_stream); break;
         }
         if (rc) return rc;
         if (ev) MST_HIP_TRY(hipEventRecord(ev[n + 1], (hipStream_t)stream));
@@ -611,9 +633,11 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
 
 }  // namespace
 
-extern "C" int mst_tcn_set_tuning(MstTcn *t, int x3_small_tiles) {
+extern "C" int mst_tcn_set_tuning(MstTcn *t, int flags) {
     if (!t) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: null handle");
-    t->x3_small_tiles = x3_small_tiles ? 1 : 0;
+    if (flags < 0 || flags > 3) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: unknown flag bits");
+    t->x3_small_tiles = flags & 1;
+    t->bf16_stream = (flags >> 1) & 1;
     return MST_OK;
 }
 

@@ -28,6 +28,57 @@ __device__ __forceinline__ float mst_fmax(float a, float b) {
     return r;
 }
 
+// ---- LDS-DMA (global_load_lds_dwordx4): the 64 lanes of the calling wave copy 16 bytes each from their OWN global address straight into
+// LDS at lds_wave_base + 16 * lane (the destination is lane-linear: a swizzled LDS image is made by permuting the SOURCE addresses).
+// No VGPR round trip, no ds_write; the copy is asynchronous and counted on vmcnt, in order with the wave's other loads.  hipcc does not
+// know about it (inline asm): its own counted waits stay counted (never a vmcnt(0) drain), and the data is retired by
+// mst_dma_wait_barrier<N>() - N = loads the wave has issued AFTER the copy that may still be in flight - followed by the barrier every
+// reader has to pass.  M0 (the LDS base register of the instruction) is saved and restored inside the statement.
+__device__ __forceinline__ void mst_dma16(const void *gsrc, void *lds_wave_base) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);      // low 32 bits of a flat LDS address = LDS offset
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+// wait until at most N of this wave's vector-memory operations are outstanding (in-order counter: everything older has landed) and all
+// its LDS operations have returned, then the workgroup barrier - a raw s_barrier: __syncthreads() would drain vmcnt to 0
+template <int N> __device__ __forceinline__ void mst_dma_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// v_permlane16_swap_b32: rows (16 lanes) 1 and 3 of `a` trade places with rows 0 and 2 of `b`
+typedef __attribute__((ext_vector_type(2))) unsigned mst_u32x2;
+__device__ __forceinline__ void mst_row_swap(unsigned &a, unsigned &b) {
+    const mst_u32x2 r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+// a read-only array streamed with buffer loads: address = base + voffset (per lane, VGPR) + soffset (wave-uniform, SGPR) - the uniform part
+// of the address never occupies vector registers (hipcc otherwise keeps one 64-bit VGPR address per unrolled load and spills them)
+typedef __attribute__((ext_vector_type(4))) unsigned mst_u32x4;
+struct MstStream16 {
+    __amdgpu_buffer_rsrc_t rsrc;
+};
+__device__ __forceinline__ MstStream16 mst_stream16(const void *base, unsigned bytes) {
+    return MstStream16{__builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000)};
+}
+__device__ __forceinline__ mst_u32x4 mst_stream_load16(MstStream16 s, unsigned voffset, unsigned soffset) {
+    return __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, (int)voffset, (int)soffset, 0);
+}
+// compute units of the current device (grid size of the persistent kernels)
+static inline int mst_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
 // hipFFT entry points bound at first use (no link-time dependency); returns false when the library cannot be loaded
 #include <dlfcn.h>
 static inline bool mst_fft_bind(void **plan_many, void **set_stream, void **exec_r2c, void **exec_c2r, void **destroy) {

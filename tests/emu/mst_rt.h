@@ -187,6 +187,25 @@ template <typename T> static inline T __shfl_up(T v, int d, int = 64) {
     const int l = emu::lane_id();
     return emu_shfl(v, l - d >= 0 ? l - d : l);
 }
+// LDS-DMA stand-ins: the copy happens at issue (the emulator runs one fiber at a time), the wait is the workgroup barrier
+static inline void mst_dma16(const void *gsrc, void *lds_wave_base) { memcpy((unsigned char *)lds_wave_base + 16 * emu::lane_id(), gsrc, 16); }
+template <int N> static inline void mst_dma_wait_barrier() { __syncthreads(); }
+static inline void mst_row_swap(unsigned &a, unsigned &b) {      // v_permlane16_swap_b32: rows 1, 3 of a <-> rows 0, 2 of b
+    struct AB { unsigned a, b; } me = {a, b};
+    const unsigned char *base = emu::wave_publish(&me, sizeof(me));
+    const int l = emu::lane_id();
+    if ((l >> 4) & 1) a = ((const AB *)(base + 64 * (l - 16)))->b;
+    else b = ((const AB *)(base + 64 * (l + 16)))->a;
+}
+typedef __attribute__((ext_vector_type(4))) unsigned mst_u32x4;
+struct MstStream16 { const unsigned char *base; };
+static inline MstStream16 mst_stream16(const void *base, unsigned) { return MstStream16{(const unsigned char *)base}; }
+static inline mst_u32x4 mst_stream_load16(MstStream16 s, unsigned voffset, unsigned soffset) {
+    mst_u32x4 v;
+    memcpy(&v, s.base + voffset + soffset, 16);
+    return v;
+}
+static inline int mst_num_cus() { return 4; }      // a small persistent grid: every workgroup walks several tiles
 #define __builtin_amdgcn_readfirstlane(v) emu_shfl((v), 0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)

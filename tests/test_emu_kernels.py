@@ -59,6 +59,34 @@ def test_tcn_large_dilation_and_odd_growth_emulated(emu_default):
     assert torch.equal(m2(x5, cond), y5)
 
 
+def test_tcn_bf16_stream_kernel_emulated(emu_default):
+    """The persistent LDS-DMA-streamed bf16 block kernel (mst_tcn_set_tuning bit 1): same arithmetic as the one-tile-per-workgroup
+    kernel with the fp32 accumulation running chunk-major - against the oracle at the bf16 tolerance, and against the other form
+    to accumulation rounding.  The emulated grid has 8 workgroups: several tiles per workgroup, XCD-ordered tile ranges, every
+    phase count P, per-item FiLM rows, the fused output head."""
+    cond = synth.synth_audio((1, 64), seed=2)
+    cases = [(4, 2, (2, 2, 777), cond),                                   # P = 2, 4, 8; 2 x 8 tiles over 8 workgroups
+             (4, 3, (1, 2, 300), cond),                                   # odd dilations: P = 1
+             (6, 2, (1, 2, 200), cond),                                   # short segment: P = 8 / 16 tiles, zero rows, skipped column tiles
+             (3, 2, (3, 2, 2500), synth.synth_audio((3, 64), seed=11))]   # 3 x 10 tiles: uneven walks, one FiLM row per item
+    for nb, growth, shape, cnd in cases:
+        m, sd = _tcn(nb, growth=growth)
+        m.precision = "bf16"
+        x = synth.synth_audio(shape, seed=1)
+        col = []
+        y_ref = R.tcn_forward(sd, x, cnd, nblocks=nb, dilation_growth=growth, collect=col)
+        y0 = m(x, cnd)
+        a0 = m.forward_blocks(x, cnd, nb)
+        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 3), "tuning")
+        y1 = m(x, cnd)
+        a1 = m.forward_blocks(x, cnd, nb)
+        assert float((y1 - y_ref).abs().max()) <= 4e-2
+        assert float((a1 - col[nb - 1]).abs().max()) <= 4e-2 * float(col[nb - 1].abs().max())
+        assert float((y1 - y0).abs().max()) <= 5e-3 and float((a1 - a0).abs().max()) <= 5e-2
+    with pytest.raises(ValueError):
+        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 4), "tuning")
+
+
 def test_tcn_condition_forms_emulated(emu_default):
     m, sd = _tcn(2)
     x = synth.synth_audio((2, 2, 260), seed=7)

@@ -102,6 +102,39 @@ def test_tcn_bf16_vs_oracle(nets):
         tcn.precision = "fp32"
 
 
+@pytest.mark.parametrize("form", [1, 3])
+def test_tcn_bf16_block_kernel_forms_vs_oracle(nets, form):
+    """Both forms of the bf16 block kernel (mst_tcn_set_tuning bit 1: 0 = one tile per workgroup, 1 = persistent, input rows streamed
+    by LDS-DMA) against the oracle - per block and on the waveform, ragged length (tiles that end outside the segment), per-item
+    FiLM rows, a batch larger than the persistent grid's first wave of tiles."""
+    from music_mixing_style_transfer_amd import _lib
+    from music_mixing_style_transfer_amd.utils import synth
+    from oracle import networks_ref as R
+    tcn = nets["tcn"]
+    lib = _lib.lib()
+    x = synth.synth_audio((3, 2, 20011), seed=21)
+    cond = synth.synth_audio((3, 2048), seed=9, amp=0.5).abs()
+    col = []
+    y_ref = R.tcn_forward(nets["tcn_sd"], x, cond, collect=col)
+    tcn.precision = "bf16"
+    try:
+        tcn._ensure(lib)
+        lib.check(lib.mst_tcn_set_tuning(tcn._handle, form), "mst_tcn_set_tuning")
+        for n in (2, 3, 7, 13, 14):
+            a = tcn.forward_blocks(x.cuda(), cond.cuda(), n).cpu()
+            err = float((a - col[n - 1]).abs().max())
+            assert err <= 3e-2 * float(col[n - 1].abs().max()), f"form {form} block {n}: {err}"
+        y = tcn(x.cuda(), cond.cuda()).cpu()
+        err = float((y - y_ref).abs().max())
+        print(f"bf16 block kernel form {form}: waveform max-abs vs oracle {err:.2e}")
+        assert err <= 1e-2
+        assert torch.equal(tcn(x.cuda(), cond.cuda()).cpu(), y)          # deterministic
+        assert torch.equal(tcn(x[1:2].cuda(), cond[1:2].cuda()).cpu()[0], y[1])      # segments are independent, whatever tile walks them
+    finally:
+        lib.check(lib.mst_tcn_set_tuning(tcn._handle, _lib.TCN_TUNING_DEFAULT), "mst_tcn_set_tuning")
+        tcn.precision = "fp32"
+
+
 @pytest.mark.parametrize("B,L", [(2, 16384), (1, 20001)])
 def test_encoder_vs_oracle(nets, B, L):
     from music_mixing_style_transfer_amd.utils import synth
