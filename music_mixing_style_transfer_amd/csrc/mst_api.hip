@@ -131,6 +131,7 @@ struct MstTcn {
     bool out_loaded = false;
     void *zero_row = nullptr;     // 1 KB of zeros: what the block kernels stage for time steps outside the segment
     int x3_small_tiles = 1;       // bf16x3 mode: 128-time tiles of <= 2 phases, two workgroups per CU (mst_tcn_set_tuning; measured 5.13 vs 5.45 ms)
+    int xflags = 0;
     int bf16_stream = 0;          // bf16 mode: the persistent LDS-DMA-streamed block kernel (mst_tcn_set_tuning bit 1)
     std::vector<hipEvent_t> ev;   // timing hook: (nblocks + 2) events per recorded forward
     int ev_max = 0, ev_used = 0;
@@ -386,15 +387,62 @@ template <int P, int NQ> int launch_block_stream(TcnBlockArgs a, void *stream) {
     }
     if (a.y_out)
         MST_LAUNCH((tcn_block_bf16_stream_kernel<P, true, NQ>), dim3((unsigned)grid), dim3(256), stream, a);
+    else if (P == 4 && a.xflags == 1)
+        MST_LAUNCH((tcn_block_bf16_stream_kernel<P, false, NQ, 1>), dim3((unsigned)grid), dim3(256), stream, a);
+    else if (P == 4 && a.xflags == 4)
+        MST_LAUNCH((tcn_block_bf16_stream_kernel<P, false, NQ, 4>), dim3((unsigned)grid), dim3(256), stream, a);
+    else if (P == 4 && a.xflags == 8)
+        MST_LAUNCH((tcn_block_bf16_stream_kernel<P, false, NQ, 8>), dim3((unsigned)grid), dim3(256), stream, a);
+    else if (P == 4 && a.xflags == 12)
+        MST_LAUNCH((tcn_block_bf16_stream_kernel<P, false, NQ, 12>), dim3((unsigned)grid), dim3(256), stream, a);
+    else if (P == 4 && a.xflags == 16)
+        MST_LAUNCH((tcn_block_bf16_stream_kernel<P, false, NQ, 16>), dim3((unsigned)grid), dim3(256), stream, a);
+    else if (P == 4 && a.xflags == 30)
+        MST_LAUNCH((tcn_block_bf16_stream_kernel<P, false, NQ, 30>), dim3((unsigned)grid), dim3(256), stream, a);
     else
         MST_LAUNCH((tcn_block_bf16_stream_kernel<P, false, NQ>), dim3((unsigned)grid), dim3(256), stream, a);
     MST_CHECK_LAUNCH("tcn_block_bf16_stream_kernel");
     return MST_OK;
 }
 
+// the persistent double-tile bf16 kernel: one workgroup per CU
+template <int P, int NQ> int launch_block_duo(TcnBlockArgs a, void *stream) {
+    const long nsteps = ((long)a.L + a.d - 1) / a.d;
+    a.tiles_step = (int)((nsteps + (32 * NQ) / P - 1) / ((32 * NQ) / P));
+    const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
+    long grid = mst_num_cus();
+    if (grid > ntiles) grid = ntiles;
+    a.xcd_tiles = 0;
+    if (grid >= 8) {
+        grid -= grid % 8;
+        a.xcd_tiles = (int)((ntiles + 7) / 8);
+    }
+    if (a.y_out)
+        MST_LAUNCH((tcn_block_bf16_duo_kernel<P, true, NQ>), dim3((unsigned)grid), dim3(256), stream, a);
+    else if (P == 4 && a.xflags == 1)
+        MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ, 1>), dim3((unsigned)grid), dim3(256), stream, a);
+    else if (P == 4 && a.xflags == 2)
+        MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ, 2>), dim3((unsigned)grid), dim3(256), stream, a);
+    else if (P == 4 && a.xflags == 3)
+        MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ, 3>), dim3((unsigned)grid), dim3(256), stream, a);
+    else if (P == 4 && a.xflags == 4)
+        MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ, 4>), dim3((unsigned)grid), dim3(256), stream, a);
+    else if (P == 4 && a.xflags == 16)
+        MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ, 16>), dim3((unsigned)grid), dim3(256), stream, a);
+    else if (P == 4 && a.xflags == 18)
+        MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ, 18>), dim3((unsigned)grid), dim3(256), stream, a);
+    else
+        MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ>), dim3((unsigned)grid), dim3(256), stream, a);
+    MST_CHECK_LAUNCH("tcn_block_bf16_duo_kernel");
+    return MST_OK;
+}
+
 template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream, int x3_small = 0, int bf16_stream = 0) {
     TcnBlockArgs a = a0;
-    if (precision == MST_PREC_BF16 && bf16_stream) return launch_block_stream<P, (P == 8 ? 4 : 8)>(a, stream);
+    if (precision == MST_PREC_BF16 && bf16_stream == 2) {
+        if constexpr (P < 16) return launch_block_duo<P, (P == 8 ? 4 : 8)>(a, stream);
+    }
+    if (precision == MST_PREC_BF16 && bf16_stream == 1) return launch_block_stream<P, (P == 8 ? 4 : 8)>(a, stream);
     if (precision == MST_PREC_BF16X3) {
         if constexpr (P <= 2) {
             if (x3_small) {          // 128-time tiles: 2 x 39 KB of LDS, two workgroups (8 waves) per CU
@@ -438,6 +486,8 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
             if (xcd_on && grid % 8 == 0) a.xcd_tiles = grid / 8;
             if (a.y_out)
                 MST_LAUNCH((tcn_block_bf16_kernel<P, true, 8>), dim3(grid), dim3(256), stream, a);
+            else if (P == 4 && a.xflags == 64)      // EXPERIMENT: one workgroup per CU (40 KB of unused LDS)
+                MST_LAUNCH((tcn_block_bf16_kernel<4, false, 8, 40>), dim3(grid), dim3(256), stream, a);
             else
                 MST_LAUNCH((tcn_block_bf16_kernel<P, false, 8>), dim3(grid), dim3(256), stream, a);
         }
@@ -582,6 +632,7 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         a.y_out = fuse_out ? y : nullptr;
         a.nout = t->d.noutputs;
         a.xcd_tiles = 0;
+        a.xflags = t->xflags;
         a.zeros = t->zero_row;
         if (grid > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_tcn_forward: grid too large");
         int rc;
@@ -635,9 +686,14 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
 
 extern "C" int mst_tcn_set_tuning(MstTcn *t, int flags) {
     if (!t) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: null handle");
-    if (flags < 0 || flags > 3) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: unknown flag bits");
+    if (flags < 0 || flags > 1023) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: unknown flag bits");
     t->x3_small_tiles = flags & 1;
     t->bf16_stream = (flags >> 1) & 1;
+    t->xflags = flags >> 2;
+    if (t->xflags >= 128) {
+        t->bf16_stream = 2;
+        t->xflags -= 128;
+    }
     return MST_OK;
 }
 

@@ -188,7 +188,13 @@ template <typename T> static inline T __shfl_up(T v, int d, int = 64) {
     return emu_shfl(v, l - d >= 0 ? l - d : l);
 }
 // LDS-DMA stand-ins: the copy happens at issue (the emulator runs one fiber at a time), the wait is the workgroup barrier
-static inline void mst_dma16(const void *gsrc, void *lds_wave_base) { memcpy((unsigned char *)lds_wave_base + 16 * emu::lane_id(), gsrc, 16); }
+// (the wave meets first: on the GPU a wave's earlier LDS reads have been issued by ALL its lanes before the copy is - the emulator runs the lanes one by one)
+static inline void mst_dma16(const void *gsrc, void *lds_wave_base) {
+    (void)emu_shfl(0, 0);
+    memcpy((unsigned char *)lds_wave_base + 16 * emu::lane_id(), gsrc, 16);
+}
+static inline void mst_dma16_sbase(const void *sbase, unsigned voff, void *lds_wave_base) { mst_dma16((const unsigned char *)sbase + voff, lds_wave_base); }
+static inline void mst_dma16_nosave(const void *gsrc, void *lds_wave_base) { mst_dma16(gsrc, lds_wave_base); }
 template <int N> static inline void mst_dma_wait_barrier() { __syncthreads(); }
 static inline void mst_row_swap(unsigned &a, unsigned &b) {      // v_permlane16_swap_b32: rows 1, 3 of a <-> rows 0, 2 of b
     struct AB { unsigned a, b; } me = {a, b};
