@@ -289,7 +289,7 @@ def main():
     ap.add_argument("--workload", default="all", choices=["all", "configs1", "track60"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--x3-large-tiles", action="store_true", help="bf16x3: 256-time tiles, one workgroup per CU (mst_tcn_set_tuning 0)")
-    ap.add_argument("--tcn-tuning", type=int, default=None, help="mst_tcn_set_tuning flags (bit 0: bf16x3 small tiles, bit 1: persistent LDS-DMA bf16 block kernel)")
+    ap.add_argument("--tcn-tuning", type=int, default=None, help="mst_tcn_set_tuning flags (bit 0: bf16x3 small tiles, bits 1-2: form of the bf16 block kernel, include/mst_hip.h)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

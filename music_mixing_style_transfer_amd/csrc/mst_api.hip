@@ -131,8 +131,7 @@ struct MstTcn {
     bool out_loaded = false;
     void *zero_row = nullptr;     // 1 KB of zeros: what the block kernels stage for time steps outside the segment
     int x3_small_tiles = 1;       // bf16x3 mode: 128-time tiles of <= 2 phases, two workgroups per CU (mst_tcn_set_tuning; measured 5.13 vs 5.45 ms)
-    int xflags = 0;
-    int bf16_stream = 0;          // bf16 mode: the persistent LDS-DMA-streamed block kernel (mst_tcn_set_tuning bit 1)
+    int bf16_form = 0;            // bf16 mode, form of the block kernel (mst_tcn_set_tuning bits 1-2): 0 one tile per workgroup (default), 1 stream, 2 duo
     std::vector<hipEvent_t> ev;   // timing hook: (nblocks + 2) events per recorded forward
     int ev_max = 0, ev_used = 0;
 };
@@ -387,18 +386,6 @@ template <int P, int NQ> int launch_block_stream(TcnBlockArgs a, void *stream) {
     }
     if (a.y_out)
         MST_LAUNCH((tcn_block_bf16_stream_kernel<P, true, NQ>), dim3((unsigned)grid), dim3(256), stream, a);
-    else if (P == 4 && a.xflags == 1)
-        MST_LAUNCH((tcn_block_bf16_stream_kernel<P, false, NQ, 1>), dim3((unsigned)grid), dim3(256), stream, a);
-    else if (P == 4 && a.xflags == 4)
-        MST_LAUNCH((tcn_block_bf16_stream_kernel<P, false, NQ, 4>), dim3((unsigned)grid), dim3(256), stream, a);
-    else if (P == 4 && a.xflags == 8)
-        MST_LAUNCH((tcn_block_bf16_stream_kernel<P, false, NQ, 8>), dim3((unsigned)grid), dim3(256), stream, a);
-    else if (P == 4 && a.xflags == 12)
-        MST_LAUNCH((tcn_block_bf16_stream_kernel<P, false, NQ, 12>), dim3((unsigned)grid), dim3(256), stream, a);
-    else if (P == 4 && a.xflags == 16)
-        MST_LAUNCH((tcn_block_bf16_stream_kernel<P, false, NQ, 16>), dim3((unsigned)grid), dim3(256), stream, a);
-    else if (P == 4 && a.xflags == 30)
-        MST_LAUNCH((tcn_block_bf16_stream_kernel<P, false, NQ, 30>), dim3((unsigned)grid), dim3(256), stream, a);
     else
         MST_LAUNCH((tcn_block_bf16_stream_kernel<P, false, NQ>), dim3((unsigned)grid), dim3(256), stream, a);
     MST_CHECK_LAUNCH("tcn_block_bf16_stream_kernel");
@@ -419,30 +406,18 @@ template <int P, int NQ> int launch_block_duo(TcnBlockArgs a, void *stream) {
     }
     if (a.y_out)
         MST_LAUNCH((tcn_block_bf16_duo_kernel<P, true, NQ>), dim3((unsigned)grid), dim3(256), stream, a);
-    else if (P == 4 && a.xflags == 1)
-        MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ, 1>), dim3((unsigned)grid), dim3(256), stream, a);
-    else if (P == 4 && a.xflags == 2)
-        MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ, 2>), dim3((unsigned)grid), dim3(256), stream, a);
-    else if (P == 4 && a.xflags == 3)
-        MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ, 3>), dim3((unsigned)grid), dim3(256), stream, a);
-    else if (P == 4 && a.xflags == 4)
-        MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ, 4>), dim3((unsigned)grid), dim3(256), stream, a);
-    else if (P == 4 && a.xflags == 16)
-        MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ, 16>), dim3((unsigned)grid), dim3(256), stream, a);
-    else if (P == 4 && a.xflags == 18)
-        MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ, 18>), dim3((unsigned)grid), dim3(256), stream, a);
     else
         MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ>), dim3((unsigned)grid), dim3(256), stream, a);
     MST_CHECK_LAUNCH("tcn_block_bf16_duo_kernel");
     return MST_OK;
 }
 
-template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream, int x3_small = 0, int bf16_stream = 0) {
+template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream, int x3_small = 0, int bf16_form = 0) {
     TcnBlockArgs a = a0;
-    if (precision == MST_PREC_BF16 && bf16_stream == 2) {
+    if (precision == MST_PREC_BF16 && bf16_form == 2) {
         if constexpr (P < 16) return launch_block_duo<P, (P == 8 ? 4 : 8)>(a, stream);
     }
-    if (precision == MST_PREC_BF16 && bf16_stream == 1) return launch_block_stream<P, (P == 8 ? 4 : 8)>(a, stream);
+    if (precision == MST_PREC_BF16 && bf16_form == 1) return launch_block_stream<P, (P == 8 ? 4 : 8)>(a, stream);
     if (precision == MST_PREC_BF16X3) {
         if constexpr (P <= 2) {
             if (x3_small) {          // 128-time tiles: 2 x 39 KB of LDS, two workgroups (8 waves) per CU
@@ -486,8 +461,6 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
             if (xcd_on && grid % 8 == 0) a.xcd_tiles = grid / 8;
             if (a.y_out)
                 MST_LAUNCH((tcn_block_bf16_kernel<P, true, 8>), dim3(grid), dim3(256), stream, a);
-            else if (P == 4 && a.xflags == 64)      // EXPERIMENT: one workgroup per CU (40 KB of unused LDS)
-                MST_LAUNCH((tcn_block_bf16_kernel<4, false, 8, 40>), dim3(grid), dim3(256), stream, a);
             else
                 MST_LAUNCH((tcn_block_bf16_kernel<P, false, 8>), dim3(grid), dim3(256), stream, a);
         }
@@ -632,16 +605,15 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         a.y_out = fuse_out ? y : nullptr;
         a.nout = t->d.noutputs;
         a.xcd_tiles = 0;
-        a.xflags = t->xflags;
         a.zeros = t->zero_row;
         if (grid > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_tcn_forward: grid too large");
         int rc;
         switch (P) {
-            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small, t->bf16_stream); break;
-            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_stream); break;
-            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_stream); break;
-            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_stream); break;
-            default: rc = launch_block<16>(precision, a, (int)grid, stream, 0, t->bf16_stream); break;
+            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small, t->bf16_form); break;
+            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_form); break;
+            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_form); break;
+            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_form); break;
+            default: rc = launch_block<16>(precision, a, (int)grid, stream, 0, t->bf16_form); break;
         }
         if (rc) return rc;
         if (ev) MST_HIP_TRY(hipEventRecord(ev[n + 1], (hipStream_t)stream));
@@ -686,14 +658,9 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
 
 extern "C" int mst_tcn_set_tuning(MstTcn *t, int flags) {
     if (!t) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: null handle");
-    if (flags < 0 || flags > 1023) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: unknown flag bits");
+    if (flags < 0 || flags > 5) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: unknown flag bits");
     t->x3_small_tiles = flags & 1;
-    t->bf16_stream = (flags >> 1) & 1;
-    t->xflags = flags >> 2;
-    if (t->xflags >= 128) {
-        t->bf16_stream = 2;
-        t->xflags -= 128;
-    }
+    t->bf16_form = flags >> 1;
     return MST_OK;
 }
 

@@ -42,18 +42,6 @@ __device__ __forceinline__ void mst_dma16(const void *gsrc, void *lds_wave_base)
                  : "v"(gsrc), "s"(dst)
                  : "memory");
 }
-// EXPERIMENT: without saving / restoring M0
-__device__ __forceinline__ void mst_dma16_nosave(const void *gsrc, void *lds_wave_base) {
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(dst) : "memory");
-}
-// EXPERIMENT: SGPR base + 32-bit lane offset, M0 not preserved
-__device__ __forceinline__ void mst_dma16_sbase(const void *sbase, unsigned voff, void *lds_wave_base) {
-    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)lds_wave_base);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)sbase), hi = __builtin_amdgcn_readfirstlane((unsigned)((size_t)sbase >> 32));
-    const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sb), "s"(dst) : "memory");
-}
 // wait until at most N of this wave's vector-memory operations are outstanding (in-order counter: everything older has landed) and all
 // its LDS operations have returned, then the workgroup barrier - a raw s_barrier: __syncthreads() would drain vmcnt to 0
 template <int N> __device__ __forceinline__ void mst_dma_wait_barrier() {

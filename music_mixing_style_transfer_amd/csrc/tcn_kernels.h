@@ -42,7 +42,6 @@ struct TcnBlockArgs {
     float *y_out;
     int nout;
     const void *zeros;    // >= 256 bytes of zeros in device memory: the row staged for time steps outside the segment
-    int xflags;           // EXPERIMENT (timing only): 1 b2b3 swizzle, 2 no DMA in the loop, 4 no residual loads, 8 no stores, 16 no phase barrier
     int xcd_tiles;        // > 0: tiles per XCD; workgroup i (dispatched to XCD i % 8) takes tile (i % 8) * xcd_tiles + i / 8, so that
                           // neighbouring time tiles (which share their halo rows) run on the same XCD and meet in its L2
 };
@@ -58,19 +57,15 @@ struct TcnBlockArgs {
 // B fragment feeds two MFMAs) - and under the chip's power limit it runs 15 % faster: on realistic operands the bare instruction
 // stream sustains 1934-1982 TFLOP/s against 1666-1685, the whole main loop 1570-1585 against 1367-1377
 // (tools/micro/tcn_mainloop_variants.hip, profiles/r02_micro_tcn_mainloop_variants.txt).
-template <int P, bool FUSE_OUT, int NQ, int PAD = 0>
+template <int P, bool FUSE_OUT, int NQ>
 __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1))) void tcn_block_bf16_kernel(TcnBlockArgs a) {
     constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NC = 2 * NQ;
-    __shared__ unsigned char padbuf[PAD ? PAD * 1024 : 16];      // EXPERIMENT: occupancy limiter
-    if (PAD && a.B < 0) padbuf[threadIdx.x * 97 % (PAD * 1024)] = (unsigned char)a.L;
     __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
     __shared__ __attribute__((aligned(16))) float par[4 * 128];     // shift | FiLM r | FiLM b | res of this block / batch item
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l16 = lane & 15, g = lane >> 4;
 
     int tile = a.xcd_tiles > 0 ? (int)(blockIdx.x & 7) * a.xcd_tiles + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    if (a.xflags > 0 && a.xflags < 16 && blockIdx.x >= 256 && blockIdx.x < 512)      // EXPERIMENT: the second workgroup of every CU starts late
-        for (int i = 0; i < a.xflags; ++i) __builtin_amdgcn_s_sleep(127);
     const int mg = tile % a.tiles_step;
     tile /= a.tiles_step;
     const int pg = tile % a.tiles_phase;
@@ -307,7 +302,7 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
 // 16 (q & ~1) + 16 (g & 1) + l16 and back.  Same arithmetic as tcn_block_bf16_kernel except the ORDER of the fp32 accumulation
 // (chunk-major instead of tap-major): results agree to accumulation rounding, not bit for bit.
 // ------------------------------------------------------------------------------------------------
-template <int P, bool FUSE_OUT, int NQ, int XF = 0>
+template <int P, bool FUSE_OUT, int NQ>
 __global__ __launch_bounds__(256, 2) void tcn_block_bf16_stream_kernel(TcnBlockArgs a) {
     constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NC = 2 * NQ;
     constexpr int NK = (R + 15) / 16;            // 1 KB DMA pieces (16 rows x 64 B) per chunk buffer
@@ -347,8 +342,7 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16_stream_kernel(TcnBlockA
         b = (int)(r / a.tiles_phase);
         m0 = mg * MT;
     };
-    constexpr int xsw = XF & 1;
-    const int dsl = (lane & 3) ^ (xsw ? ((lane >> 4) & 3) : ((lane >> 3) & 2));       // the chunk slot this lane fetches (the LDS swizzle, on the source side)
+    const int dsl = (lane & 3) ^ ((lane >> 3) & 2);       // the chunk slot this lane fetches (the LDS swizzle, on the source side)
     auto dma_sources = [&](int m0, int phi0) {
         const int rl = lane >> 2;
 #pragma unroll
@@ -421,8 +415,7 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16_stream_kernel(TcnBlockA
         for (int c = 0; c < 4; ++c) {
             const int buf = c & 1;
             // the chunk behind this one travels while this one is computed on
-            if constexpr ((XF & 2) != 0) {
-            } else if (c < 3) {
+            if (c < 3) {
                 dma_issue(b, c + 1, buf ^ 1);
             } else if (has_next) {
                 tile_geometry(tnext, tb, tm0, tphi0);
@@ -438,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16_stream_kernel(TcnBlockA
             static_assert(NC % RB == 0, "the ring divides the column tiles");
             bf16x8 bf[RB];
             {
-                const unsigned char *rp0 = xs + 64 * l16 + 16 * (g ^ (xsw ? ((l16 >> 2) & 3) : ((l16 >> 1) & 2)));
+                const unsigned char *rp0 = xs + 64 * l16 + 16 * (g ^ ((l16 >> 1) & 2));
 #pragma unroll
                 for (int q = 0; q < RB; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 1024);
             }
@@ -458,8 +451,8 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16_stream_kernel(TcnBlockA
                             if (!(s_hi < 0 || s_lo >= nsteps)) live |= 1u << q;
                         }
                     }
-                    const unsigned char *cp = xs + 64 * rb0 + 16 * (g ^ (xsw ? ((rb0 >> 2) & 3) : ((rb0 >> 1) & 2)));
-                    const unsigned char *np = xs + 64 * rb1 + 16 * (g ^ (xsw ? ((rb1 >> 2) & 3) : ((rb1 >> 1) & 2)));
+                    const unsigned char *cp = xs + 64 * rb0 + 16 * (g ^ ((rb0 >> 1) & 2));
+                    const unsigned char *np = xs + 64 * rb1 + 16 * (g ^ ((rb1 >> 1) & 2));
 #pragma unroll
                     for (int q = 0; q < NC; ++q) {
                         if (P < 16 || ((live >> q) & 1u)) {
@@ -479,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16_stream_kernel(TcnBlockA
             }
             // this wave's DMA pieces have landed (they are older than the >= 10 fragment loads that may still be in flight), every
             // wave is done reading this chunk's buffer
-            if constexpr (!(XF & 16)) mst_dma_wait_barrier<2 * RA>();
+            mst_dma_wait_barrier<2 * RA>();
         }
 
         // ---- fused epilogue straight from / to global memory, 16 bytes per lane: the lane of accumulator row group g handles time
@@ -509,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16_stream_kernel(TcnBlockA
 #pragma unroll
                 for (int pr = 0; pr < NC / 2; ++pr) {
                     const long t = t0 + pr * dtp;
-                    xr[pr] = (XF & 4) ? u32x4{0u, 0u, 0u, 0u} : *(const u32x4 *)(t < a.L ? xb + t * 128 + ch + 16 * m : (const __bf16 *)a.zeros);
+                    xr[pr] = *(const u32x4 *)(t < a.L ? xb + t * 128 + ch + 16 * m : (const __bf16 *)a.zeros);
                 }
 #pragma unroll
                 for (int pr = 0; pr < NC / 2; ++pr) {
@@ -538,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16_stream_kernel(TcnBlockA
                     if constexpr (!FUSE_OUT) {
                         mst_row_swap(o[0], o[2]);      // back to 8 consecutive channels of one time step per lane
                         mst_row_swap(o[1], o[3]);
-                        if (t < a.L && !((XF & 8) && o[0] != 0x12345u)) *(u32x4 *)(yb + t * 128 + ch + 16 * m) = u32x4{o[0], o[1], o[2], o[3]};
+                        if (t < a.L) *(u32x4 *)(yb + t * 128 + ch + 16 * m) = u32x4{o[0], o[1], o[2], o[3]};
                     }
                 }
             }
@@ -589,14 +582,13 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16_stream_kernel(TcnBlockA
 // Wave w owns the DMA pieces k = w (mod 4) = exactly the rows it reads itself in the store pass of the epilogue, so the refill of a
 // buffer needs no barrier beyond the two of the epilogue.
 // ------------------------------------------------------------------------------------------------
-template <int P, bool FUSE_OUT, int NQ, int XF = 0>
+template <int P, bool FUSE_OUT, int NQ>
 __global__ __launch_bounds__(256, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs a) {
     constexpr int T = 32 * NQ, R = T + 14 * P, R4 = (R + 3) / 4 * 4, MT = T / P, NC = 2 * NQ;
     constexpr int NK = R4 / 4;                   // 1 KB DMA pieces (4 rows x 256 B) per tile
     constexpr int NI = (NK + 3) / 4;             // pieces per wave
     constexpr int BUF = R4 * 256;
     static_assert(NI <= 30, "two pieces per tap");
-    constexpr bool DBG_SYNC_DMA = false;
     static_assert(2 * BUF + 2048 <= 160 * 1024, "two tiles + parameters fit the CU's LDS");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
     __shared__ __attribute__((aligned(16))) float par[4 * 128];     // shift | FiLM r | FiLM b | res
@@ -629,23 +621,13 @@ __global__ __launch_bounds__(256, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
     // the i-th DMA piece of this wave for tile (b, m0, phi0): rows 4k .. 4k + 3, k = w + 4 i, into buffer buf
     auto dma_piece = [&](int b, int m0, int phi0, int i, int buf) {
         const int k = w + 4 * i;
-        if constexpr (XF & 16) {       // EXPERIMENT: the cheapest possible address (wrong rows, same traffic shape)
-            if (k < NK) {
-                const unsigned char *xb = (const unsigned char *)a.x + ((size_t)b * a.Lp + (((long)m0 * a.d + phi0) % (a.L > 2048 ? a.L - 1024 : 1))) * 256;
-                mst_dma16_sbase(xb, (unsigned)(k * 1024 + lane * 16), smem + buf * BUF + k * 1024);
-            }
-        } else
         if (k < NK) {
             const int row = 4 * k + (lane >> 4);
             const long t = (long)(m0 + row / P - 7) * a.d + phi0 + (row % P);
             const bool ok = row < R && t >= 0 && t < a.L;
             const int slot = (lane & 15) ^ (row & 15);
             const unsigned char *src = (ok ? (const unsigned char *)a.x + ((size_t)b * a.Lp + t) * 256 : (const unsigned char *)a.zeros) + slot * 16;
-            if constexpr (XF & 8) {        // EXPERIMENT: a plain 16-byte load instead of the copy
-                u32x4 v = *(const u32x4 *)src;
-                asm volatile("" : : "v"(v));
-            } else if constexpr (XF & 4) mst_dma16_nosave(src, smem + buf * BUF + k * 1024);
-            else mst_dma16(src, smem + buf * BUF + k * 1024);
+            mst_dma16(src, smem + buf * BUF + k * 1024);
         }
     };
     auto stage_film = [&](int b) {
@@ -728,7 +710,7 @@ __global__ __launch_bounds__(256, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
                     const unsigned char *cp = sm + rb0 * 256 + (((4 * kk + g) ^ (rb0 & 15)) << 4);
                     const unsigned char *np = sm + rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
                     // the next tile travels while this one is computed on: one piece every other k-step
-                    if (!(XF & 1) && (kk & 1) == 0 && has_next && 2 * j + (kk >> 1) < NI) dma_piece(tb, tm0, tphi0, 2 * j + (kk >> 1), cur ^ 1);
+                    if ((kk & 1) == 0 && has_next && 2 * j + (kk >> 1) < NI) dma_piece(tb, tm0, tphi0, 2 * j + (kk >> 1), cur ^ 1);
 #pragma unroll
                     for (int q = 0; q < NC; ++q) {
                         acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][u][kk], bf[q % RB], acc[0][q], 0, 0, 0);
@@ -746,15 +728,6 @@ __global__ __launch_bounds__(256, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
 
         // ---- fused epilogue (the one of tcn_block_bf16_kernel): residual rows -> registers, barrier, arithmetic, transposed tile -> LDS,
         //      barrier, whole-row stores
-        if constexpr (XF & 2) {
-            float sink = 0.0f;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int q = 0; q < NC; ++q) sink += acc[m][q][0] + acc[m][q][1] + acc[m][q][2] + acc[m][q][3];
-            if (sink == 1.2345f) yb[tid] = (__bf16)sink;
-            mst_dma_wait_barrier<8 * TU>();
-        } else {
         bf16x4 xin[2][NC];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
@@ -836,14 +809,7 @@ __global__ __launch_bounds__(256, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
                 dstp += dt * 128;
             }
         }
-        }
         if (!has_next) break;
-        if (DBG_SYNC_DMA) {
-            mst_dma_wait_barrier<0>();
-#pragma unroll
-            for (int i = 0; i < NI; ++i) dma_piece(tb, tm0, tphi0, i, cur ^ 1);
-            mst_dma_wait_barrier<0>();
-        }
         tile = tnext;
         cur ^= 1;
     }

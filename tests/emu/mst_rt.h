@@ -193,8 +193,6 @@ static inline void mst_dma16(const void *gsrc, void *lds_wave_base) {
     (void)emu_shfl(0, 0);
     memcpy((unsigned char *)lds_wave_base + 16 * emu::lane_id(), gsrc, 16);
 }
-static inline void mst_dma16_sbase(const void *sbase, unsigned voff, void *lds_wave_base) { mst_dma16((const unsigned char *)sbase + voff, lds_wave_base); }
-static inline void mst_dma16_nosave(const void *gsrc, void *lds_wave_base) { mst_dma16(gsrc, lds_wave_base); }
 template <int N> static inline void mst_dma_wait_barrier() { __syncthreads(); }
 static inline void mst_row_swap(unsigned &a, unsigned &b) {      // v_permlane16_swap_b32: rows 1, 3 of a <-> rows 0, 2 of b
     struct AB { unsigned a, b; } me = {a, b};

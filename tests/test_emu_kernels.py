@@ -59,8 +59,8 @@ def test_tcn_large_dilation_and_odd_growth_emulated(emu_default):
     assert torch.equal(m2(x5, cond), y5)
 
 
-def test_tcn_bf16_stream_kernel_emulated(emu_default):
-    """The persistent LDS-DMA-streamed bf16 block kernel (mst_tcn_set_tuning bit 1): same arithmetic as the one-tile-per-workgroup
+def test_tcn_bf16_stream_and_duo_kernels_emulated(emu_default):
+    """The persistent LDS-DMA-fed forms of the bf16 block kernel (mst_tcn_set_tuning bits 1-2).  Form 1 ("stream"): same arithmetic as the one-tile-per-workgroup
     kernel with the fp32 accumulation running chunk-major - against the oracle at the bf16 tolerance, and against the other form
     to accumulation rounding.  The emulated grid has 8 workgroups: several tiles per workgroup, XCD-ordered tile ranges, every
     phase count P, per-item FiLM rows, the fused output head."""
@@ -83,8 +83,11 @@ def test_tcn_bf16_stream_kernel_emulated(emu_default):
         assert float((y1 - y_ref).abs().max()) <= 4e-2
         assert float((a1 - col[nb - 1]).abs().max()) <= 4e-2 * float(col[nb - 1].abs().max())
         assert float((y1 - y0).abs().max()) <= 5e-3 and float((a1 - a0).abs().max()) <= 5e-2
+        # form 2 ("duo": one workgroup per CU, two tile buffers, the next tile by LDS-DMA during the main loop): the same bits as form 0
+        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 5), "tuning")
+        assert torch.equal(m(x, cnd), y0) and torch.equal(m.forward_blocks(x, cnd, nb), a0)
     with pytest.raises(ValueError):
-        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 4), "tuning")
+        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 6), "tuning")
 
 
 def test_tcn_condition_forms_emulated(emu_default):

@@ -102,10 +102,10 @@ def test_tcn_bf16_vs_oracle(nets):
         tcn.precision = "fp32"
 
 
-@pytest.mark.parametrize("form", [1, 3])
+@pytest.mark.parametrize("form", [1, 3, 5])
 def test_tcn_bf16_block_kernel_forms_vs_oracle(nets, form):
-    """Both forms of the bf16 block kernel (mst_tcn_set_tuning bit 1: 0 = one tile per workgroup, 1 = persistent, input rows streamed
-    by LDS-DMA) against the oracle - per block and on the waveform, ragged length (tiles that end outside the segment), per-item
+    """The three forms of the bf16 block kernel (mst_tcn_set_tuning bits 1-2: 0 = one tile per workgroup, 1 = "stream", 2 = "duo";
+    the two persistent forms get their input rows by LDS-DMA) against the oracle - per block and on the waveform, ragged length (tiles that end outside the segment), per-item
     FiLM rows, a batch larger than the persistent grid's first wave of tiles."""
     from music_mixing_style_transfer_amd import _lib
     from music_mixing_style_transfer_amd.utils import synth
@@ -130,6 +130,9 @@ def test_tcn_bf16_block_kernel_forms_vs_oracle(nets, form):
         assert err <= 1e-2
         assert torch.equal(tcn(x.cuda(), cond.cuda()).cpu(), y)          # deterministic
         assert torch.equal(tcn(x[1:2].cuda(), cond[1:2].cuda()).cpu()[0], y[1])      # segments are independent, whatever tile walks them
+        if form == 5:          # the duo form runs the default form's arithmetic in the default form's order
+            lib.check(lib.mst_tcn_set_tuning(tcn._handle, 1), "mst_tcn_set_tuning")
+            assert torch.equal(tcn(x.cuda(), cond.cuda()).cpu(), y)
     finally:
         lib.check(lib.mst_tcn_set_tuning(tcn._handle, _lib.TCN_TUNING_DEFAULT), "mst_tcn_set_tuning")
         tcn.precision = "fp32"
