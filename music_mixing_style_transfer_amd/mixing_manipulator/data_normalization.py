@@ -45,6 +45,7 @@ class Audio_Effects_Normalizer:
         else:
             features_mean = np.load(precomputed_feature_path, allow_pickle="TRUE")[()]
         self.features_mean = self.smooth_feature(features_mean)
+        self.haas_chain = None      # extension: the chain normalize_imager applies to an almost-mono stem (None = the reference's random Haas)
 
     def normalize_audio(self, audio, src):
         assert src in self.STEMS
@@ -86,7 +87,7 @@ class Audio_Effects_Normalizer:
             elif effect == "imager":
                 mono_threshold = 0.99 if src == "bass" else 0.975          # threshold of applying the Haas effect
                 matched = normalize_imager(output_audio, target_side_mid_bal=self.features_mean[effect][src],
-                                           mono_threshold=mono_threshold, sr=self.SR)
+                                           mono_threshold=mono_threshold, sr=self.SR, haas=self.haas_chain)
                 np.copyto(output_audio, matched, casting="same_kind")
         return output_audio[self.FFT_SIZE:self.FFT_SIZE + audio.shape[0]]
 

@@ -66,14 +66,17 @@ def imager_matrix(M, target_side_mid_bal, eps=1e-04):
     return np.stack([(mid + side) / 2, (mid - side) / 2])
 
 
-def normalize_imager(data, target_side_mid_bal=0.9, mono_threshold=0.95, sr=44100, eps=1e-04, verbose=False):
-    """data [L, 2] (numpy, or a device tensor that then stays on the device) -> the image-normalised signal [L, 2]."""
+def normalize_imager(data, target_side_mid_bal=0.9, mono_threshold=0.95, sr=44100, eps=1e-04, verbose=False, haas=None):
+    """data [L, 2] (numpy, or a device tensor that then stays on the device) -> the image-normalised signal [L, 2].
+    haas (extension; the reference has no such argument): the chain applied to an almost-mono signal instead of a freshly randomised
+    AugmentationChain([Haas]) - what makes that branch reproducible (tests pass a chain with fixed parameters)."""
     is_np = isinstance(data, np.ndarray)
     x = D.to_device(data)
     M = _moments(x)
     mid_e, side_e = _energy(M, np.array([1.0, 1.0])), _energy(M, np.array([1.0, -1.0]))
     if mid_e / (mid_e + side_e) > mono_threshold:               # Haas effect on an almost-mono signal (randomised parameters)
-        x = AugmentationChain(fxs=[(Haas(sample_rate=sr), 1, True)])([x])[0]
+        chain = haas if haas is not None else AugmentationChain(fxs=[(Haas(sample_rate=sr), 1, True)])
+        x = chain([x])[0]
         M = _moments(x)
     W = imager_matrix(M, target_side_mid_bal, eps)
     lib = _lib.lib()

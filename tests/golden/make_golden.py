@@ -76,7 +76,28 @@ def install_stubs():
             setattr(self, p.name, p)
 
     class Processor:
-        pass
+        """stand-in for pymixconsole.processor.Processor: what the reference's processors need from their base class; randomize()
+        draws every parameter uniformly from its range / options with numpy's global generator (pymixconsole's published behaviour),
+        so that a seeded run of the reference is reproducible here"""
+
+        def __init__(self, name="Processor", parameters=None, block_size=None, sample_rate=None):
+            self.name, self.parameters, self.block_size, self.sample_rate = name, parameters, block_size, sample_rate
+
+        def randomize(self):
+            for p in vars(self.parameters).values():
+                if p.kind == "int":
+                    p.value = int(np.random.randint(p.minimum, p.maximum + 1))
+                elif p.kind == "float":
+                    p.value = float(np.random.uniform(p.minimum, p.maximum))
+                elif p.kind == "string":
+                    p.value = p.options[int(np.random.randint(len(p.options)))]
+            self.update(None)
+
+        def update(self, parameter_name=None):
+            pass
+
+        def reset_state(self):
+            pass
 
     par.Parameter, plist.ParameterList, proc.Processor = Parameter, ParameterList, Processor
     pymc.parameter, pymc.parameter_list, pymc.processor = par, plist, proc
@@ -491,6 +512,34 @@ def normalizer_goldens():
     out["imager_narrow_bal0.6"] = ni.normalize_imager(narrow, target_side_mid_bal=0.6, mono_threshold=1.1)     # Haas never applied
     pb = ni.process_balance(wide[:, 0], wide[:, 1], tgt_e1_bal=0.35, eps=1e-4)
     out["balance_0.35"] = np.stack(pb, 1)
+    # the HAAS branch of normalize_imager (normalization_imager.py:43-47): a near-mono "bass" stem with the imager target of the reference's
+    # own features file.  The reference widens it through AugmentationChain([Haas]) with randomised parameters; the parameters this
+    # (seeded) run drew are recorded next to its output, so that the oracle and the product can be driven with the same Haas.
+    feat = np.load(os.path.join(REF, "weights", "musdb18_fxfeatures_eqcompimagegain.npy"), allow_pickle=True)[()]
+    low = scipy.signal.lfilter([0.05], [1.0, -0.95], synth.synth_music(2, Lf, seed=15).numpy(), axis=1).T
+    t = np.arange(Lf)
+    tone = 0.5 * np.sin(2 * np.pi * 55.0 * t / 44100.0) * (1.0 + 0.5 * np.sin(2 * np.pi * 1.3 * t / 44100.0))
+    bass = np.stack([tone + low[:, 0], tone + 0.97 * low[:, 0] + 0.03 * low[:, 1]], 1).astype(np.float32)
+    drawn = {}
+    _process = ni.Haas.process
+
+    def recording_process(self, x):
+        drawn.update(delay=self.parameters.delay.value, feedback=self.parameters.feedback.value, wet=self.parameters.wet_channel.value)
+        return _process(self, x)
+    ni.Haas.process = recording_process
+    np.random.seed(20260927)
+    out["imager_haas_x"] = bass
+    out["imager_haas_y"] = ni.normalize_imager(bass.copy(), target_side_mid_bal=float(feat["imager"]["bass"]), mono_threshold=0.99)
+    ni.Haas.process = _process
+    assert drawn, "the near-mono stem did not take the Haas branch"
+    out["imager_haas_delay_feedback_wetleft"] = np.array([drawn["delay"], drawn["feedback"], 1.0 if drawn["wet"] == "left" else 0.0])
+    # the reference's real features (weights/musdb18_fxfeatures_eqcompimagegain.npy) for two stems, with the file's own dtypes and shapes
+    # (eq float32 [32769], compression float64 [2], imager 0-d float32, loudness float64 [1]) - DATA of the reference; the file itself
+    # is not stored.  feat_eq_*_smooth64 = every 64th value of the reference's smoothing (data_normalization.py:160-169).
+    for stem_name in ("bass", "drums"):
+        for eff in ("eq", "compression", "imager", "loudness"):
+            out[f"feat_{eff}_{stem_name}"] = np.asarray(feat[eff][stem_name])
+        out[f"feat_eq_{stem_name}_smooth64"] = scipy.signal.savgol_filter(feat["eq"][stem_name], 151, 1, mode="mirror")[::64]
     # EQ matching (reference glue; third-party stand-ins)
     nfft, hop = 4096, 1024
     x1 = (0.4 * synth.synth_music(1, 60000, seed=12).numpy()[0]).astype(np.float32)
