@@ -109,6 +109,7 @@ def lufs_normalize(x, sr, lufs, log=True):
     if log:
         print("original loudness: ", loudness, " max value: ", float(xd.abs().max()))
     gain = np.power(10.0, (lufs - loudness) / 20.0)             # pyloudnorm.normalize.loudness
+    gain = float(np.asarray(gain).reshape(-1)[0])                # the reference's features file holds the targets as shape-(1,) arrays
     y = xd * np.float32(gain)                                    # float32 array times a scalar stays float32 (NumPy 1.x promotion)
     peak = float(D.range_reduce(y.reshape(1, -1, 1), [0], [0], [y.numel()], 0, "max")[0])
     y = y / np.float32(np.maximum(1.0, 1e-6 + peak))
