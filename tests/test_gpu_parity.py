@@ -955,13 +955,13 @@ def test_input_normalizer_chain_and_cli_with_normalize_input(tmp_path, oracle_fx
         ref_mix = ref_mix + O.reassemble(ob, L_in)
     assert mix.shape == (2, L_in)
     # normaliser tolerance (1e-4 relative on O(0.1) signals) carried through the converter, plus the PCM16 step (half an LSB = 1.5e-5 per
-    # stem file, the mixture is the sum of four): measured 1.5e-4 on the MI355X (round 3), bound = 2 x measured
+    # stem file, the mixture is the sum of four): measured 3.2e-5 on the MI355X (round 3), bound = 2 x measured
     dev = float(np.abs(mix - np.clip(ref_mix, -1, 1)).max())
     print(f"--normalize_input True CLI: mixture max-abs vs oracle normaliser + oracle networks {dev:.2e} (max |mix| {float(np.abs(mix).max()):.2f})")
     assert dev <= MIX_TOL_NORMALIZE_INPUT
 
 
-MIX_TOL_NORMALIZE_INPUT = 2e-3      # set from the measurement printed above
+MIX_TOL_NORMALIZE_INPUT = 7e-5      # 2 x the 3.2e-5 measured (round 2 accepted 2e-3)
 
 
 def test_haas_branch_and_real_features_file_on_gpu(oracle_fx_lib):
