@@ -40,7 +40,7 @@ typedef enum {
 /* arithmetic mode of the dense convolutions (TCN blocks 1..n-1, all FXencoder convs) */
 typedef enum {
     MST_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32, fp32 activations in HBM: the parity mode */
-    MST_PREC_BF16 = 1,  /* v_mfma_f32_32x32x16_bf16, bf16 activations in HBM, fp32 accumulate */
+    MST_PREC_BF16 = 1,  /* bf16 operands / fp32 accumulate (TCN blocks: v_mfma_f32_16x16x32_bf16, FXencoder: v_mfma_f32_32x32x16_bf16), bf16 activations in HBM */
     MST_PREC_BF16X3 = 2 /* TCN: every fp32 operand split x = hi + lo into two bf16 values, three bf16 MFMAs per product
                          * (hi*hi + hi*lo + lo*hi), fp32 activations in HBM: fp32-class accuracy (<= 1e-4 on the waveform)
                          * at a third of the bf16 rate.  FXencoder: same as MST_PREC_F32. */

@@ -250,9 +250,6 @@ __global__ __launch_bounds__(NB) void fx_biquad_scan_kernel(const double *ends, 
         }
         __syncthreads();
         int cur = 0;
-#ifdef MST_SCAN_PROBE
-        if (nchunks < 0)                 // tools/micro/fx_scan_probe.hip: the load / store shell alone
-#endif
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const int d = 1 << l;
@@ -612,9 +609,6 @@ __global__ __launch_bounds__(64) MST_WAVES_PER_SIMD(4) MST_HEAVY_UNROLL void fx_
 // so a test decided by rounding picks an equally valid piece.  The slope is a constant of the lane.  The 32 steps of a batch are
 // unrolled: entries are prefetched three chunks ahead with immediate offsets, the chunk start values are parked in lane c of a
 // register (v_writelane) and stored once per batch.
-#ifndef MST_CHAIN_PROBE
-#define MST_CHAIN_PROBE 0      // tools/micro/fx_chain_variants.hip: 1 = the helper waves alone, 2 = the walker alone (timing probes)
-#endif
 #define MST_CHAIN_HELPERS 4
 #define MST_CHAIN_THREADS 384
 __global__ __launch_bounds__(MST_CHAIN_THREADS) void fx_comp_chain_kernel(CompMapArgs a) {
@@ -687,10 +681,10 @@ __global__ __launch_bounds__(MST_CHAIN_THREADS) void fx_comp_chain_kernel(CompMa
     for (int bt = 0; bt < nbatch; ++bt) {
         const int cur = bt & 1;
         if (helper) {
-            if (bt + 1 < nbatch && (MST_CHAIN_PROBE != 2 || bt == 0)) {
+            if (bt + 1 < nbatch) {
                 cook(cur ^ 1, bt + 1);
             }
-        } else if (wave == 0 && MST_CHAIN_PROBE != 1) {
+        } else if (wave == 0) {
             const int nc = a.nchunks - bt * CB < CB ? a.nchunks - bt * CB : CB;
             struct Piece { double pb, u; };
             const double *base = cooked[cur] + 2 * pl;

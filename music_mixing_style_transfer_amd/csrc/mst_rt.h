@@ -1,5 +1,6 @@
 // HIP runtime glue for the gfx950 build (hipcc).  The test-only CPU emulator substitutes its own file of
-// the same name (tests/emu/mst_rt.h) earlier on the include path; product sources carry no #ifdefs.
+// the same name (tests/emu/mst_rt.h) earlier on the include path; product sources carry no #ifdefs (the timing probes of
+// tools/micro are patched into a generated copy by tools/micro/probe_patch.py).
 #pragma once
 #include <hip/hip_runtime.h>
 

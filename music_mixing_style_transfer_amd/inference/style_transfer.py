@@ -2,15 +2,17 @@
 (reference :27-177 Mixing_Style_Transfer_Inference, :181-270 interpolation, :344-389 arguments).
 
 Same command-line flags and defaults, same directory layout, same checkpoint format, same configuration record; the
-two networks run on libmst_hip.so.  Run plainly it drives one GPU, batch by batch like the reference; launched under
+two networks run on libmst_hip.so.  Run plainly it drives one GPU; launched under
 `python -m torch.distributed.run --nproc-per-node N` with an initialised process group (main() initialises "nccl" when
 WORLD_SIZE > 1) every stem's segments are sharded across the N GPUs (`inference/engine.py::StyleTransferEngine.transfer_stem`:
-one all-gather of segment embeddings, canonical-order mean, so the result does not depend on N) and rank 0 writes the files.
-Not implemented: Demucs separation (pass --do_not_separate True) and the input FX normaliser
-(--normalize_input False); both are outside the accelerated hot path.
+one all-gather of segment embeddings, canonical-order mean, so the result does not depend on N) and every rank writes its own time
+range of the output files.  The input FX normaliser (--normalize_input True, the reference's default) is implemented
+(mixing_manipulator/data_normalization.py; its BS.1770 meter and onset detector are restatements: parity unpinned).
+Not implemented: Demucs separation - the reference shells out to `demucs`; pass --do_not_separate True with the stems already
+under <song>/separated/{input,reference}/ (the default --do_not_separate False raises NotImplementedError).
 
     python -m music_mixing_style_transfer_amd.inference.style_transfer --target_dir ./samples/style_transfer/ \
-        --ckpt_path_enc FXencoder_ps.pt --ckpt_path_conv MixFXcloner_ps.pt --do_not_separate True --normalize_input False
+        --ckpt_path_enc FXencoder_ps.pt --ckpt_path_conv MixFXcloner_ps.pt --do_not_separate True
 """
 import argparse
 import os

@@ -142,9 +142,9 @@ class _EncoderRunner:
 
 
 class FXencoder(_DeviceState, nn.Module):
-    _DEVICE_STATE = (("_runner", None),)
-
     """Audio-effects encoder: stereo waveform [B, 2, L] -> FX embedding [B, channels[-1]]."""
+
+    _DEVICE_STATE = (("_runner", None),)
 
     def __init__(self, config):
         super().__init__()
@@ -290,14 +290,14 @@ class TCNBlock(_DeviceState, nn.Module):
 
 
 class TCNModel(_DeviceState, nn.Module):
-    _DEVICE_STATE = (("_handle", None), ("_lib", None), ("_sig", None), ("_ws", lambda: _Workspace()))
-
     """Temporal convolutional network with FiLM conditioning (the MixFXcloner).
 
     forward(x [B, ninputs, L], cond [1|B, cond_dim] or list of nblocks such tensors) -> [B, noutputs, L] in [-1, 1].
     `precision` selects the arithmetic of the dense dilated convolutions: "fp32" (exact fp32 on the matrix
     cores, the parity mode, default) or "bf16" (bf16 operands / fp32 accumulate, the throughput mode).
     """
+
+    _DEVICE_STATE = (("_handle", None), ("_lib", None), ("_sig", None), ("_ws", lambda: _Workspace()))
 
     def __init__(self, nparams, ninputs=1, noutputs=1, nblocks=10, kernel_size=3, dilation_growth=1, channel_growth=1,
                  channel_width=32, stack_size=10, cond_dim=2048, grouped=False, causal=False, skip_connections=False,

@@ -141,9 +141,9 @@ class Conv1d_layer(_DeviceState, nn.Module):
 
 
 class Res_ConvBlock(_DeviceState, nn.Module):
-    _DEVICE_STATE = (("_runner", None),)
-
     """conv2(conv1(x) + x): the skip is added after conv1's activation; only conv2 strides / changes channels."""
+
+    _DEVICE_STATE = (("_runner", None),)
 
     def __init__(self, dimension, in_channels, out_channels, kernel_size, stride=1, padding="SAME", dilation=1,
                  bias=True, norm="batch", activation="relu", last_activation="relu", mode="conv"):

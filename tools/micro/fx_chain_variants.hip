@@ -1,7 +1,7 @@
 // Micro-benchmark (round 2): who sets the pace of the compressor's chain kernel (fx_comp_chain_kernel) - the walker wave or the wave
 // that brings the records into LDS.  Runs the product's own map kernel on 128 sequences x 131072 samples of noise whose level
 // wanders around the threshold, then times the map kernel and the chain kernel.  Compile three times:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../music_mixing_style_transfer_amd/csrc -DMST_CHAIN_PROBE=0 -o fx_chain_p0 fx_chain_variants.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I_gen -I../../music_mixing_style_transfer_amd/csrc -DMST_CHAIN_PROBE=0 -o fx_chain_p0 fx_chain_variants.hip
 //   ... -DMST_CHAIN_PROBE=1 (helper waves alone) ... -DMST_CHAIN_PROBE=2 (walker alone, on the first two batches' entries)
 #include "fx_kernels.h"
 

@@ -1,5 +1,5 @@
 // Timing probe for fx_biquad_scan_kernel: the whole kernel against its load / store shell (MST_SCAN_PROBE=1 skips the levels).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../music_mixing_style_transfer_amd/csrc [-DMST_SCAN_PROBE=1] -o fx_scan_probe fx_scan_probe.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I_gen -I../../music_mixing_style_transfer_amd/csrc [-DMST_SCAN_PROBE=1] -o fx_scan_probe fx_scan_probe.hip
 #include "fx_kernels.h"
 
 #include <vector>
