@@ -436,6 +436,9 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
             a.tiles_step = (int)((nsteps + (32 * NQ) / P - 1) / ((32 * NQ) / P));
             const long g2 = (long)a.B * a.tiles_phase * a.tiles_step;
             if (g2 % 8 == 0) a.xcd_tiles = (int)(g2 / 8);
+            if constexpr (P == 8)      // 8-phase tiles: the input staged in two halves of 64 channels (60 KB of LDS, two workgroups per CU)
+                MST_LAUNCH((tcn_block_bf16x3_half_kernel<P, NQ>), dim3((unsigned)g2), dim3(256), stream, a);
+            else
             MST_LAUNCH((tcn_block_bf16x3_kernel<P, NQ>), dim3((unsigned)g2), dim3(256), stream, a);
             MST_CHECK_LAUNCH("tcn_block_bf16x3_kernel");
             return MST_OK;

@@ -984,6 +984,155 @@ __global__ __launch_bounds__(256, (NQ == 4 && P <= 2) ? 2 : 1) void tcn_block_bf
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16x3, large dilations: the same kernel with the input staged in TWO HALVES of 64 channels (round 3).  The 8-phase tiles the
+// d >= 4096 blocks need (few steps per phase: 32 / 16 at L = 131072) have 240 rows; two whole (hi, lo) tiles are 120 KB of LDS = one
+// workgroup per CU (measured 6.4 ms per launch against 4.76 ms for the blocks that run two per CU).  Staged as [240 rows][64 channels]
+// hi + lo = 60 KB the kernel keeps two workgroups per CU; the price is one more barrier pair per tile and a reduction that runs
+// half-major (channels 0..63 of all taps, then 64..127): same terms, another fp32 summation order.
+// LDS image: 128-byte rows (8 slots of 16 B), slot ^ ((row >> 1) & 7): conflict free for ds_read_b128's lane groups at the start rows
+// that occur (multiples of 8).
+// ------------------------------------------------------------------------------------------------
+template <int P, int NQ>
+__global__ __launch_bounds__(256, 2) void tcn_block_bf16x3_half_kernel(TcnBlockArgs a) {
+    constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NC = 2 * NQ;
+    static_assert(P % 8 == 0, "the swizzle is conflict free for start rows that are multiples of 8");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * R * 128];      // [hi | lo] half tiles
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    unsigned char *const sm_hi = smem, *const sm_lo = smem + R * 128;
+    const int l16 = lane & 15, g = lane >> 4;
+
+    int tile = a.xcd_tiles > 0 ? (int)(blockIdx.x & 7) * a.xcd_tiles + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int mg = tile % a.tiles_step;
+    tile /= a.tiles_step;
+    const int pg = tile % a.tiles_phase;
+    const int b = tile / a.tiles_phase;
+    const int m0 = mg * MT, phi0 = pg * P;
+    const float *xb = (const float *)a.x + (size_t)b * a.Lp * 128;
+    float *yb = (float *)a.y + (size_t)b * a.Lp * 128;
+
+    f32x4 acc[2][NC];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {          // accumulators start from the BN shift of their channel
+        const f32x4 sh = *(const f32x4 *)(a.shift + 32 * w + 16 * m + 4 * g);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) acc[m][q] = sh;
+    }
+    const unsigned char *wbase = (const unsigned char *)a.wpk;
+    const unsigned aoff = (unsigned)(w * 64 + lane) * 16u;
+    constexpr size_t LO_IMG = (size_t)120 * 4096;
+    constexpr int RB = 8;
+    static_assert(NC == RB, "one ring turn per k-step");
+
+#pragma unroll 1
+    for (int c = 0; c < 2; ++c) {
+        if (c) __syncthreads();            // every wave is done reading the first half
+        // ---- stage channels 64 c .. 64 c + 63 of the R rows: a thread owns one 16-byte slot (8 channels) of rows prow, prow + 32, ...
+        {
+            const int slot = tid & 7, prow = tid >> 3;
+            constexpr int NPASS = (R + 31) / 32;
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) {
+                const int row = prow + 32 * i;
+                const long t = (long)(m0 + row / P - 7) * a.d + phi0 + (row % P);
+                f32x4 v0 = {0.0f, 0.0f, 0.0f, 0.0f}, v1 = v0;
+                if (row < R && t >= 0 && t < a.L) {
+                    const float *src = xb + t * 128 + 64 * c + slot * 8;
+                    v0 = *(const f32x4 *)src;
+                    v1 = *(const f32x4 *)(src + 4);
+                }
+                if (row < R) {
+                    bf16x8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hi[e] = (__bf16)v0[e];
+                        lo[e] = (__bf16)(v0[e] - (float)hi[e]);
+                        hi[4 + e] = (__bf16)v1[e];
+                        lo[4 + e] = (__bf16)(v1[e] - (float)hi[4 + e]);
+                    }
+                    const int off = row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
+                    *(bf16x8 *)(sm_hi + off) = hi;
+                    *(bf16x8 *)(sm_lo + off) = lo;
+                }
+            }
+        }
+        __syncthreads();
+
+        // A fragments: wpk[part][ks = j*4 + kk][row tile m][wave][lane], kk = 2 c + kl; one k-step of (hi, lo) fragments in flight ahead
+        bf16x8 ah[2][2], al[2][2], bh[RB], bl[RB];
+#pragma unroll
+        for (int kl = 0; kl < 2; ++kl)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ah[kl][m] = *(const bf16x8 *)(wbase + (size_t)((2 * c + kl) * 2 + m) * 4096 + aoff);
+                al[kl][m] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)((2 * c + kl) * 2 + m) * 4096 + aoff);
+            }
+        {
+            const int o0 = l16 * 128 + ((g ^ ((l16 >> 1) & 7)) << 4);
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                bh[q] = *(const bf16x8 *)(sm_hi + o0 + q * 2048);
+                bl[q] = *(const bf16x8 *)(sm_lo + o0 + q * 2048);
+            }
+        }
+        for (int j = 0; j < 15; ++j) {
+            const int jn = j < 14 ? j + 1 : 14;
+            const int rb0 = j * P + l16, rb1 = jn * P + l16;
+#pragma unroll
+            for (int kl = 0; kl < 2; ++kl) {
+                const int rbn = kl ? rb1 : rb0;
+                const int kn = kl ^ 1;
+                const int on = rbn * 128 + (((4 * kn + g) ^ ((rbn >> 1) & 7)) << 4);
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[kl][m], bh[q], acc[m][q], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kl][m], bl[q], acc[m][q], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kl][m], bh[q], acc[m][q], 0, 0, 0);
+                    bh[q] = *(const bf16x8 *)(sm_hi + on + q * 2048);
+                    bl[q] = *(const bf16x8 *)(sm_lo + on + q * 2048);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                const int ksn = jn * 4 + 2 * c + kl;          // the same k-step of the next tap (behind the last tap: loaded again, unused)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    ah[kl][m] = *(const bf16x8 *)(wbase + (size_t)(ksn * 2 + m) * 4096 + aoff);
+                    al[kl][m] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)(ksn * 2 + m) * 4096 + aoff);
+                }
+            }
+        }
+    }
+
+    // ---- exact fp32 epilogue: LeakyReLU -> FiLM -> + res * x_in (x_in re-read in fp32 from global memory)
+    const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int co0 = 32 * w + 16 * m + 4 * g;
+        const f32x4 fr = *(const f32x4 *)(frow + co0);
+        const f32x4 fb = *(const f32x4 *)(frow + 128 + co0);
+        const f32x4 rs = *(const f32x4 *)(a.res + co0);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            const int o = 16 * q + l16;
+            const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
+            if (t < a.L) {
+                const f32x4 xin = *(const f32x4 *)(xb + t * 128 + co0);
+                f32x4 out;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float v = leaky_relu(acc[m][q][i]);
+                    v = fr[i] * v + fb[i];
+                    out[i] = v + rs[i] * xin[i];
+                }
+                *(f32x4 *)(yb + t * 128 + co0) = out;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // blocks 1..n-1, exact fp32 (v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain), fp32 activations.
 // The parity mode.  Input channels are staged in 4 chunks of 32 (128 B per row) to keep LDS small.
 // ------------------------------------------------------------------------------------------------
