@@ -296,6 +296,7 @@ __global__ __launch_bounds__(256) void enc_conv_bf16_kernel(EncConvArgs a) {
 // ================================================================================================
 struct EncDirectArgs {
     const float *x;      // [B][Cin][Lin] fp32
+    void *ylo;           // OUT_NLC and non-null: split mode - the low parts' plane (y then holds the high parts)
     void *y;             // OUT_NLC ? bf16 [B][Lout][Cout] : fp32 [B][Cout][Lout]
     const float *w;      // [Cout][Cin][ksz] BN-folded
     const float *shift;  // [Cout]
@@ -358,13 +359,18 @@ __global__ __launch_bounds__(256) void enc_direct_kernel(EncDirectArgs a) {
     }
     if (OUT_NLC) {
         __bf16 *yp = (__bf16 *)a.y + ((size_t)b * a.Lout + to) * a.Cout;
+        __bf16 *ypl = a.ylo ? (__bf16 *)a.ylo + ((size_t)b * a.Lout + to) * a.Cout : nullptr;
 #pragma unroll
         for (int c8 = 0; c8 < CM / 8; ++c8) {
             if (c8 * 8 < a.Cout) {
-                bf16x8 o;
+                bf16x8 o, ol;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = (__bf16)acc[c8 * 8 + i];
+                for (int i = 0; i < 8; ++i) {
+                    o[i] = (__bf16)acc[c8 * 8 + i];
+                    ol[i] = (__bf16)(acc[c8 * 8 + i] - (float)o[i]);
+                }
                 *(bf16x8 *)(yp + c8 * 8) = o;
+                if (ypl) *(bf16x8 *)(ypl + c8 * 8) = ol;
             }
         }
     } else {
@@ -378,6 +384,9 @@ __global__ __launch_bounds__(256) void enc_direct_kernel(EncDirectArgs a) {
 struct EncNlcArgs {
     const __bf16 *x;     // [B][Lin][Cin]
     __bf16 *y;           // [B][Lout][Cout]
+    const __bf16 *xlo;   // split mode (X3): the low parts of the input, same layout (x = x_hi + x_lo, both bf16)
+    __bf16 *ylo;         // split mode: the low parts of the output
+    const void *wpk_lo;  // split mode: the low parts of the folded weights, same fragment order
     float *part;         // split-K partial sums [S][Ntot][Cout] fp32 (null when S == 1)
     const void *wpk;     // bf16 A fragments [co_tiles][nchunks][4][MW][64][8], k = j*Cin + ci
     const float *shift;  // [co_tiles*MT]
@@ -389,11 +398,23 @@ struct EncNlcArgs {
 
 // implicit-GEMM convolution on NLC bf16 activations, v_mfma_f32_32x32x16_bf16, K-chunk = 64 (8 slots per row).
 // Tile (32*MW) channels x (128*4/MW) columns; optional split-K over blockIdx.z for the short, wide late layers.
-template <int MW>
+// split mode ("bf16x3", the encoder's <= 1e-4 mode on the bf16 matrix cores): every fp32 value travels as two bf16 values
+// x = x_hi + x_lo (x_hi = bf16(x), x_lo = bf16(x - x_hi): 16 significant bits; products of bf16 values are exact in fp32), activations as
+// two NLC planes, weights as two fragment images, and a product is three MFMAs W_lo x_hi + W_hi x_lo + W_hi x_hi into one fp32 accumulator.
+__device__ __forceinline__ void enc_split4(const float (&v)[4], bf16x4 &hi, bf16x4 &lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (__bf16)v[i];
+        lo[i] = (__bf16)(v[i] - (float)hi[i]);
+    }
+}
+
+template <int MW, bool X3 = false>
 __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
     constexpr int NW = 4 / MW, MT = 32 * MW, NT = 128 * NW;
     constexpr int NL = NT / 32;                        // 16-byte loads per thread per chunk
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[NT * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[(X3 ? 2 : 1) * NT * 128];
+    unsigned char *const Bl = Bs + NT * 128;           // split mode: the low parts' tile
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ln = lane & 31, h = lane >> 5;
     const int mi = w % MW, ni = w / MW;
@@ -422,11 +443,16 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
 
     const bf16x8 *wtile = (const bf16x8 *)a.wpk + (size_t)cot * a.nchunks * 4 * MW * 64;
+    const bf16x8 *wtile_lo = (const bf16x8 *)a.wpk_lo + (size_t)cot * a.nchunks * 4 * MW * 64;
     bf16x8 anxt[4], acur[4], breg[NL];
+    bf16x8 anxt_lo[X3 ? 4 : 1], acur_lo[X3 ? 4 : 1], breg_lo[X3 ? NL : 1];
 
     auto fetch = [&](int kc) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) anxt[ks] = wtile[((size_t)(kc * 4 + ks) * MW + mi) * 64 + lane];
+        for (int ks = 0; ks < 4; ++ks) {
+            anxt[ks] = wtile[((size_t)(kc * 4 + ks) * MW + mi) * 64 + lane];
+            if constexpr (X3) anxt_lo[ks] = wtile_lo[((size_t)(kc * 4 + ks) * MW + mi) * 64 + lane];
+        }
         const int joff = a.stab[(kc * 8 + slot) * 2], ci0 = a.stab[(kc * 8 + slot) * 2 + 1];
 #pragma unroll
         for (int e = 0; e < NL; ++e) {
@@ -439,6 +465,10 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
             const size_t off = ok ? ((size_t)rowb[e] * a.Lin + ti) * a.Cin + ci0 : 0;
             const bf16x8 ld = *(const bf16x8 *)(a.x + off);
             breg[e] = ok ? ld : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if constexpr (X3) {
+                const bf16x8 ll = *(const bf16x8 *)(a.xlo + off);
+                breg_lo[e] = ok ? ll : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
         }
     };
 
@@ -449,9 +479,13 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
         for (int e = 0; e < NL; ++e) {
             const int n = (tid >> 3) + 32 * e;
             *(bf16x8 *)(Bs + n * 128 + ((slot ^ ((n >> 1) & 7)) << 4)) = breg[e];
+            if constexpr (X3) *(bf16x8 *)(Bl + n * 128 + ((slot ^ ((n >> 1) & 7)) << 4)) = breg_lo[e];
         }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) acur[ks] = anxt[ks];
+        for (int ks = 0; ks < 4; ++ks) {
+            acur[ks] = anxt[ks];
+            if constexpr (X3) acur_lo[ks] = anxt_lo[ks];
+        }
         __syncthreads();
         if (kc + 1 < kc_hi) fetch(kc + 1);
 #pragma unroll
@@ -459,7 +493,13 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int nl = 128 * ni + 32 * q + ln;
-                const bf16x8 bv = *(const bf16x8 *)(Bs + nl * 128 + (((2 * ks + h) ^ ((nl >> 1) & 7)) << 4));
+                const int off = nl * 128 + (((2 * ks + h) ^ ((nl >> 1) & 7)) << 4);
+                const bf16x8 bv = *(const bf16x8 *)(Bs + off);
+                if constexpr (X3) {          // the small terms first
+                    const bf16x8 bl = *(const bf16x8 *)(Bl + off);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur_lo[ks], bv, acc[q], 0, 0, 0);
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[ks], bl, acc[q], 0, 0, 0);
+                }
                 acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[ks], bv, acc[q], 0, 0, 0);
             }
         }
@@ -483,8 +523,18 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
                         const f32x4 sh = *(const f32x4 *)(a.shift + co0);
                         bf16x4 o, r = {0, 0, 0, 0};
                         if (a.residual) r = *(const bf16x4 *)(a.x + ((size_t)b * a.Lin + to) * a.Cin + co0);
+                        if constexpr (X3) {
+                            bf16x4 rl = {0, 0, 0, 0}, ol;
+                            if (a.residual) rl = *(const bf16x4 *)(a.xlo + ((size_t)b * a.Lin + to) * a.Cin + co0);
+                            float v[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) o[i] = (__bf16)(fmaxf(acc[q][4 * g + i] + sh[i], 0.0f) + (float)r[i]);
+                            for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[q][4 * g + i] + sh[i], 0.0f) + ((float)r[i] + (float)rl[i]);
+                            enc_split4(v, o, ol);
+                            *(bf16x4 *)(a.ylo + ((size_t)b * a.Lout + to) * a.Cout + co0) = ol;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) o[i] = (__bf16)(fmaxf(acc[q][4 * g + i] + sh[i], 0.0f) + (float)r[i]);
+                        }
                         *(bf16x4 *)(a.y + ((size_t)b * a.Lout + to) * a.Cout + co0) = o;
                     }
                 }
@@ -504,10 +554,11 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
 // consecutive LDS rows an odd number of 16-byte units apart: conflict-free ds_read_b128.
 // Host-side eligibility: Cin % 16 == 0, no split-K (>= 512 tiles), Lout >= NT, rows fit 64 KB.
 // ------------------------------------------------------------------------------------------------
-template <int MW>
+template <int MW, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void enc_conv_rows_kernel(EncNlcArgs a) {
     constexpr int NW = 4 / MW, MT = 32 * MW, NT = 128 * NW;
-    __shared__ __attribute__((aligned(16))) unsigned char rows[64 * 1024];
+    constexpr int ROWS_BYTES = X3 ? 80 * 1024 : 64 * 1024;       // split mode: the high parts' rows, then the low parts' (host: both fit)
+    __shared__ __attribute__((aligned(16))) unsigned char rows[ROWS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ln = lane & 31, h = lane >> 5;
     const int mi = w % MW, ni = w / MW;
@@ -517,6 +568,8 @@ __global__ __launch_bounds__(256, 2) void enc_conv_rows_kernel(EncNlcArgs a) {
     const int s = a.stride, pitch = a.Cin * 2 + 16, c8n = a.Cin / 8;
     const int R = (NT - 1) * s + a.ksz, rpp = (R + s - 1) / s;
     const __bf16 *xb = a.x + (size_t)b * a.Lin * a.Cin;
+    const __bf16 *xbl = X3 ? a.xlo + (size_t)b * a.Lin * a.Cin : nullptr;
+    const int lo_off = s * rpp * pitch;                               // split mode: byte offset of the low parts' rows
     for (int p = tid; p < R * c8n; p += 256) {
         const int r = p / c8n, c8 = p - r * c8n;
         int ti = to0 * s - a.pad_l + r;
@@ -525,6 +578,10 @@ __global__ __launch_bounds__(256, 2) void enc_conv_rows_kernel(EncNlcArgs a) {
         const bool ok = ti >= 0 && ti < a.Lin;                       // rows of a ragged last tile can fall outside even after reflection
         const bf16x8 ld = *(const bf16x8 *)(xb + (size_t)(ok ? ti : 0) * a.Cin + c8 * 8);
         *(bf16x8 *)(rows + ((r % s) * rpp + r / s) * pitch + c8 * 16) = ok ? ld : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (X3) {
+            const bf16x8 ll = *(const bf16x8 *)(xbl + (size_t)(ok ? ti : 0) * a.Cin + c8 * 8);
+            *(bf16x8 *)(rows + lo_off + ((r % s) * rpp + r / s) * pitch + c8 * 16) = ok ? ll : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
     }
     f32x16 acc[4];
 #pragma unroll
@@ -532,18 +589,30 @@ __global__ __launch_bounds__(256, 2) void enc_conv_rows_kernel(EncNlcArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
     const bf16x8 *wtile = (const bf16x8 *)a.wpk + (size_t)cot * a.nchunks * 4 * MW * 64 + mi * 64 + lane;
+    const bf16x8 *wtile_lo = (const bf16x8 *)a.wpk_lo + (size_t)cot * a.nchunks * 4 * MW * 64 + mi * 64 + lane;
     const int nks = (a.Cin * a.ksz) / 16;                             // k-steps that carry weights (K = Cin * ksz is a multiple of 16)
-    bf16x8 anext = wtile[0];
+    bf16x8 anext = wtile[0], anext_lo = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (X3) anext_lo = wtile_lo[0];
     __syncthreads();
     const unsigned char *lanebase = rows + (128 * ni + ln) * pitch + 16 * h;
     for (int ks = 0; ks < nks; ++ks) {
-        const bf16x8 acur = anext;
-        if (ks + 1 < nks) anext = wtile[(size_t)(ks + 1) * MW * 64];
+        const bf16x8 acur = anext, acur_lo = anext_lo;
+        if (ks + 1 < nks) {
+            anext = wtile[(size_t)(ks + 1) * MW * 64];
+            if constexpr (X3) anext_lo = wtile_lo[(size_t)(ks + 1) * MW * 64];
+        }
         const int k0 = ks * 16, j = k0 / a.Cin, ci0 = k0 - j * a.Cin;
         const unsigned char *bp = lanebase + ((j % s) * rpp + j / s) * pitch + ci0 * 2;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur, *(const bf16x8 *)(bp + 32 * q * pitch), acc[q], 0, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+            const bf16x8 bv = *(const bf16x8 *)(bp + 32 * q * pitch);
+            if constexpr (X3) {
+                const bf16x8 bl = *(const bf16x8 *)(bp + lo_off + 32 * q * pitch);
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur_lo, bv, acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur, bl, acc[q], 0, 0, 0);
+            }
+            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur, bv, acc[q], 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -556,8 +625,18 @@ __global__ __launch_bounds__(256, 2) void enc_conv_rows_kernel(EncNlcArgs a) {
                     const f32x4 sh = *(const f32x4 *)(a.shift + co0);
                     bf16x4 o, r = {0, 0, 0, 0};
                     if (a.residual) r = *(const bf16x4 *)(xb + (size_t)to * a.Cin + co0);
+                    if constexpr (X3) {
+                        bf16x4 rl = {0, 0, 0, 0}, ol;
+                        if (a.residual) rl = *(const bf16x4 *)(xbl + (size_t)to * a.Cin + co0);
+                        float v[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (__bf16)(fmaxf(acc[q][4 * g + i] + sh[i], 0.0f) + (float)r[i]);
+                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[q][4 * g + i] + sh[i], 0.0f) + ((float)r[i] + (float)rl[i]);
+                        enc_split4(v, o, ol);
+                        *(bf16x4 *)(a.ylo + ((size_t)b * a.Lout + to) * a.Cout + co0) = ol;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = (__bf16)(fmaxf(acc[q][4 * g + i] + sh[i], 0.0f) + (float)r[i]);
+                    }
                     *(bf16x4 *)(a.y + ((size_t)b * a.Lout + to) * a.Cout + co0) = o;
                 }
             }
@@ -566,8 +645,10 @@ __global__ __launch_bounds__(256, 2) void enc_conv_rows_kernel(EncNlcArgs a) {
 }
 
 // split-K epilogue: sum the S partial tiles, + shift, ReLU, + residual, -> bf16 NLC
+// (xres_lo / y_lo non-null: split mode - the residual is x_hi + x_lo, the result leaves as two planes)
 __global__ __launch_bounds__(256) void enc_splitk_finalize_kernel(const float *part, int S, long Ntot, int Cout,
-                                                                  const float *shift, const __bf16 *xres, __bf16 *y) {
+                                                                  const float *shift, const __bf16 *xres, __bf16 *y,
+                                                                  const __bf16 *xres_lo, __bf16 *y_lo) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;       // one thread per 4 channels
     const long total = Ntot * (Cout / 4);
     if (i >= total) return;
@@ -578,8 +659,18 @@ __global__ __launch_bounds__(256) void enc_splitk_finalize_kernel(const float *p
     const f32x4 sh = *(const f32x4 *)(shift + co0);
     bf16x4 r = {0, 0, 0, 0}, o;
     if (xres) r = *(const bf16x4 *)(xres + (size_t)n * Cout + co0);
+    if (y_lo) {
+        bf16x4 rl = {0, 0, 0, 0}, ol;
+        if (xres_lo) rl = *(const bf16x4 *)(xres_lo + (size_t)n * Cout + co0);
+        float v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = (__bf16)(fmaxf(s[k] + sh[k], 0.0f) + (float)r[k]);
+        for (int k = 0; k < 4; ++k) v[k] = fmaxf(s[k] + sh[k], 0.0f) + ((float)r[k] + (float)rl[k]);
+        enc_split4(v, o, ol);
+        *(bf16x4 *)(y_lo + (size_t)n * Cout + co0) = ol;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (__bf16)(fmaxf(s[k] + sh[k], 0.0f) + (float)r[k]);
+    }
     *(bf16x4 *)(y + (size_t)n * Cout + co0) = o;
 }
 
@@ -600,24 +691,27 @@ __global__ __launch_bounds__(256) void enc_splitk_finalize_ncl_kernel(const floa
 }
 
 // global average pool over time of an NLC bf16 activation -> fp32 [B][C]
-__global__ __launch_bounds__(256) void enc_avgpool_nlc_kernel(const __bf16 *x, float *y, int B, int Lf, int C) {
+__global__ __launch_bounds__(256) void enc_avgpool_nlc_kernel(const __bf16 *x, const __bf16 *xlo, float *y, int B, int Lf, int C) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long)B * C) return;
     const int b = (int)(i / C), c = (int)(i % C);
     float s = 0.0f;
-    for (int t = 0; t < Lf; ++t) s += (float)x[((size_t)b * Lf + t) * C + c];
+    for (int t = 0; t < Lf; ++t) {
+        const size_t o = ((size_t)b * Lf + t) * C + c;
+        s += xlo ? (float)x[o] + (float)xlo[o] : (float)x[o];
+    }
     y[i] = s / (float)Lf;
 }
 
 // NLC bf16 -> NCL fp32 (parity probe only)
-__global__ void enc_unpack_nlc_kernel(const __bf16 *x, float *y, int B, int L, int C) {
+__global__ void enc_unpack_nlc_kernel(const __bf16 *x, const __bf16 *xlo, float *y, int B, int L, int C) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)B * L * C) return;
     const int c = i % C;
     const size_t bt = i / C;
     const int t = bt % L;
     const int b = bt / L;
-    y[((size_t)b * C + c) * L + t] = (float)x[i];
+    y[((size_t)b * C + c) * L + t] = xlo ? (float)x[i] + (float)xlo[i] : (float)x[i];
 }
 
 // AdaptiveAvgPool1d(1) + squeeze (architectures.py:62,67): one wave per (b, c) row.

@@ -59,6 +59,7 @@ struct MstEncConv {
     int *ktab = nullptr;
     float *w_direct = nullptr;   // [Cout][Cin][ksz] folded fp32 (layers with Cin < 8: direct kernel)
     __bf16 *wpk_nlc = nullptr;   // NLC pipeline A fragments, k = j*Cin + ci, K-chunk 64
+    __bf16 *wpk_nlc_lo = nullptr;   // split mode: bf16(W' - bf16(W')) in the same fragment order
     int *stab = nullptr;         // NLC pipeline slot table
     int nchunks64 = 0;
     int cin = 0, cout = 0, ksz = 0, stride = 1, dil = 1, pad_l = 0, pad_r = 0, nchunks = 0, nchunks32 = 0, mw = 4;
@@ -761,6 +762,7 @@ extern "C" int mst_enc_destroy(MstEnc *e) {
         (void)hipFree(c.wpk16);
         (void)hipFree(c.w_direct);
         (void)hipFree(c.wpk_nlc);
+        (void)hipFree(c.wpk_nlc_lo);
         (void)hipFree(c.stab);
         (void)hipFree(c.shift);
         (void)hipFree(c.ktab);
@@ -819,7 +821,7 @@ extern "C" int mst_enc_load_conv(MstEnc *e, int block, int which, const float *w
     } else if (c.cin % 8 == 0) {
         // NLC pipeline: contraction index k = j*Cin + ci; fragments [cot][kc64][ks 0..3][mi][lane][e]
         c.nchunks64 = (K + 63) / 64;
-        std::vector<__bf16> wn((size_t)co_tiles * c.nchunks64 * 4 * c.mw * 64 * 8);
+        std::vector<__bf16> wn((size_t)co_tiles * c.nchunks64 * 4 * c.mw * 64 * 8), wl(wn.size());
         for (int cot = 0; cot < co_tiles; ++cot)
             for (int kc = 0; kc < c.nchunks64; ++kc)
                 for (int ks = 0; ks < 4; ++ks)
@@ -830,7 +832,9 @@ extern "C" int mst_enc_load_conv(MstEnc *e, int block, int which, const float *w
                                 const int k = kc * 64 + ks * 16 + 8 * (l >> 5) + e;
                                 float v = 0.0f;
                                 if (co < c.cout && k < K) v = w[((size_t)co * c.cin + (k % c.cin)) * c.ksz + k / c.cin] * scale[co];
-                                wn[((((((size_t)cot * c.nchunks64 + kc) * 4 + ks) * c.mw + mi) * 64 + l) * 8) + e] = (__bf16)v;
+                                const size_t at = ((((((size_t)cot * c.nchunks64 + kc) * 4 + ks) * c.mw + mi) * 64 + l) * 8) + e;
+                                wn[at] = (__bf16)v;
+                                wl[at] = (__bf16)(v - (float)wn[at]);
                             }
         std::vector<int> st((size_t)c.nchunks64 * 8 * 2);
         for (int sidx = 0; sidx < c.nchunks64 * 8; ++sidx) {
@@ -839,6 +843,7 @@ extern "C" int mst_enc_load_conv(MstEnc *e, int block, int which, const float *w
             st[2 * sidx + 1] = k0 < K ? k0 % c.cin : -1;
         }
         if ((rc = upload(&c.wpk_nlc, wn))) return rc;
+        if ((rc = upload(&c.wpk_nlc_lo, wl))) return rc;
         if ((rc = upload(&c.stab, st))) return rc;
     }
     if ((rc = upload(&c.wpk, wp))) return rc;
@@ -996,12 +1001,13 @@ size_t enc_scratch_floats(const MstEnc *e, int B, int L) {
 }
 
 int enc_launch_direct(const MstEncConv &c, const float *x, void *y, bool out_nlc, int B, int Lin, int Lout, int residual,
-                      void *stream) {
+                      void *stream, void *ylo = nullptr) {
     if (Lin <= c.pad_l || Lin <= c.pad_r)
         return fail(MST_ERR_ARG, "mst_enc_forward: reflection padding needs the input to be longer than the padding");
     EncDirectArgs a;
     a.x = x;
     a.y = y;
+    a.ylo = ylo;
     a.w = c.w_direct;
     a.shift = c.shift;
     a.B = B;
@@ -1036,14 +1042,18 @@ int enc_launch_direct(const MstEncConv &c, const float *x, void *y, bool out_nlc
     return MST_OK;
 }
 
+// x3: split mode - x / y point at the high parts' planes, the low parts' planes follow at B * L * C elements
 int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scratch, int B, int Lin, int Lout, int residual,
-                   long rows_min_tiles, void *stream) {
+                   long rows_min_tiles, void *stream, bool x3 = false) {
     if (Lin <= c.pad_l || Lin <= c.pad_r)
         return fail(MST_ERR_ARG, "mst_enc_forward: reflection padding needs the input to be longer than the padding");
     EncNlcArgs a;
     a.x = x;
     a.y = y;
+    a.xlo = x3 ? x + (size_t)B * Lin * c.cin : nullptr;
+    a.ylo = x3 ? y + (size_t)B * Lout * c.cout : nullptr;
     a.wpk = c.wpk_nlc;
+    a.wpk_lo = x3 ? c.wpk_nlc_lo : c.wpk_nlc;
     a.shift = c.shift;
     a.stab = c.stab;
     a.B = B;
@@ -1064,10 +1074,18 @@ int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scrat
         const long tiles_item = (Lout + NT - 1) / NT;
         const long R = (long)(NT - 1) * c.stride + c.ksz, rpp = (R + c.stride - 1) / c.stride;
         const long lds = (long)c.stride * rpp * (c.cin * 2 + 16);
-        if (rows_min_tiles >= 0 && c.dil == 1 && c.cin % 16 == 0 && Lout >= NT && lds <= 64 * 1024 && (long)B * tiles_item * cotiles >= rows_min_tiles) {
+        const bool fits = x3 ? 2 * lds <= 80 * 1024 : lds <= 64 * 1024;
+        if (rows_min_tiles >= 0 && c.dil == 1 && c.cin % 16 == 0 && Lout >= NT && fits && (long)B * tiles_item * cotiles >= rows_min_tiles) {
             a.S = 1;
             a.part = nullptr;
             const dim3 grid((unsigned)(B * tiles_item), (unsigned)cotiles);
+            if (x3) {
+                switch (c.mw) {
+                    case 1: MST_LAUNCH((enc_conv_rows_kernel<1, true>), grid, dim3(256), stream, a); break;
+                    case 2: MST_LAUNCH((enc_conv_rows_kernel<2, true>), grid, dim3(256), stream, a); break;
+                    default: MST_LAUNCH((enc_conv_rows_kernel<4, true>), grid, dim3(256), stream, a); break;
+                }
+            } else
             switch (c.mw) {
                 case 1: MST_LAUNCH((enc_conv_rows_kernel<1>), grid, dim3(256), stream, a); break;
                 case 2: MST_LAUNCH((enc_conv_rows_kernel<2>), grid, dim3(256), stream, a); break;
@@ -1080,6 +1098,13 @@ int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scrat
     a.S = enc_splitk(ntiles * cotiles, c.nchunks64);
     a.part = a.S > 1 ? scratch : nullptr;
     const dim3 grid((unsigned)ntiles, (unsigned)cotiles, (unsigned)a.S);
+    if (x3) {
+        switch (c.mw) {
+            case 1: MST_LAUNCH((enc_conv_nlc_kernel<1, true>), grid, dim3(256), stream, a); break;
+            case 2: MST_LAUNCH((enc_conv_nlc_kernel<2, true>), grid, dim3(256), stream, a); break;
+            default: MST_LAUNCH((enc_conv_nlc_kernel<4, true>), grid, dim3(256), stream, a); break;
+        }
+    } else
     switch (c.mw) {
         case 1: MST_LAUNCH((enc_conv_nlc_kernel<1>), grid, dim3(256), stream, a); break;
         case 2: MST_LAUNCH((enc_conv_nlc_kernel<2>), grid, dim3(256), stream, a); break;
@@ -1089,13 +1114,14 @@ int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scrat
     if (a.S > 1) {
         const long total = a.Ntot * (c.cout / 4);
         MST_LAUNCH(enc_splitk_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, (const float *)scratch,
-                   a.S, a.Ntot, c.cout, (const float *)c.shift, residual ? x : (const __bf16 *)nullptr, y);
+                   a.S, a.Ntot, c.cout, (const float *)c.shift, residual ? x : (const __bf16 *)nullptr, y,
+                   residual ? a.xlo : (const __bf16 *)nullptr, a.ylo);
         MST_CHECK_LAUNCH("enc_splitk_finalize_kernel");
     }
     return MST_OK;
 }
 
-int enc_run_nlc(MstEnc *e, const float *x, float *emb, float *blk_out, int B, int L, int n_run, void *ws, void *stream) {
+int enc_run_nlc(MstEnc *e, const float *x, float *emb, float *blk_out, int B, int L, int n_run, void *ws, void *stream, bool x3 = false) {
     const size_t nb = align_up(enc_buf_floats(e, B, L) * sizeof(float), 256);
     unsigned char *base = (unsigned char *)ws;
     void *t1 = base;
@@ -1107,10 +1133,11 @@ int enc_run_nlc(MstEnc *e, const float *x, float *emb, float *blk_out, int B, in
         const int lout = (len - 1) / e->d.strides[i] + 1;
         if (i == 0) {
             if ((rc = enc_launch_direct(e->conv[0], (const float *)cur, t1, false, B, len, len, 1, stream))) return rc;
-            if ((rc = enc_launch_direct(e->conv[1], (const float *)t1, o[pp], true, B, len, lout, 0, stream))) return rc;
+            void *lo_plane = x3 ? (void *)((__bf16 *)o[pp] + (size_t)B * lout * e->conv[1].cout) : nullptr;
+            if ((rc = enc_launch_direct(e->conv[1], (const float *)t1, o[pp], true, B, len, lout, 0, stream, lo_plane))) return rc;
         } else {
-            if ((rc = enc_launch_nlc(e->conv[2 * i], (const __bf16 *)cur, (__bf16 *)t1, scratch, B, len, len, 1, e->rows_min_tiles, stream))) return rc;
-            if ((rc = enc_launch_nlc(e->conv[2 * i + 1], (const __bf16 *)t1, (__bf16 *)o[pp], scratch, B, len, lout, 0, e->rows_min_tiles, stream))) return rc;
+            if ((rc = enc_launch_nlc(e->conv[2 * i], (const __bf16 *)cur, (__bf16 *)t1, scratch, B, len, len, 1, e->rows_min_tiles, stream, x3))) return rc;
+            if ((rc = enc_launch_nlc(e->conv[2 * i + 1], (const __bf16 *)t1, (__bf16 *)o[pp], scratch, B, len, lout, 0, e->rows_min_tiles, stream, x3))) return rc;
         }
         cur = o[pp];
         pp ^= 1;
@@ -1119,11 +1146,13 @@ int enc_run_nlc(MstEnc *e, const float *x, float *emb, float *blk_out, int B, in
     const int C = e->d.channels[n_run];
     if (blk_out) {
         const size_t total = (size_t)B * len * C;
-        MST_LAUNCH(enc_unpack_nlc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, (const __bf16 *)cur, blk_out, B, len, C);
+        MST_LAUNCH(enc_unpack_nlc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, (const __bf16 *)cur,
+                   x3 ? (const __bf16 *)cur + total : (const __bf16 *)nullptr, blk_out, B, len, C);
         MST_CHECK_LAUNCH("enc_unpack_nlc_kernel");
     }
     if (emb) {
-        MST_LAUNCH(enc_avgpool_nlc_kernel, dim3((unsigned)(((long)B * C + 255) / 256)), dim3(256), stream, (const __bf16 *)cur, emb, B, len, C);
+        MST_LAUNCH(enc_avgpool_nlc_kernel, dim3((unsigned)(((long)B * C + 255) / 256)), dim3(256), stream, (const __bf16 *)cur,
+                   x3 ? (const __bf16 *)cur + (size_t)B * len * C : (const __bf16 *)nullptr, emb, B, len, C);
         MST_CHECK_LAUNCH("enc_avgpool_nlc_kernel");
     }
     return MST_OK;
@@ -1134,12 +1163,15 @@ int enc_run(MstEnc *e, const float *x, float *emb, float *blk_out, int B, int L,
     if (!e || !x || B < 1 || L < 1) return fail(MST_ERR_ARG, "mst_enc_forward: bad argument");
     if (e && e->d.valid_padding)
         return fail(MST_ERR_UNSUPPORTED, "mst_enc_forward: a Res_ConvBlock needs 'SAME' padding (conv1(x) + x); VALID layers run through mst_enc_forward_conv");
-    if (precision == MST_PREC_BF16X3) precision = MST_PREC_F32;          // the encoder's high-accuracy mode is its exact-fp32 path
-    if (precision != MST_PREC_F32 && precision != MST_PREC_BF16) return fail(MST_ERR_ARG, "mst_enc_forward: bad precision");
+    // bf16x3: the channel-minor pipeline in split mode (two bf16 planes per activation, three MFMAs per product); configurations the
+    // pipeline does not cover run the exact-fp32 path
+    if (precision == MST_PREC_BF16X3 && !enc_nlc_eligible(e)) precision = MST_PREC_F32;
+    if (precision != MST_PREC_F32 && precision != MST_PREC_BF16 && precision != MST_PREC_BF16X3) return fail(MST_ERR_ARG, "mst_enc_forward: bad precision");
     for (auto &c : e->conv)
         if (!c.loaded) return fail(MST_ERR_STATE, "mst_enc_forward: conv weights not loaded");
     if (!ws || ws_bytes < mst_enc_workspace_bytes(e, B, L)) return fail(MST_ERR_WORKSPACE, "mst_enc_forward: workspace too small");
     if (precision == MST_PREC_BF16 && enc_nlc_eligible(e)) return enc_run_nlc(e, x, emb, blk_out, B, L, n_run, ws, stream);
+    if (precision == MST_PREC_BF16X3) return enc_run_nlc(e, x, emb, blk_out, B, L, n_run, ws, stream, true);
     const size_t nb = align_up(enc_buf_floats(e, B, L) * sizeof(float), 256);
     float *t1 = (float *)ws;
     float *o[2] = {(float *)((unsigned char *)ws + nb), (float *)((unsigned char *)ws + 2 * nb)};

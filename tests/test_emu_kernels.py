@@ -148,6 +148,15 @@ def test_encoder_nlc_bf16_pipeline_emulated(emu_default):
         assert a.shape == col[n - 1].shape
         assert float((a - col[n - 1]).abs().max()) <= 2e-2 * float(col[n - 1].abs().max())
     assert float((enc(x) - R.fxencoder_forward(sd, cfg, x)).abs().max()) <= 2e-2
+    # bf16x3: the same pipeline in split mode (every activation as two bf16 planes x = hi + lo, folded weights likewise, three MFMAs
+    # per product): fp32-class accuracy on the bf16 matrix cores
+    enc.precision = "bf16x3"
+    for n in range(1, 6):
+        a = enc.forward_blocks(x, n)
+        assert a.shape == col[n - 1].shape
+        assert float((a - col[n - 1]).abs().max()) <= 5e-5 * float(col[n - 1].abs().max()), n
+    e_ref = R.fxencoder_forward(sd, cfg, x)
+    assert float((enc(x) - e_ref).abs().max()) <= 2e-5 * float(e_ref.abs().max())
 
 
 def test_tiny_reference_goldens_through_the_product(emu_default):
@@ -431,6 +440,14 @@ def test_encoder_rows_kernel_matches_im2col_emulated(emu_default):
         assert torch.equal(got, ref), shape
         emb = R.fxencoder_forward(sd, cfg, x)
         assert float((got - emb).abs().max()) <= 3e-2 * float(emb.abs().max())
+        enc.precision = "bf16x3"          # split mode: both forms again bit for bit, and fp32-class accuracy
+        emu_default.check(emu_default.mst_enc_set_tuning(run.handle, -1), "tuning")
+        ref3 = enc(x).clone()
+        emu_default.check(emu_default.mst_enc_set_tuning(run.handle, 0), "tuning")
+        got3 = enc(x)
+        assert torch.equal(got3, ref3), shape
+        assert float((got3 - emb).abs().max()) <= 2e-5 * float(emb.abs().max())
+        enc.precision = "bf16"
 
 
 def test_algorithmic_reverb_emulated(emu_default):

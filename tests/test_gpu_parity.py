@@ -183,6 +183,35 @@ def test_tcn_bf16x3_vs_oracle(nets):
         tcn.precision = "fp32"
 
 
+def test_encoder_bf16x3_vs_oracle_and_reference_golden(nets):
+    """FXencoder in the split-bf16 mode (two bf16 planes per activation, three MFMAs per product): per block and on the embedding
+    against the oracle, and at 2 x 131072 against the reference's own embedding (nets_full.npz) - the fp32 tolerance."""
+    from music_mixing_style_transfer_amd.utils import synth
+    from oracle import networks_ref as R
+    enc = nets["enc"]
+    x = synth.synth_audio((2, 2, 32768), seed=77)
+    col = []
+    R.fxencoder_blocks(x, nets["enc_sd"], nets["enc_cfg"], collect=col)
+    e_ref = R.fxencoder_forward(nets["enc_sd"], nets["enc_cfg"], x)
+    g = np.load(os.path.join(GOLD, "nets_full.npz"))
+    enc.precision = "bf16x3"
+    try:
+        for n in (1, 2, 3, 6, 9, 12):
+            a = enc.forward_blocks(x.cuda(), n).cpu()
+            err = float((a - col[n - 1]).abs().max())
+            assert err <= 1e-4 * max(1.0, float(col[n - 1].abs().max())), f"block {n}: {err}"
+        e = enc(x.cuda()).cpu()
+        d_o = float((e - e_ref).abs().max()) / float(e_ref.abs().max())
+        xg = synth.synth_audio((1, 2, 131072), seed=0)
+        eg = enc(xg.cuda()).cpu()[0]
+        ref_g = torch.from_numpy(g["enc_emb"])[0]
+        d_g = float((eg - ref_g).abs().max()) / float(ref_g.abs().max())
+        print(f"FXencoder bf16x3: embedding rel dev {d_o:.2e} vs oracle (2 x 2x32768), {d_g:.2e} vs the reference's golden (2x131072)")
+        assert d_o <= 1e-4 and d_g <= 1e-4
+    finally:
+        enc.precision = "fp32"
+
+
 def test_encoder_bf16_vs_oracle(nets):
     from music_mixing_style_transfer_amd.utils import synth
     from oracle import networks_ref as R
