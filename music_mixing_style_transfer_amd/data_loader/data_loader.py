@@ -8,11 +8,13 @@ When args.normalize_input is set (the reference CLI's default) the INPUT stems g
 args.precomputed_normalization_feature and the effect order args.normalization_order (reference :559-563, :586-587).
 """
 import os
+import queue
+import threading
 from glob import glob
 
 import torch
 
-from .loader_utils import load_wav_segment
+from .loader_utils import load_wav_device, load_wav_segment
 
 
 class Song_Dataset_Inference:
@@ -32,12 +34,29 @@ class Song_Dataset_Inference:
             from ..mixing_manipulator.data_normalization import Audio_Effects_Normalizer
             self.normalization_chain = Audio_Effects_Normalizer(precomputed_feature_path=args.precomputed_normalization_feature,
                                                                 STEMS=args.instruments, EFFECTS=args.normalization_order)
+        # device: set by the runner (Mixing_Style_Transfer_Inference) to the GPU the stems are converted on - the stems are then decoded,
+        # normalised and clamped THERE and returned as device tensors (the file's PCM bytes are what crosses PCIe); None = host arrays
+        # like the reference.  workers (args.workers, the reference's DataLoader(num_workers=...)): > 0 = songs are prepared by a
+        # background thread one song ahead of the consumer.
+        self.device = None
+        self.workers = int(getattr(args, "workers", 0) or 0)
 
     def __len__(self):
         return len(self.data_dir_paths)
 
     def _stem(self, idx, which, inst, normalize=False):
         path = os.path.join(self.data_dir_paths[idx], self.stem_level_directory_name, which, inst + ".wav")
+        if self.device is not None:
+            try:
+                wav = load_wav_device(path, self.device, sample_rate=self.args.sample_rate)            # float32 [2, L] on the device
+            except ValueError as e:
+                if "stereo files only" not in str(e):
+                    raise
+                wav = None
+            if wav is not None:
+                if normalize:
+                    wav = self.normalization_chain.normalize_audio(wav.t().contiguous(), src=inst).t().contiguous()
+                return torch.clamp(wav.float(), min=-1, max=1)
         wav = load_wav_segment(path, axis=0, sample_rate=self.args.sample_rate)
         if normalize:           # only the input stems are normalised (:586-587)
             wav = self.normalization_chain.normalize_audio(wav.transpose(), src=inst).transpose()
@@ -53,5 +72,38 @@ class Song_Dataset_Inference:
         return torch.stack(inputs, 0), torch.stack(refs, 0), dir_name
 
     def __iter__(self):
-        for i in range(len(self)):
-            yield self[i]
+        if self.workers <= 0 or len(self) < 2:
+            for i in range(len(self)):
+                yield self[i]
+            return
+        # one song ahead: a daemon thread decodes + normalises song i + 1 (its kernels run on its own stream) while song i is converted
+        q = queue.Queue(maxsize=1)
+
+        def produce():
+            try:
+                if self.device is not None:
+                    torch.cuda.set_device(self.device)
+                    stream = torch.cuda.Stream(self.device)
+                for i in range(len(self)):
+                    if self.device is not None:
+                        with torch.cuda.stream(stream):
+                            item = self[i]
+                        stream.synchronize()
+                    else:
+                        item = self[i]
+                    q.put(("item", item))
+                q.put(("done", None))
+            except BaseException as e:          # surfaces in the consumer
+                q.put(("error", e))
+        threading.Thread(target=produce, daemon=True).start()
+        while True:
+            kind, payload = q.get()
+            if kind == "done":
+                return
+            if kind == "error":
+                raise payload
+            if self.device is not None:         # made on the producer's stream, used on the consumer's: tell the caching allocator
+                for t in payload:
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(torch.cuda.current_stream(self.device))
+            yield payload

@@ -37,13 +37,40 @@ def load_wav_segment(audio_path, start_point=None, duration=None, axis=1, sample
     return X
 
 
+def load_wav_device(audio_path, device, sample_rate=44100):
+    """The whole file as a float32 DEVICE tensor [2, L] (load_wav_segment(path, axis=0) followed by the dataset's `.float()`): the raw
+    PCM frames are uploaded as they are (2 or 4 bytes per sample instead of a float64 array made on the host) and de-interleaved /
+    scaled on the device - int / 2**15 (2**31) in float64, then rounded to float32, exactly the reference's two steps.  Stereo only
+    (what the stems are); other channel counts go through load_wav_segment."""
+    import torch
+    with wave.open(audio_path, "r") as w:
+        if w.getframerate() != sample_rate:
+            raise ValueError(f"ValueError: input audio's sample rate should be {sample_rate}")
+        width, nch, n = w.getsampwidth(), w.getnchannels(), w.getnframes()
+        raw = w.readframes(n)
+    if width not in (2, 4):
+        raise ValueError("ValueError: input audio's bit depth should be 16 or 32-bit")
+    if nch != 2:
+        raise ValueError("load_wav_device: stereo files only")
+    host = torch.frombuffer(bytearray(raw), dtype=torch.int16 if width == 2 else torch.int32)
+    dev = host.to(device, non_blocking=False).view(-1, 2)
+    x = dev.to(torch.float64) / float(2 ** 15 if width == 2 else 2 ** 31)
+    return x.to(torch.float32).t().contiguous()
+
+
+def pcm16_device(x):
+    """float device tensor [..., L, C] in [-1, 1] -> int16 tensor, the arithmetic of pcm16(): round-half-even(x * 32767), clipped."""
+    import torch
+    return torch.clamp(torch.round(x.to(torch.float32) * 32767.0), -32768, 32767).to(torch.int16)
+
+
 def save_wav_pcm16(audio_path, data, sample_rate=44100):
     """data float [L, C] in [-1, 1] -> 16-bit PCM (what sf.write(..., 'PCM_16') is used for at
     inference/style_transfer.py:174,177): round(x * 32767), clipped."""
     data = np.asarray(data)
     if data.ndim == 1:
         data = data[:, None]
-    pcm = pcm16(data)
+    pcm = data.astype("<i2") if data.dtype == np.int16 else pcm16(data)          # int16 in: already converted (on the device)
     with wave.open(audio_path, "w") as w:
         w.setnchannels(pcm.shape[1])
         w.setsampwidth(2)
@@ -83,6 +110,6 @@ class SlicedWavWriter:
             return
         fd = os.open(self.path, os.O_WRONLY)
         try:
-            os.pwrite(fd, pcm16(data).tobytes(), 44 + int(t0) * self.nch * 2)
+            os.pwrite(fd, (data.astype("<i2") if data.dtype == np.int16 else pcm16(data)).tobytes(), 44 + int(t0) * self.nch * 2)
         finally:
             os.close(fd)

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 import yaml
 
-from ..data_loader import SlicedWavWriter, Song_Dataset_Inference, save_wav_pcm16
+from ..data_loader import SlicedWavWriter, Song_Dataset_Inference, pcm16_device, save_wav_pcm16
 from ..networks import FXencoder, TCNModel
 from . import segmentation as seg
 from .engine import embedding_mean
@@ -61,6 +61,7 @@ class Mixing_Style_Transfer_Inference:
         self.reload_weights({"effects_encoder": args.ckpt_path_enc, "mixing_converter": args.ckpt_path_conv},
                             ddp=trained_w_ddp)
         self.data_loader = Song_Dataset_Inference(args)
+        self.data_loader.device = self.device          # stems are decoded / normalised on the GPU and stay there
         if self._world() is None or self._world().get_rank() == 0:
             self.save_args(args)
 
@@ -113,7 +114,9 @@ class Mixing_Style_Transfer_Inference:
         return StyleTransferEngine(self.models["effects_encoder"], self.models["mixing_converter"], device=self.device)
 
     def _host(self, stem):
-        """Stems go to the engine in page-locked host memory: its passes overlap H2D / compute / D2H."""
+        """Host stems go to the engine in page-locked memory (its passes overlap H2D / compute / D2H); device stems as they are."""
+        if stem.device.type != "cpu":
+            return stem
         return stem.pin_memory() if self.device.type == "cuda" and not stem.is_pinned() else stem
 
     def inference(self):
@@ -148,7 +151,6 @@ class Mixing_Style_Transfer_Inference:
                 res = eng.transfer_stem(self._host(input_stems[i]), self._host(reference_stems[i]), a.segment_length,
                                         a.segment_length_ref, dir_name)
                 stem_out, t_range = (res, (0, L)) if dist is None else res
-                stem_out = stem_out.cpu().numpy()
                 inst_outputs.append(stem_out)
                 if a.save_each_inst:
                     self._write(dist, writers[f"{inst}_{tag}.wav"], t_range[0], stem_out)
@@ -158,11 +160,17 @@ class Mixing_Style_Transfer_Inference:
 
     @staticmethod
     def _write(dist, writer, t0, data):
-        """data [2, n]: the whole stem (one process: the plain wav writer) or this rank's time range starting at t0."""
-        if dist is None:
-            save_wav_pcm16(writer.path, data.transpose(-1, -2), writer.sr)
+        """data [2, n] float tensor: the whole stem (one process: the plain wav writer) or this rank's time range starting at t0.
+        A device tensor is rounded to 16-bit PCM on the device (round-half-even(x * 32767), clipped - the writer's own arithmetic) and
+        only the int16 samples travel to the host."""
+        if data.device.type != "cpu":
+            pcm = pcm16_device(data.transpose(-1, -2).contiguous()).cpu().numpy()
         else:
-            writer.write(t0, data.transpose(-1, -2))
+            pcm = data.numpy().transpose(-1, -2)
+        if dist is None:
+            save_wav_pcm16(writer.path, pcm, writer.sr)
+        else:
+            writer.write(t0, pcm)
 
     def inference_interpolation(self):
         print("\n======= Start to inference interpolation examples =======")

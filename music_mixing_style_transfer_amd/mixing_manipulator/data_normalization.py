@@ -48,13 +48,54 @@ class Audio_Effects_Normalizer:
         self.haas_chain = None      # extension: the chain normalize_imager applies to an almost-mono stem (None = the reference's random Haas)
 
     def normalize_audio(self, audio, src):
+        """audio [L, 2] numpy -> numpy like the reference; a float32 DEVICE tensor in stays on the device through all the effects
+        (padded, gated, matched and un-padded there; one tensor back) - the same kernels on the same values, without the host
+        round trips of the array interface."""
         assert src in self.STEMS
         normalized_audio = audio
         for cur_effect in self.EFFECTS:
             normalized_audio = self.normalize_audio_per_effect(normalized_audio, src=src, effect=cur_effect)
         return normalized_audio
 
+    def _per_effect_device(self, audio, src, effect):
+        import torch
+        audio = audio.to(torch.float32)
+        track = torch.nn.functional.pad(audio, (0, 0, self.FFT_SIZE, self.FFT_SIZE))
+        assert track.dim() == 2
+        if track.shape[1] == 1:
+            track = track.repeat(1, 2)
+        out = track.clone()
+        max_db = amp_to_db(float(out.abs().max()))
+        if max_db > self.MIN_DB:
+            if effect == "eq":
+                for ch in range(track.shape[1]):
+                    out[:, ch] = get_eq_matching(out[:, ch].contiguous(), self.features_mean[effect][src], sr=self.SR, n_fft=self.FFT_SIZE,
+                                                 hop_length=self.HOP_LENGTH, min_db=self.MIN_DB, ntaps=self.NTAPS, lufs=self.LUFS)
+            elif effect == "compression":
+                assert len(self.features_mean[effect][src]) == 2
+                for ch in range(track.shape[1]):
+                    try:
+                        s = self.comp_settings[src]
+                        matched = get_comp_matching(out[:, ch].contiguous(), self.features_mean[effect][src][0],
+                                                    self.features_mean[effect][src][1], s["ratio"], s["attack"], s["release"],
+                                                    sr=self.SR, min_db=self.MIN_DB, min_th=self.COMP_MIN_TH,
+                                                    comp_peak_norm=self.COMP_PEAK_NORM, max_ratio=self.COMP_MAX_RATIO,
+                                                    n_mels=s["n_mels"], true_peak=self.COMP_TRUE_PEAK,
+                                                    percentile=self.COMP_PERCENTILE, expander=self.COMP_USE_EXPANDER)
+                        out[:, ch] = matched[:, 0]
+                    except Exception:               # the reference swallows every failure of a channel and stops (:131-132)
+                        break
+            elif effect == "loudness":
+                out = fx_utils.lufs_normalize(out, self.SR, self.features_mean[effect][src], log=False)
+            elif effect == "imager":
+                mono_threshold = 0.99 if src == "bass" else 0.975
+                out = normalize_imager(out, target_side_mid_bal=self.features_mean[effect][src], mono_threshold=mono_threshold,
+                                       sr=self.SR, haas=self.haas_chain)
+        return out[self.FFT_SIZE:self.FFT_SIZE + audio.shape[0]]
+
     def normalize_audio_per_effect(self, audio, src, effect):
+        if not isinstance(audio, np.ndarray):
+            return self._per_effect_device(audio, src, effect)
         audio = audio.astype(dtype=np.float32)
         audio_track = np.pad(audio, ((self.FFT_SIZE, self.FFT_SIZE), (0, 0)), mode="constant")
         assert len(audio_track.shape) == 2          # always expects two dimensions

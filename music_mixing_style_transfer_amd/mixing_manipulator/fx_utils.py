@@ -41,18 +41,21 @@ def kweighting_coefficients(rate):
 
 
 def gated_loudness(z, G=(1.0, 1.0, 1.0, 1.41, 1.41)):
-    """Block mean squares z [channels, blocks] -> integrated loudness (BS.1770-4 gating, pyloudnorm Meter.integrated_loudness)."""
-    n_ch, n_blocks = z.shape
-    with np.errstate(divide="ignore"):
-        lj = [-0.691 + 10.0 * np.log10(np.sum([G[i] * z[i, j] for i in range(n_ch)])) for j in range(n_blocks)]
-    gamma_a = -70.0
+    """Block mean squares z [channels, blocks] -> integrated loudness (BS.1770-4 gating, pyloudnorm Meter.integrated_loudness).
+    Array form of pyloudnorm's per-block Python loops: the same sums in the same order (channels added one after the other, block
+    means by numpy's mean over the selected blocks), a few thousand blocks in microseconds instead of 7 ms per call."""
+    z = np.asarray(z, dtype=np.float64)
+    n_ch = z.shape[0]
+    g = np.asarray(G[:n_ch], dtype=np.float64)[:, None]
     with np.errstate(divide="ignore", invalid="ignore"), _quiet():
-        Jg = [j for j, v in enumerate(lj) if v >= gamma_a]
-        z_avg = [np.mean([z[i, j] for j in Jg]) for i in range(n_ch)]
-        gamma_r = -0.691 + 10.0 * np.log10(np.sum([G[i] * z_avg[i] for i in range(n_ch)])) - 10.0
-        Jg = [j for j, v in enumerate(lj) if (v > gamma_r and v > gamma_a)]
-        z_avg = np.nan_to_num(np.array([np.mean([z[i, j] for j in Jg]) for i in range(n_ch)]))
-        return float(-0.691 + 10.0 * np.log10(np.sum([G[i] * z_avg[i] for i in range(n_ch)])))
+        lj = -0.691 + 10.0 * np.log10(np.add.reduce(g * z, axis=0))
+        gamma_a = -70.0
+        Jg = lj >= gamma_a
+        z_avg = np.array([np.mean(z[i, Jg]) for i in range(n_ch)])
+        gamma_r = -0.691 + 10.0 * np.log10(np.add.reduce(g[:, 0] * z_avg)) - 10.0
+        Jg = (lj > gamma_r) & (lj > gamma_a)
+        z_avg = np.nan_to_num(np.array([np.mean(z[i, Jg]) for i in range(n_ch)]))
+        return float(-0.691 + 10.0 * np.log10(np.add.reduce(g[:, 0] * z_avg)))
 
 
 class _quiet:

@@ -58,19 +58,33 @@ def _filtfilt_fir(taps, x):
     return y[edge:edge + L]
 
 
+def _is_device(x):
+    import torch
+    return isinstance(x, torch.Tensor)
+
+
 def get_eq_matching(audio_t, ref_spec, sr=44100, n_fft=65536, hop_length=16384, min_db=-50, ntaps=101, lufs=-30):
-    """audio_t: one channel [L]; ref_spec: the target mean magnitude spectrum [n_fft/2+1] -> the EQ-matched channel [L]."""
-    audio_t = np.copy(audio_t)
-    max_db = amp_to_db(np.max(np.abs(audio_t)))
-    if not max_db > min_db:
-        return audio_t
-    x = fx_utils.lufs_normalize(D.to_device(audio_t), sr, lufs, log=False)            # device [L, 1], float32
+    """audio_t: one channel [L]; ref_spec: the target mean magnitude spectrum [n_fft/2+1] -> the EQ-matched channel [L].
+    numpy in -> numpy out (the reference's interface); a device tensor in -> a device tensor out (the device-resident normaliser)."""
+    on_device = _is_device(audio_t)
+    if on_device:
+        max_db = amp_to_db(float(audio_t.abs().max()))
+        if not max_db > min_db:
+            return audio_t
+        x = fx_utils.lufs_normalize(D.to_device(audio_t), sr, lufs, log=False)
+    else:
+        audio_t = np.copy(audio_t)
+        max_db = amp_to_db(np.max(np.abs(audio_t)))
+        if not max_db > min_db:
+            return audio_t
+        x = fx_utils.lufs_normalize(D.to_device(audio_t), sr, lufs, log=False)            # device [L, 1], float32
     audio_D_avg = _stft(n_fft, hop_length)(x, 0)
     m = ref_spec.shape[0]
     frq = np.arange(m) / (m / sr) / 2
     diff_eq = np.sqrt(db_to_amp(amp_to_db(ref_spec) - amp_to_db(audio_D_avg)))
     diff_filter = scipy.signal.firwin2(ntaps, frq / np.max(frq), diff_eq, nfreqs=None, window="hamming", antisymmetric=False)
-    return _filtfilt_fir(diff_filter, x)[:, 0].cpu().numpy()
+    y = _filtfilt_fir(diff_filter, x)[:, 0]
+    return y if on_device else y.cpu().numpy()
 
 
 # ------------------------------------------------------------------------------------------------ compressor matching
@@ -135,15 +149,25 @@ def compress(processor, audio, sr, th, ratio, attack, release):
 
 def get_comp_matching(audio, ref_peak, ref_std, ratio, attack, release, sr=44100, min_db=-50, comp_peak_norm=-10.0, min_th=-40,
                       max_ratio=20, n_mels=128, true_peak=False, percentile=75, expander=True, batch=16):
-    x = audio.copy()
-    if x.ndim < 2:
-        x = np.expand_dims(x, 1)
-    max_db = amp_to_db(np.max(np.abs(x)))
-    if not max_db > min_db:
-        return x
-    gain = np.power(10.0, comp_peak_norm / 20.0) / np.max(np.abs(x))              # pyloudnorm.normalize.peak
-    x = x * (np.float32(gain) if x.dtype == np.float32 else gain)                 # a float32 signal stays float32 (NumPy 1.x promotion)
-    xd = D.to_device(x)
+    on_device = _is_device(audio)
+    out = (lambda t: t) if on_device else (lambda t: t.cpu().numpy())
+    if on_device:                                   # device in -> device out: the same steps, the same float32 arithmetic
+        x = D.to_device(audio)
+        mx = float(x.abs().max())
+        if not amp_to_db(mx) > min_db:
+            return x
+        x = x * np.float32(np.power(10.0, comp_peak_norm / 20.0) / np.float32(mx))
+        xd = x
+    else:
+        x = audio.copy()
+        if x.ndim < 2:
+            x = np.expand_dims(x, 1)
+        max_db = amp_to_db(np.max(np.abs(x)))
+        if not max_db > min_db:
+            return x
+        gain = np.power(10.0, comp_peak_norm / 20.0) / np.max(np.abs(x))              # pyloudnorm.normalize.peak
+        x = x * (np.float32(gain) if x.dtype == np.float32 else gain)                 # a float32 signal stays float32 (NumPy 1.x promotion)
+        xd = D.to_device(x)
     peak, std = _mean_peak_device(xd[None], sr, percentile)[0]
     if (ref_peak - ref_std) < peak < (ref_peak + ref_std):
         return x
@@ -167,6 +191,6 @@ def get_comp_matching(audio, ref_peak, ref_std, ratio, attack, release, sr=44100
                 if st is None:                      # the reference would fail on `peak, std = None` here (caught by the caller)
                     raise TypeError("cannot unpack non-iterable NoneType object")
                 if (down and st[0] < (ref_peak + ref_std)) or (not down and st[0] > (ref_peak - ref_std)):
-                    return y[i].cpu().numpy()
+                    return out(y[i])
             last = y[len(th_chunk) - 1]
-    return last.cpu().numpy()                       # no setting qualified: the reference returns the last one it tried
+    return out(last)                                # no setting qualified: the reference returns the last one it tried

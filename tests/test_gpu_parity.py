@@ -951,6 +951,10 @@ def test_input_normalizer_chain_and_cli_with_normalize_input(tmp_path, oracle_fx
     y0 = norm.normalize_audio(x0, "drums")
     r0 = N.normalize_audio(x0, "drums", feats, order, compress_fn=cc)
     assert y0.shape == (L_in, 2) and float(np.abs(y0 - r0).max() / np.abs(r0).max()) <= 1e-4
+    # the device-resident form (a device tensor in: padded, matched and un-padded on the GPU, no host round trip per effect) runs the
+    # same kernels on the same values: bit for bit the array interface's result
+    y0_dev = norm.normalize_audio(torch.from_numpy(x0).cuda(), "drums")
+    assert y0_dev.is_cuda and np.array_equal(y0_dev.cpu().numpy(), y0)
     # the runner
     enc_cfg, _ = _cfgs()
     enc_sd, tcn_sd = synth.fxencoder_state_dict(enc_cfg, seed=0), synth.tcn_state_dict(seed=0)
@@ -991,6 +995,23 @@ def test_input_normalizer_chain_and_cli_with_normalize_input(tmp_path, oracle_fx
 
 
 MIX_TOL_NORMALIZE_INPUT = 7e-5      # 2 x the 3.2e-5 measured (round 2 accepted 2e-3)
+
+
+def test_device_wav_decode_and_pcm16_are_the_host_arithmetic(tmp_path):
+    """load_wav_device (PCM bytes uploaded, scaled on the GPU) = load_wav_segment + .float(); pcm16_device = pcm16 (round half to even,
+    clipping) - the file-to-file path moves int16 over PCIe in both directions and keeps the host versions' bits."""
+    from music_mixing_style_transfer_amd.data_loader import load_wav_device, load_wav_segment, pcm16_device
+    from music_mixing_style_transfer_amd.data_loader.loader_utils import pcm16
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1.2, 1.2, size=(2, 50001)).astype(np.float32)
+    x[:, :9] = np.array([0.5 / 32767, 1.5 / 32767, 2.5 / 32767, -0.5 / 32767, -1.5 / 32767, 1.0, -1.0, 32767.5 / 32767, -32768.5 / 32767], np.float32)
+    _write_wav(tmp_path / "a.wav", np.clip(x, -1, 1))
+    host = torch.from_numpy(load_wav_segment(str(tmp_path / "a.wav"), axis=0)).float()
+    dev = load_wav_device(str(tmp_path / "a.wav"), torch.device("cuda:0"))
+    assert dev.is_cuda and dev.dtype == torch.float32 and torch.equal(dev.cpu(), host)
+    assert np.array_equal(pcm16_device(torch.from_numpy(x).cuda().t().contiguous()).cpu().numpy(), pcm16(x.T))
+    with pytest.raises(ValueError):
+        load_wav_device(str(tmp_path / "a.wav"), torch.device("cuda:0"), sample_rate=48000)
 
 
 def test_haas_branch_and_real_features_file_on_gpu(oracle_fx_lib):
