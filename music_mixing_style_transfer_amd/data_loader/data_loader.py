@@ -40,6 +40,28 @@ class Song_Dataset_Inference:
         # background thread one song ahead of the consumer.
         self.device = None
         self.workers = int(getattr(args, "workers", 0) or 0)
+        # dist (set by the runner when it runs on several ranks): the stems that need host / normaliser work are prepared by ONE rank each
+        # (stem j by rank j % world) and broadcast - the normaliser, the expensive part of a song's preparation, is sharded by stems
+        self.dist = None
+
+    def _prepared_by_owner(self, idx, which, inst, j):
+        """Input stem j of a multi-rank run: decoded + normalised by rank j % world, received by the others (one broadcast of [2, L])."""
+        from .loader_utils import load_wav_length
+        dist = self.dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        owner = j % world
+        path = os.path.join(self.data_dir_paths[idx], self.stem_level_directory_name, which, inst + ".wav")
+        if rank == owner:
+            t = self._stem(idx, which, inst, normalize=True).contiguous()
+        else:
+            dev = self.device if (self.device is not None and dist.get_backend() == "nccl") else "cpu"
+            t = torch.empty(2, load_wav_length(path), dtype=torch.float32, device=dev)
+        if dist.get_backend() != "nccl" and t.is_cuda:          # test hook (gloo with several ranks on one GPU): through the host
+            h = t.cpu()
+            dist.broadcast(h, src=owner)
+            return h.to(t.device)
+        dist.broadcast(t, src=owner)
+        return t.to(self.device) if self.device is not None else t
 
     def __len__(self):
         return len(self.data_dir_paths)
@@ -63,7 +85,10 @@ class Song_Dataset_Inference:
         return torch.clamp(torch.from_numpy(wav).float(), min=-1, max=1)
 
     def __getitem__(self, idx):
-        inputs = [self._stem(idx, self.input_name, i, normalize=self.args.normalize_input) for i in self.instruments]
+        if self.dist is not None and self.args.normalize_input:
+            inputs = [self._prepared_by_owner(idx, self.input_name, inst, j) for j, inst in enumerate(self.instruments)]
+        else:
+            inputs = [self._stem(idx, self.input_name, i, normalize=self.args.normalize_input) for i in self.instruments]
         refs = [self._stem(idx, self.reference_name, i) for i in self.instruments]
         dir_name = os.path.dirname(self.data_dir_paths[idx])
         if self.interpolate:

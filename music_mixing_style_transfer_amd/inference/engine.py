@@ -166,9 +166,15 @@ class StyleTransferEngine:
     @torch.no_grad()
     def stem_embedding(self, reference_stem, segment_length, segment_length_ref, song_name="song"):
         """Mean FX embedding [D] of a reference stem (style_transfer.py:133-153), sharded over the ranks."""
+        n_ref, ref_len = seg.plan_reference(reference_stem.shape[-1], song_name, segment_length, segment_length_ref)
+        return self.mean_embedding(reference_stem, n_ref, ref_len)
+
+    @torch.no_grad()
+    def mean_embedding(self, reference_stem, n_ref, ref_len):
+        """Mean FX embedding [D] over the n_ref segments of ref_len samples of a stem (ref_len None: the stem as ONE item), the
+        segments sharded over the ranks, one all-gather of the rows, canonical-order mean."""
         device = self._device()
         h2d, _ = self._copy_streams(device) if reference_stem.device.type == "cpu" else (None, None)
-        n_ref, ref_len = seg.plan_reference(reference_stem.shape[-1], song_name, segment_length, segment_length_ref)
         if ref_len is None:                     # short reference: one [1, 2, L] item, encoded by the first rank
             counts = [1] + [0] * (self.world - 1)
             rows = [self.enc(reference_stem.unsqueeze(0).to(device))] if self.rank == 0 else []
@@ -185,16 +191,22 @@ class StyleTransferEngine:
         stem through the MixFXcloner with `embedding` [D] (or a callable pass-index -> [D]).  Returns
         (y [2, t_hi - t_lo], (t_lo, t_hi)): the converted samples of the time range this rank owns, cropped to the
         stem's length; on the device for a device stem, in (pinned) host memory for a host stem (or `out`)."""
+        n_in, in_len = seg.plan_input(input_stem.shape[-1], song_name, segment_length)
+        cond = embedding if callable(embedding) else (lambda k: embedding)
+        return self.convert_segments(input_stem, n_in, in_len, lambda p, k0, k1: cond(p).unsqueeze(0), out=out)
+
+    @torch.no_grad()
+    def convert_segments(self, input_stem, n_in, in_len, cond_rows, out=None):
+        """This rank's shard of the n_in segments of in_len samples (in_len None: the stem as ONE item) through the MixFXcloner.
+        cond_rows(pass index, k0, k1) -> the FiLM condition of segments [k0, k1): [1, D] (shared) or [k1 - k0, D] (one row per segment)."""
         device = self._device()
         L = input_stem.shape[-1]
         host = input_stem.device.type == "cpu" and device.type == "cuda"
         h2d, d2h = self._copy_streams(device) if host else (None, None)
-        n_in, in_len = seg.plan_input(L, song_name, segment_length)
-        cond = embedding if callable(embedding) else (lambda k: embedding)
         if in_len is None:                      # short input: one unsegmented item, converted by the first rank
             if self.rank != 0:
                 return input_stem[:, :0], (0, 0)
-            y = self.tcn(input_stem.unsqueeze(0).to(device), cond(0).unsqueeze(0))[0]
+            y = self.tcn(input_stem.unsqueeze(0).to(device), cond_rows(0, 0, 1))[0]
             return (y.to(input_stem.device) if host else y), (0, L)
         lo, hi = seg.shard_range(n_in, self.rank, self.world)
         t_lo, t_hi = min(L, lo * in_len), min(L, hi * in_len)
@@ -202,7 +214,7 @@ class StyleTransferEngine:
             out = torch.empty(2, t_hi - t_lo, dtype=torch.float32, device=input_stem.device, pin_memory=host)
         pending = []
         for p, (k0, k1, x) in enumerate(_ShardFeed(input_stem, in_len, lo, hi, self._per_pass(in_len), device, h2d)):
-            y = self.tcn(x, cond(p).unsqueeze(0))
+            y = self.tcn(x, cond_rows(p, k0, k1))
             a, b = k0 * in_len - t_lo, min(k1 * in_len, L) - t_lo
             slab = y.transpose(0, 1).reshape(2, (k1 - k0) * in_len)            # cat(unbind(batch), time) (:165-166)
             if host:

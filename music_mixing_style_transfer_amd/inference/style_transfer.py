@@ -62,6 +62,7 @@ class Mixing_Style_Transfer_Inference:
                             ddp=trained_w_ddp)
         self.data_loader = Song_Dataset_Inference(args)
         self.data_loader.device = self.device          # stems are decoded / normalised on the GPU and stay there
+        self.data_loader.dist = self._world()          # several ranks: input stem j is normalised by rank j % N and broadcast
         if self._world() is None or self._world().get_rank() == 0:
             self.save_args(args)
 
@@ -173,37 +174,59 @@ class Mixing_Style_Transfer_Inference:
             writer.write(t0, pcm)
 
     def inference_interpolation(self):
+        """reference :181-270.  Like inference(): every segment of a stem in flight through the engine, the segments sharded over the
+        ranks (the two reference embeddings by one all-gather each), every rank writes the time range it produced.  The reference's
+        bookkeeping is kept: the input is cut into `interpolate_segments` pieces of L // S + 1 samples, reference B is cut by
+        segment_length (not _ref, :212), and the interpolation weight follows the BATCH index of a segment (:245)."""
         print("\n======= Start to inference interpolation examples =======")
         tag = "output_interpolation" if self.args.normalize_input else "output_notnormed_interpolation"
         a = self.args
         dist = self._world()
-        writer = dist is None or dist.get_rank() == 0        # interpolation is not sharded: every rank computes, rank 0 writes
+        rank = dist.get_rank() if dist is not None else 0
+        eng = self._engine()
+        S = a.interpolate_segments
         for input_stems, ref_a, ref_b, dir_name in self.data_loader:
             out_dir = dir_name.replace(self.target_dir, self.output_dir)
-            if writer:
+            L = input_stems.shape[-1]
+            names = [f"{inst}_{tag}.wav" for inst in a.instruments] if a.save_each_inst else []
+            writers = {n: SlicedWavWriter(os.path.join(out_dir, n), L, 2, a.sample_rate) for n in names + [f"mixture_{tag}.wav"]}
+            if dist is not None:
+                if rank == 0:
+                    os.makedirs(out_dir, exist_ok=True)
+                    for w in writers.values():
+                        w.create()
+                dist.barrier()
+            else:
                 os.makedirs(out_dir, exist_ok=True)
-            inst_outputs = []
+            inst_outputs, t_range = [], (0, L)
             for i, inst in enumerate(a.instruments):
-                seg_len = input_stems[i].shape[1] // a.interpolate_segments + 1
-                in_b = seg.batchwise_segmentization(input_stems[i], dir_name, seg_len, a.batch_size, min_length=a.segment_length)
-                ra = seg.batchwise_segmentization(ref_a[i], dir_name, a.segment_length_ref, a.batch_size, min_length=a.segment_length) \
-                    if ref_a[i].shape[-1] > a.segment_length_ref else [ref_a[i].unsqueeze(0)]
-                # the reference cuts reference B by segment_length (not _ref) - kept (style_transfer.py:212)
-                rb = seg.batchwise_segmentization(ref_b[i], dir_name, a.segment_length, a.batch_size, min_length=a.segment_length) \
-                    if ref_b[i].shape[-1] > a.segment_length_ref else [ref_b[i].unsqueeze(0)]
-                emb_a, emb_b = self._embed(ra), self._embed(rb)
-                S = a.interpolate_segments
+                seg_len = input_stems[i].shape[1] // S + 1
+                seg._check_duration(L, a.segment_length, dir_name)
 
-                def emb_for(idx):
-                    w = (S - 1 - idx) / (S - 1)                  # weight by BATCH index, like the reference (:245)
-                    return w * emb_a + (1 - w) * emb_b
-                outs = self._convert(in_b, emb_for)
-                stem_out = seg.reassemble([o.cpu() for o in outs], input_stems[i].shape[-1]).numpy()
+                def emb_of(stem, cut):
+                    if stem.shape[-1] > a.segment_length_ref:
+                        seg._check_duration(stem.shape[-1], a.segment_length, dir_name)
+                        n = seg.segment_count(stem.shape[-1], cut)
+                        if n > a.batch_size and n % a.batch_size:        # the reference's torch.stack of ragged batches (:152)
+                            raise RuntimeError(f"stack expects each tensor to be equal size, but got [{a.batch_size}, 2048] at entry 0 "
+                                               f"and [{n % a.batch_size}, 2048] at entry {n // a.batch_size}")
+                        return eng.mean_embedding(self._host(stem), n, cut)
+                    return eng.mean_embedding(self._host(stem), 1, None)
+                emb_a, emb_b = emb_of(ref_a[i], a.segment_length_ref), emb_of(ref_b[i], a.segment_length)
+
+                def rows(p, k0, k1):
+                    out = []
+                    for k in range(k0, k1):
+                        w = (S - 1 - k // a.batch_size) / (S - 1)          # weight by BATCH index, like the reference (:245)
+                        out.append(w * emb_a + (1 - w) * emb_b)
+                    return torch.stack(out)
+                stem_out, t_range = eng.convert_segments(self._host(input_stems[i]), seg.segment_count(L, seg_len), seg_len, rows)
                 inst_outputs.append(stem_out)
-                if a.save_each_inst and writer:
-                    save_wav_pcm16(os.path.join(out_dir, f"{inst}_{tag}.wav"), stem_out.transpose(-1, -2), a.sample_rate)
-            if writer:
-                save_wav_pcm16(os.path.join(out_dir, f"mixture_{tag}.wav"), sum(inst_outputs).transpose(-1, -2), a.sample_rate)
+                if a.save_each_inst:
+                    self._write(dist, writers[f"{inst}_{tag}.wav"], t_range[0], stem_out)
+            self._write(dist, writers[f"mixture_{tag}.wav"], t_range[0], sum(inst_outputs))
+            if dist is not None:
+                dist.barrier()
 
 
 def str2bool(v):

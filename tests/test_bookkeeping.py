@@ -95,9 +95,13 @@ def test_inference_and_interpolation_orchestration_match_reference(emu_default, 
             return torch.cat([x.mean(-1), x.abs().mean(-1), (x * x).mean(-1)], dim=1)
 
     class Conv:
+        """the golden run's closed-form converter; like the real TCN it takes one condition row for the batch or one row per item (the
+        engine converts all segments of a stem in one pass, every segment with the row of ITS batch of the reference's loop)"""
+
         def __call__(self, x, cond):
-            c = cond[0]
-            return x * (1.0 + c[0] - 0.5 * c[3]) + 0.1 * c[1] - 0.2 * c[4] + 0.05 * (c[2] + c[5]) * torch.flip(x, dims=(1,))
+            c = cond.expand(x.shape[0], -1) if cond.shape[0] == 1 else cond
+            col = lambda k: c[:, k][:, None, None]
+            return x * (1.0 + col(0) - 0.5 * col(3)) + 0.1 * col(1) - 0.2 * col(4) + 0.05 * (col(2) + col(5)) * torch.flip(x, dims=(1,))
 
     written = {}
     monkeypatch.setattr(st, "save_wav_pcm16", lambda path, data, sr: written.__setitem__(os.path.basename(path), np.array(data)))

@@ -122,3 +122,130 @@ def test_cli_runner_sharded_equals_single(tmp_path, emu):
         a, b = os.path.join(one, "song", k), os.path.join(two, "song", k)
         assert load_wav_length(a) == L_IN
         assert open(a, "rb").read() == open(b, "rb").read(), k
+
+
+def _norm_features():
+    import numpy as np
+    k = np.arange(32769)
+    eq = lambda a, b: (a / (1.0 + (k / b) ** 1.3) + 0.02).astype(np.float64)
+    return {"eq": {"drums": eq(40.0, 900.0), "bass": eq(60.0, 150.0)}, "compression": {"drums": [-14.0, 2.0], "bass": [-12.0, 2.5]},
+            "imager": {"drums": 0.8, "bass": 0.9}, "loudness": {"drums": -20.0, "bass": -22.0}}
+
+
+def _cli_files_worker(rank, world, port, root):
+    """The runner over FILES with --normalize_input True: Song_Dataset_Inference decodes the wavs and normalises the input stems -
+    on two ranks stem j is normalised by rank j % 2 only and broadcast, every rank writes its time range of the output files."""
+    import types
+    import numpy as np
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MST_EMU_THREADS="8")
+    torch.set_num_threads(4)
+    from music_mixing_style_transfer_amd import _lib
+    from music_mixing_style_transfer_amd.data_loader import Song_Dataset_Inference
+    from music_mixing_style_transfer_amd.inference import style_transfer as st
+    from music_mixing_style_transfer_amd.mixing_manipulator.data_normalization import Audio_Effects_Normalizer
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from emu_binding import bind_emulator
+    _lib.set_default_binding(bind_emulator(build=False))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+    orig = Audio_Effects_Normalizer.normalize_audio
+    Audio_Effects_Normalizer.normalize_audio = lambda self, audio, src: (calls.append(src), orig(self, audio, src))[1]
+    enc, tcn = _models()
+    a = types.SimpleNamespace(normalize_input=True, instruments=["drums", "bass"], segment_length=SEG, segment_length_ref=SEG, batch_size=1,
+                              save_each_inst=True, sample_rate=44100, target_dir=os.path.join(root, "data") + "/", interpolation=False,
+                              input_file_name="input", reference_file_name="reference", stem_level_directory_name="separated",
+                              do_not_separate=True, precomputed_normalization_feature=_norm_features(),
+                              normalization_order=["loudness", "eq", "compression", "imager", "loudness"], workers=0)
+    runner = object.__new__(st.Mixing_Style_Transfer_Inference)
+    runner.args, runner.device = a, torch.device("cpu")
+    runner.target_dir, runner.output_dir = a.target_dir, os.path.join(root, f"out{world}") + "/"
+    runner.models = {"effects_encoder": enc, "mixing_converter": tcn}
+    runner.data_loader = Song_Dataset_Inference(a)
+    runner.data_loader.dist = runner._world()
+    runner.inference()
+    np.save(os.path.join(root, f"calls_w{world}_r{rank}.npy"), np.array(calls))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_cli_files_with_normalize_input_sharded_by_stems(tmp_path, emu):
+    """--normalize_input True on two ranks: byte-identical output files, and each rank ran the normaliser on ONE of the two input stems."""
+    import wave
+    import numpy as np
+    from music_mixing_style_transfer_amd import _lib
+    from music_mixing_style_transfer_amd.utils import synth
+    root = str(tmp_path)
+    L = 20000
+    t = np.arange(L)
+    for kind, seed in (("input", 50), ("reference", 60)):
+        d = os.path.join(root, "data", "song", "separated", kind)
+        os.makedirs(d)
+        for k, s in enumerate(("drums", "bass")):
+            base = synth.synth_music(2, L, seed=seed + k).numpy().T
+            hits = sum(a * np.exp(-np.maximum(0, t - n0) / 1200.0) * (t >= n0) * np.sin(2 * np.pi * (90.0 + 40 * k) * t / 44100.0)
+                       for n0, a in ((1500, 0.9), (7000, 0.6), (12500, 0.8)))
+            x = np.clip(0.3 * base + np.stack([hits, 0.8 * hits], 1), -1, 1)
+            with wave.open(os.path.join(d, s + ".wav"), "w") as w:
+                w.setnchannels(2)
+                w.setsampwidth(2)
+                w.setframerate(44100)
+                w.writeframes(np.clip(np.rint(x * 32767), -32768, 32767).astype("<i2").tobytes())
+    prev = _lib._default
+    try:
+        _cli_files_worker(0, 1, 0, root)
+    finally:
+        _lib.set_default_binding(prev)
+    mp.spawn(_cli_files_worker, args=(2, 29667, root), nprocs=2, join=True)
+    names = ["bass_output.wav", "drums_output.wav", "mixture_output.wav"]
+    for k in names:
+        a, b = os.path.join(root, "out1", "song", k), os.path.join(root, "out2", "song", k)
+        assert open(a, "rb").read() == open(b, "rb").read(), k
+    assert list(np.load(os.path.join(root, "calls_w1_r0.npy"))) == ["drums", "bass"]
+    assert list(np.load(os.path.join(root, "calls_w2_r0.npy"))) == ["drums"] and list(np.load(os.path.join(root, "calls_w2_r1.npy"))) == ["bass"]
+
+
+def _interp_worker(rank, world, port, out_path):
+    """inference_interpolation(): every rank converts its shard of the `interpolate_segments` pieces and writes its time range."""
+    import types
+    sys.path.insert(0, REPO)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MST_EMU_THREADS="2")
+    torch.set_num_threads(1)
+    from music_mixing_style_transfer_amd import _lib
+    from music_mixing_style_transfer_amd.inference import style_transfer as st
+    from music_mixing_style_transfer_amd.utils import synth
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from emu_binding import bind_emulator
+    _lib.set_default_binding(bind_emulator(build=False))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    enc, tcn = _models()
+    runner = object.__new__(st.Mixing_Style_Transfer_Inference)
+    runner.args = types.SimpleNamespace(normalize_input=False, instruments=["drums", "bass"], segment_length=SEG, segment_length_ref=SEG,
+                                        batch_size=2, save_each_inst=True, sample_rate=44100, interpolate_segments=5)
+    runner.device = torch.device("cpu")
+    runner.target_dir, runner.output_dir = "/data/", out_path + "/"
+    runner.models = {"effects_encoder": enc, "mixing_converter": tcn}
+    stems_in = torch.stack([synth.synth_audio((2, L_IN), seed=5), synth.synth_audio((2, L_IN), seed=7)])
+    ref_a = torch.stack([synth.synth_audio((2, 4 * SEG - 7), seed=6), synth.synth_audio((2, 4 * SEG - 7), seed=8)])       # 4 segments
+    ref_b = torch.stack([synth.synth_audio((2, SEG - 30), seed=16), synth.synth_audio((2, SEG - 30), seed=18)])           # encoded whole
+    runner.data_loader = [(stems_in, ref_a, ref_b, "/data/song/")]
+    runner.inference_interpolation()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_interpolation_mode_sharded_equals_single(tmp_path, emu):
+    from music_mixing_style_transfer_amd import _lib
+    one, two = str(tmp_path / "one"), str(tmp_path / "two")
+    prev = _lib._default
+    try:
+        _interp_worker(0, 1, 0, one)
+    finally:
+        _lib.set_default_binding(prev)
+    mp.spawn(_interp_worker, args=(2, 29679, two), nprocs=2, join=True)
+    names = ["bass_output_notnormed_interpolation.wav", "drums_output_notnormed_interpolation.wav", "mixture_output_notnormed_interpolation.wav"]
+    assert sorted(os.listdir(os.path.join(one, "song"))) == sorted(os.listdir(os.path.join(two, "song"))) == names
+    for k in names:
+        assert open(os.path.join(one, "song", k), "rb").read() == open(os.path.join(two, "song", k), "rb").read(), k
