@@ -390,6 +390,9 @@ def main():
             out["bf16x3_mode"] = bench_parity_mode(engine, enc, tcn, lib, ref, inp, dev, enc_cfg, enc_sd, tcn_sd, "bf16x3")
             out["fx_chain"] = bench_fx_chain(dev)
             out["input_normalizer"] = bench_input_normalizer()
+            sys.path.insert(0, os.path.join(REPO, "tools"))
+            import bench_cli
+            out["file_to_file"] = bench_cli.run(180.0, "bf16", songs=2)      # the runner, wav to wav, second pass over two 3-minute songs
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(enc_cfg, enc_sd, tcn_sd)
         print(json.dumps(out), flush=True)
