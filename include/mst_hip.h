@@ -110,16 +110,17 @@ int mst_tcn_forward(MstTcn *tcn, const float *x_dev, float *y_dev, int B, int L,
 int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int B, int L, int precision, int n_run,
                            void *workspace, size_t workspace_bytes, void *stream);
 
-/* tuning flags (choose between forms of the block kernels; flags = x3_small_tiles | bf16_form << 1, default 1):
+/* tuning flags (choose between forms of the block kernels; flags = x3_small_tiles | bf16_form << 1, default 5):
  * bit 0 (bf16x3 mode; default 1, measured 5.13 instead of 5.45 ms per launch at 32 x 131072): the split-bf16 block kernel on 128-time
  *   tiles of <= 2 phases (two workgroups per CU) wherever the segment has at least 64 steps per phase, 0 = 256-time tiles (one
  *   workgroup per CU); identical results.
- * bits 1-2 (bf16 mode), form of the dense block kernel - all measured at 32 x 131072, profiles/r03_tcn_block_forms_summary.md:
- *   0 (default) tcn_block_bf16_kernel: one tile per workgroup, two workgroups per CU                                   1.50-1.53 ms
+ * bits 1-2 (bf16 mode), form of the dense block kernel - measured at 32 x 131072, profiles/r03_tcn_block_forms_summary.md:
+ *   0 tcn_block_bf16_kernel: one tile per workgroup, two workgroups per CU                                              1.49-1.51 ms
  *   1 tcn_block_bf16_stream_kernel: persistent, input rows by LDS-DMA one 32-channel chunk ahead of the matrix cores,
  *     epilogue straight from / to global memory; the fp32 accumulation runs chunk-major (agrees to accumulation rounding)   1.67 ms
- *   2 tcn_block_bf16_duo_kernel: persistent, one workgroup per CU, two tile buffers, the next tile by LDS-DMA during the
- *     main loop; bit-identical to form 0 (phase counts without a duo form - 16 - run form 0)                                1.60 ms */
+ *   2 (default) tcn_block_bf16_duo_kernel for the blocks with 256-time tiles of <= 4 phases (form 0 for the others and for the last
+ *     block): persistent, one workgroup of 4 matrix waves + 4 loader waves per CU, two tile buffers, the next tile by LDS-DMA and
+ *     the previous tile's row stores during the main loop; bit-identical to form 0                                       1.47-1.48 ms */
 int mst_tcn_set_tuning(MstTcn *tcn, int flags);
 
 /* measurement hook (bench.py's roofline leg): between _begin and _end every mst_tcn_forward records HIP events

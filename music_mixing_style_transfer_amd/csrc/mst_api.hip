@@ -132,7 +132,7 @@ struct MstTcn {
     bool out_loaded = false;
     void *zero_row = nullptr;     // 1 KB of zeros: what the block kernels stage for time steps outside the segment
     int x3_small_tiles = 1;       // bf16x3 mode: 128-time tiles of <= 2 phases, two workgroups per CU (mst_tcn_set_tuning; measured 5.13 vs 5.45 ms)
-    int bf16_form = 0;            // bf16 mode, form of the block kernel (mst_tcn_set_tuning bits 1-2): 0 one tile per workgroup (default), 1 stream, 2 duo
+    int bf16_form = 2;            // bf16 mode, form of the block kernel (mst_tcn_set_tuning bits 1-2): 0 one tile per workgroup, 1 stream, 2 duo (default)
     std::vector<hipEvent_t> ev;   // timing hook: (nblocks + 2) events per recorded forward
     int ev_max = 0, ev_used = 0;
 };
@@ -405,10 +405,7 @@ template <int P, int NQ> int launch_block_duo(TcnBlockArgs a, void *stream) {
         grid -= grid % 8;
         a.xcd_tiles = (int)((ntiles + 7) / 8);
     }
-    if (a.y_out)
-        MST_LAUNCH((tcn_block_bf16_duo_kernel<P, true, NQ>), dim3((unsigned)grid), dim3(256), stream, a);
-    else
-        MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ>), dim3((unsigned)grid), dim3(256), stream, a);
+    MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ>), dim3((unsigned)grid), dim3(512), stream, a);
     MST_CHECK_LAUNCH("tcn_block_bf16_duo_kernel");
     return MST_OK;
 }
@@ -416,7 +413,12 @@ template <int P, int NQ> int launch_block_duo(TcnBlockArgs a, void *stream) {
 template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream, int x3_small = 0, int bf16_form = 0) {
     TcnBlockArgs a = a0;
     if (precision == MST_PREC_BF16 && bf16_form == 2) {
-        if constexpr (P < 16) return launch_block_duo<P, (P == 8 ? 4 : 8)>(a, stream);
+        // 256-time tiles only: at P = 8 (128-time tiles: half the work per tile for the same two barriers) the duo form measured
+        // 1.62-1.82 ms against 1.50 ms, those blocks run the one-tile-per-workgroup kernel
+        // (the last block - fused output head, 32 more live registers - spills in the duo form and runs the one-tile kernel too)
+        if constexpr (P <= 4) {
+            if (!a.y_out) return launch_block_duo<P, 8>(a, stream);
+        }
     }
     if (precision == MST_PREC_BF16 && bf16_form == 1) return launch_block_stream<P, (P == 8 ? 4 : 8)>(a, stream);
     if (precision == MST_PREC_BF16X3) {

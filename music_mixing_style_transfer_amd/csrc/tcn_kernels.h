@@ -569,31 +569,33 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16_stream_kernel(TcnBlockA
 
 // ------------------------------------------------------------------------------------------------
 // blocks 1..n-1, bf16: the PERSISTENT DOUBLE-TILE form of tcn_block_bf16_kernel ("duo" kernel, round 3) - same tiles, same LDS image, same
-// main loop and epilogue, bit-identical results; what changes is how a tile gets into LDS and how many workgroups share a CU:
-//   * ONE workgroup per CU (one wave per SIMD), persistent, walking its share of the tiles of one XCD's contiguous tile range;
-//   * TWO tile buffers (2 x 78 KB at P = 4): while the matrix cores work on tile i, tile i + 1 arrives in the other buffer by LDS-DMA
-//     (global_load_lds_dwordx4: no VGPR round trip, no ds_write), one 1 KB piece (4 rows) every other k-step of the first ten taps,
-//     with the XOR swizzle of the LDS image applied on the SOURCE side (lane l of a piece fetches slot (l & 15) ^ (row & 15));
-//   * nothing of a tile's staging is exposed any more; the only non-MFMA time left is the epilogue (LDS-transposed row stores).
-// Measured motivation (MI355X, 32 x 131072, d = 4 ... 2048): the one-tile-per-workgroup kernel at two workgroups per CU 1.50 ms per
-// launch; the SAME kernel restricted to one workgroup per CU - staging and epilogue fully exposed - 1.60 ms: a single wave per SIMD
-// sustains the 16 x 16 x 32 MFMA stream (17 clocks per MFMA against 16), so the second workgroup buys little more than cover for the
-// prologue, and the prologue is what this form removes.
-// Wave w owns the DMA pieces k = w (mod 4) = exactly the rows it reads itself in the store pass of the epilogue, so the refill of a
-// buffer needs no barrier beyond the two of the epilogue.
+// main loop and epilogue arithmetic, bit-identical results; what changes is who does what:
+//   * ONE workgroup of EIGHT waves per CU, persistent, walking its share of the tiles of one XCD's contiguous tile range;
+//   * waves 0-3 (one per SIMD) are the MATRIX waves: main loop, epilogue arithmetic, transposed tile -> LDS.  They issue no staging
+//     load, no DMA and no global store;
+//   * waves 4-7 (one per SIMD) are the LOADER waves: while the matrix waves work on tile i (buffer i & 1) they store tile i - 1 out of
+//     the other buffer (whole 256-byte rows) and then refill that buffer with tile i + 1 by LDS-DMA (global_load_lds_dwordx4: no VGPR
+//     round trip, no ds_write; the XOR swizzle of the LDS image sits on the SOURCE side: lane l of a 4-row piece fetches slot
+//     (l & 15) ^ (row & 15)).  An LDS-DMA piece occupies its wave for ~100-150 clocks at issue - on a loader wave that is free;
+//   * TWO tile buffers (2 x 78 KB at P = 4) and two workgroup barriers per tile: (1) the matrix waves are done reading tile i AND
+//     tile i + 1 has landed, (2) the transposed output tile is complete.
+// Measured motivation (MI355X, 32 x 131072, d = 4 ... 2048; profiles/r03_tcn_block_forms_summary.md): the main loop alone runs at
+// 1.27 ms per launch at one wave per SIMD as at two; the one-tile-per-workgroup kernel 1.50-1.53 ms; a first persistent double-tile
+// form whose four waves did everything themselves 1.60 ms (0.2 ms for issuing the copy, 0.2 ms for the epilogue).
 // ------------------------------------------------------------------------------------------------
 template <int P, bool FUSE_OUT, int NQ>
-__global__ __launch_bounds__(256, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs a) {
+__global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs a) {
     constexpr int T = 32 * NQ, R = T + 14 * P, R4 = (R + 3) / 4 * 4, MT = T / P, NC = 2 * NQ;
     constexpr int NK = R4 / 4;                   // 1 KB DMA pieces (4 rows x 256 B) per tile
-    constexpr int NI = (NK + 3) / 4;             // pieces per wave
+    constexpr int NI = (NK + 3) / 4;             // pieces per loader wave
     constexpr int BUF = R4 * 256;
-    static_assert(NI <= 30, "two pieces per tap");
     static_assert(2 * BUF + 2048 <= 160 * 1024, "two tiles + parameters fit the CU's LDS");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
     __shared__ __attribute__((aligned(16))) float par[4 * 128];     // shift | FiLM r | FiLM b | res
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wv >= 4;
+    const int w = wv & 3;                        // matrix wave: its channel quarter; loader wave: its share of pieces / rows
     const int l16 = lane & 15, g = lane >> 4;
 
     // ---- this workgroup's tiles: workgroup i runs on XCD i % 8 and walks tiles (i % 8) * xcd_tiles + i / 8 + n * gridDim.x / 8
@@ -618,19 +620,37 @@ __global__ __launch_bounds__(256, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
         b = (int)(r / a.tiles_phase);
         m0 = mg * MT;
     };
-    // the i-th DMA piece of this wave for tile (b, m0, phi0): rows 4k .. 4k + 3, k = w + 4 i, into buffer buf
-    auto dma_piece = [&](int b, int m0, int phi0, int i, int buf) {
-        const int k = w + 4 * i;
-        if (k < NK) {
-            const int row = 4 * k + (lane >> 4);
-            const long t = (long)(m0 + row / P - 7) * a.d + phi0 + (row % P);
-            const bool ok = row < R && t >= 0 && t < a.L;
-            const int slot = (lane & 15) ^ (row & 15);
-            const unsigned char *src = (ok ? (const unsigned char *)a.x + ((size_t)b * a.Lp + t) * 256 : (const unsigned char *)a.zeros) + slot * 16;
-            mst_dma16(src, smem + buf * BUF + k * 1024);
+    // loader waves: all pieces of tile (b, m0, phi0) that belong to this wave (k = w mod 4), into buffer buf.  A tile that lies inside the
+    // segment (all but the first / last of a phase group) needs no bounds test: the pieces of a wave are 16 rows = 16 / P steps apart,
+    // one 64-bit add per piece (the loader shares its SIMD's issue slots with a matrix wave: every instruction here is taken from it)
+    auto dma_tile = [&](int b, int m0, int phi0, int buf) {
+        static_assert(16 % P == 0, "pieces advance by a whole number of steps");
+        const int row0 = 4 * w + (lane >> 4);
+        const long t0 = (long)(m0 + row0 / P - 7) * a.d + phi0 + (row0 % P);
+        const long dt = (long)(16 / P) * a.d;
+        const int slot = (lane & 15) ^ (row0 & 15);          // row & 15 is the same for all pieces of a lane
+        const long t_first = (long)(m0 - 7) * a.d + phi0, t_last = (long)(m0 + (R4 - 1) / P - 7) * a.d + phi0 + (P - 1);
+        unsigned char *dst = smem + buf * BUF + w * 1024;
+        if (t_first >= 0 && t_last < a.L) {                   // uniform
+            const unsigned char *src = (const unsigned char *)a.x + ((size_t)b * a.Lp + t0) * 256 + slot * 16;
+#pragma unroll 1
+            for (int k = w; k < NK; k += 4) {
+                mst_dma16(src, dst);
+                src += dt * 256;
+                dst += 4096;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int row = row0 + 16 * i;
+                const long t = t0 + i * dt;
+                const bool ok = row < R && t >= 0 && t < a.L;
+                const unsigned char *src = (ok ? (const unsigned char *)a.x + ((size_t)b * a.Lp + t) * 256 : (const unsigned char *)a.zeros) + slot * 16;
+                if (w + 4 * i < NK) mst_dma16(src, dst + i * 4096);
+            }
         }
     };
-    auto stage_film = [&](int b) {
+    auto stage_film = [&](int b) {          // matrix waves only (tid < 256)
         if (tid < 128) {
             const float *frow0 = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
             par[128 + tid] = frow0[tid];
@@ -640,46 +660,89 @@ __global__ __launch_bounds__(256, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
 
     int tb, tm0, tphi0;
     tile_geometry(tile, tb, tm0, tphi0);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) dma_piece(tb, tm0, tphi0, i, 0);
-    if (tid < 128) {
-        par[tid] = a.shift[tid];
-        par[384 + tid] = a.res[tid];
+    if (loader) {
+        dma_tile(tb, tm0, tphi0, 0);
+    } else {
+        if (tid < 128) {
+            par[tid] = a.shift[tid];
+            par[384 + tid] = a.res[tid];
+        }
+        stage_film(tb);
     }
-    stage_film(tb);
-    int bprev = tb;
     mst_dma_wait_barrier<0>();
 
-    // A fragments: wpk[ks = j*4 + kk][row tile m][wave][lane] = 8 bf16; a ring of TU taps = 4 TU k-steps that runs on across tiles (every
-    // tile multiplies by the same weights: behind the last taps the fragments of the first taps are requested again).  The ring is this
-    // deep because of the DMA: vmcnt retires in order, so a fragment wait also waits for every DMA piece issued before that fragment's
-    // load - with a four-k-step ring each piece had to land within ~2 k clocks of its issue or stall the only wave of the SIMD
-    // (measured: 1.60 ms per launch, no better than the one-tile kernel at one workgroup per CU); twelve k-steps give it ~6.5 k clocks.
-    constexpr int TU = 3;
-    static_assert(15 % TU == 0, "the tap loop is unrolled by the ring depth");
+    if (loader) {
+        // =================================================================== loader waves
+        // iteration i: [next tile -> the other buffer] (barrier 1 of tile i) (barrier 2 of tile i) [tile i's output rows -> global memory]
+        int cur = 0;
+        const int lt = tid - 256;                      // 0..255: thread (prow, slot) of the row passes, like the one-tile kernel's
+        for (;;) {
+            const int b = tb, m0 = tm0, phi0 = tphi0;
+            const long tnext = tile + tstep;
+            const bool has_next = tnext < tend;
+            if (has_next) {
+                tile_geometry(tnext, tb, tm0, tphi0);
+                dma_tile(tb, tm0, tphi0, cur ^ 1);      // the buffer whose rows this wave stored out itself one iteration ago
+            }
+            mst_dma_wait_barrier<0>();                  // (1) the next tile has landed (and this wave's stores have left)
+            if constexpr (FUSE_OUT) {
+                mst_dma_wait_barrier<63>();             // (2a) the output head's partial sums are complete (matrix waves finish the tile)
+                mst_dma_wait_barrier<63>();             // (2b) ... and have been read: the buffer may be refilled
+            } else {
+                mst_dma_wait_barrier<63>();             // (2) the transposed output tile is complete
+                const unsigned char *sm = smem + cur * BUF;
+                __bf16 *yb = (__bf16 *)a.y + (size_t)b * a.Lp * 128;
+                const int slot = lt & 15, prow = lt >> 4;
+                const long dt = (long)(16 / P) * a.d;
+                long t = (long)(m0 + prow / P) * a.d + phi0 + (prow % P);
+                __bf16 *dstp = yb + t * 128 + slot * 8;
+                const unsigned char *srcp = sm + prow * 256 + ((slot ^ (prow & 15)) << 4);
+                if ((long)(m0 + (T - 1) / P) * a.d + phi0 + (P - 1) < a.L) {        // uniform: every row of the tile is inside the segment
+#pragma unroll
+                    for (int i = 0; i < T / 16; ++i) {
+                        *(bf16x8 *)dstp = *(const bf16x8 *)(srcp + i * 4096);
+                        dstp += dt * 128;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < T / 16; ++i) {
+                        if (t < a.L) *(bf16x8 *)dstp = *(const bf16x8 *)(srcp + i * 4096);
+                        t += dt;
+                        dstp += dt * 128;
+                    }
+                }
+            }
+            if (!has_next) break;
+            tile = tnext;
+            cur ^= 1;
+        }
+        return;
+    }
+
+    // ======================================================================= matrix waves
+    __builtin_amdgcn_s_setprio(2);          // the loader wave of the SIMD takes the issue slots this wave leaves, never the other way round
+    // A fragments: wpk[ks = j*4 + kk][row tile m][wave][lane] = 8 bf16; a ring of four k-steps that runs on across tiles (every tile
+    // multiplies by the same weights: behind the last tap the fragments of tap 0 are requested again)
     const MstStream16 wst = mst_stream16(a.wpk, 60u * 2u * 4096u);
     const unsigned aoff = (unsigned)(w * 64 + lane) * 16u;
     constexpr int RB = 8;
     static_assert(NC % RB == 0, "the ring divides the column tiles");
-    bf16x8 af[2][TU][4], bf[RB];
+    bf16x8 af[2][4], bf[RB];
 #pragma unroll
-    for (int u = 0; u < TU; ++u)
+    for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) af[m][u][kk] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)(u * 4 + kk) * 8192u));
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int m = 0; m < 2; ++m) af[m][kk] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)kk * 8192u));
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
-    int cur = 0;
+    int cur = 0, bprev = tb;
     for (;;) {
         const int b = tb, m0 = tm0, phi0 = tphi0;
         const long tnext = tile + tstep;
         const bool has_next = tnext < tend;
         if (has_next) tile_geometry(tnext, tb, tm0, tphi0);
         unsigned char *const sm = smem + cur * BUF;
-        __bf16 *yb = (__bf16 *)a.y + (size_t)b * a.Lp * 128;
-        if (b != bprev) {              // a new batch item: its FiLM row (every wave is past the previous tile's epilogue arithmetic: barrier 2)
+        if (b != bprev) {              // a new batch item: its FiLM row (every matrix wave is past the previous tile's epilogue: barrier 2)
             stage_film(b);
             bprev = b;
         }
@@ -697,56 +760,57 @@ __global__ __launch_bounds__(256, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
             for (int q = 0; q < RB; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 4096);
         }
 #pragma unroll 1
-        for (int jt = 0; jt < 15 / TU; ++jt) {
+        for (int j = 0; j < 15; ++j) {
+            const int jn = j < 14 ? j + 1 : 0;
+            const int rb0 = j * P + l16, rb1 = (j < 14 ? j + 1 : 14) * P + l16;
 #pragma unroll
-            for (int u = 0; u < TU; ++u) {
-                const int j = jt * TU + u;
-                const int jn = j + TU < 15 ? j + TU : j + TU - 15;
-                const int rb0 = j * P + l16, rb1 = (j < 14 ? j + 1 : 14) * P + l16;
+            for (int kk = 0; kk < 4; ++kk) {
+                const int rbn = (kk == 3) ? rb1 : rb0;
+                const int kn = (kk + 1) & 3;
+                const unsigned char *cp = sm + rb0 * 256 + (((4 * kk + g) ^ (rb0 & 15)) << 4);
+                const unsigned char *np = sm + rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int rbn = (kk == 3) ? rb1 : rb0;
-                    const int kn = (kk + 1) & 3;
-                    const unsigned char *cp = sm + rb0 * 256 + (((4 * kk + g) ^ (rb0 & 15)) << 4);
-                    const unsigned char *np = sm + rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
-                    // the next tile travels while this one is computed on: one piece every other k-step
-                    if ((kk & 1) == 0 && has_next && 2 * j + (kk >> 1) < NI) dma_piece(tb, tm0, tphi0, 2 * j + (kk >> 1), cur ^ 1);
-#pragma unroll
-                    for (int q = 0; q < NC; ++q) {
-                        acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][u][kk], bf[q % RB], acc[0][q], 0, 0, 0);
-                        acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][u][kk], bf[q % RB], acc[1][q], 0, 0, 0);
-                        bf[q % RB] = (q + RB < NC) ? *(const bf16x8 *)(cp + (q + RB) * 4096) : *(const bf16x8 *)(np + (q + RB - NC) * 4096);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    }
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) af[m][u][kk] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)(jn * 4 + kk) * 8192u));
-                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                for (int q = 0; q < NC; ++q) {
+                    acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][kk], bf[q % RB], acc[0][q], 0, 0, 0);
+                    acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][kk], bf[q % RB], acc[1][q], 0, 0, 0);
+                    bf[q % RB] = (q + RB < NC) ? *(const bf16x8 *)(cp + (q + RB) * 4096) : *(const bf16x8 *)(np + (q + RB - NC) * 4096);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) af[m][kk] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)(jn * 4 + kk) * 8192u));
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
             }
         }
 
-        // ---- fused epilogue (the one of tcn_block_bf16_kernel): residual rows -> registers, barrier, arithmetic, transposed tile -> LDS,
-        //      barrier, whole-row stores
-        bf16x4 xin[2][NC];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int co0 = 32 * w + 16 * m + 4 * g;
+        // ---- epilogue arithmetic (the one of tcn_block_bf16_kernel): residual rows -> registers, barrier, transposed tile -> LDS, barrier
+        // (the residual rows of row tile 1 are read behind the barrier: they sit in this wave's own channel columns, which no other wave
+        //  writes and which its own row-tile-0 results do not touch - 32 registers instead of 64 next to the accumulators)
+        // (lane coordinates made opaque once per tile: otherwise hipcc keeps ~36 tile-invariant LDS addresses of this epilogue live across
+        //  the main loop - and, at the 256-register limit of an eight-wave workgroup, spills them)
+        int l16e = l16, ge = g;
+        asm volatile("" : "+v"(l16e), "+v"(ge));
+        bf16x4 xin[NC];
+        auto read_xin = [&](int m) {
+            const int co0 = 32 * w + 16 * m + 4 * ge;
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
-                const int row = 16 * q + l16 + 7 * P;
-                xin[m][q] = *(const bf16x4 *)(sm + row * 256 + (((co0 >> 3) ^ (row & 15)) << 4) + 2 * (co0 & 7));
+                const int row = 16 * q + l16e + 7 * P;
+                xin[q] = *(const bf16x4 *)(sm + row * 256 + (((co0 >> 3) ^ (row & 15)) << 4) + 2 * (co0 & 7));
             }
-        }
-        // every wave is done reading this tile; this wave's pieces of the next tile have landed (they are older than the 8 TU fragment
-        // loads that may still be in flight)
-        mst_dma_wait_barrier<8 * TU>();
+        };
+        read_xin(0);
+        mst_dma_wait_barrier<63>();            // (1) every matrix wave is done reading this tile (the weight fragments in flight stay in flight)
         float hs0[NC], hs1[NC];
 #pragma unroll
         for (int q = 0; q < NC; ++q) hs0[q] = hs1[q] = 0.0f;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            const int co0 = 32 * w + 16 * m + 4 * g;
+            if (m) {
+                read_xin(1);
+                __builtin_amdgcn_wave_barrier();      // all lanes of the wave have read before any of them writes these columns (lockstep on the GPU)
+            }
+            const int co0 = 32 * w + 16 * m + 4 * ge;
             const f32x4 fr = *(const f32x4 *)(par + 128 + co0);
             const f32x4 fb = *(const f32x4 *)(par + 256 + co0);
             const f32x4 rs = *(const f32x4 *)(par + 384 + co0);
@@ -757,9 +821,9 @@ __global__ __launch_bounds__(256, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
             }
 #pragma unroll
             for (int q = 0; q < NC; ++q) {
-                const int o = 16 * q + l16;
+                const int o = 16 * q + l16e;
                 const float v4[4] = {acc[m][q][0], acc[m][q][1], acc[m][q][2], acc[m][q][3]};
-                const bf16x4 out = tcn_epilogue4(v4, fr, fb, rs, xin[m][q]);
+                const bf16x4 out = tcn_epilogue4(v4, fr, fb, rs, xin[q]);
                 if constexpr (FUSE_OUT) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -783,7 +847,7 @@ __global__ __launch_bounds__(256, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
                     part[(w * 2 + 1) * T + 16 * q + l16] = hs1[q];
                 }
             }
-            mst_dma_wait_barrier<63>();
+            mst_dma_wait_barrier<63>();          // (2a)
 #pragma unroll
             for (int i = 0; i < 2 * T / 256; ++i) {
                 const int idx = tid + 256 * i, c = idx / T, o = idx % T;
@@ -794,20 +858,9 @@ __global__ __launch_bounds__(256, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
                     a.y_out[((size_t)b * a.nout + c) * a.L + t] = fminf(1.0f, fmaxf(-1.0f, v));
                 }
             }
-            mst_dma_wait_barrier<63>();          // the partial sums are read across waves: the refill of this buffer waits for all of them
+            mst_dma_wait_barrier<63>();          // (2b) the partial sums have been read: the loader waves may refill this buffer
         } else {
-            mst_dma_wait_barrier<63>();          // LDS only
-            const int slot = tid & 15, prow = tid >> 4;
-            const long dt = (long)(16 / P) * a.d;
-            long t = (long)(m0 + prow / P) * a.d + phi0 + (prow % P);
-            __bf16 *dstp = yb + t * 128 + slot * 8;
-            const unsigned char *srcp = sm + prow * 256 + ((slot ^ (prow & 15)) << 4);
-#pragma unroll
-            for (int i = 0; i < T / 16; ++i) {
-                if (t < a.L) *(bf16x8 *)dstp = *(const bf16x8 *)(srcp + i * 4096);
-                t += dt;
-                dstp += dt * 128;
-            }
+            mst_dma_wait_barrier<63>();          // (2) the transposed output tile is complete: the loader waves store it
         }
         if (!has_next) break;
         tile = tnext;

@@ -75,6 +75,8 @@ def test_tcn_bf16_stream_and_duo_kernels_emulated(emu_default):
         x = synth.synth_audio(shape, seed=1)
         col = []
         y_ref = R.tcn_forward(sd, x, cnd, nblocks=nb, dilation_growth=growth, collect=col)
+        m._ensure(emu_default)
+        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 1), "tuning")           # form 0: one tile per workgroup
         y0 = m(x, cnd)
         a0 = m.forward_blocks(x, cnd, nb)
         emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 3), "tuning")
@@ -83,7 +85,8 @@ def test_tcn_bf16_stream_and_duo_kernels_emulated(emu_default):
         assert float((y1 - y_ref).abs().max()) <= 4e-2
         assert float((a1 - col[nb - 1]).abs().max()) <= 4e-2 * float(col[nb - 1].abs().max())
         assert float((y1 - y0).abs().max()) <= 5e-3 and float((a1 - a0).abs().max()) <= 5e-2
-        # form 2 ("duo": one workgroup per CU, two tile buffers, the next tile by LDS-DMA during the main loop): the same bits as form 0
+        # form 2, the default ("duo": 4 matrix + 4 loader waves per CU, two tile buffers, the next tile by LDS-DMA during the main loop):
+        # the same bits as form 0
         emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 5), "tuning")
         assert torch.equal(m(x, cnd), y0) and torch.equal(m.forward_blocks(x, cnd, nb), a0)
     with pytest.raises(ValueError):
