@@ -883,7 +883,7 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
 template <int P, int NQ>
 __global__ __launch_bounds__(256, (NQ == 4 && P <= 2) ? 2 : 1) void tcn_block_bf16x3_kernel(TcnBlockArgs a) {
     constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * R * 256];      // [hi | lo] tiles
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * R * 256];      // [hi | lo] tiles; later the fp32 output tile (T x 512 B <= 2 R x 256 B)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     unsigned char *const sm_hi = smem, *const sm_lo = smem + R * 256;
 
@@ -1009,28 +1009,42 @@ __global__ __launch_bounds__(256, (NQ == 4 && P <= 2) ? 2 : 1) void tcn_block_bf
         }
     }
 
-    // ---- exact fp32 epilogue: LeakyReLU -> FiLM -> + res * x_in (x_in re-read in fp32 from global memory)
+    // ---- exact fp32 epilogue: LeakyReLU -> FiLM in the accumulator layout, transposed through LDS (the input tiles are dead; fp32 rows of
+    //      512 B, 16-byte slots XOR-swizzled by the row), then whole rows: + res * x_in (x_in re-read from global memory, L2-hot) -> store.
+    //      Straight from the accumulator layout a lane's 16 bytes are a 64-byte run of its row (16 rows per instruction, for the residual
+    //      load as for the store): measured on the bf16 twin of this access pattern at ~0.3 ms per launch (profiles/r03_tcn_block_forms_summary.md)
     const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+    __syncthreads();                       // every wave is done reading the input tiles
+    float *st = (float *)smem;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int co0 = 32 * w + 16 * m + 4 * g;
         const f32x4 fr = *(const f32x4 *)(frow + co0);
         const f32x4 fb = *(const f32x4 *)(frow + 128 + co0);
-        const f32x4 rs = *(const f32x4 *)(a.res + co0);
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
             const int o = 16 * q + l16;
+            f32x4 z;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[i] = fr[i] * leaky_relu(acc[m][q][i]) + fb[i];
+            *(f32x4 *)(st + o * 128 + (((co0 >> 2) ^ (o & 31)) << 2)) = z;
+        }
+    }
+    __syncthreads();
+    {
+        const int s4 = tid & 31;                                   // this thread's 4 channels, the same in every pass
+        const f32x4 rs = *(const f32x4 *)(a.res + 4 * s4);
+#pragma unroll
+        for (int i = 0; i < T / 8; ++i) {
+            const int o = (tid >> 5) + 8 * i;
             const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
             if (t < a.L) {
-                const f32x4 xin = *(const f32x4 *)(xb + t * 128 + co0);
+                const f32x4 z = *(const f32x4 *)(st + o * 128 + ((s4 ^ (o & 31)) << 2));
+                const f32x4 xin = *(const f32x4 *)(xb + t * 128 + 4 * s4);
                 f32x4 out;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = leaky_relu(acc[m][q][i]);
-                    v = fr[i] * v + fb[i];
-                    out[i] = v + rs[i] * xin[i];
-                }
-                *(f32x4 *)(yb + t * 128 + co0) = out;
+                for (int k = 0; k < 4; ++k) out[k] = z[k] + rs[k] * xin[k];
+                *(f32x4 *)(yb + t * 128 + 4 * s4) = out;
             }
         }
     }
@@ -1049,7 +1063,7 @@ template <int P, int NQ>
 __global__ __launch_bounds__(256, 2) void tcn_block_bf16x3_half_kernel(TcnBlockArgs a) {
     constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NC = 2 * NQ;
     static_assert(P % 8 == 0, "the swizzle is conflict free for start rows that are multiples of 8");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * R * 128];      // [hi | lo] half tiles
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * R * 128 > T * 512) ? 2 * R * 128 : T * 512];      // [hi | lo] half tiles; later the fp32 output tile
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     unsigned char *const sm_hi = smem, *const sm_lo = smem + R * 128;
     const int l16 = lane & 15, g = lane >> 4;
@@ -1158,28 +1172,42 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16x3_half_kernel(TcnBlockA
         }
     }
 
-    // ---- exact fp32 epilogue: LeakyReLU -> FiLM -> + res * x_in (x_in re-read in fp32 from global memory)
+    // ---- exact fp32 epilogue: LeakyReLU -> FiLM in the accumulator layout, transposed through LDS (the input tiles are dead; fp32 rows of
+    //      512 B, 16-byte slots XOR-swizzled by the row), then whole rows: + res * x_in (x_in re-read from global memory, L2-hot) -> store.
+    //      Straight from the accumulator layout a lane's 16 bytes are a 64-byte run of its row (16 rows per instruction, for the residual
+    //      load as for the store): measured on the bf16 twin of this access pattern at ~0.3 ms per launch (profiles/r03_tcn_block_forms_summary.md)
     const float *frow = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+    __syncthreads();                       // every wave is done reading the input tiles
+    float *st = (float *)smem;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int co0 = 32 * w + 16 * m + 4 * g;
         const f32x4 fr = *(const f32x4 *)(frow + co0);
         const f32x4 fb = *(const f32x4 *)(frow + 128 + co0);
-        const f32x4 rs = *(const f32x4 *)(a.res + co0);
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
             const int o = 16 * q + l16;
+            f32x4 z;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[i] = fr[i] * leaky_relu(acc[m][q][i]) + fb[i];
+            *(f32x4 *)(st + o * 128 + (((co0 >> 2) ^ (o & 31)) << 2)) = z;
+        }
+    }
+    __syncthreads();
+    {
+        const int s4 = tid & 31;                                   // this thread's 4 channels, the same in every pass
+        const f32x4 rs = *(const f32x4 *)(a.res + 4 * s4);
+#pragma unroll
+        for (int i = 0; i < T / 8; ++i) {
+            const int o = (tid >> 5) + 8 * i;
             const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
             if (t < a.L) {
-                const f32x4 xin = *(const f32x4 *)(xb + t * 128 + co0);
+                const f32x4 z = *(const f32x4 *)(st + o * 128 + ((s4 ^ (o & 31)) << 2));
+                const f32x4 xin = *(const f32x4 *)(xb + t * 128 + 4 * s4);
                 f32x4 out;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float v = leaky_relu(acc[m][q][i]);
-                    v = fr[i] * v + fb[i];
-                    out[i] = v + rs[i] * xin[i];
-                }
-                *(f32x4 *)(yb + t * 128 + co0) = out;
+                for (int k = 0; k < 4; ++k) out[k] = z[k] + rs[k] * xin[k];
+                *(f32x4 *)(yb + t * 128 + 4 * s4) = out;
             }
         }
     }
