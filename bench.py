@@ -393,7 +393,9 @@ def main():
             out["input_normalizer"] = bench_input_normalizer()
             sys.path.insert(0, os.path.join(REPO, "tools"))
             import bench_cli
-            out["file_to_file"] = bench_cli.run(180.0, "bf16", songs=2)      # the runner, wav to wav, second pass over two 3-minute songs
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):      # the runner prints its progress like the reference CLI: keep stdout to the ONE line
+                out["file_to_file"] = bench_cli.run(180.0, "bf16", songs=2)      # wav to wav, second pass over two 3-minute songs
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(enc_cfg, enc_sd, tcn_sd)
         print(json.dumps(out), flush=True)
