@@ -366,7 +366,7 @@ def main():
 
     if rank == 0:
         traffic = None      # HBM bytes per launch of the dominant kernel: offline rocprofv3 --pmc passes (tools/pmc_traffic.py)
-        for name in ("r02_tcn_block_bf16_traffic.json", "r01_tcn_block_bf16_traffic.json"):
+        for name in ("r03_tcn_block_bf16_traffic.json", "r02_tcn_block_bf16_traffic.json", "r01_tcn_block_bf16_traffic.json"):
             tpath = os.path.join(REPO, "profiles", name)
             if args.precision == "bf16" and B == BATCH and os.path.exists(tpath):
                 with open(tpath) as f:
