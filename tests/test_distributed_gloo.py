@@ -15,14 +15,15 @@ ENC_CFG = {"channels": [16, 40, 64], "kernels": [25, 5, 4], "strides": [4, 2, 2]
 SEG, L_IN, L_REF = 512, 2300, 2900          # 5 input segments, 6 reference segments (uneven over 2 ranks)
 
 
-def _models():
+def _models(nblocks=3, enc_cfg=None):
     from music_mixing_style_transfer_amd.networks import FXencoder, TCNModel
     from music_mixing_style_transfer_amd.utils import synth
-    enc = FXencoder({k: (list(v) if isinstance(v, list) else v) for k, v in ENC_CFG.items()})
-    enc.load_state_dict(synth.fxencoder_state_dict(ENC_CFG, seed=1))
-    tcn = TCNModel(nparams=64, ninputs=2, noutputs=2, nblocks=3, dilation_growth=2, kernel_size=15, channel_width=128,
+    enc_cfg = ENC_CFG if enc_cfg is None else enc_cfg
+    enc = FXencoder({k: (list(v) if isinstance(v, list) else v) for k, v in enc_cfg.items()})
+    enc.load_state_dict(synth.fxencoder_state_dict(enc_cfg, seed=1))
+    tcn = TCNModel(nparams=64, ninputs=2, noutputs=2, nblocks=nblocks, dilation_growth=2, kernel_size=15, channel_width=128,
                    stack_size=15, cond_dim=64, causal=False)
-    tcn.load_state_dict(synth.tcn_state_dict(nblocks=3, cond_dim=64, seed=2))
+    tcn.load_state_dict(synth.tcn_state_dict(nblocks=nblocks, cond_dim=64, seed=2))
     return enc.eval(), tcn.eval()
 
 
@@ -152,12 +153,13 @@ def _cli_files_worker(rank, world, port, root):
     calls = []
     orig = Audio_Effects_Normalizer.normalize_audio
     Audio_Effects_Normalizer.normalize_audio = lambda self, audio, src: (calls.append(src), orig(self, audio, src))[1]
-    enc, tcn = _models()
-    a = types.SimpleNamespace(normalize_input=True, instruments=["drums", "bass"], segment_length=SEG, segment_length_ref=SEG, batch_size=1,
+    enc, tcn = _models(nblocks=2, enc_cfg={"channels": [16, 64], "kernels": [25, 5], "strides": [8, 4], "dilation": [1, 1], "bias": True,
+                                           "norm": "batch", "conv_block": "res", "activation": "relu"})      # 20 000-sample stems: a light pair of nets
+    a = types.SimpleNamespace(normalize_input=True, instruments=["drums", "bass"], segment_length=4096, segment_length_ref=4096, batch_size=1,
                               save_each_inst=True, sample_rate=44100, target_dir=os.path.join(root, "data") + "/", interpolation=False,
                               input_file_name="input", reference_file_name="reference", stem_level_directory_name="separated",
                               do_not_separate=True, precomputed_normalization_feature=_norm_features(),
-                              normalization_order=["loudness", "eq", "compression", "imager", "loudness"], workers=0)
+                              normalization_order=["loudness", "eq", "imager", "loudness"], workers=0)      # (compression matching: a minute on the emulator; test_normalizer.py)
     runner = object.__new__(st.Mixing_Style_Transfer_Inference)
     runner.args, runner.device = a, torch.device("cpu")
     runner.target_dir, runner.output_dir = a.target_dir, os.path.join(root, f"out{world}") + "/"
