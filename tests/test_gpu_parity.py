@@ -527,6 +527,54 @@ def test_style_transfer_cli_end_to_end(tmp_path):
     assert np.abs(mix - np.clip(ref_mix, -1, 1)).max() <= 1e-4 + 1.0 / 32767
 
 
+def test_song_prefetch_thread_and_host_path_give_the_same_files(tmp_path):
+    """Three songs through the runner with --normalize_input True: (a) songs prepared one ahead by the background thread (--workers 1:
+    decode + normaliser on their own stream while the previous song converts), (b) inline (--workers 0), (c) the dataset's host path
+    (numpy arrays like the reference, `data_loader.device = None`) - byte-identical output files in all three."""
+    from music_mixing_style_transfer_amd.inference import style_transfer as st
+    from music_mixing_style_transfer_amd.utils import synth
+    enc_cfg, _ = _cfgs()
+    synth.save_reference_format_checkpoint(str(tmp_path / "enc.pt"), synth.fxencoder_state_dict(enc_cfg, seed=0))
+    synth.save_reference_format_checkpoint(str(tmp_path / "tcn.pt"), synth.tcn_state_dict(seed=0))
+    np.save(str(tmp_path / "features.npy"), _norm_features())
+    stems = ["drums", "bass", "other", "vocals"]
+    L_in, L_ref, seg_len = 30000, 50000, 16384          # reference: 4 segments (an odd count would raise the reference's ragged-stack error)
+    hits = ((2000, 0.9), (9000, 0.6), (16000, 0.8), (23000, 0.5))
+    for n in range(3):
+        for kind, L in (("input", L_in), ("reference", L_ref)):
+            d = tmp_path / "data" / f"song{n}" / "separated" / kind
+            d.mkdir(parents=True)
+            for k, s in enumerate(stems):
+                base = synth.synth_music(2, L, seed=100 * n + 10 * k + (0 if kind == "input" else 5)).numpy().T
+                dr = _drum_like(L, 60 + 2 * k + n, [(n0 + 200 * k, a) for n0, a in hits if n0 + 200 * k < L - 2000])
+                _write_wav(d / (s + ".wav"), np.clip(0.25 * base + np.stack([dr, 0.6 * dr], 1), -1, 1).T)
+    with open(os.path.join(REPO, "music_mixing_style_transfer_amd", "networks", "configs.yaml")) as f:
+        cfgs = yaml.full_load(f)
+
+    def run(tag, workers, host):
+        args = st.build_parser().parse_args([
+            "--target_dir", str(tmp_path / "data") + "/", "--output_dir", str(tmp_path / tag) + "/", "--ckpt_path_enc", str(tmp_path / "enc.pt"),
+            "--ckpt_path_conv", str(tmp_path / "tcn.pt"), "--do_not_separate", "True", "--precomputed_normalization_feature",
+            str(tmp_path / "features.npy"), "--segment_length", str(seg_len), "--segment_length_ref", str(seg_len), "--batch_size", "2",
+            "--workers", str(workers), "--save_each_inst", "True"])
+        import copy          # FXencoder.__init__ inserts the input channel count into the caller's list, like the reference (architectures.py:30)
+        args.cfg_encoder, args.cfg_converter = copy.deepcopy(cfgs["Effects_Encoder"]["default"]), cfgs["TCN"]["default"]
+        runner = st.Mixing_Style_Transfer_Inference(args)
+        if host:
+            runner.data_loader.device = None
+        runner.inference()
+    run("out_thread", 1, False)
+    run("out_inline", 0, False)
+    run("out_host", 0, True)
+    for n in range(3):
+        names = sorted(os.listdir(tmp_path / "out_inline" / f"song{n}"))
+        assert len(names) == 5
+        for k in names:
+            ref = open(tmp_path / "out_inline" / f"song{n}" / k, "rb").read()
+            assert open(tmp_path / "out_thread" / f"song{n}" / k, "rb").read() == ref, (n, k, "prefetch thread")
+            assert open(tmp_path / "out_host" / f"song{n}" / k, "rb").read() == ref, (n, k, "host path")
+
+
 def test_config2_three_minute_stem_at_full_segment_length(nets):
     """BASELINE config 2 at its real sizes: one 3-minute stereo stem pair (7 938 000 samples), segment_length 2**19 =>
     16 segments (15 full + zero-padded tail) for both roles, fp32 mode.  The whole converted stem is checked through
