@@ -157,6 +157,10 @@ int mst_enc_load_conv(MstEnc *enc, int block, int which, const float *w, const f
  * (enc_conv_rows_kernel) instead of gathering an im2col slice per k-chunk; default 512, 0 = whenever the layer qualifies,
  * negative = never.  Both forms produce identical bits. */
 int mst_enc_set_tuning(MstEnc *enc, long rows_min_tiles);
+/* workgroup order of the channel-minor conv kernel (bf16 / bf16x3 modes).  bit 0 (default on): layers with more weight bytes than
+ * activation bytes run their workgroups in weight-major order - all column tiles of one (channel tile, k-slice) on one XCD, so a
+ * weight slice crosses the fabric once instead of once per XCD.  Same bits either way. */
+int mst_enc_set_schedule(MstEnc *enc, int flags);
 size_t mst_enc_workspace_bytes(const MstEnc *enc, int B, int L);
 /* replaces FXencoder.forward (architectures.py:65-70): x_dev fp32 [B, 2, L] -> emb_dev fp32 [B, C_last].
  * precision: MST_PREC_F32 (exact fp32 MFMA, parity mode) or MST_PREC_BF16 (bf16 operands, fp32 accumulate;

@@ -394,6 +394,8 @@ struct EncNlcArgs {
     int B, Cin, Lin, Cout, Lout, stride, nchunks, residual, S;
     long Ntot;
     int ksz, pad_l;      // enc_conv_rows_kernel only
+    int wmajor;          // enc_conv_nlc_kernel: > 0 = 1-d grid in WEIGHT-major order, value = number of channel tiles (see the kernel)
+    const void *zeros;   // enc_conv_nlc_kernel: 16 bytes of zeros (rows / k-slots outside the problem are fetched from here)
 };
 
 // implicit-GEMM convolution on NLC bf16 activations, v_mfma_f32_32x32x16_bf16, K-chunk = 64 (8 slots per row).
@@ -418,8 +420,23 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ln = lane & 31, h = lane >> 5;
     const int mi = w % MW, ni = w / MW;
-    const long n0 = (long)blockIdx.x * NT;
-    const int cot = blockIdx.y, z = blockIdx.z;
+    // workgroup -> (column tile, channel tile, k-slice).  Workgroups go round-robin over the 8 XCDs (their own L2 each).  Default order:
+    // column tile fastest - the channel tiles / k-slices of a column tile meet in one L2 and share its ACTIVATION rows.  The short wide late
+    // layers (1024 columns, 10-42 MB of weights) are the other way round: there every XCD fetched the whole weight image (8 x 42 MB
+    // through the fabric per launch); in weight-major order (channel tile, k-slice) runs fastest, so that all column tiles of one weight
+    // slice sit on ONE XCD and the slice crosses the fabric once.
+    long n0;
+    int cot, z;
+    if (a.wmajor > 0) {
+        const int cz = a.wmajor * a.S, q = (int)(blockIdx.x % cz);
+        n0 = (long)(blockIdx.x / cz) * NT;
+        cot = q % a.wmajor;
+        z = q / a.wmajor;
+    } else {
+        n0 = (long)blockIdx.x * NT;
+        cot = blockIdx.y;
+        z = blockIdx.z;
+    }
     const int kc_lo = (int)((long)z * a.nchunks / a.S), kc_hi = (int)((long)(z + 1) * a.nchunks / a.S);
     const int slot = tid & 7;
 
@@ -447,32 +464,42 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
     bf16x8 anxt[4], acur[4], breg[NL];
     bf16x8 anxt_lo[X3 ? 4 : 1], acur_lo[X3 ? 4 : 1], breg_lo[X3 ? NL : 1];
 
+    // The loads of chunk kc + 1 are issued at the top of chunk kc's MFMA block and must stay in flight across it.  Two things kept them
+    // from doing so (ISA of round 3: `s_waitcnt vmcnt(0)` BEFORE the MFMAs, i.e. two serial memory latencies per chunk and no overlap
+    // inside a wave): (1) the row addresses depend on the slot table entry, itself a load - the entry is now fetched one chunk earlier
+    // (sj / sc); (2) rows / k-slots outside the problem were zeroed by a select on the loaded value, which hipcc schedules right behind the
+    // load - they are now fetched from a zero page instead (select on the ADDRESS, nothing to do on the value).
+    int sj = 0, sc = -1;                              // slot table entry of the chunk the next fetch() stages
+    auto stab_entry = [&](int kc) {
+        const int k2 = kc < kc_hi ? kc : kc_hi - 1;
+        const u32x2 e = *(const u32x2 *)(a.stab + (k2 * 8 + slot) * 2);
+        sj = (int)e[0];
+        sc = (int)e[1];
+    };
     auto fetch = [&](int kc) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             anxt[ks] = wtile[((size_t)(kc * 4 + ks) * MW + mi) * 64 + lane];
             if constexpr (X3) anxt_lo[ks] = wtile_lo[((size_t)(kc * 4 + ks) * MW + mi) * 64 + lane];
         }
-        const int joff = a.stab[(kc * 8 + slot) * 2], ci0 = a.stab[(kc * 8 + slot) * 2 + 1];
+        const int joff = sj, ci0 = sc;
 #pragma unroll
         for (int e = 0; e < NL; ++e) {
-            // never a predicated load (hipcc branches around it and drains vmcnt(0) behind it): rows / k-slots outside the
-            // problem read element 0 of the activation and are zeroed by a select
             const bool ok = ci0 >= 0 && rowb[e] >= 0;
             int ti = rowt[e] + joff;
             if (ti < 0) ti = -ti;
             if (ti >= a.Lin) ti = 2 * (a.Lin - 1) - ti;
-            const size_t off = ok ? ((size_t)rowb[e] * a.Lin + ti) * a.Cin + ci0 : 0;
-            const bf16x8 ld = *(const bf16x8 *)(a.x + off);
-            breg[e] = ok ? ld : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if constexpr (X3) {
-                const bf16x8 ll = *(const bf16x8 *)(a.xlo + off);
-                breg_lo[e] = ok ? ll : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            }
+            const size_t off = ((size_t)rowb[e] * a.Lin + ti) * a.Cin + ci0;
+            breg[e] = *(const bf16x8 *)(ok ? (const void *)(a.x + off) : a.zeros);
+            if constexpr (X3) breg_lo[e] = *(const bf16x8 *)(ok ? (const void *)(a.xlo + off) : a.zeros);
         }
+        stab_entry(kc + 1);
     };
 
-    if (kc_lo < kc_hi) fetch(kc_lo);
+    if (kc_lo < kc_hi) {
+        stab_entry(kc_lo);
+        fetch(kc_lo);
+    }
     for (int kc = kc_lo; kc < kc_hi; ++kc) {
         if (kc > kc_lo) __syncthreads();
 #pragma unroll

@@ -398,6 +398,7 @@ template <int P, int NQ> int launch_block_duo(TcnBlockArgs a, void *stream) {
     const long nsteps = ((long)a.L + a.d - 1) / a.d;
     a.tiles_step = (int)((nsteps + (32 * NQ) / P - 1) / ((32 * NQ) / P));
     const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
+    if (ntiles > 0x7fffffffL) return fail(MST_ERR_ARG, "tcn_block_bf16_duo_kernel: more than 2^31 tiles");
     long grid = mst_num_cus();
     if (grid > ntiles) grid = ntiles;
     a.xcd_tiles = 0;
@@ -725,6 +726,8 @@ extern "C" int mst_tcn_forward_blocks(MstTcn *t, const float *x, float *act, int
 struct MstEnc {
     MstEncDesc d;
     std::vector<MstEncConv> conv;   // 2 per block
+    int schedule = 1;               // bit 0: weight-major workgroup order for the weight-heavy layers (mst_enc_set_schedule)
+    void *zeros = nullptr;          // 256 bytes of zeros: what the channel-minor conv kernel fetches for rows / k-slots outside the problem
     long rows_min_tiles = 512;      // bf16 mode: layers with at least this many tiles keep their input rows resident in LDS (mst_enc_set_tuning)
 };
 
@@ -736,6 +739,11 @@ extern "C" int mst_enc_create(const MstEncDesc *desc, MstEnc **out) {
             desc->channels[i + 1] < 1)
             return fail(MST_ERR_ARG, "mst_enc_create: bad layer description");
     MstEnc *e = new MstEnc();
+    if (hipMalloc(&e->zeros, 256) != hipSuccess || hipMemset(e->zeros, 0, 256) != hipSuccess) {
+        (void)hipFree(e->zeros);
+        delete e;
+        return fail(MST_ERR_HIP, "mst_enc_create: hipMalloc failed");
+    }
     e->d = *desc;
     e->conv.resize(2 * desc->nblocks);
     for (int i = 0; i < desc->nblocks; ++i)
@@ -769,6 +777,7 @@ extern "C" int mst_enc_destroy(MstEnc *e) {
         (void)hipFree(c.shift);
         (void)hipFree(c.ktab);
     }
+    (void)hipFree(e->zeros);
     delete e;
     return MST_OK;
 }
@@ -853,6 +862,12 @@ extern "C" int mst_enc_load_conv(MstEnc *e, int block, int which, const float *w
     if ((rc = upload(&c.shift, sh))) return rc;
     if ((rc = upload(&c.ktab, kt))) return rc;
     c.loaded = true;
+    return MST_OK;
+}
+
+extern "C" int mst_enc_set_schedule(MstEnc *e, int flags) {
+    if (!e || flags < 0 || flags > 1) return fail(MST_ERR_ARG, "mst_enc_set_schedule: flags 0..1");
+    e->schedule = flags;
     return MST_OK;
 }
 
@@ -1046,7 +1061,7 @@ int enc_launch_direct(const MstEncConv &c, const float *x, void *y, bool out_nlc
 
 // x3: split mode - x / y point at the high parts' planes, the low parts' planes follow at B * L * C elements
 int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scratch, int B, int Lin, int Lout, int residual,
-                   long rows_min_tiles, void *stream, bool x3 = false) {
+                   long rows_min_tiles, void *stream, bool x3 = false, int schedule = 0, const void *zeros = nullptr) {
     if (Lin <= c.pad_l || Lin <= c.pad_r)
         return fail(MST_ERR_ARG, "mst_enc_forward: reflection padding needs the input to be longer than the padding");
     EncNlcArgs a;
@@ -1071,6 +1086,9 @@ int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scrat
     const long ntiles = (a.Ntot + NT - 1) / NT, cotiles = (c.cout + MT - 1) / MT;
     a.ksz = c.ksz;
     a.pad_l = c.pad_l;
+    a.wmajor = 0;
+    a.zeros = zeros;
+    if (!zeros) return fail(MST_ERR_ARG, "enc_launch_nlc: no zero page");
     {
         // long early layers: the tile's input rows resident in LDS instead of an im2col slice per k-chunk
         const long tiles_item = (Lout + NT - 1) / NT;
@@ -1099,7 +1117,12 @@ int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scrat
     }
     a.S = enc_splitk(ntiles * cotiles, c.nchunks64);
     a.part = a.S > 1 ? scratch : nullptr;
-    const dim3 grid((unsigned)ntiles, (unsigned)cotiles, (unsigned)a.S);
+    dim3 grid((unsigned)ntiles, (unsigned)cotiles, (unsigned)a.S);
+    // weight-heavy layers (more weight bytes than activation bytes, at least 8 weight slices): weight-major workgroup order (see the kernel)
+    if ((schedule & 1) && (long)c.cout * c.cin * c.ksz > a.Ntot * c.cin && cotiles * a.S >= 8) {
+        a.wmajor = (int)cotiles;
+        grid = dim3((unsigned)(ntiles * cotiles * a.S));
+    }
     if (x3) {
         switch (c.mw) {
             case 1: MST_LAUNCH((enc_conv_nlc_kernel<1, true>), grid, dim3(256), stream, a); break;
@@ -1138,8 +1161,8 @@ int enc_run_nlc(MstEnc *e, const float *x, float *emb, float *blk_out, int B, in
             void *lo_plane = x3 ? (void *)((__bf16 *)o[pp] + (size_t)B * lout * e->conv[1].cout) : nullptr;
             if ((rc = enc_launch_direct(e->conv[1], (const float *)t1, o[pp], true, B, len, lout, 0, stream, lo_plane))) return rc;
         } else {
-            if ((rc = enc_launch_nlc(e->conv[2 * i], (const __bf16 *)cur, (__bf16 *)t1, scratch, B, len, len, 1, e->rows_min_tiles, stream, x3))) return rc;
-            if ((rc = enc_launch_nlc(e->conv[2 * i + 1], (const __bf16 *)t1, (__bf16 *)o[pp], scratch, B, len, lout, 0, e->rows_min_tiles, stream, x3))) return rc;
+            if ((rc = enc_launch_nlc(e->conv[2 * i], (const __bf16 *)cur, (__bf16 *)t1, scratch, B, len, len, 1, e->rows_min_tiles, stream, x3, e->schedule, e->zeros))) return rc;
+            if ((rc = enc_launch_nlc(e->conv[2 * i + 1], (const __bf16 *)t1, (__bf16 *)o[pp], scratch, B, len, lout, 0, e->rows_min_tiles, stream, x3, e->schedule, e->zeros))) return rc;
         }
         cur = o[pp];
         pp ^= 1;

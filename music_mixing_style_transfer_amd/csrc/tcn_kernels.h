@@ -599,12 +599,13 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
     const int l16 = lane & 15, g = lane >> 4;
 
     // ---- this workgroup's tiles: workgroup i runs on XCD i % 8 and walks tiles (i % 8) * xcd_tiles + i / 8 + n * gridDim.x / 8
-    const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
-    long tile, tstep, tend;
+    // (32-bit tile numbers - the launcher checks the count: a 64-bit division is ~100 instructions, taken from the matrix wave's issue slots)
+    const unsigned ntiles = (unsigned)a.B * (unsigned)a.tiles_phase * (unsigned)a.tiles_step;
+    unsigned tile, tstep, tend;
     if (a.xcd_tiles > 0) {
-        tile = (long)(blockIdx.x & 7) * a.xcd_tiles + (blockIdx.x >> 3);
+        tile = (blockIdx.x & 7) * (unsigned)a.xcd_tiles + (blockIdx.x >> 3);
         tstep = gridDim.x >> 3;
-        tend = (long)((blockIdx.x & 7) + 1) * a.xcd_tiles;
+        tend = ((blockIdx.x & 7) + 1) * (unsigned)a.xcd_tiles;
         if (tend > ntiles) tend = ntiles;
     } else {
         tile = blockIdx.x;
@@ -613,12 +614,12 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
     }
     if (tile >= tend) return;       // uniform
 
-    auto tile_geometry = [&](long tl, int &b, int &m0, int &phi0) {
-        const int mg = (int)(tl % a.tiles_step);
-        const long r = tl / a.tiles_step;
-        phi0 = (int)(r % a.tiles_phase) * P;
-        b = (int)(r / a.tiles_phase);
-        m0 = mg * MT;
+    auto tile_geometry = [&](unsigned tl, int &b, int &m0, int &phi0) {
+        const unsigned r = tl / (unsigned)a.tiles_step, mg = tl - r * (unsigned)a.tiles_step;
+        const unsigned bb = r / (unsigned)a.tiles_phase;
+        phi0 = (int)(r - bb * (unsigned)a.tiles_phase) * P;
+        b = (int)bb;
+        m0 = (int)mg * MT;
     };
     // loader waves: all pieces of tile (b, m0, phi0) that belong to this wave (k = w mod 4), into buffer buf.  A tile that lies inside the
     // segment (all but the first / last of a phase group) needs no bounds test: the pieces of a wave are 16 rows = 16 / P steps apart,
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
         const int lt = tid - 256;                      // 0..255: thread (prow, slot) of the row passes, like the one-tile kernel's
         for (;;) {
             const int b = tb, m0 = tm0, phi0 = tphi0;
-            const long tnext = tile + tstep;
+            const unsigned tnext = tile + tstep;
             const bool has_next = tnext < tend;
             if (has_next) {
                 tile_geometry(tnext, tb, tm0, tphi0);
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
     int cur = 0, bprev = tb;
     for (;;) {
         const int b = tb, m0 = tm0, phi0 = tphi0;
-        const long tnext = tile + tstep;
+        const unsigned tnext = tile + tstep;
         const bool has_next = tnext < tend;
         if (has_next) tile_geometry(tnext, tb, tm0, tphi0);
         unsigned char *const sm = smem + cur * BUF;
