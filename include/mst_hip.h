@@ -197,14 +197,22 @@ int mst_embedding_mean(const float *emb_dev, int n_rows, int dim, float *out_dev
  * ---------------------------------------------------------------------------------------------- */
 /* Chain fusion (AugmentationChain.apply_processor :115-148 without its extra passes).  A processor entry point that takes an
  * MstFxFuse reads its input as x * (float)in_scale_dev[item] - the PENDING factor of the previous processor's rms-normalise,
- * applied in float32 exactly like the separate scale pass would - and adds sum(y^2) of every item of its raw output to
- * out_sumsq_dev[item] (float64; zeroed by the caller; the imager writes its closed form), so that an rms-normalise step costs
+ * applied in float32 exactly like the separate scale pass would - and leaves sum(y^2) of every item of its raw output in
+ * out_sumsq_dev[item] (float64; the first launch of the call clears the slots, the caller need not; the imager writes its closed
+ * form), so that an rms-normalise step costs
  * one tiny mst_fx_rms_pending launch instead of two energy passes and a scale pass over the audio.  fuse = NULL or both
  * members NULL: the plain processor.  mst_fx_scale_items applies a pending factor when a chain ends with one. */
 #define MST_SUMSQ_SLOTS 64     /* an energy sum is kept as 64 partial sums per item (producers spread their atomics over them) */
 typedef struct {
     const double *in_scale_dev;   /* [n_items] or NULL */
-    double *out_sumsq_dev;        /* [n_items][MST_SUMSQ_SLOTS] or NULL, zeroed by the caller */
+    double *out_sumsq_dev;        /* [n_items][MST_SUMSQ_SLOTS] or NULL; overwritten */
+    /* tail folding (mst_fx_midside_imager only; the other entry points refuse post_rms != 0): the rms-normalise that FOLLOWS the
+     * processor and a Gain behind it happen in the processor's own last pass, y_out = (y * s) * post_gain in float32 - the values the
+     * separate mst_fx_rms_pending + mst_fx_gain launches produce - with s from in_sumsq_dev = sum(x_raw^2) of the processor's raw input
+     * ([n_items][MST_SUMSQ_SLOTS]) and the closed-form energy of y */
+    const double *in_sumsq_dev;
+    int post_rms;
+    float post_gain;
 } MstFxFuse;
 int mst_fx_sumsq(const float *x_dev, int n_items, long per_item, double *out_dev, void *stream);   /* out[item][slot]: partial sums of x^2 */
 /* scale_out[item] = float32(sqrt(mean(x_true^2) / max(1e-7, mean(y^2)))), mean(x_true^2) = scale_x^2 sum_slots(sumsq_x) / per_x
@@ -228,7 +236,7 @@ size_t mst_fx_compressor_scratch_bytes(int n_items, long L, int C);
 int mst_fx_compressor(const float *x_dev, float *y_dev, int n_items, long L, int C, double threshold_db,
                       double attack_ms, double release_ms, double ratio, double sample_rate, double *scratch_dev,
                       size_t scratch_bytes, const MstFxFuse *fuse, void *stream);
-/* MidSideImager.process (:964-1007), stereo only; scratch_dev: >= n_items*2 doubles */
+/* MidSideImager.process (:964-1007), stereo only; scratch_dev: >= n_items * 2 * MST_SUMSQ_SLOTS doubles (partial energy sums) */
 int mst_fx_midside_imager(const float *x_dev, float *y_dev, int n_items, long L, double bal, double *scratch_dev,
                           const MstFxFuse *fuse, void *stream);
 /* Haas.process / haas_process (:768-786, :826-843): y = x, y[:, wet] += feedback * np.roll(x[:, wet], delay) - the roll is

@@ -66,6 +66,7 @@ __global__ __launch_bounds__(64) void fx_biquad_kernel(BiquadArgs a) {
 // energy sums of the chain fusion are kept as MST_SUMSQ_SLOTS partial sums per item (producers spread their atomics over the slots:
 // a 64-segment batch is 4096 tiles per kernel onto 64 items - one address per item serialises ~2000 atomics, measured +0.4 ms)
 #define MST_SUMSQ_SLOTS 64
+#define MST_IMAGER_FRAMES 2048    // frames per workgroup of fx_imager_apply_kernel
 
 struct BiquadChunkArgs {
     const float *x;
@@ -86,6 +87,10 @@ struct BiquadChunkArgs {
 template <bool APPLY, int NBANDS>
 __global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) {
     const long gid = (long)blockIdx.x * 64 + threadIdx.x;
+    if constexpr (!APPLY) {          // the state pass clears the energy slots the apply pass adds to (no memset launch in front of the call)
+        if (a.out_sumsq)
+            for (long i = gid; i < (long)(a.n_seq / a.C) * MST_SUMSQ_SLOTS; i += (long)gridDim.x * 64) a.out_sumsq[i] = 0.0;
+    }
     if (gid >= (long)a.n_seq * a.nchunks) return;
     // lanes: channel fastest, then chunk, then item - neighbouring lanes read neighbouring samples of a frame
     const int c = (int)(gid % a.C);
@@ -543,6 +548,10 @@ __global__ __launch_bounds__(64) MST_WAVES_PER_SIMD(4) MST_HEAVY_UNROLL void fx_
     // the level differences x_l are computed here from the audio (a lane walks its own sequence: 32 frames = 256 contiguous bytes that
     // it shares with the lane of the other channel), not read from a float64 scratch that a separate pass would have to write
     for (int i = threadIdx.x; i < 256; i += 64) tab[i] = a.log_tab[i];
+    if (ca.out_sumsq) {             // the first launch of a compressor call clears the energy slots its apply pass adds to
+        const long nthr = (long)gridDim.x * gridDim.y * 64, me = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 64 + threadIdx.x;
+        for (long i = me; i < (long)(ca.n_seq / ca.C) * MST_SUMSQ_SLOTS; i += nthr) ca.out_sumsq[i] = 0.0;
+    }
     const int item = (int)(sq / ca.C);
     const FxCompCurve cv = fx_comp_curve(ca, item);
     const float *xp = ca.x + ((size_t)(ca.shared_x ? 0 : item) * ca.L) * ca.C + sq % ca.C;
@@ -852,30 +861,95 @@ __global__ __launch_bounds__(256) void fx_energy_kernel(const float *x, double *
     }
 }
 
+// the imager's two energies without atomics and without a cleared accumulator: workgroup (item, chunk) leaves its two partial sums at
+// part[item][chunk][2]; the apply kernel adds the `chunks` partials of its item in order (a deterministic sum)
+__global__ __launch_bounds__(256) void fx_energy_parts_kernel(const float *x, double *part, long L, int chunks) {
+    __shared__ double red[2][4];
+    const int item = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const long per_chunk = (L + chunks - 1) / chunks;
+    const long lo = chunk * per_chunk, hi = (lo + per_chunk < L) ? lo + per_chunk : L;
+    const float *xp = x + (size_t)item * L * 2;
+    double s0 = 0.0, s1 = 0.0;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) {
+        const float l = xp[2 * i], r = xp[2 * i + 1];
+        const float m = l + r, s = l - r;
+        s0 += (double)(m * m);
+        s1 += (double)(s * s);
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s0;
+        red[1][threadIdx.x >> 6] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((size_t)item * chunks + chunk) * 2 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        part[((size_t)item * chunks + chunk) * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
 // MidSideImager.process (:964-1007): gains from the two energies, applied in float32 like the reference
 // chain fusion: in_scale = the pending rms factor of the previous processor (the energies of the raw input scale with its square, the
 // samples are multiplied in float32 like the separate scale pass would); out_sumsq[item] = sum(y^2), here in closed form from the gains
-__global__ __launch_bounds__(256) void fx_imager_apply_kernel(const float *x, float *y, const double *acc, long L,
-                                                              double bal_rounded, const double *in_scale, double *out_sumsq) {
+// tail folding (in_sumsq non-null): the rms-normalise behind the imager and a gain behind that, in this pass: s is the factor
+// fx_rms_pending_kernel computes (energy of the true input = sf^2 * sum of the raw input's slots), the store is (y * s) * post_gain
+// like fx_scale_kernel's x * sf * g
+__global__ __launch_bounds__(256) void fx_imager_apply_kernel(const float *x, float *y, const double *part, int chunks, long L,
+                                                              double bal_rounded, const double *in_scale, double *out_sumsq,
+                                                              const double *in_sumsq, float post_gain) {
+    // a workgroup = MST_IMAGER_FRAMES frames of one item; its first wave adds the item's partial energies (and, when folding, the
+    // slots of the input's energy) - one load per lane and the wave's butterfly sum, the order fx_rms_pending_kernel uses too
+    __shared__ double sh[3];
     const int item = blockIdx.y;
+    if (threadIdx.x < 64) {
+        const int t = threadIdx.x;
+        double e0 = t < chunks ? part[((size_t)item * chunks + t) * 2 + 0] : 0.0;
+        double e1 = t < chunks ? part[((size_t)item * chunks + t) * 2 + 1] : 0.0;
+        double q = in_sumsq ? in_sumsq[item * MST_SUMSQ_SLOTS + t] : 0.0;
+        e0 = wave_sum(e0);
+        e1 = wave_sum(e1);
+        q = wave_sum(q);
+        if (t == 0) {
+            sh[0] = e0;
+            sh[1] = e1;
+            sh[2] = q;
+        }
+    }
+    __syncthreads();
     const float sf = in_scale ? (float)in_scale[item] : 1.0f;
     const double s2 = (double)sf * (double)sf;
-    const double mid_e = acc[item * 2] * s2, side_e = acc[item * 2 + 1] * s2;
+    const double mid_e = sh[0] * s2, side_e = sh[1] * s2;
     const double total_e = mid_e + side_e;
     const double max_side = sqrt(total_e / (side_e + 1e-3));
     const double side_gain = (bal_rounded <= 1.0) ? bal_rounded : max_side * (bal_rounded - 1.0);
     const double mid_gain = sqrt((total_e - side_e * side_gain * side_gain) / (mid_e + 1e-3));
     const float sg = (float)side_gain, mg = (float)mid_gain;
-    if (out_sumsq && blockIdx.x == 0 && threadIdx.x == 0)      // sum(l'^2 + r'^2) = (mg^2 sum(mid^2) + sg^2 sum(side^2)) / 2
-        out_sumsq[item * MST_SUMSQ_SLOTS] = ((double)mg * mg * mid_e + (double)sg * sg * side_e) / 2.0;     // slot 0; the others stay zero
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= L) return;
-    const float *xp = x + ((size_t)item * L + i) * 2;
-    float *yp = y + ((size_t)item * L + i) * 2;
-    const float l = xp[0] * sf, r = xp[1] * sf;
-    const float nm = (l + r) * mg, ns = (l - r) * sg;
-    yp[0] = (nm + ns) / 2.0f;
-    yp[1] = (nm - ns) / 2.0f;
+    const double sumsq_y = ((double)mg * mg * mid_e + (double)sg * sg * side_e) / 2.0;     // sum(l'^2 + r'^2), closed form
+    if (out_sumsq && blockIdx.x == 0 && threadIdx.x < MST_SUMSQ_SLOTS)                     // slot 0; the others are cleared
+        out_sumsq[item * MST_SUMSQ_SLOTS + threadIdx.x] = threadIdx.x == 0 ? sumsq_y : 0.0;
+    float ps = 1.0f;
+    if (in_sumsq) {
+        const double ex = s2 * sh[2] / (double)(2 * L), ey = sumsq_y / (double)(2 * L);
+        ps = (float)sqrt(ex / fmax(1e-7, ey));
+    }
+#pragma unroll
+    for (int j = 0; j < MST_IMAGER_FRAMES / 256; ++j) {
+        const long i = (long)blockIdx.x * MST_IMAGER_FRAMES + j * 256 + threadIdx.x;
+        if (i < L) {
+            const float *xp = x + ((size_t)item * L + i) * 2;
+            float *yp = y + ((size_t)item * L + i) * 2;
+            const float l = xp[0] * sf, r = xp[1] * sf;
+            const float nm = (l + r) * mg, ns = (l - r) * sg;
+            float o0 = (nm + ns) / 2.0f, o1 = (nm - ns) / 2.0f;
+            if (in_sumsq) {
+                o0 = o0 * ps * post_gain;
+                o1 = o1 * ps * post_gain;
+            }
+            yp[0] = o0;
+            yp[1] = o1;
+        }
+    }
 }
 
 // Gain.process (:1041-1051) and the final multiply of the rms normalise (:145-146)
@@ -1254,19 +1328,14 @@ __global__ __launch_bounds__(256) void fx_reverb_mix_kernel(const float *x, cons
 // Rounded to float32 like the reference's scale factor.
 __global__ __launch_bounds__(64) void fx_rms_pending_kernel(const double *s_x, const double *sumsq_x, long per_x, const double *sumsq_y,
                                                            long per_y, double *s_out, int n_items) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n_items) return;
+    const int i = blockIdx.x;          // one wave per item: a slot per lane, the wave's butterfly sum
     const float sx = s_x ? (float)s_x[i] : 1.0f;
-    double qx = 0.0, qy = 0.0;
-    for (int k = 0; k < MST_SUMSQ_SLOTS; ++k) {
-        qx += sumsq_x[i * MST_SUMSQ_SLOTS + k];
-        qy += sumsq_y[i * MST_SUMSQ_SLOTS + k];
-    }
+    const double qx = wave_sum(sumsq_x[i * MST_SUMSQ_SLOTS + threadIdx.x]), qy = wave_sum(sumsq_y[i * MST_SUMSQ_SLOTS + threadIdx.x]);
     const double ex = (double)sx * (double)sx * qx / (double)per_x, ey = qy / (double)per_y;
-    s_out[i] = (double)(float)sqrt(ex / fmax(1e-7, ey));
+    if (threadIdx.x == 0) s_out[i] = (double)(float)sqrt(ex / fmax(1e-7, ey));
 }
 
-// out[item] += sum of x^2 over the chunk-th part of the item (float64); grid n_items * chunks
+// out[item][chunk] = sum of x^2 over the chunk-th part of the item (float64), slots chunks .. 63 cleared; grid n_items * chunks, chunks <= 64
 __global__ __launch_bounds__(256) void fx_sumsq_kernel(const float *x, double *out, long per_item, int chunks) {
     __shared__ double red[4];
     const int item = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
@@ -1281,5 +1350,6 @@ __global__ __launch_bounds__(256) void fx_sumsq_kernel(const float *x, double *o
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&out[item * MST_SUMSQ_SLOTS + (chunk & (MST_SUMSQ_SLOTS - 1))], (red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) out[item * MST_SUMSQ_SLOTS + chunk] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (chunk == 0 && threadIdx.x >= chunks && threadIdx.x < MST_SUMSQ_SLOTS) out[item * MST_SUMSQ_SLOTS + threadIdx.x] = 0.0;
 }

@@ -3,6 +3,7 @@
 #include "../../include/mst_hip.h"
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1331,6 +1332,7 @@ extern "C" size_t mst_fx_biquad_scratch_bytes(int n_items, long L, int C, int n_
 extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long L, int C, const double *coef, int n_bands,
                                      double *scratch, size_t scratch_bytes, const MstFxFuse *fuse, void *stream) {
     if (!x || !y || !coef || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_biquad_cascade: bad argument");
+    if (fuse && fuse->post_rms) return fail(MST_ERR_UNSUPPORTED, "mst_fx_biquad_cascade: tail folding (post_rms) is the imager's");
     if (n_bands < 0 || n_bands > MST_MAX_BANDS) return fail(MST_ERR_UNSUPPORTED, "mst_fx_biquad_cascade: at most 8 bands");
     const int M = biquad_chunk(L, (long)n_items * C);
     const long nchunks = (L + M - 1) / M;
@@ -1460,6 +1462,26 @@ extern "C" size_t mst_fx_compressor_scratch_bytes(int n_items, long L, int C) {
 }
 
 namespace {
+// fx_log10_table_kernel's 256 doubles, one copy per device, made by the first compressor call there (kept for the life of the process)
+const double *log10_table(void *stream) {
+    static std::mutex mu;
+    static double *tabs[64] = {};
+    const int dev = mst_current_device();
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!tabs[dev]) {
+        double *t = nullptr;
+        if (hipMalloc((void **)&t, 256 * sizeof(double)) != hipSuccess) return nullptr;
+        MST_LAUNCH(fx_log10_table_kernel, dim3(1), dim3(128), stream, t);
+        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+            (void)hipFree(t);
+            return nullptr;
+        }
+        tabs[dev] = t;
+    }
+    return tabs[dev];
+}
+
 int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size_t scratch_bytes, void *stream) {
     if (scratch) {
         if (scratch_bytes < mst_fx_compressor_scratch_bytes(n_items, L, C))
@@ -1467,15 +1489,15 @@ int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size
         const dim3 tiles((unsigned)((L + 63) / 64), (unsigned)((a.n_seq + 63) / 64));      // 64 x 64 (time x sequence) tiles
         const CompScratch cs = comp_scratch(n_items, L, C);
         if (cs.nchunks < 4) {
+            if (a.out_sumsq) MST_HIP_TRY(hipMemsetAsync(a.out_sumsq, 0, (size_t)n_items * MST_SUMSQ_SLOTS * sizeof(double), (hipStream_t)stream));
             MST_LAUNCH(fx_comp_gain_kernel, tiles, dim3(256), stream, a, scratch);
             MST_CHECK_LAUNCH("fx_comp_gain_kernel");
             MST_LAUNCH(fx_comp_smooth_kernel, dim3((a.n_seq + 63) / 64), dim3(64), stream, a, scratch);
             MST_CHECK_LAUNCH("fx_comp_smooth_kernel");
         } else {       // the smoother parallel in time: chunk maps (convex piecewise-linear), a chain over chunks, the rest in one pass
             CompMapArgs m;
-            double *tab = (double *)((unsigned char *)scratch + cs.xl + cs.maps + cs.ystart);
-            MST_LAUNCH(fx_log10_table_kernel, dim3(1), dim3(128), stream, tab);
-            MST_CHECK_LAUNCH("fx_log10_table_kernel");
+            const double *tab = log10_table(stream);          // a constant of the device: built on first use
+            if (!tab) return fail(MST_ERR_HIP, "mst_fx_compressor: log10 table");
             m.log_tab = tab;
             m.maps = (double *)((unsigned char *)scratch + cs.xl);
             m.ystart = (double *)((unsigned char *)scratch + cs.xl + cs.maps);
@@ -1500,7 +1522,7 @@ int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size
             MST_CHECK_LAUNCH("fx_comp_map_kernel");
             MST_LAUNCH(fx_comp_chain_kernel, dim3(a.n_seq), dim3(MST_CHAIN_THREADS), stream, m);
             MST_CHECK_LAUNCH("fx_comp_chain_kernel");
-            MST_LAUNCH((fx_comp_apply_kernel<true>), tiles, dim3(256), stream, a, (const double *)tab, (const double *)m.ystart, m.nchunks);
+            MST_LAUNCH((fx_comp_apply_kernel<true>), tiles, dim3(256), stream, a, tab, (const double *)m.ystart, m.nchunks);
             MST_CHECK_LAUNCH("fx_comp_apply_kernel");
             return MST_OK;
         }
@@ -1520,6 +1542,7 @@ extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, 
     if (!x || !y || n_items < 1 || L < 1 || C < 1 || attack_ms <= 0 || release_ms <= 0 || ratio <= 0 || sample_rate <= 0)
         return fail(MST_ERR_ARG, "mst_fx_compressor: bad argument");
     const bool fused = fuse && (fuse->in_scale_dev || fuse->out_sumsq_dev);
+    if (fuse && fuse->post_rms) return fail(MST_ERR_UNSUPPORTED, "mst_fx_compressor: tail folding (post_rms) is the imager's");
     if (fused && (!scratch || (threshold_db == 0.0 && ratio == 1.0)))
         return fail(MST_ERR_UNSUPPORTED, "mst_fx_compressor: chain fusion needs the scratch buffer and an active compressor");
     if (threshold_db == 0.0 && ratio == 1.0) {   // bypass (common_audioeffects.py:637)
@@ -1616,12 +1639,17 @@ int energy(const float *x, double *acc, int n_items, long per_item, int mode, vo
 extern "C" int mst_fx_midside_imager(const float *x, float *y, int n_items, long L, double bal, double *scratch, const MstFxFuse *fuse,
                                      void *stream) {
     if (!x || !y || !scratch || n_items < 1 || L < 1) return fail(MST_ERR_ARG, "mst_fx_midside_imager: bad argument");
-    int rc;
-    if ((rc = energy(x, scratch, n_items, 2 * L, 1, stream))) return rc;
+    const bool fold = fuse && fuse->post_rms;
+    if (fold && !fuse->in_sumsq_dev) return fail(MST_ERR_ARG, "mst_fx_midside_imager: post_rms needs in_sumsq_dev");
+    int chunks = (int)std::min<long>(MST_SUMSQ_SLOTS, (L + 8191) / 8192);
+    if (chunks < 1) chunks = 1;
+    MST_LAUNCH(fx_energy_parts_kernel, dim3(n_items * chunks), dim3(256), stream, x, scratch, L, chunks);
+    MST_CHECK_LAUNCH("fx_energy_parts_kernel");
     const double bal_r = std::round(bal * 1000.0) / 1000.0;   // round(bal, 3) (:980)
-    MST_LAUNCH(fx_imager_apply_kernel, dim3((unsigned)((L + 255) / 256), n_items), dim3(256), stream, x, y,
-               (const double *)scratch, L, bal_r, fuse ? fuse->in_scale_dev : (const double *)nullptr,
-               fuse ? fuse->out_sumsq_dev : (double *)nullptr);
+    MST_LAUNCH(fx_imager_apply_kernel, dim3((unsigned)((L + MST_IMAGER_FRAMES - 1) / MST_IMAGER_FRAMES), n_items), dim3(256), stream, x, y,
+               (const double *)scratch, chunks, L, bal_r, fuse ? fuse->in_scale_dev : (const double *)nullptr,
+               fuse ? fuse->out_sumsq_dev : (double *)nullptr, fold ? fuse->in_sumsq_dev : (const double *)nullptr,
+               fold ? fuse->post_gain : 1.0f);
     MST_CHECK_LAUNCH("fx_imager_apply_kernel");
     return MST_OK;
 }
@@ -1629,6 +1657,7 @@ extern "C" int mst_fx_midside_imager(const float *x, float *y, int n_items, long
 extern "C" int mst_fx_gain(const float *x, float *y, int n_items, long L, int C, double gain_db, int invert, const MstFxFuse *fuse,
                            void *stream) {
     if (!x || !y || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_gain: bad argument");
+    if (fuse && fuse->post_rms) return fail(MST_ERR_UNSUPPORTED, "mst_fx_gain: tail folding (post_rms) is the imager's");
     double g = std::pow(10.0, gain_db / 20.0);
     if (invert) g = -g;
     const long per = L * C;
@@ -1793,8 +1822,7 @@ extern "C" int mst_fx_rms_normalize(const float *x, float *y, int n_items, long 
 // ---- chain fusion helpers -------------------------------------------------------------------------------------------------
 extern "C" int mst_fx_sumsq(const float *x, int n_items, long per_item, double *out, void *stream) {
     if (!x || !out || n_items < 1 || per_item < 1) return fail(MST_ERR_ARG, "mst_fx_sumsq: bad argument");
-    MST_HIP_TRY(hipMemsetAsync(out, 0, (size_t)n_items * MST_SUMSQ_SLOTS * sizeof(double), (hipStream_t)stream));
-    int chunks = (int)std::min<long>(64, (per_item + 8191) / 8192);
+    int chunks = (int)std::min<long>(MST_SUMSQ_SLOTS, (per_item + 8191) / 8192);
     if (chunks < 1) chunks = 1;
     MST_LAUNCH(fx_sumsq_kernel, dim3(n_items * chunks), dim3(256), stream, x, out, per_item, chunks);
     MST_CHECK_LAUNCH("fx_sumsq_kernel");
@@ -1804,7 +1832,7 @@ extern "C" int mst_fx_sumsq(const float *x, int n_items, long per_item, double *
 extern "C" int mst_fx_rms_pending(const double *scale_x, const double *sumsq_x, long per_x, const double *sumsq_y, long per_y,
                                   double *scale_out, int n_items, void *stream) {
     if (!sumsq_x || !sumsq_y || !scale_out || n_items < 1 || per_x < 1 || per_y < 1) return fail(MST_ERR_ARG, "mst_fx_rms_pending: bad argument");
-    MST_LAUNCH(fx_rms_pending_kernel, dim3((n_items + 63) / 64), dim3(64), stream, scale_x, sumsq_x, per_x, sumsq_y, per_y, scale_out, n_items);
+    MST_LAUNCH(fx_rms_pending_kernel, dim3(n_items), dim3(64), stream, scale_x, sumsq_x, per_x, sumsq_y, per_y, scale_out, n_items);
     MST_CHECK_LAUNCH("fx_rms_pending_kernel");
     return MST_OK;
 }

@@ -69,6 +69,11 @@ __device__ __forceinline__ MstStream16 mst_stream16(const void *base, unsigned b
 __device__ __forceinline__ mst_u32x4 mst_stream_load16(MstStream16 s, unsigned voffset, unsigned soffset) {
     return __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, (int)voffset, (int)soffset, 0);
 }
+// the device the calling thread is bound to (per-device constants), -1 on error
+static inline int mst_current_device() {
+    int dev = 0;
+    return hipGetDevice(&dev) == hipSuccess ? dev : -1;
+}
 // compute units of the current device (grid size of the persistent kernels)
 static inline int mst_num_cus() {
     static int n = 0;

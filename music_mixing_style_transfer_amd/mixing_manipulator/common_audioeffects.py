@@ -104,13 +104,16 @@ class _Dev:
     def scratch(self, n_doubles):
         return torch.empty(n_doubles, dtype=torch.float64, device=self.x.device)
 
-    def fuse(self, in_scale, want_sumsq):
-        """(MstFxFuse pointer or None, sumsq tensor or None) for a processor call inside a fused chain."""
-        if in_scale is None and not want_sumsq:
+    def fuse(self, in_scale, want_sumsq, in_sumsq=None, post_gain=None):
+        """(MstFxFuse pointer or None, sumsq tensor or None) for a processor call inside a fused chain.
+        in_sumsq + post_gain: tail folding (the rms-normalise behind the processor and a gain behind that in the processor's last pass)."""
+        if in_scale is None and not want_sumsq and in_sumsq is None:
             return None, None
-        sumsq = torch.zeros(self.n * SUMSQ_SLOTS, dtype=torch.float64, device=self.x.device) if want_sumsq else None
-        f = _lib.MstFxFuse(in_scale.data_ptr() if in_scale is not None else None, sumsq.data_ptr() if want_sumsq else None)
-        self._keep = (f, in_scale, sumsq)              # alive until the launches are queued
+        sumsq = torch.empty(self.n * SUMSQ_SLOTS, dtype=torch.float64, device=self.x.device) if want_sumsq else None   # cleared by the producer
+        f = _lib.MstFxFuse(in_scale.data_ptr() if in_scale is not None else None, sumsq.data_ptr() if want_sumsq else None,
+                           in_sumsq.data_ptr() if in_sumsq is not None else None, 1 if in_sumsq is not None else 0,
+                           float(post_gain) if post_gain is not None else 1.0)
+        self._keep = (f, in_scale, sumsq, in_sumsq)    # alive until the launches are queued
         return C.byref(f), sumsq
 
     def out(self, y):
@@ -272,13 +275,14 @@ class MidSideImager(Processor):
     def fusable(self, d):
         return d.C == 2
 
-    def _run(self, d, in_scale, want_sumsq):
+    def _run(self, d, in_scale, want_sumsq, bal=None, in_sumsq=None, post_gain=None):
         if d.C != 2:
             raise ValueError("MidSideImager needs stereo audio [L, 2]")
         y = torch.empty_like(d.x)
-        sc = d.scratch(2 * d.n)
-        fuse, sumsq = d.fuse(in_scale, want_sumsq)
-        d.lib.check(d.lib.mst_fx_midside_imager(d.x.data_ptr(), y.data_ptr(), d.n, d.L, float(self.parameters.bal.value),
+        sc = d.scratch(2 * SUMSQ_SLOTS * d.n)
+        fuse, sumsq = d.fuse(in_scale, want_sumsq, in_sumsq, post_gain)
+        d.lib.check(d.lib.mst_fx_midside_imager(d.x.data_ptr(), y.data_ptr(), d.n, d.L,
+                                                float(self.parameters.bal.value if bal is None else bal),
                                                 sc.data_ptr(), fuse, d.stream), "mst_fx_midside_imager")
         return y, sumsq
 
@@ -300,6 +304,11 @@ class Gain(Processor):
 
     def fusable(self, d):
         return True
+
+    def factor(self):
+        """The float32 multiplier mst_fx_gain applies: float(10 ** (gain_db / 20)), negated when inverting."""
+        g = math.pow(10.0, float(self.parameters.gain.value) / 20.0)
+        return -g if bool(self.parameters.invert.value) else g
 
     def _run(self, d, in_scale, want_sumsq):
         y = torch.empty_like(d.x)
@@ -523,10 +532,30 @@ def _sumsq(d, t):
 class _Pending:
     """An array on its way through an AugmentationChain: device batch t [n, L, C], the per-item factor still to be applied to it
     (scale, float64 [n] or None) and sum(t^2) per item when its producer left it behind (sumsq, float64 [n] or None)."""
-    __slots__ = ("dev", "t", "scale", "sumsq")
+    __slots__ = ("dev", "t", "scale", "sumsq", "deferred")
 
-    def __init__(self, dev, t, scale, sumsq):
+    def __init__(self, dev, t, scale, sumsq, deferred=None):
         self.dev, self.t, self.scale, self.sumsq = dev, t, scale, sumsq
+        # deferred = (imager, bal): an rms-normalised MidSideImager step that has NOT run yet - if a Gain is next, the imager's pass
+        # applies the rms factor and the gain itself (MstFxFuse tail folding); anything else runs it first (flush)
+        self.deferred = deferred
+
+    def flush(self, gain=None):
+        """Run the deferred imager step (+ its rms-normalise); with `gain` (a float factor): and that gain, all in one pass."""
+        if self.deferred is None:
+            return self
+        imager, bal = self.deferred
+        d = self.dev.rebind(self.t)
+        sumsq_x = self.sumsq if self.sumsq is not None else _sumsq(d, self.t)
+        if gain is not None:
+            y, _ = imager._run(d, self.scale, False, bal=bal, in_sumsq=sumsq_x, post_gain=gain)
+            return _Pending(d, y, None, None)
+        y, sumsq_y = imager._run(d, self.scale, True, bal=bal)
+        scale = torch.empty(d.n, dtype=torch.float64, device=y.device)
+        d.lib.check(d.lib.mst_fx_rms_pending(self.scale.data_ptr() if self.scale is not None else None, sumsq_x.data_ptr(),
+                                             self.t.shape[1] * self.t.shape[2], sumsq_y.data_ptr(), y.shape[1] * y.shape[2],
+                                             scale.data_ptr(), d.n, d.stream), "mst_fx_rms_pending")
+        return _Pending(d, y, scale, sumsq_y)
 
     @staticmethod
     def wrap(x):
@@ -535,6 +564,8 @@ class _Pending:
 
     def materialize(self):
         """The true batch [n, L, C] on the device."""
+        if self.deferred is not None:
+            return self.flush().materialize()
         if self.scale is None:
             return self.t
         d = self.dev.rebind(self.t)
@@ -568,7 +599,13 @@ class AugmentationChain:
             if rms_normalize:
                 y = rms_normalize_(x, y)
             return y
+        if x.deferred is not None:          # an imager + rms step waiting for its successor: a plain Gain folds into its pass
+            if isinstance(processor, Gain) and not rms_normalize:
+                return x.flush(gain=processor.factor())
+            x = x.flush()
         d = x.dev
+        if isinstance(processor, MidSideImager) and rms_normalize and processor.fusable(d.rebind(x.t)):
+            return _Pending(d, x.t, x.scale, x.sumsq, deferred=(processor, float(processor.parameters.bal.value)))
         if hasattr(processor, "fusable") and processor.fusable(d):
             # the pending rms factor of the previous step is folded into this processor's loads; its output leaves sum(y^2) behind
             d.rebind(x.t)

@@ -209,6 +209,7 @@ static inline mst_u32x4 mst_stream_load16(MstStream16 s, unsigned voffset, unsig
     memcpy(&v, s.base + voffset + soffset, 16);
     return v;
 }
+static inline int mst_current_device() { return 0; }
 static inline int mst_num_cus() { return 4; }      // a small persistent grid: every workgroup walks several tiles
 #define __builtin_amdgcn_readfirstlane(v) emu_shfl((v), 0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

@@ -231,6 +231,18 @@ def test_fx_emulated(emu_default):
                               randomize_param_value=False)
     y = chain([x.copy()])[0]
     assert np.abs(y - F.fx_chain(x.copy())).max() <= 5e-6
+    # tail folding: an rms-normalised imager followed by a Gain runs as ONE pass (MstFxFuse.post_rms) - the same bits as the imager's
+    # chain followed by a separate gain call; inverted gain; an imager followed by something else runs first (flush)
+    one = lambda fxs: AugmentationChain(fxs, randomize_param_value=False)([x.copy()])[0]
+    for invert in (False, True):
+        gn.parameters.invert.value = invert
+        assert np.array_equal(one([(im, 1.0, True), (gn, 1.0, False)]), gn.process(one([(im, 1.0, True)])))
+        assert np.array_equal(one([(eq, 1.0, True), (im, 1.0, True), (gn, 1.0, False)]), gn.process(one([(eq, 1.0, True), (im, 1.0, True)])))
+    gn.parameters.invert.value = False
+    ref1 = AugmentationChain([(gn, 1.0, True)], randomize_param_value=False)([one([(im, 1.0, True)])])[0]      # a normalised gain does not fold
+    assert np.abs(one([(im, 1.0, True), (gn, 1.0, True)]) - ref1).max() <= 1e-6
+    ref2 = AugmentationChain([(eq, 1.0, True)], randomize_param_value=False)([one([(im, 1.0, True)])])[0]
+    assert np.abs(one([(im, 1.0, True), (eq, 1.0, True)]) - ref2).max() <= 1e-6
     # batched [n_items, L, C] input
     xb = np.stack([x, 0.5 * x[::-1].copy()])
     yb = comp.process(xb)
