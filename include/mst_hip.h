@@ -144,6 +144,8 @@ typedef struct {
     int strides[MST_MAX_BLOCKS];
     int dilations[MST_MAX_BLOCKS];
     int valid_padding;                 /* Conv1d_layer(padding="VALID"): no reflection padding, L_out = (L - (k-1)d - 1)/s + 1   */
+    float act_slope;                   /* activation of every layer (network_utils.py:76-80) as the slope for negative values:
+                                        * 0 = ReLU (config "relu", the zero-initialised default), 0.01 = LeakyReLU ("lrelu"), 1 = none */
 } MstEncDesc;
 
 int mst_enc_create(const MstEncDesc *desc, MstEnc **out);
@@ -161,6 +163,9 @@ int mst_enc_set_tuning(MstEnc *enc, long rows_min_tiles);
  * activation bytes run their workgroups in weight-major order - all column tiles of one (channel tile, k-slice) on one XCD, so a
  * weight slice crosses the fabric once instead of once per XCD.  Same bits either way. */
 int mst_enc_set_schedule(MstEnc *enc, int flags);
+/* nn.AdaptiveAvgPool1d(1) on its own (architectures.py:63,67; FXencoder(conv_block='conv') runs its ConvBlocks one by one through
+ * mst_enc_forward_conv and pools here): x_dev fp32 [rows, L] -> y_dev[rows] = mean over L. */
+int mst_global_avgpool(const float *x_dev, float *y_dev, long rows, int L, void *stream);
 size_t mst_enc_workspace_bytes(const MstEnc *enc, int B, int L);
 /* replaces FXencoder.forward (architectures.py:65-70): x_dev fp32 [B, 2, L] -> emb_dev fp32 [B, C_last].
  * precision: MST_PREC_F32 (exact fp32 MFMA, parity mode) or MST_PREC_BF16 (bf16 operands, fp32 accumulate;

@@ -37,7 +37,7 @@ class MstFxFuse(C.Structure):
 
 class MstEncDesc(C.Structure):
     _fields_ = [("nblocks", C.c_int), ("channels", C.c_int * (MST_MAX_BLOCKS + 1)), ("kernels", C.c_int * MST_MAX_BLOCKS),
-                ("strides", C.c_int * MST_MAX_BLOCKS), ("dilations", C.c_int * MST_MAX_BLOCKS), ("valid_padding", C.c_int)]
+                ("strides", C.c_int * MST_MAX_BLOCKS), ("dilations", C.c_int * MST_MAX_BLOCKS), ("valid_padding", C.c_int), ("act_slope", C.c_float)]
 
 
 _P = C.c_void_p
@@ -63,6 +63,7 @@ SIGNATURES = {
     "mst_enc_load_conv": (C.c_int, [_P, C.c_int, C.c_int, _F, _F, _F, _F, _F, _F, C.c_float, _P]),
     "mst_enc_set_tuning": (C.c_int, [_P, C.c_long]),
     "mst_enc_set_schedule": (C.c_int, [_P, C.c_int]),
+    "mst_global_avgpool": (C.c_int, [_F, _F, C.c_long, C.c_int, _P]),
     "mst_enc_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int]),
     "mst_enc_forward": (C.c_int, [_P, _F, _F, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "mst_enc_forward_blocks": (C.c_int, [_P, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),

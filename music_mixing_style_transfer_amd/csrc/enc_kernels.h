@@ -16,6 +16,10 @@
 #pragma once
 #include "mst_dev.h"
 
+// the encoder's activation (Conv1d_layer, network_utils.py:76-80): ReLU (slope 0), LeakyReLU(0.01) or none (slope 1) as
+// max(v, 0) + slope * min(v, 0); with slope 0 the second term is a signed zero and the sum is exactly max(v, 0)
+__device__ __forceinline__ float enc_act(float v, float slope) { return fmaxf(v, 0.0f) + slope * fminf(v, 0.0f); }
+
 struct EncConvArgs {
     const float *x;      // [B][Cin][Lin]
     float *y;            // [B][Cout][Lout]
@@ -38,6 +42,7 @@ struct EncConvArgs {
     // raw partial sums to part[z][co][n]; enc_splitk_finalize_ncl_kernel adds the slices in order and applies the epilogue.
     // Used for the short wide late layers, whose 128 tiles would otherwise leave half of the 256 CUs idle.
     float *part = nullptr;
+    float slope = 0.0f;  // epi 0: activation slope for negative values (enc_act)
 };
 
 template <int MW>
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
                 if (co < a.Cout) {
                     float v = acc[q][r] + a.shift[co];
                     if (a.epi == 0) {
-                        v = fmaxf(v, 0.0f);
+                        v = enc_act(v, a.slope);
                         if (a.residual) v += a.x[((long)b * a.Cin + co) * a.Lin + to];
                     } else if (a.epi == 1) {
                         const float *fr = a.film + (a.film_rows > 1 ? (size_t)b * 2 * a.Cout : 0);
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256) void enc_conv_bf16_kernel(EncConvArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int co = cot * MT + 32 * mi + mfma32_row(r, lane);
                 if (co < a.Cout) {
-                    float v = fmaxf(acc[q][r] + a.shift[co], 0.0f);
+                    float v = enc_act(acc[q][r] + a.shift[co], a.slope);
                     if (a.residual) v += a.x[((long)b * a.Cin + co) * a.Lin + to];
                     a.y[((long)b * a.Cout + co) * a.Lout + to] = v;
                 }
@@ -301,6 +306,7 @@ struct EncDirectArgs {
     const float *w;      // [Cout][Cin][ksz] BN-folded
     const float *shift;  // [Cout]
     int B, Cin, Lin, Cout, Lout, ksz, stride, dil, pad_l, residual;
+    float slope;         // activation slope for negative values (enc_act)
 };
 
 // direct VALU convolution for tiny channel counts (Cin <= 4, Cout <= 32): one thread per output time step
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(256) void enc_direct_kernel(EncDirectArgs a) {
 #pragma unroll
     for (int co = 0; co < CM; ++co) {
         if (co < a.Cout) {
-            float v = fmaxf(acc[co] + a.shift[co], 0.0f);
+            float v = enc_act(acc[co] + a.shift[co], a.slope);
             if (a.residual) v += xs[co * span + tid + a.pad_l];
             acc[co] = v;
         }
@@ -394,6 +400,7 @@ struct EncNlcArgs {
     int B, Cin, Lin, Cout, Lout, stride, nchunks, residual, S;
     long Ntot;
     int ksz, pad_l;      // enc_conv_rows_kernel only
+    float slope;         // activation slope for negative values (enc_act)
     int wmajor;          // enc_conv_nlc_kernel: > 0 = 1-d grid in WEIGHT-major order, value = number of channel tiles (see the kernel)
     const void *zeros;   // enc_conv_nlc_kernel: 16 bytes of zeros (rows / k-slots outside the problem are fetched from here)
 };
@@ -555,12 +562,12 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
                             if (a.residual) rl = *(const bf16x4 *)(a.xlo + ((size_t)b * a.Lin + to) * a.Cin + co0);
                             float v[4];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[q][4 * g + i] + sh[i], 0.0f) + ((float)r[i] + (float)rl[i]);
+                            for (int i = 0; i < 4; ++i) v[i] = enc_act(acc[q][4 * g + i] + sh[i], a.slope) + ((float)r[i] + (float)rl[i]);
                             enc_split4(v, o, ol);
                             *(bf16x4 *)(a.ylo + ((size_t)b * a.Lout + to) * a.Cout + co0) = ol;
                         } else {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) o[i] = (__bf16)(fmaxf(acc[q][4 * g + i] + sh[i], 0.0f) + (float)r[i]);
+                            for (int i = 0; i < 4; ++i) o[i] = (__bf16)(enc_act(acc[q][4 * g + i] + sh[i], a.slope) + (float)r[i]);
                         }
                         *(bf16x4 *)(a.y + ((size_t)b * a.Lout + to) * a.Cout + co0) = o;
                     }
@@ -657,12 +664,12 @@ __global__ __launch_bounds__(256, 2) void enc_conv_rows_kernel(EncNlcArgs a) {
                         if (a.residual) rl = *(const bf16x4 *)(xbl + (size_t)to * a.Cin + co0);
                         float v[4];
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[q][4 * g + i] + sh[i], 0.0f) + ((float)r[i] + (float)rl[i]);
+                        for (int i = 0; i < 4; ++i) v[i] = enc_act(acc[q][4 * g + i] + sh[i], a.slope) + ((float)r[i] + (float)rl[i]);
                         enc_split4(v, o, ol);
                         *(bf16x4 *)(a.ylo + ((size_t)b * a.Lout + to) * a.Cout + co0) = ol;
                     } else {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) o[i] = (__bf16)(fmaxf(acc[q][4 * g + i] + sh[i], 0.0f) + (float)r[i]);
+                        for (int i = 0; i < 4; ++i) o[i] = (__bf16)(enc_act(acc[q][4 * g + i] + sh[i], a.slope) + (float)r[i]);
                     }
                     *(bf16x4 *)(a.y + ((size_t)b * a.Lout + to) * a.Cout + co0) = o;
                 }
@@ -675,7 +682,7 @@ __global__ __launch_bounds__(256, 2) void enc_conv_rows_kernel(EncNlcArgs a) {
 // (xres_lo / y_lo non-null: split mode - the residual is x_hi + x_lo, the result leaves as two planes)
 __global__ __launch_bounds__(256) void enc_splitk_finalize_kernel(const float *part, int S, long Ntot, int Cout,
                                                                   const float *shift, const __bf16 *xres, __bf16 *y,
-                                                                  const __bf16 *xres_lo, __bf16 *y_lo) {
+                                                                  const __bf16 *xres_lo, __bf16 *y_lo, float slope) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;       // one thread per 4 channels
     const long total = Ntot * (Cout / 4);
     if (i >= total) return;
@@ -691,19 +698,19 @@ __global__ __launch_bounds__(256) void enc_splitk_finalize_kernel(const float *p
         if (xres_lo) rl = *(const bf16x4 *)(xres_lo + (size_t)n * Cout + co0);
         float v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = fmaxf(s[k] + sh[k], 0.0f) + ((float)r[k] + (float)rl[k]);
+        for (int k = 0; k < 4; ++k) v[k] = enc_act(s[k] + sh[k], slope) + ((float)r[k] + (float)rl[k]);
         enc_split4(v, o, ol);
         *(bf16x4 *)(y_lo + (size_t)n * Cout + co0) = ol;
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = (__bf16)(fmaxf(s[k] + sh[k], 0.0f) + (float)r[k]);
+        for (int k = 0; k < 4; ++k) o[k] = (__bf16)(enc_act(s[k] + sh[k], slope) + (float)r[k]);
     }
     *(bf16x4 *)(y + (size_t)n * Cout + co0) = o;
 }
 
 // split-K finalize of the fp32 NCL kernel (encoder epilogue): y[b][co][to] = relu(sum_z part[z][co][n] + shift[co]) (+ x[b][co][to])
 __global__ __launch_bounds__(256) void enc_splitk_finalize_ncl_kernel(const float *part, int S, long Ntot, int Cout, int Lout,
-                                                                      const float *shift, const float *xres, float *y) {
+                                                                      const float *shift, const float *xres, float *y, float slope) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= Ntot * Cout) return;
     const int co = (int)(i / Ntot);
@@ -712,7 +719,7 @@ __global__ __launch_bounds__(256) void enc_splitk_finalize_ncl_kernel(const floa
     for (int z = 0; z < S; ++z) s += part[((size_t)z * Cout + co) * Ntot + n];
     const long b = n / Lout, to = n % Lout;
     const size_t o = ((size_t)b * Cout + co) * Lout + to;
-    float v = fmaxf(s + shift[co], 0.0f);
+    float v = enc_act(s + shift[co], slope);
     if (xres) v += xres[o];
     y[o] = v;
 }

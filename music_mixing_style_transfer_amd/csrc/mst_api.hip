@@ -60,6 +60,7 @@ struct MstEncConv {
     int *ktab = nullptr;
     float *w_direct = nullptr;   // [Cout][Cin][ksz] folded fp32 (layers with Cin < 8: direct kernel)
     __bf16 *wpk_nlc = nullptr;   // NLC pipeline A fragments, k = j*Cin + ci, K-chunk 64
+    float slope = 0.0f;             // activation slope for negative values: 0 ReLU, 0.01 LeakyReLU, 1 none (MstEncDesc.act_slope)
     __bf16 *wpk_nlc_lo = nullptr;   // split mode: bf16(W' - bf16(W')) in the same fragment order
     int *stab = nullptr;         // NLC pipeline slot table
     int nchunks64 = 0;
@@ -735,6 +736,7 @@ struct MstEnc {
 extern "C" int mst_enc_create(const MstEncDesc *desc, MstEnc **out) {
     if (!desc || !out) return fail(MST_ERR_ARG, "mst_enc_create: null argument");
     if (desc->nblocks < 1 || desc->nblocks > MST_MAX_BLOCKS) return fail(MST_ERR_ARG, "mst_enc_create: nblocks out of range");
+    if (!(desc->act_slope >= 0.0f && desc->act_slope <= 1.0f)) return fail(MST_ERR_ARG, "mst_enc_create: act_slope outside [0, 1]");
     for (int i = 0; i < desc->nblocks; ++i)
         if (desc->kernels[i] < 1 || desc->strides[i] < 1 || desc->dilations[i] < 1 || desc->channels[i] < 1 ||
             desc->channels[i + 1] < 1)
@@ -761,6 +763,7 @@ extern "C" int mst_enc_create(const MstEncDesc *desc, MstEnc **out) {
             c.nchunks = (c.cin * c.ksz + 15) / 16;
             c.nchunks32 = (c.cin * c.ksz + 31) / 32;
             c.mw = c.cout <= 32 ? 1 : (c.cout <= 64 ? 2 : 4);
+            c.slope = desc->act_slope;
         }
     *out = e;
     return MST_OK;
@@ -866,6 +869,13 @@ extern "C" int mst_enc_load_conv(MstEnc *e, int block, int which, const float *w
     return MST_OK;
 }
 
+extern "C" int mst_global_avgpool(const float *x, float *y, long rows, int L, void *stream) {
+    if (!x || !y || rows < 1 || L < 1) return fail(MST_ERR_ARG, "mst_global_avgpool: bad argument");
+    MST_LAUNCH(enc_avgpool_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), stream, x, y, rows, L);
+    MST_CHECK_LAUNCH("enc_avgpool_kernel");
+    return MST_OK;
+}
+
 extern "C" int mst_enc_set_schedule(MstEnc *e, int flags) {
     if (!e || flags < 0 || flags > 1) return fail(MST_ERR_ARG, "mst_enc_set_schedule: flags 0..1");
     e->schedule = flags;
@@ -945,6 +955,7 @@ int enc_launch(const MstEncConv &c, const float *x, float *y, int B, int Lin, in
     a.res = nullptr;
     a.film_rows = 1;
     a.res_div = 1;
+    a.slope = c.slope;
     const int MT = 32 * c.mw, NT = 128 * (4 / c.mw);
     dim3 grid((unsigned)((a.Ntot + NT - 1) / NT), (unsigned)((c.cout + MT - 1) / MT));
     int S = 1;
@@ -972,7 +983,7 @@ int enc_launch(const MstEncConv &c, const float *x, float *y, int B, int Lin, in
     if (S > 1) {
         const long total = a.Ntot * c.cout;
         MST_LAUNCH(enc_splitk_finalize_ncl_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, (const float *)scratch, S, a.Ntot,
-                   c.cout, Lout, (const float *)c.shift, residual ? x : (const float *)nullptr, y);
+                   c.cout, Lout, (const float *)c.shift, residual ? x : (const float *)nullptr, y, c.slope);
         MST_CHECK_LAUNCH("enc_splitk_finalize_ncl_kernel");
     }
     return MST_OK;
@@ -1028,6 +1039,7 @@ int enc_launch_direct(const MstEncConv &c, const float *x, void *y, bool out_nlc
     a.ylo = ylo;
     a.w = c.w_direct;
     a.shift = c.shift;
+    a.slope = c.slope;
     a.B = B;
     a.Cin = c.cin;
     a.Lin = Lin;
@@ -1088,6 +1100,7 @@ int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scrat
     a.ksz = c.ksz;
     a.pad_l = c.pad_l;
     a.wmajor = 0;
+    a.slope = c.slope;
     a.zeros = zeros;
     if (!zeros) return fail(MST_ERR_ARG, "enc_launch_nlc: no zero page");
     {
@@ -1141,7 +1154,7 @@ int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scrat
         const long total = a.Ntot * (c.cout / 4);
         MST_LAUNCH(enc_splitk_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, (const float *)scratch,
                    a.S, a.Ntot, c.cout, (const float *)c.shift, residual ? x : (const __bf16 *)nullptr, y,
-                   residual ? a.xlo : (const __bf16 *)nullptr, a.ylo);
+                   residual ? a.xlo : (const __bf16 *)nullptr, a.ylo, c.slope);
         MST_CHECK_LAUNCH("enc_splitk_finalize_kernel");
     }
     return MST_OK;

@@ -79,11 +79,15 @@ class _EncoderRunner:
         if self.handle is not None and sig == self.sig and self.lib is b:
             return
         self.close()
+        slopes = {c.act_slope() for blk in self.blocks for c in (blk.conv1, blk.conv2)}
         for blk in self.blocks:
             if not (blk.conv1.hip_supported() and blk.conv2.hip_supported()):
-                raise NotImplementedError("FXencoder: only norm='batch', activation='relu', padding='SAME' blocks "
-                                          "are implemented on gfx950")
+                raise NotImplementedError("Res_ConvBlock stack: padding='SAME' blocks only on gfx950")
+        if len(slopes) != 1:
+            raise NotImplementedError("Res_ConvBlock stack: one activation for all layers (activation == last_activation, as FXencoder "
+                                      "builds them) on gfx950")
         d = _lib.MstEncDesc()
+        d.act_slope = slopes.pop()
         d.nblocks = len(self.blocks)
         d.channels[0] = self.blocks[0].conv1.in_channels
         for i, blk in enumerate(self.blocks):
@@ -174,12 +178,22 @@ class FXencoder(_DeviceState, nn.Module):
         if self._runner is None:
             blocks = list(self.encoder)
             if not all(isinstance(b, Res_ConvBlock) for b in blocks):
-                raise NotImplementedError("FXencoder: conv_block='conv' is not implemented on gfx950 (the shipped "
-                                          "configs.yaml uses 'res')")
+                raise NotImplementedError("FXencoder: the fused encoder handle exists for conv_block='res' stacks")
             self._runner = _EncoderRunner(blocks)
         return self._runner
 
     def forward(self, input):
+        if len(self.encoder) and not isinstance(self.encoder[0], Res_ConvBlock):
+            # conv_block='conv' (architectures.py:46-58): VALID-padded single convolutions, layer by layer through mst_enc_forward_conv
+            # (exact-fp32 kernels whatever self.precision says), then the global average pool
+            b = _check_device(input, "FXencoder.forward")
+            x = self.encoder(input)
+            with b.device_ctx(x):
+                x = x.contiguous()
+                out = torch.empty(x.shape[0], x.shape[1], dtype=torch.float32, device=x.device)
+                b.check(b.mst_global_avgpool(x.data_ptr(), out.data_ptr(), x.shape[0] * x.shape[1], x.shape[2], _stream_ptr(x)),
+                        "mst_global_avgpool")
+            return out
         return self._get_runner().run(input, pooled=True, precision=self.precision)
 
     def forward_blocks(self, input, n_run):

@@ -80,9 +80,13 @@ class Conv1d_layer(_DeviceState, nn.Module):
         elif activation == "lrelu":
             self.conv1d.add_module("lrelu", nn.LeakyReLU())
 
+    def act_slope(self):
+        """The activation as MstEncDesc.act_slope: what the layer does to negative values (ReLU 0, nn.LeakyReLU() 0.01, none 1)."""
+        return {"relu": 0.0, "lrelu": 0.01}.get(self.activation, 1.0)
+
     def hip_supported(self):
-        return self.norm == "batch" and self.activation == "relu" and self.padding_area == same_padding(
-            self.kernel_size, self.dilation)
+        """Usable inside an encoder handle (Res_ConvBlock stack): SAME padding; any norm / activation the reference's layer accepts."""
+        return self.padding_area == same_padding(self.kernel_size, self.dilation)
 
     # ---- the layer on its own (reference :86-89) ------------------------------------------------
     def _ensure(self, b):
@@ -90,9 +94,8 @@ class Conv1d_layer(_DeviceState, nn.Module):
         if self._handle is not None and sig == self._sig and self._hlib is b:
             return
         self._close()
-        if self.norm != "batch" or self.activation != "relu":
-            raise NotImplementedError("Conv1d_layer: only norm='batch', activation='relu' layers are implemented on gfx950")
         d = _lib.MstEncDesc()
+        d.act_slope = self.act_slope()
         d.nblocks = 1
         d.channels[0], d.channels[1] = self.in_channels, self.out_channels
         d.kernels[0], d.strides[0], d.dilations[0] = self.kernel_size, self.stride, self.dilation
@@ -134,8 +137,12 @@ class Conv1d_layer(_DeviceState, nn.Module):
 
     def export_arrays(self):
         """Host fp32 arrays in the reference's layouts for mst_enc_load_conv."""
-        conv, bn = self.conv1d.conv1d, self.conv1d.batch_norm
+        conv = self.conv1d.conv1d
         f = lambda t: None if t is None else t.detach().to("cpu", torch.float32).contiguous()
+        if self.norm != "batch":        # no normalisation layer (network_utils.py:70-73): the identity in BatchNorm form, folded exactly
+            one, zero = torch.ones(self.out_channels), torch.zeros(self.out_channels)
+            return dict(w=f(conv.weight), bias=f(conv.bias), bn_w=one, bn_b=zero, bn_mean=zero.clone(), bn_var=one.clone(), eps=0.0)
+        bn = self.conv1d.batch_norm
         return dict(w=f(conv.weight), bias=f(conv.bias), bn_w=f(bn.weight), bn_b=f(bn.bias), bn_mean=f(bn.running_mean),
                     bn_var=f(bn.running_var), eps=float(bn.eps))
 

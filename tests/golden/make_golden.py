@@ -589,7 +589,8 @@ def modules_goldens():
     install_stubs()
     sys.path.insert(0, os.path.join(REF, "mixing_style_transfer"))
     from networks.architectures import TCNBlock, TCNModel  # the reference
-    from networks.network_utils import Conv1d_layer, ConvBlock, FiLM
+    from networks.architectures import FXencoder
+    from networks.network_utils import Conv1d_layer, ConvBlock, FiLM, Res_ConvBlock
     torch.set_num_threads(8)
     out = {}
 
@@ -609,6 +610,16 @@ def modules_goldens():
     run("conv_same_k4_s2", Conv1d_layer(6, 10, 4, stride=2, padding="SAME", dilation=1), 1, x)
     run("conv_valid_k5_d2", Conv1d_layer(6, 7, 5, stride=1, padding="VALID", dilation=2), 2, x)
     run("convblock_valid", ConvBlock(1, 2, 6, 9, 5, stride=2, padding="VALID", dilation=1), 3, x)
+    # constructor arguments the shipped configuration does not use: LeakyReLU / no activation, no normalisation layer, the plain-convolution
+    # encoder (conv_block='conv': VALID padding, one layer per block)
+    run("conv_lrelu", Conv1d_layer(6, 10, 5, stride=1, padding="SAME", activation="lrelu"), 11, x)
+    run("conv_nonorm_noact", Conv1d_layer(6, 8, 3, stride=2, padding="SAME", norm="none", activation="none"), 12, x)
+    run("resblock_lrelu", Res_ConvBlock(1, 6, 12, 5, stride=2, activation="lrelu", last_activation="lrelu"), 13, x)
+    xe = synth.synth_audio((2, 2, 401), seed=41)
+    enc_cfg = lambda block: dict(channels=[8, 16, 24], kernels=[5, 5, 3], strides=[2, 2, 1], dilation=[1, 1, 1], bias=True, norm="batch",
+                                 conv_block=block, activation="lrelu")
+    run("fxenc_conv_lrelu", FXencoder(enc_cfg("conv")), 14, xe)
+    run("fxenc_res_lrelu", FXencoder(enc_cfg("res")), 15, xe)
     run("film_conv", FiLM(24, 6), 4, x, synth.synth_audio((2, 24), seed=32))
     run("film_bcast", FiLM(24, 6), 5, x, synth.synth_audio((1, 24), seed=33))
     xb = synth.synth_audio((2, 8, 211), seed=34)

@@ -1100,15 +1100,25 @@ def test_haas_branch_and_real_features_file_on_gpu(oracle_fx_lib):
     assert yb.shape == x.shape and yb.dtype == np.float32 and d_chain <= 1e-4
 
 
-@pytest.mark.parametrize("name", ["conv_same_k4_s2", "conv_valid_k5_d2", "convblock_valid", "film_conv", "film_bcast", "tcnblock_8_8_d3",
+@pytest.mark.parametrize("name", ["conv_same_k4_s2", "conv_valid_k5_d2", "convblock_valid", "conv_lrelu", "conv_nonorm_noact", "resblock_lrelu",
+                                  "fxenc_conv_lrelu", "fxenc_res_lrelu", "film_conv", "film_bcast", "tcnblock_8_8_d3",
                                   "tcnblock_2_8", "tcnblock_causal", "tcnblock_grouped", "tcn_causal", "tcn_grouped", "tcn_causal_grouped"])
 def test_standalone_modules_on_gpu(name):
-    """Conv1d_layer / ConvBlock / FiLM / TCNBlock on their own and causal / grouped TCNModels on the MI355X against the outputs of the
-    real reference modules (tests/golden/modules.npz)."""
+    """Conv1d_layer / ConvBlock / Res_ConvBlock / FiLM / TCNBlock on their own, the LeakyReLU / no-norm / plain-convolution encoder variants
+    and causal / grouped TCNModels on the MI355X against the outputs of the real reference modules (tests/golden/modules.npz)."""
     import sys
     sys.path.insert(0, os.path.join(REPO, "tests"))
     from test_modules_standalone import check
     check(name, "cuda")
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-4), ("bf16", 3e-2)])
+def test_lrelu_encoder_bf16_modes_on_gpu(precision, tol):
+    """activation='lrelu' through the channel-minor bf16 / split-bf16 encoder pipeline on the MI355X vs the real reference's FXencoder."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_modules_standalone import lrelu_encoder_check
+    lrelu_encoder_check("cuda", precision, tol)
 
 
 def test_fx_manipulator_chains_and_algorithmic_reverb_on_gpu(tmp_path):
