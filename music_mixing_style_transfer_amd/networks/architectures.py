@@ -352,20 +352,21 @@ class TCNModel(_DeviceState, nn.Module):
             return
         self._close()
         hp = self.hparams
-        if hp.channel_growth > 1:
-            raise NotImplementedError("TCNModel: channel_growth > 1 (a different width per block) is not implemented on gfx950")
         if not hp.nparams > 0:
             raise AttributeError("'TCNBlock' object has no attribute 'film'")       # nparams = 0 builds blocks without FiLM; the
         d = _lib.MstTcnDesc()                                                          # reference's forward fails the same way
-        d.nblocks, d.ninputs, d.noutputs = hp.nblocks, hp.ninputs, hp.noutputs
-        d.channels, d.kernel_size, d.cond_dim, d.causal = hp.channel_width, hp.kernel_size, hp.cond_dim, int(bool(hp.causal))
-        for n, blk in enumerate(self.blocks):
+        # channel_growth > 1 (a different width per block, reference :112-115): the handle holds the LAST block + the output head, the
+        # blocks in front of it run one by one through their own one-block handles (TCNBlock.forward) - all on the generic fp32 kernels
+        held = list(self.blocks)[-1:] if hp.channel_growth > 1 else list(self.blocks)
+        d.nblocks, d.ninputs, d.noutputs = len(held), held[0].in_ch, hp.noutputs
+        d.channels, d.kernel_size, d.cond_dim, d.causal = held[-1].out_ch, hp.kernel_size, hp.cond_dim, int(bool(hp.causal))
+        for n, blk in enumerate(held):
             d.dilations[n] = blk.dilation
         h = C.c_void_p()
         b.check(b.mst_tcn_create(C.byref(d), C.byref(h)), "mst_tcn_create")
         self._handle, self._lib = h, b
         f = lambda t: t.detach().to("cpu", torch.float32).contiguous()
-        for n, blk in enumerate(self.blocks):
+        for n, blk in enumerate(held):
             _load_tcn_block(b, h, n, blk)
         ow, ob = f(self.output.weight), f(self.output.bias)
         b.check(b.mst_tcn_load_output(h, ow.data_ptr(), ob.data_ptr(), None), "mst_tcn_load_output")
@@ -387,6 +388,8 @@ class TCNModel(_DeviceState, nn.Module):
         if isinstance(cond, (list, tuple)):     # one condition per block (reference's SeFa branch, :139-140)
             if len(cond) != hp.nblocks:
                 raise ValueError("TCNModel.forward: a condition list needs one entry per block")
+            if hp.channel_growth > 1:
+                cond = cond[-1:]                # the handle holds the last block only
             c = torch.stack([ci.to(x.device, torch.float32) for ci in cond], 0).contiguous()   # [nblocks, rows, D]
             rows, stride = c.shape[1], c.shape[1] * c.shape[2]
         else:
@@ -418,6 +421,15 @@ class TCNModel(_DeviceState, nn.Module):
             raise ValueError(f"TCNModel.forward: expected [B, {hp.ninputs}, L], got {tuple(x.shape)}")
         self._ensure(b)
         prec = _lib.PRECISIONS[self.precision]
+        if hp.channel_growth > 1:
+            if n_run is not None:
+                raise NotImplementedError("TCNModel.forward_blocks: the probe exists for channel_growth == 1 nets")
+            prec = _lib.MST_PREC_F32
+            per_block = isinstance(cond, (list, tuple))
+            if per_block and len(cond) != hp.nblocks:
+                raise ValueError("TCNModel.forward: a condition list needs one entry per block")
+            for idx, blk in enumerate(list(self.blocks)[:-1]):
+                x = blk(x, cond[idx] if per_block else cond)
         x = x.contiguous()
         B, _, L = x.shape
         keep = self._set_cond(b, x, cond)

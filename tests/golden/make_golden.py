@@ -635,6 +635,8 @@ def modules_goldens():
     for name, kw in (("tcn_causal", dict(causal=True)), ("tcn_grouped", dict(grouped=True)), ("tcn_causal_grouped", dict(causal=True, grouped=True))):
         run(name, TCNModel(nparams=16, ninputs=2, noutputs=2, nblocks=4, dilation_growth=2, kernel_size=5, channel_width=8, stack_size=15,
                            cond_dim=16, **kw), 10, xt, cond)
+    run("tcn_growth2", TCNModel(nparams=16, ninputs=2, noutputs=2, nblocks=3, dilation_growth=2, kernel_size=5, channel_growth=2, stack_size=15,
+                                cond_dim=16), 16, xt, cond)
     np.savez_compressed(os.path.join(HERE, "modules.npz"), **out)
     print("modules.npz", os.path.getsize(os.path.join(HERE, "modules.npz")), len(out), "arrays")
 
