@@ -298,7 +298,7 @@ def main():
     ap.add_argument("--workload", default="all", choices=["all", "configs1", "track60"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--x3-large-tiles", action="store_true", help="bf16x3: 256-time tiles, one workgroup per CU (mst_tcn_set_tuning 0)")
-    ap.add_argument("--enc-schedule", type=int, default=None, help="mst_enc_set_schedule flags (bit 0: weight-major workgroup order of the weight-heavy encoder layers)")
+    ap.add_argument("--enc-schedule", type=int, default=None, help="mst_enc_set_schedule flags (bit 0: weight-major workgroup order of the weight-heavy encoder layers, bit 1: 2 x 2 wave tiling of the 128-channel conv kernel)")
     ap.add_argument("--tcn-tuning", type=int, default=None, help="mst_tcn_set_tuning flags (bit 0: bf16x3 small tiles, bits 1-2: form of the bf16 block kernel, include/mst_hip.h)")
     args = ap.parse_args()
 

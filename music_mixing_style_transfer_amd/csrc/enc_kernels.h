@@ -578,6 +578,180 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The 128-channel x 128-column tile with its four waves 2 x 2 ("nlc22", round 3).  In the kernel above a wave owns 32 channels x all
+// columns of the tile: one A fragment per k-step and one ds_read_b128 PER MFMA - four SIMDs issuing a 32x32x16 MFMA every 32 clocks read
+// 4 KB per 32 clocks = the CU's whole LDS bandwidth, and with every global load, barrier and ds_write taken out the loop still ran at
+// 0.41 of the MFMA peak (knock-out runs, profiles/r03_enc_*).  Here a wave owns 64 channels x 64 columns: two A fragments (from L2, as
+// before) x two B fragments per k-step = four MFMAs for two LDS reads.  The A fragments have ONE register set: the fragment of k-step ks
+// is reloaded for the next chunk right behind its last MFMA (a second set to copy into costs 32 registers = a workgroup per CU less).
+// Same tile, same operands, same k order per accumulator as enc_conv_nlc_kernel<4>: bit-identical results.
+// MEASURED (MI355X, 32 x 2 x 131072, 15 launches of the default encoder): 7-12 % SLOWER than the 4 x 1 form (2048 -> 2048 channels,
+// 1024 columns: 70 vs 62 us; encoder pass 1.23 vs 1.16 ms; split mode 2.16 vs 2.12 ms) - every weight fragment is now fetched by two
+// waves and waits for its MFMAs before it can be re-requested, which costs more than the LDS reads saved.  Kept selectable
+// (mst_enc_set_schedule bit 1, default off) with the emulator test that pins the bits.
+// ------------------------------------------------------------------------------------------------
+template <bool X3 = false>
+__global__ __launch_bounds__(256) void enc_conv_nlc22_kernel(EncNlcArgs a) {
+    constexpr int MW = 4, MT = 128, NT = 128, NL = 4;
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[(X3 ? 2 : 1) * NT * 128];
+    unsigned char *const Bl = Bs + NT * 128;           // split mode: the low parts' tile
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int ln = lane & 31, h = lane >> 5;
+    const int mi2 = w & 1, ni2 = w >> 1;               // this wave: channels [64 mi2, +64), columns [64 ni2, +64) of the tile
+    long n0;
+    int cot, z;
+    if (a.wmajor > 0) {                                 // weight-major workgroup order (see enc_conv_nlc_kernel)
+        const int cz = a.wmajor * a.S, q = (int)(blockIdx.x % cz);
+        n0 = (long)(blockIdx.x / cz) * NT;
+        cot = q % a.wmajor;
+        z = q / a.wmajor;
+    } else {
+        n0 = (long)blockIdx.x * NT;
+        cot = blockIdx.y;
+        z = blockIdx.z;
+    }
+    const int kc_lo = (int)((long)z * a.nchunks / a.S), kc_hi = (int)((long)(z + 1) * a.nchunks / a.S);
+    const int slot = tid & 7;
+
+    int rowb[NL], rowt[NL];                           // batch item / first input time of the rows this thread stages
+#pragma unroll
+    for (int e = 0; e < NL; ++e) {
+        const long n = n0 + (tid >> 3) + 32 * e;
+        if (n < a.Ntot) {
+            rowb[e] = (int)(n / a.Lout);
+            rowt[e] = (int)(n % a.Lout) * a.stride;
+        } else {
+            rowb[e] = -1;
+            rowt[e] = 0;
+        }
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ma][q][i] = 0.0f;
+
+    const bf16x8 *wtile = (const bf16x8 *)a.wpk + (size_t)cot * a.nchunks * 4 * MW * 64 + (2 * mi2) * 64 + lane;
+    const bf16x8 *wtile_lo = (const bf16x8 *)a.wpk_lo + (size_t)cot * a.nchunks * 4 * MW * 64 + (2 * mi2) * 64 + lane;
+    bf16x8 areg[4][2], breg[NL];
+    bf16x8 areg_lo[X3 ? 4 : 1][2], breg_lo[X3 ? NL : 1];
+
+    int sj = 0, sc = -1;                              // slot table entry of the chunk the next fetch_b() stages (a chunk ahead, see above)
+    auto stab_entry = [&](int kc) {
+        const int k2 = kc < kc_hi ? kc : kc_hi - 1;
+        const u32x2 e = *(const u32x2 *)(a.stab + (k2 * 8 + slot) * 2);
+        sj = (int)e[0];
+        sc = (int)e[1];
+    };
+    auto fetch_a = [&](int kc, int ks) {
+#pragma unroll
+        for (int ma = 0; ma < 2; ++ma) {
+            areg[ks][ma] = wtile[((size_t)(kc * 4 + ks) * MW + ma) * 64];
+            if constexpr (X3) areg_lo[ks][ma] = wtile_lo[((size_t)(kc * 4 + ks) * MW + ma) * 64];
+        }
+    };
+    auto fetch_b = [&](int kc) {
+        const int joff = sj, ci0 = sc;
+#pragma unroll
+        for (int e = 0; e < NL; ++e) {
+            const bool ok = ci0 >= 0 && rowb[e] >= 0;
+            int ti = rowt[e] + joff;
+            if (ti < 0) ti = -ti;
+            if (ti >= a.Lin) ti = 2 * (a.Lin - 1) - ti;
+            const size_t off = ((size_t)rowb[e] * a.Lin + ti) * a.Cin + ci0;
+            breg[e] = *(const bf16x8 *)(ok ? (const void *)(a.x + off) : a.zeros);
+            if constexpr (X3) breg_lo[e] = *(const bf16x8 *)(ok ? (const void *)(a.xlo + off) : a.zeros);
+        }
+        stab_entry(kc + 1);
+    };
+
+    if (kc_lo < kc_hi) {
+        stab_entry(kc_lo);
+        fetch_b(kc_lo);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fetch_a(kc_lo, ks);
+    }
+    for (int kc = kc_lo; kc < kc_hi; ++kc) {
+        if (kc > kc_lo) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NL; ++e) {
+            const int n = (tid >> 3) + 32 * e;
+            *(bf16x8 *)(Bs + n * 128 + ((slot ^ ((n >> 1) & 7)) << 4)) = breg[e];
+            if constexpr (X3) *(bf16x8 *)(Bl + n * 128 + ((slot ^ ((n >> 1) & 7)) << 4)) = breg_lo[e];
+        }
+        __syncthreads();
+        const bool more = kc + 1 < kc_hi;
+        if (more) fetch_b(kc + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 bv[2], bl[X3 ? 2 : 1];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int nl = 64 * ni2 + 32 * q + ln;
+                const int off = nl * 128 + (((2 * ks + h) ^ ((nl >> 1) & 7)) << 4);
+                bv[q] = *(const bf16x8 *)(Bs + off);
+                if constexpr (X3) bl[q] = *(const bf16x8 *)(Bl + off);
+            }
+#pragma unroll
+            for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if constexpr (X3) {          // the small terms first
+                        acc[ma][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg_lo[ks][ma], bv[q], acc[ma][q], 0, 0, 0);
+                        acc[ma][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[ks][ma], bl[q], acc[ma][q], 0, 0, 0);
+                    }
+                    acc[ma][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[ks][ma], bv[q], acc[ma][q], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);          // the reload below stays behind the MFMAs that read the same registers
+            if (more) fetch_a(kc + 1, ks);
+        }
+    }
+
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const long n = n0 + 64 * ni2 + 32 * q + ln;
+        if (n < a.Ntot) {
+            const int b = (int)(n / a.Lout), to = (int)(n % a.Lout);
+#pragma unroll
+            for (int ma = 0; ma < 2; ++ma) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co0 = cot * MT + 64 * mi2 + 32 * ma + 8 * g + 4 * h;
+                    if (co0 < a.Cout) {
+                        if (a.part) {
+                            f32x4 o;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) o[i] = acc[ma][q][4 * g + i];
+                            *(f32x4 *)(a.part + ((size_t)z * a.Ntot + n) * a.Cout + co0) = o;
+                        } else {
+                            const f32x4 sh = *(const f32x4 *)(a.shift + co0);
+                            bf16x4 o, r = {0, 0, 0, 0};
+                            if (a.residual) r = *(const bf16x4 *)(a.x + ((size_t)b * a.Lin + to) * a.Cin + co0);
+                            if constexpr (X3) {
+                                bf16x4 rl = {0, 0, 0, 0}, ol;
+                                if (a.residual) rl = *(const bf16x4 *)(a.xlo + ((size_t)b * a.Lin + to) * a.Cin + co0);
+                                float v[4];
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) v[i] = enc_act(acc[ma][q][4 * g + i] + sh[i], a.slope) + ((float)r[i] + (float)rl[i]);
+                                enc_split4(v, o, ol);
+                                *(bf16x4 *)(a.ylo + ((size_t)b * a.Lout + to) * a.Cout + co0) = ol;
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) o[i] = (__bf16)(enc_act(acc[ma][q][4 * g + i] + sh[i], a.slope) + (float)r[i]);
+                            }
+                            *(bf16x4 *)(a.y + ((size_t)b * a.Lout + to) * a.Cout + co0) = o;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The same convolution for the long early layers, with the input rows of a tile RESIDENT in LDS.  The im2col form above
 // stages a fresh 64-k slice of the B operand per chunk, i.e. it reads every input row ksz times (and once more per
 // channel tile) from L2: 3.6 GB per encoder pass, the bound of those launches.  Here a workgroup owns NT consecutive

@@ -728,7 +728,7 @@ extern "C" int mst_tcn_forward_blocks(MstTcn *t, const float *x, float *act, int
 struct MstEnc {
     MstEncDesc d;
     std::vector<MstEncConv> conv;   // 2 per block
-    int schedule = 1;               // bit 0: weight-major workgroup order for the weight-heavy layers (mst_enc_set_schedule)
+    int schedule = 1;               // bit 1: 2 x 2 wave tiling of the 128-channel conv kernel (measured slower: off); bit 0: weight-major workgroup order for the weight-heavy layers (mst_enc_set_schedule)
     void *zeros = nullptr;          // 256 bytes of zeros: what the channel-minor conv kernel fetches for rows / k-slots outside the problem
     long rows_min_tiles = 512;      // bf16 mode: layers with at least this many tiles keep their input rows resident in LDS (mst_enc_set_tuning)
 };
@@ -877,7 +877,7 @@ extern "C" int mst_global_avgpool(const float *x, float *y, long rows, int L, vo
 }
 
 extern "C" int mst_enc_set_schedule(MstEnc *e, int flags) {
-    if (!e || flags < 0 || flags > 1) return fail(MST_ERR_ARG, "mst_enc_set_schedule: flags 0..1");
+    if (!e || flags < 0 || flags > 3) return fail(MST_ERR_ARG, "mst_enc_set_schedule: flags 0..3");
     e->schedule = flags;
     return MST_OK;
 }
@@ -1137,17 +1137,24 @@ int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scrat
         a.wmajor = (int)cotiles;
         grid = dim3((unsigned)(ntiles * cotiles * a.S));
     }
+    const bool w22 = c.mw == 4 && (schedule & 2);          // the 128 x 128 tile with its waves 2 x 2 (two MFMAs per LDS read)
     if (x3) {
         switch (c.mw) {
             case 1: MST_LAUNCH((enc_conv_nlc_kernel<1, true>), grid, dim3(256), stream, a); break;
             case 2: MST_LAUNCH((enc_conv_nlc_kernel<2, true>), grid, dim3(256), stream, a); break;
-            default: MST_LAUNCH((enc_conv_nlc_kernel<4, true>), grid, dim3(256), stream, a); break;
+            default:
+                if (w22) MST_LAUNCH((enc_conv_nlc22_kernel<true>), grid, dim3(256), stream, a);
+                else MST_LAUNCH((enc_conv_nlc_kernel<4, true>), grid, dim3(256), stream, a);
+                break;
         }
     } else
     switch (c.mw) {
         case 1: MST_LAUNCH((enc_conv_nlc_kernel<1>), grid, dim3(256), stream, a); break;
         case 2: MST_LAUNCH((enc_conv_nlc_kernel<2>), grid, dim3(256), stream, a); break;
-        default: MST_LAUNCH((enc_conv_nlc_kernel<4>), grid, dim3(256), stream, a); break;
+        default:
+            if (w22) MST_LAUNCH((enc_conv_nlc22_kernel<false>), grid, dim3(256), stream, a);
+            else MST_LAUNCH((enc_conv_nlc_kernel<4>), grid, dim3(256), stream, a);
+            break;
     }
     MST_CHECK_LAUNCH("enc_conv_nlc_kernel");
     if (a.S > 1) {

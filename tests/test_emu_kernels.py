@@ -465,6 +465,33 @@ def test_encoder_rows_kernel_matches_im2col_emulated(emu_default):
         enc.precision = "bf16"
 
 
+def test_encoder_wave_tilings_and_workgroup_orders_match_emulated(emu_default):
+    """bf16 / split-bf16 FXencoder, 128-channel layers: the conv kernel with its waves 2 x 2 (two MFMAs per LDS read) and the weight-major
+    workgroup order (mst_enc_set_schedule) against the 4 x 1 / column-major forms - same operands, same k order per accumulator: the same bits;
+    split-K slices included (short wide layers)."""
+    from music_mixing_style_transfer_amd.networks import FXencoder
+    cfg = {"channels": [16, 32, 128, 256], "kernels": [25, 10, 5, 5], "strides": [4, 2, 2, 1], "dilation": [1, 1, 1, 1],
+           "bias": True, "norm": "batch", "conv_block": "res", "activation": "relu"}
+    sd = synth.fxencoder_state_dict(cfg, seed=12)
+    enc = FXencoder({k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()})
+    enc.load_state_dict(sd)
+    x = synth.synth_audio((3, 2, 3000), seed=77)
+    emb = R.fxencoder_forward(sd, cfg, x)
+    for precision, tol in (("bf16", 3e-2), ("bf16x3", 2e-5)):
+        enc.precision = precision
+        run = enc._get_runner()
+        run._ensure(emu_default)
+        outs = []
+        for flags in (0, 1, 2, 3):
+            emu_default.check(emu_default.mst_enc_set_schedule(run.handle, flags), "schedule")
+            outs.append(enc(x).clone())
+        emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 1), "schedule")          # the default
+        assert all(torch.equal(o, outs[0]) for o in outs[1:]), precision
+        assert float((outs[0] - emb).abs().max()) <= tol * float(emb.abs().max())
+    with pytest.raises(ValueError):
+        emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 4), "schedule")
+
+
 def test_algorithmic_reverb_emulated(emu_default):
     """f-3 / AlgorithmicReverb (comb bank as block-wise linear scans, all-pass sections as D independent recurrences) against the
     oracle's sample-by-sample restatement: stereo, mono, a batch; block boundaries (several comb periods), extreme parameters."""
