@@ -447,12 +447,21 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
     const int kc_lo = (int)((long)z * a.nchunks / a.S), kc_hi = (int)((long)(z + 1) * a.nchunks / a.S);
     const int slot = tid & 7;
 
-    int rowb[NL], rowt[NL];                           // batch item / first input time of the rows this thread stages
+    // Operand loads as raw buffer loads (round 3): the address of a load is a 32-bit per-lane byte offset + a scalar offset on top of a
+    // workgroup-uniform descriptor - no 64-bit address arithmetic in vector registers (the im2col gather spent ~80 VALU instructions per
+    // wave and chunk on it, in front of every 16 MFMAs), and an offset beyond the descriptor's size returns ZEROS, which is what rows /
+    // k-slots outside the problem need.  Activation descriptor: from the first batch item of this tile on (a tile spans at most NT items).
+    const int item0 = (int)(n0 / a.Lout);
+    const size_t item_elems = (size_t)a.Lin * a.Cin, left = ((size_t)a.B - item0) * item_elems * 2;
+    const unsigned xbytes = left < 0x7fffffffu ? (unsigned)left : 0x7fffffffu;
+    const MstStream16 xs = mst_stream16(a.x + (size_t)item0 * item_elems, xbytes);
+    const MstStream16 xls = mst_stream16((X3 ? a.xlo : a.x) + (size_t)item0 * item_elems, xbytes);
+    int rowb[NL], rowt[NL];                           // element offset of the row's batch item in the descriptor (-1: no row) / first input time
 #pragma unroll
     for (int e = 0; e < NL; ++e) {
         const long n = n0 + (tid >> 3) + 32 * e;
         if (n < a.Ntot) {
-            rowb[e] = (int)(n / a.Lout);
+            rowb[e] = (int)((n / a.Lout - item0) * (long)item_elems);
             rowt[e] = (int)(n % a.Lout) * a.stride;
         } else {
             rowb[e] = -1;
@@ -466,8 +475,10 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
 
-    const bf16x8 *wtile = (const bf16x8 *)a.wpk + (size_t)cot * a.nchunks * 4 * MW * 64;
-    const bf16x8 *wtile_lo = (const bf16x8 *)a.wpk_lo + (size_t)cot * a.nchunks * 4 * MW * 64;
+    const unsigned wbytes = (unsigned)a.nchunks * 4u * MW * 64u * 16u;                      // one channel tile's fragments (host: < 2^31)
+    const MstStream16 ws = mst_stream16((const unsigned char *)a.wpk + (size_t)cot * wbytes, wbytes);
+    const MstStream16 wls = mst_stream16((const unsigned char *)a.wpk_lo + (size_t)cot * wbytes, wbytes);
+    const unsigned wlane = (unsigned)(mi * 64 + lane) * 16u;
     bf16x8 anxt[4], acur[4], breg[NL];
     bf16x8 anxt_lo[X3 ? 4 : 1], acur_lo[X3 ? 4 : 1], breg_lo[X3 ? NL : 1];
 
@@ -486,8 +497,9 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
     auto fetch = [&](int kc) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            anxt[ks] = wtile[((size_t)(kc * 4 + ks) * MW + mi) * 64 + lane];
-            if constexpr (X3) anxt_lo[ks] = wtile_lo[((size_t)(kc * 4 + ks) * MW + mi) * 64 + lane];
+            const unsigned so = (unsigned)(kc * 4 + ks) * (MW * 64u * 16u);
+            anxt[ks] = __builtin_bit_cast(bf16x8, mst_stream_load16(ws, wlane, so));
+            if constexpr (X3) anxt_lo[ks] = __builtin_bit_cast(bf16x8, mst_stream_load16(wls, wlane, so));
         }
         const int joff = sj, ci0 = sc;
 #pragma unroll
@@ -496,9 +508,9 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
             int ti = rowt[e] + joff;
             if (ti < 0) ti = -ti;
             if (ti >= a.Lin) ti = 2 * (a.Lin - 1) - ti;
-            const size_t off = ((size_t)rowb[e] * a.Lin + ti) * a.Cin + ci0;
-            breg[e] = *(const bf16x8 *)(ok ? (const void *)(a.x + off) : a.zeros);
-            if constexpr (X3) breg_lo[e] = *(const bf16x8 *)(ok ? (const void *)(a.xlo + off) : a.zeros);
+            const unsigned off = ok ? (unsigned)(rowb[e] + mst_mul24(ti, a.Cin) + ci0) * 2u : 0xfffffff0u;      // beyond the descriptor: zeros
+            breg[e] = __builtin_bit_cast(bf16x8, mst_stream_load16(xs, off, 0u));
+            if constexpr (X3) breg_lo[e] = __builtin_bit_cast(bf16x8, mst_stream_load16(xls, off, 0u));
         }
         stab_entry(kc + 1);
     };

@@ -1102,6 +1102,12 @@ int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scrat
     a.wmajor = 0;
     a.slope = c.slope;
     a.zeros = zeros;
+    {   // 32-bit offsets of the im2col kernel's buffer loads: a tile's rows lie within NT batch items of one descriptor; 24-bit row multiply
+        const long span_items = std::min<long>(128 * (4 / c.mw), B);
+        if (Lin >= (1 << 24) || c.cin >= (1 << 24) || (double)span_items * Lin * c.cin * 2.0 >= 2147483647.0 ||
+            (double)c.nchunks64 * 4.0 * c.mw * 64.0 * 16.0 >= 2147483647.0)
+            return fail(MST_ERR_UNSUPPORTED, "mst_enc_forward: activation too long for the channel-minor pipeline (use MST_PREC_F32)");
+    }
     if (!zeros) return fail(MST_ERR_ARG, "enc_launch_nlc: no zero page");
     {
         // long early layers: the tile's input rows resident in LDS instead of an im2col slice per k-chunk

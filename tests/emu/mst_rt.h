@@ -202,13 +202,15 @@ static inline void mst_row_swap(unsigned &a, unsigned &b) {      // v_permlane16
     else b = ((const AB *)(base + 64 * (l + 16)))->a;
 }
 typedef __attribute__((ext_vector_type(4))) unsigned mst_u32x4;
-struct MstStream16 { const unsigned char *base; };
-static inline MstStream16 mst_stream16(const void *base, unsigned) { return MstStream16{(const unsigned char *)base}; }
+struct MstStream16 { const unsigned char *base; unsigned bytes; };
+static inline MstStream16 mst_stream16(const void *base, unsigned bytes) { return MstStream16{(const unsigned char *)base, bytes}; }
 static inline mst_u32x4 mst_stream_load16(MstStream16 s, unsigned voffset, unsigned soffset) {
-    mst_u32x4 v;
-    memcpy(&v, s.base + voffset + soffset, 16);
+    mst_u32x4 v = {0u, 0u, 0u, 0u};          // a raw buffer load beyond num_records returns zeros
+    const unsigned long off = (unsigned long)voffset + soffset;
+    if (off + 16 <= s.bytes) memcpy(&v, s.base + off, 16);
     return v;
 }
+static inline int mst_mul24(int a, int b) { return a * b; }
 static inline int mst_current_device() { return 0; }
 static inline int mst_num_cus() { return 4; }      // a small persistent grid: every workgroup walks several tiles
 #define __builtin_amdgcn_readfirstlane(v) emu_shfl((v), 0)
