@@ -587,6 +587,7 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         if (ev) MST_HIP_TRY(hipEventRecord(ev[1], (hipStream_t)stream));
     }
     int cur = 0;
+    bool fused_head = false;
     for (int n = 1; n < n_run; ++n) {
         const int d = t->d.dilations[n];
         const int P = choose_phases(d, L, (precision == MST_PREC_BF16X3 && t->x3_small_tiles) ? MST_PREC_BF16X3 + 100 : precision);
@@ -607,8 +608,11 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         const long nsteps = ((long)L + d - 1) / d;
         a.tiles_step = (int)((nsteps + 256 / P - 1) / (256 / P));
         const long grid = (long)B * a.tiles_phase * a.tiles_step;
-        // bf16 mode: the last block applies the output head in its epilogue (no separate output kernel)
-        const bool fuse_out = precision == MST_PREC_BF16 && !act_out && n == t->d.nblocks - 1;
+        // bf16 / bf16x3 modes: the last block applies the output head in its epilogue (no separate output kernel; the split mode's
+        // kernels exist for up to 8 phases - every dilation of a 2^19-sample segment - otherwise the separate head runs)
+        const bool fuse_out = (precision == MST_PREC_BF16 || (precision == MST_PREC_BF16X3 && P <= 8 && t->d.noutputs <= 2)) && !act_out &&
+                              n == t->d.nblocks - 1;
+        fused_head = fused_head || fuse_out;
         a.out_w = t->out_w;
         a.out_b = t->out_b;
         a.y_out = fuse_out ? y : nullptr;
@@ -638,7 +642,7 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         MST_CHECK_LAUNCH("tcn_unpack_kernel");
         return MST_OK;
     }
-    if (precision == MST_PREC_BF16 && n_run == t->d.nblocks && t->d.nblocks > 1) {
+    if (fused_head && n_run == t->d.nblocks && t->d.nblocks > 1) {
         if (ev) {      // the output head ran inside the last block kernel
             MST_HIP_TRY(hipEventRecord(ev[t->d.nblocks + 1], (hipStream_t)stream));
         }

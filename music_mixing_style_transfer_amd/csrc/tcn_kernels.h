@@ -1035,6 +1035,37 @@ __global__ __launch_bounds__(256, (NQ == 4 && P <= 2) ? 2 : 1) void tcn_block_bf
     {
         const int s4 = tid & 31;                                   // this thread's 4 channels, the same in every pass
         const f32x4 rs = *(const f32x4 *)(a.res + 4 * s4);
+        if (a.y_out) {
+            // last block: the 1x1 output conv + bias + clamp(-1, 1) (reference architectures.py:133,145) on the finished rows - a row's 128
+            // channels sit in 32 lanes (half a wave): 4 products per lane, a 5-step butterfly; the activation itself is not stored
+            // (the separate head kernel read 2.1 GB for it at 32 x 131072)
+            const f32x4 ow0 = *(const f32x4 *)(a.out_w + 4 * s4);
+            const f32x4 ow1 = a.nout > 1 ? *(const f32x4 *)(a.out_w + 128 + 4 * s4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < T / 8; ++i) {
+                const int o = (tid >> 5) + 8 * i;
+                const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
+                float h0 = 0.0f, h1 = 0.0f;
+                if (t < a.L) {
+                    const f32x4 z = *(const f32x4 *)(st + o * 128 + ((s4 ^ (o & 31)) << 2));
+                    const f32x4 xin = *(const f32x4 *)(xb + t * 128 + 4 * s4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float out = z[k] + rs[k] * xin[k];
+                        h0 = fmaf(ow0[k], out, h0);
+                        h1 = fmaf(ow1[k], out, h1);
+                    }
+                }
+#pragma unroll
+                for (int mm = 16; mm >= 1; mm >>= 1) {
+                    h0 += __shfl_xor(h0, mm);
+                    h1 += __shfl_xor(h1, mm);
+                }
+                if (s4 < a.nout && t < a.L)
+                    a.y_out[((size_t)b * a.nout + s4) * a.L + t] = fminf(1.0f, fmaxf(-1.0f, (s4 ? h1 : h0) + a.out_b[s4]));
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < T / 8; ++i) {
             const int o = (tid >> 5) + 8 * i;
@@ -1198,6 +1229,37 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16x3_half_kernel(TcnBlockA
     {
         const int s4 = tid & 31;                                   // this thread's 4 channels, the same in every pass
         const f32x4 rs = *(const f32x4 *)(a.res + 4 * s4);
+        if (a.y_out) {
+            // last block: the 1x1 output conv + bias + clamp(-1, 1) (reference architectures.py:133,145) on the finished rows - a row's 128
+            // channels sit in 32 lanes (half a wave): 4 products per lane, a 5-step butterfly; the activation itself is not stored
+            // (the separate head kernel read 2.1 GB for it at 32 x 131072)
+            const f32x4 ow0 = *(const f32x4 *)(a.out_w + 4 * s4);
+            const f32x4 ow1 = a.nout > 1 ? *(const f32x4 *)(a.out_w + 128 + 4 * s4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < T / 8; ++i) {
+                const int o = (tid >> 5) + 8 * i;
+                const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
+                float h0 = 0.0f, h1 = 0.0f;
+                if (t < a.L) {
+                    const f32x4 z = *(const f32x4 *)(st + o * 128 + ((s4 ^ (o & 31)) << 2));
+                    const f32x4 xin = *(const f32x4 *)(xb + t * 128 + 4 * s4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float out = z[k] + rs[k] * xin[k];
+                        h0 = fmaf(ow0[k], out, h0);
+                        h1 = fmaf(ow1[k], out, h1);
+                    }
+                }
+#pragma unroll
+                for (int mm = 16; mm >= 1; mm >>= 1) {
+                    h0 += __shfl_xor(h0, mm);
+                    h1 += __shfl_xor(h1, mm);
+                }
+                if (s4 < a.nout && t < a.L)
+                    a.y_out[((size_t)b * a.nout + s4) * a.L + t] = fminf(1.0f, fmaxf(-1.0f, (s4 ? h1 : h0) + a.out_b[s4]));
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < T / 8; ++i) {
             const int o = (tid >> 5) + 8 * i;
