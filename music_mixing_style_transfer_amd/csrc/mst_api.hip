@@ -1107,7 +1107,7 @@ int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scrat
     a.slope = c.slope;
     a.zeros = zeros;
     {   // 32-bit offsets of the im2col kernel's buffer loads: a tile's rows lie within NT batch items of one descriptor; 24-bit row multiply
-        const long span_items = std::min<long>(128 * (4 / c.mw), B);
+        const long NTl = 128 * (4 / c.mw), span_items = std::min<long>(B, NTl / std::max(1, Lout) + 2);      // items a tile of NT columns can touch
         if (Lin >= (1 << 24) || c.cin >= (1 << 24) || (double)span_items * Lin * c.cin * 2.0 >= 2147483647.0 ||
             (double)c.nchunks64 * 4.0 * c.mw * 64.0 * 16.0 >= 2147483647.0)
             return fail(MST_ERR_UNSUPPORTED, "mst_enc_forward: activation too long for the channel-minor pipeline (use MST_PREC_F32)");

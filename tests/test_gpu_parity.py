@@ -212,6 +212,33 @@ def test_encoder_bf16x3_vs_oracle_and_reference_golden(nets):
         enc.precision = "fp32"
 
 
+def test_encoder_batch_size_and_ragged_lengths_do_not_change_the_rows(nets):
+    """The channel-minor pipeline addresses its operands with 32-bit offsets on per-workgroup descriptors (tiles that span several
+    batch items in the late layers, rows / k-slots outside the problem read as zeros): a batch of 70 segments gives, row by row, what the
+    same segments give in batches of 3 and 1 (not the same bits: the split-K width and with it the fp32 summation order follow the tile
+    count), in both bf16 modes - and a ragged length (not a multiple of any stride product) still agrees with the oracle."""
+    from music_mixing_style_transfer_amd.utils import synth
+    from oracle import networks_ref as R
+    enc = nets["enc"]
+    x = synth.synth_audio((70, 2, 32768), seed=123).cuda()
+    try:
+        for precision in ("bf16", "bf16x3"):
+            enc.precision = precision
+            big = enc(x)
+            tol = 2e-2 if precision == "bf16" else 2e-5
+            for lo, hi in ((11, 14), (69, 70), (0, 1)):
+                dev = float((big[lo:hi] - enc(x[lo:hi])).abs().max()) / float(big.abs().max())
+                print(f"FXencoder {precision}: rows {lo}:{hi} of a 70-segment batch vs their own batch: rel dev {dev:.2e}")
+                assert dev <= tol, (precision, lo, dev)
+        xr = synth.synth_audio((3, 2, 30011), seed=5)
+        e_ref = R.fxencoder_forward(nets["enc_sd"], nets["enc_cfg"], xr)
+        enc.precision = "bf16x3"
+        d = float((enc(xr.cuda()).cpu() - e_ref).abs().max()) / float(e_ref.abs().max())
+        assert d <= 1e-4, d
+    finally:
+        enc.precision = "fp32"
+
+
 def test_encoder_bf16_vs_oracle(nets):
     from music_mixing_style_transfer_amd.utils import synth
     from oracle import networks_ref as R
