@@ -299,6 +299,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--x3-large-tiles", action="store_true", help="bf16x3: 256-time tiles, one workgroup per CU (mst_tcn_set_tuning 0)")
     ap.add_argument("--enc-schedule", type=int, default=None, help="mst_enc_set_schedule flags (bit 0: weight-major workgroup order of the weight-heavy encoder layers, bit 1: 2 x 2 wave tiling of the 128-channel conv kernel)")
+    ap.add_argument("--enc-rows-min-tiles", type=int, default=None, help="mst_enc_set_tuning: tiles from which a layer keeps its rows resident in LDS (-1 never)")
     ap.add_argument("--tcn-tuning", type=int, default=None, help="mst_tcn_set_tuning flags (bit 0: bf16x3 small tiles, bits 1-2: form of the bf16 block kernel, include/mst_hip.h)")
     args = ap.parse_args()
 
@@ -338,6 +339,8 @@ def main():
     tcn._ensure(lib)
     if args.enc_schedule is not None:
         lib.check(lib.mst_enc_set_schedule(enc._get_runner().handle, args.enc_schedule), "mst_enc_set_schedule")
+    if args.enc_rows_min_tiles is not None:
+        lib.check(lib.mst_enc_set_tuning(enc._get_runner().handle, args.enc_rows_min_tiles), "mst_enc_set_tuning")
     if args.x3_large_tiles:
         lib.check(lib.mst_tcn_set_tuning(tcn._handle, 0), "mst_tcn_set_tuning")
     if args.tcn_tuning is not None:
