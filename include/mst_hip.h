@@ -155,7 +155,7 @@ int mst_enc_destroy(MstEnc *enc);
 int mst_enc_load_conv(MstEnc *enc, int block, int which, const float *w, const float *bias,
                       const float *bn_weight, const float *bn_bias, const float *bn_mean, const float *bn_var,
                       float bn_eps, void *stream);
-/* tuning (bf16 / bf16x3 modes): a conv layer (bf16 mode: with at most 32 input channels) whose launch has at least rows_min_tiles tiles keeps its
+/* tuning (bf16 / bf16x3 modes): a conv layer (bf16 mode: with at most 64 input channels) whose launch has at least rows_min_tiles tiles keeps its
  * input rows resident in LDS (enc_conv_rows_kernel) instead of gathering an im2col slice per k-chunk; default 512, 0 = whenever a
  * layer qualifies (any channel count), negative = never.  Both forms produce identical bits. */
 int mst_enc_set_tuning(MstEnc *enc, long rows_min_tiles);

@@ -808,30 +808,44 @@ __global__ __launch_bounds__(256, 2) void enc_conv_rows_kernel(EncNlcArgs a) {
     for (int q = 0; q < 4; ++q)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.0f;
-    const bf16x8 *wtile = (const bf16x8 *)a.wpk + (size_t)cot * a.nchunks * 4 * MW * 64 + mi * 64 + lane;
-    const bf16x8 *wtile_lo = (const bf16x8 *)a.wpk_lo + (size_t)cot * a.nchunks * 4 * MW * 64 + mi * 64 + lane;
+    // A fragments: raw buffer loads (lane offset + scalar k-step offset), a ring of four k-steps: the fragment of k-step ks + 4 is requested
+    // right behind the MFMAs of k-step ks (one k-step ahead, as before round 3, left the L2 latency of every fragment exposed: there
+    // is nothing else to wait for in this loop)
+    const unsigned wbytes = (unsigned)a.nchunks * 4u * MW * 64u * 16u;
+    const MstStream16 ws = mst_stream16((const unsigned char *)a.wpk + (size_t)cot * wbytes, wbytes);
+    const MstStream16 wls = mst_stream16((const unsigned char *)a.wpk_lo + (size_t)cot * wbytes, wbytes);
+    const unsigned wlane = (unsigned)(mi * 64 + lane) * 16u;
     const int nks = (a.Cin * a.ksz) / 16;                             // k-steps that carry weights (K = Cin * ksz is a multiple of 16)
-    bf16x8 anext = wtile[0], anext_lo = {0, 0, 0, 0, 0, 0, 0, 0};
-    if constexpr (X3) anext_lo = wtile_lo[0];
+    bf16x8 ar[4], arl[X3 ? 4 : 1];
+    auto fetch_a = [&](int ks, int u) {
+        const unsigned so = (unsigned)(ks < nks ? ks : nks - 1) * (MW * 64u * 16u);
+        ar[u] = __builtin_bit_cast(bf16x8, mst_stream_load16(ws, wlane, so));
+        if constexpr (X3) arl[u] = __builtin_bit_cast(bf16x8, mst_stream_load16(wls, wlane, so));
+    };
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fetch_a(u, u);
     __syncthreads();
     const unsigned char *lanebase = rows + (128 * ni + ln) * pitch + 16 * h;
-    for (int ks = 0; ks < nks; ++ks) {
-        const bf16x8 acur = anext, acur_lo = anext_lo;
-        if (ks + 1 < nks) {
-            anext = wtile[(size_t)(ks + 1) * MW * 64];
-            if constexpr (X3) anext_lo = wtile_lo[(size_t)(ks + 1) * MW * 64];
-        }
-        const int k0 = ks * 16, j = k0 / a.Cin, ci0 = k0 - j * a.Cin;
-        const unsigned char *bp = lanebase + ((j % s) * rpp + j / s) * pitch + ci0 * 2;
+    for (int ks0 = 0; ks0 < nks; ks0 += 4) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bf16x8 bv = *(const bf16x8 *)(bp + 32 * q * pitch);
-            if constexpr (X3) {
-                const bf16x8 bl = *(const bf16x8 *)(bp + lo_off + 32 * q * pitch);
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur_lo, bv, acc[q], 0, 0, 0);
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur, bl, acc[q], 0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+            const int ks = ks0 + u;
+            if (ks < nks) {          // uniform
+                const int k0 = ks * 16, j = k0 / a.Cin, ci0 = k0 - j * a.Cin;
+                const unsigned char *bp = lanebase + ((j % s) * rpp + j / s) * pitch + ci0 * 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bf16x8 bv = *(const bf16x8 *)(bp + 32 * q * pitch);
+                    if constexpr (X3) {
+                        const bf16x8 bl = *(const bf16x8 *)(bp + lo_off + 32 * q * pitch);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(arl[u], bv, acc[q], 0, 0, 0);
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[u], bl, acc[q], 0, 0, 0);
+                    }
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[u], bv, acc[q], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);          // the reload stays behind the MFMAs that read the same registers
+                fetch_a(ks + 4, u);
             }
-            acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur, bv, acc[q], 0, 0, 0);
         }
     }
 #pragma unroll

@@ -1119,11 +1119,11 @@ int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scrat
         const long R = (long)(NT - 1) * c.stride + c.ksz, rpp = (R + c.stride - 1) / c.stride;
         const long lds = (long)c.stride * rpp * (c.cin * 2 + 16);
         const bool fits = x3 ? 2 * lds <= 80 * 1024 : lds <= 64 * 1024;
-        // measured (round 3, after the im2col kernel's loads were fixed): the rows form wins for 16 / 32 input channels (55.8 vs 92.9, 25.7 vs
-        // 31.4, 26.0 vs 28.6 us), the im2col form from 64 channels on (35.6 vs 40.4, 32.0 vs 37.8, 35.6 vs 47.6 us); rows_min_tiles = 0 forces
-        // the rows form wherever it qualifies (tests)
-        // (split mode, same box: rows 55.1 / 54.0 / 65.0 us vs im2col 67.6 / 60.8 / 71.1 us for 64 / 64 / 128 channels - there the rows form stays)
-        const bool narrow = rows_min_tiles == 0 || x3 || c.cin <= 32;
+        // measured (round 3, same box, after the im2col kernel's loads were fixed and the rows kernel got its four-step A ring): bf16 mode -
+        // rows 52.6 / 23.2 / 22.9 / 32.4 us vs im2col 92.9 / 31.4 / 28.6 / 37.6 us for 16 / 32 / 32 / 64 input channels, equal at 64 -> 128
+        // (32.3 / 32.6), im2col ahead at 128 channels (35.7 vs 38.9); split mode - rows ahead wherever it fits (54.3 / 52.7 / 63.5 vs
+        // 67.6 / 60.8 / 71.1 us).  rows_min_tiles = 0 forces the rows form wherever it qualifies (tests).
+        const bool narrow = rows_min_tiles == 0 || x3 || c.cin <= 64;
         if (rows_min_tiles >= 0 && narrow && c.dil == 1 && c.cin % 16 == 0 && Lout >= NT && fits && (long)B * tiles_item * cotiles >= rows_min_tiles) {
             a.S = 1;
             a.part = nullptr;
