@@ -43,6 +43,7 @@ struct EncConvArgs {
     // Used for the short wide late layers, whose 128 tiles would otherwise leave half of the 256 CUs idle.
     float *part = nullptr;
     float slope = 0.0f;  // epi 0: activation slope for negative values (enc_act)
+    int buf32 = 0;       // enc_conv_kernel: the tile's activations are reachable with 32-bit byte offsets (host-checked): buffer-load gathers
 };
 
 template <int MW>
@@ -58,16 +59,23 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
     const long n0 = (long)blockIdx.x * NT;
     const int cot = blockIdx.y;
 
-    // the <= 2 columns this thread gathers for (fixed for the whole K loop)
+    // the <= 2 columns this thread gathers for (fixed for the whole K loop).  The gathers are raw buffer loads (round 3): a 32-bit byte
+    // offset per lane on a descriptor that starts at the tile's first batch item; rows of K beyond the problem, columns beyond Ntot and
+    // (zero-padding mode) taps outside the signal use an offset beyond the descriptor, which reads as 0 - no predicated load (hipcc
+    // branches around one and drains vmcnt(0) behind it: the loads of chunk k + 1 then never overlapped the MFMAs of chunk k), and the
+    // k-table entries are fetched a chunk ahead of the gathers that need them.
     constexpr int NCOL = (NT + 255) / 256;
-    long colbase[NCOL];
+    const int item0 = (int)(n0 / a.Lout);
+    const size_t item_elems = (size_t)a.Cin * a.Lin, left = ((size_t)a.B - item0) * item_elems * 4;
+    const MstStream16 xs = mst_stream16(a.x + (size_t)item0 * item_elems, left < 0x7fffffffu ? (unsigned)left : 0x7fffffffu);
+    int colbase[NCOL];                                // element offset of the column's batch item in the descriptor, -1: no column
     int colt[NCOL];
 #pragma unroll
     for (int c = 0; c < NCOL; ++c) {
         const long n = n0 + (tid + c * 256) % NT;
         if (n < a.Ntot) {
             const int b = (int)(n / a.Lout), to = (int)(n % a.Lout);
-            colbase[c] = (long)b * a.Cin * a.Lin;
+            colbase[c] = (int)((b - item0) * (long)item_elems);
             colt[c] = to * a.stride;
         } else {
             colbase[c] = -1;
@@ -84,7 +92,14 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
     f32x4 areg[NA];
     float breg[NB];
     const f32x4 *wtile = (const f32x4 *)(a.wpk + (size_t)cot * a.nchunks * 16 * MT);
+    const int kc_lo = (int)((long)blockIdx.z * a.nchunks / gridDim.z), kc_hi = (int)((long)(blockIdx.z + 1) * a.nchunks / gridDim.z);
 
+    u32x2 kt[NB];                                     // k-table entries (ci, tap offset) of the chunk the next fetch() gathers
+    auto ktab_entries = [&](int kc) {
+        const int k2 = kc < kc_hi ? kc : kc_hi - 1;
+#pragma unroll
+        for (int e = 0; e < NB; ++e) kt[e] = *(const u32x2 *)(a.ktab + (k2 * 16 + (tid + e * 256) / NT) * 2);
+    };
     auto fetch = [&](int kc) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -93,27 +108,33 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs a) {
         }
 #pragma unroll
         for (int e = 0; e < NB; ++e) {
-            const int idx = tid + e * 256;
-            const int krow = idx / NT;
             const int c = (NT > 256) ? (e & 1) : 0;
-            const int ci = a.ktab[(kc * 16 + krow) * 2], joff = a.ktab[(kc * 16 + krow) * 2 + 1];
-            float v = 0.0f;
-            if (ci >= 0 && colbase[c] >= 0) {
-                int ti = colt[c] + joff;
-                if (a.pad_zero) {
-                    if (ti >= 0 && ti < a.Lin) v = a.x[colbase[c] + (long)ci * a.Lin + ti];
-                } else {
-                    if (ti < 0) ti = -ti;
-                    if (ti >= a.Lin) ti = 2 * (a.Lin - 1) - ti;
-                    v = a.x[colbase[c] + (long)ci * a.Lin + ti];
-                }
+            const int ci = (int)kt[e][0], joff = (int)kt[e][1];
+            int ti = colt[c] + joff;
+            bool ok = ci >= 0 && colbase[c] >= 0;
+            if (a.pad_zero) {
+                ok = ok && ti >= 0 && ti < a.Lin;
+            } else {
+                if (ti < 0) ti = -ti;
+                if (ti >= a.Lin) ti = 2 * (a.Lin - 1) - ti;
             }
-            breg[e] = v;
+            if (a.buf32) {
+                const unsigned off = ok ? (unsigned)(colbase[c] + mst_mul24(ci, a.Lin) + ti) * 4u : 0xfffffff0u;
+                breg[e] = __builtin_bit_cast(float, mst_stream_load4(xs, off, 0u));
+            } else {          // activations beyond the 32-bit / 24-bit ranges (uniform): 64-bit addresses, predicated loads
+                float v = 0.0f;
+                if (ok) v = a.x[(size_t)item0 * item_elems + ((long)(n0 + (tid + (NT > 256 ? (e & 1) : 0) * 256) % NT) / a.Lout - item0) * (long)item_elems +
+                                (long)ci * a.Lin + ti];
+                breg[e] = v;
+            }
         }
+        ktab_entries(kc + 1);
     };
 
-    const int kc_lo = (int)((long)blockIdx.z * a.nchunks / gridDim.z), kc_hi = (int)((long)(blockIdx.z + 1) * a.nchunks / gridDim.z);
-    fetch(kc_lo);
+    if (kc_lo < kc_hi) {
+        ktab_entries(kc_lo);
+        fetch(kc_lo);
+    }
     for (int kc = kc_lo; kc < kc_hi; ++kc) {
         if (kc > kc_lo) __syncthreads();
 #pragma unroll

@@ -481,6 +481,12 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
     return MST_OK;
 }
 
+// enc_conv_kernel's gathers: 32-bit byte offsets on a descriptor that starts at the tile's first batch item (24-bit channel x length multiply)
+int conv_buf32(int mw, int B, int cin, long Lin, long Lout) {
+    const long NT = 128 * (4 / mw), span_items = std::min<long>(B, NT / std::max<long>(1, Lout) + 2);
+    return (Lin < (1 << 24) && cin < (1 << 24) && (double)span_items * cin * Lin * 4.0 < 2147483647.0) ? 1 : 0;
+}
+
 // generic configuration: every block is one launch of the fp32 implicit-GEMM conv kernel (NCL activations, zero
 // padding) with the TCN epilogue; the output head is the same kernel with k = 1 and the clamp epilogue
 int tcn_launch_generic(const MstEncConv &c, const float *x, float *y, int B, int L, int epi, const float *film, int film_rows,
@@ -508,6 +514,7 @@ int tcn_launch_generic(const MstEncConv &c, const float *x, float *y, int B, int
     a.res = res;
     a.film_rows = film_rows;
     a.res_div = res_div;
+    a.buf32 = conv_buf32(c.mw, B, c.cin, L, L);
     const int MT = 32 * c.mw, NT = 128 * (4 / c.mw);
     const dim3 grid((unsigned)((a.Ntot + NT - 1) / NT), (unsigned)((c.cout + MT - 1) / MT));
     switch (c.mw) {
@@ -960,6 +967,7 @@ int enc_launch(const MstEncConv &c, const float *x, float *y, int B, int Lin, in
     a.film_rows = 1;
     a.res_div = 1;
     a.slope = c.slope;
+    a.buf32 = conv_buf32(c.mw, B, c.cin, Lin, Lout);
     const int MT = 32 * c.mw, NT = 128 * (4 / c.mw);
     dim3 grid((unsigned)((a.Ntot + NT - 1) / NT), (unsigned)((c.cout + MT - 1) / MT));
     int S = 1;

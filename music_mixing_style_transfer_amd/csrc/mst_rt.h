@@ -69,6 +69,9 @@ __device__ __forceinline__ MstStream16 mst_stream16(const void *base, unsigned b
 __device__ __forceinline__ mst_u32x4 mst_stream_load16(MstStream16 s, unsigned voffset, unsigned soffset) {
     return __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, (int)voffset, (int)soffset, 0);
 }
+__device__ __forceinline__ unsigned mst_stream_load4(MstStream16 s, unsigned voffset, unsigned soffset) {      // one dword, zeros beyond the descriptor
+    return __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, (int)voffset, (int)soffset, 0);
+}
 // a * b for operands known to fit 24 bits: one full-rate instruction (v_mul_lo_u32 runs at a quarter of the rate)
 __device__ __forceinline__ int mst_mul24(int a, int b) { return __mul24(a, b); }
 // the device the calling thread is bound to (per-device constants), -1 on error

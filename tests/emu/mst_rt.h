@@ -210,6 +210,12 @@ static inline mst_u32x4 mst_stream_load16(MstStream16 s, unsigned voffset, unsig
     if (off + 16 <= s.bytes) memcpy(&v, s.base + off, 16);
     return v;
 }
+static inline unsigned mst_stream_load4(MstStream16 s, unsigned voffset, unsigned soffset) {
+    unsigned v = 0u;
+    const unsigned long off = (unsigned long)voffset + soffset;
+    if (off + 4 <= s.bytes) memcpy(&v, s.base + off, 4);
+    return v;
+}
 static inline int mst_mul24(int a, int b) { return a * b; }
 static inline int mst_current_device() { return 0; }
 static inline int mst_num_cus() { return 4; }      // a small persistent grid: every workgroup walks several tiles
