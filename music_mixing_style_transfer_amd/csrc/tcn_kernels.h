@@ -907,14 +907,15 @@ __global__ __launch_bounds__(256, (NQ == 4 && P <= 2) ? 2 : 1) void tcn_block_bf
         for (int half = 0; half < 2; ++half) {
             long t = (long)(m0 + prow / P - 7) * a.d + phi0 + (prow % P) + (long)half * HALF * dt;
             const float *src = xb + t * 128 + slot * 8;
+            const float *zsrc = (const float *)a.zeros + slot * 8;
             f32x4 v0[HALF], v1[HALF];
 #pragma unroll
             for (int i = 0; i < HALF; ++i) {
-                v0[i] = v1[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                if (prow + 16 * (half * HALF + i) < R && t >= 0 && t < a.L) {
-                    v0[i] = *(const f32x4 *)src;
-                    v1[i] = *(const f32x4 *)(src + 4);
-                }
+                // never a predicated load (hipcc branches around one and waits for it before the next: the row passes of a half ran one
+                // memory latency after the other): rows outside the segment are fetched from the zero page
+                const float *p = (prow + 16 * (half * HALF + i) < R && t >= 0 && t < a.L) ? src : zsrc;
+                v0[i] = *(const f32x4 *)p;
+                v1[i] = *(const f32x4 *)(p + 4);
                 t += dt;
                 src += dt * 128;
             }
@@ -1133,12 +1134,8 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16x3_half_kernel(TcnBlockA
             for (int i = 0; i < NPASS; ++i) {
                 const int row = prow + 32 * i;
                 const long t = (long)(m0 + row / P - 7) * a.d + phi0 + (row % P);
-                f32x4 v0 = {0.0f, 0.0f, 0.0f, 0.0f}, v1 = v0;
-                if (row < R && t >= 0 && t < a.L) {
-                    const float *src = xb + t * 128 + 64 * c + slot * 8;
-                    v0 = *(const f32x4 *)src;
-                    v1 = *(const f32x4 *)(src + 4);
-                }
+                const float *src = (row < R && t >= 0 && t < a.L) ? xb + t * 128 + 64 * c + slot * 8 : (const float *)a.zeros + slot * 8;
+                const f32x4 v0 = *(const f32x4 *)src, v1 = *(const f32x4 *)(src + 4);          // (never a predicated load: zero page)
                 if (row < R) {
                     bf16x8 hi, lo;
 #pragma unroll
@@ -1314,7 +1311,7 @@ __global__ __launch_bounds__(256, 2) void tcn_block_f32_kernel(TcnBlockArgs a) {
 #pragma unroll 2
             for (int r = tid >> 3; r < R; r += 32) {
                 const long t = (long)(m0 + r / P - 7) * a.d + phi0 + (r % P);
-                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};          // (a zero-page form of this load measured 1.7 % slower per launch, round 3)
                 if (t >= 0 && t < a.L) v = *(const f32x4 *)(xb + t * 128 + c * 32 + s * 4);
                 const int rs = r & 31;
                 f32x4 o1, o2;   // o2[i ^ (rs & 3)] = v[i] as two conditional swaps (no runtime vector indexing)
