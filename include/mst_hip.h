@@ -163,7 +163,8 @@ int mst_enc_set_tuning(MstEnc *enc, long rows_min_tiles);
  * activation bytes run their workgroups in weight-major order - all column tiles of one (channel tile, k-slice) on one XCD, so a
  * weight slice crosses the fabric once instead of once per XCD.  bit 1 (default off: measured 7-12 % slower): the 128-channel x
  * 128-column tile with its waves 2 x 2 (enc_conv_nlc22_kernel: two MFMAs per LDS read, every weight fragment fetched by two waves).
- * Same bits either way. */
+ * bit 2 (exact-fp32 mode, a test hook): gather through 64-bit addresses - the path that activations beyond the 32-bit offset range take
+ * by themselves - instead of buffer loads.  Same bits either way. */
 int mst_enc_set_schedule(MstEnc *enc, int flags);
 /* nn.AdaptiveAvgPool1d(1) on its own (architectures.py:63,67; FXencoder(conv_block='conv') runs its ConvBlocks one by one through
  * mst_enc_forward_conv and pools here): x_dev fp32 [rows, L] -> y_dev[rows] = mean over L. */

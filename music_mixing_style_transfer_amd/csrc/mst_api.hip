@@ -888,7 +888,7 @@ extern "C" int mst_global_avgpool(const float *x, float *y, long rows, int L, vo
 }
 
 extern "C" int mst_enc_set_schedule(MstEnc *e, int flags) {
-    if (!e || flags < 0 || flags > 3) return fail(MST_ERR_ARG, "mst_enc_set_schedule: flags 0..3");
+    if (!e || flags < 0 || flags > 7) return fail(MST_ERR_ARG, "mst_enc_set_schedule: flags 0..7");
     e->schedule = flags;
     return MST_OK;
 }
@@ -940,7 +940,7 @@ int enc_splitk_f32(long tiles, int nchunks) {        // slices of the fp32 NCL k
 }
 
 int enc_launch(const MstEncConv &c, const float *x, float *y, int B, int Lin, int Lout, int residual, int precision,
-               void *stream, float *scratch = nullptr) {
+               void *stream, float *scratch = nullptr, int schedule = 0) {
     if (Lin <= c.pad_l || Lin <= c.pad_r)
         return fail(MST_ERR_ARG, "mst_enc_forward: reflection padding needs the input to be longer than the padding");
     EncConvArgs a;
@@ -967,7 +967,7 @@ int enc_launch(const MstEncConv &c, const float *x, float *y, int B, int Lin, in
     a.film_rows = 1;
     a.res_div = 1;
     a.slope = c.slope;
-    a.buf32 = conv_buf32(c.mw, B, c.cin, Lin, Lout);
+    a.buf32 = (schedule & 4) ? 0 : conv_buf32(c.mw, B, c.cin, Lin, Lout);          // bit 2: the 64-bit gather path (a test hook)
     const int MT = 32 * c.mw, NT = 128 * (4 / c.mw);
     dim3 grid((unsigned)((a.Ntot + NT - 1) / NT), (unsigned)((c.cout + MT - 1) / MT));
     int S = 1;
@@ -1249,9 +1249,9 @@ int enc_run(MstEnc *e, const float *x, float *emb, float *blk_out, int B, int L,
     int len = L, rc, pp = 0;
     for (int i = 0; i < n_run; ++i) {
         const int lout = (len - 1) / e->d.strides[i] + 1;
-        if ((rc = enc_launch(e->conv[2 * i], cur, t1, B, len, len, 1, precision, stream, scratch))) return rc;
+        if ((rc = enc_launch(e->conv[2 * i], cur, t1, B, len, len, 1, precision, stream, scratch, e->schedule))) return rc;
         float *dst = (blk_out && i == n_run - 1) ? blk_out : o[pp];
-        if ((rc = enc_launch(e->conv[2 * i + 1], t1, dst, B, len, lout, 0, precision, stream, scratch))) return rc;
+        if ((rc = enc_launch(e->conv[2 * i + 1], t1, dst, B, len, lout, 0, precision, stream, scratch, e->schedule))) return rc;
         cur = dst;
         pp ^= 1;
         len = lout;
@@ -1290,7 +1290,7 @@ extern "C" int mst_enc_forward_conv(MstEnc *e, int block, int which, const float
     if (!c.loaded) return fail(MST_ERR_STATE, "mst_enc_forward_conv: conv weights not loaded");
     const int lout = conv_out_length(c, L);
     if (lout < 1) return fail(MST_ERR_ARG, "mst_enc_forward_conv: input shorter than the kernel");
-    return enc_launch(c, x, y, B, L, lout, 0, MST_PREC_F32, stream);
+    return enc_launch(c, x, y, B, L, lout, 0, MST_PREC_F32, stream, nullptr, e->schedule);
 }
 
 extern "C" int mst_film_forward(const float *w, const float *b, const float *cond, int rows, int cond_dim, int C, const float *x,

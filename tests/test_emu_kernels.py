@@ -243,6 +243,13 @@ def test_fx_emulated(emu_default):
     assert np.abs(one([(im, 1.0, True), (gn, 1.0, True)]) - ref1).max() <= 1e-6
     ref2 = AugmentationChain([(eq, 1.0, True)], randomize_param_value=False)([one([(im, 1.0, True)])])[0]
     assert np.abs(one([(im, 1.0, True), (eq, 1.0, True)]) - ref2).max() <= 1e-6
+    # tail folding is the imager's: the other entry points refuse a descriptor that asks for it
+    import ctypes as C
+    from music_mixing_style_transfer_amd import _lib
+    t = torch.from_numpy(x.copy())[None].contiguous()
+    y_t, q = torch.empty_like(t), torch.zeros(64, dtype=torch.float64)
+    f = _lib.MstFxFuse(None, None, q.data_ptr(), 1, 2.0)
+    assert emu_default.mst_fx_gain(t.data_ptr(), y_t.data_ptr(), 1, t.shape[1], 2, 0.0, 0, C.byref(f), None) == -2          # MST_ERR_UNSUPPORTED
     # batched [n_items, L, C] input
     xb = np.stack([x, 0.5 * x[::-1].copy()])
     yb = comp.process(xb)
@@ -488,8 +495,15 @@ def test_encoder_wave_tilings_and_workgroup_orders_match_emulated(emu_default):
         emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 1), "schedule")          # the default
         assert all(torch.equal(o, outs[0]) for o in outs[1:]), precision
         assert float((outs[0] - emb).abs().max()) <= tol * float(emb.abs().max())
+    # exact-fp32 mode: the buffer-load gathers against the 64-bit-address fallback (schedule bit 2) - the same bits
+    enc.precision = "fp32"
+    ref32 = enc(x).clone()
+    emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 1 | 4), "schedule")
+    assert torch.equal(enc(x), ref32)
+    emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 1), "schedule")
+    assert float((ref32 - emb).abs().max()) <= 2e-5 * float(emb.abs().max())
     with pytest.raises(ValueError):
-        emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 4), "schedule")
+        emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 8), "schedule")
 
 
 def test_algorithmic_reverb_emulated(emu_default):
