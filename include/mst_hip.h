@@ -221,6 +221,9 @@ typedef struct {
     const double *in_sumsq_dev;
     int post_rms;
     float post_gain;
+    /* mst_fx_biquad_cascade only (the others refuse it): also leave sum(x_raw^2) of the call's raw input here
+     * ([n_items][MST_SUMSQ_SLOTS], the arithmetic of mst_fx_sumsq) - the first rms-normalise of a chain then needs no energy pass over x */
+    double *out_in_sumsq_dev;
 } MstFxFuse;
 int mst_fx_sumsq(const float *x_dev, int n_items, long per_item, double *out_dev, void *stream);   /* out[item][slot]: partial sums of x^2 */
 /* scale_out[item] = float32(sqrt(mean(x_true^2) / max(1e-7, mean(y^2)))), mean(x_true^2) = scale_x^2 sum_slots(sumsq_x) / per_x

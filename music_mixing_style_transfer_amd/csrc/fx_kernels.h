@@ -82,6 +82,7 @@ struct BiquadChunkArgs {
     // to out_sumsq[item] (float64) so that the next rms-normalise needs no energy pass.  Both may be null.
     const double *in_scale = nullptr;
     double *out_sumsq = nullptr;
+    double *out_in_sumsq = nullptr;      // the apply pass also leaves sum(x_raw^2) here (the first rms-normalise of a chain needs it: no energy pass over x)
 };
 
 template <bool APPLY, int NBANDS>
@@ -90,6 +91,8 @@ __global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) 
     if constexpr (!APPLY) {          // the state pass clears the energy slots the apply pass adds to (no memset launch in front of the call)
         if (a.out_sumsq)
             for (long i = gid; i < (long)(a.n_seq / a.C) * MST_SUMSQ_SLOTS; i += (long)gridDim.x * 64) a.out_sumsq[i] = 0.0;
+        if (a.out_in_sumsq)
+            for (long i = gid; i < (long)(a.n_seq / a.C) * MST_SUMSQ_SLOTS; i += (long)gridDim.x * 64) a.out_in_sumsq[i] = 0.0;
     }
     if (gid >= (long)a.n_seq * a.nchunks) return;
     // lanes: channel fastest, then chunk, then item - neighbouring lanes read neighbouring samples of a frame
@@ -108,8 +111,9 @@ __global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) 
         z2[b] = zz.y;
     }
     const float sf = a.in_scale ? (float)a.in_scale[item] : 1.0f;
-    double ss = 0.0;
+    double ss = 0.0, ssx = 0.0;
     auto step = [&](float xi) {
+        if (APPLY) ssx += (double)(xi * xi);          // float32 square, float64 sum: the arithmetic of fx_sumsq_kernel
         double v = (double)(xi * sf);
 #pragma unroll
         for (int b = 0; b < NBANDS; ++b) {
@@ -169,8 +173,9 @@ __global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) 
         for (int b = 0; b < NBANDS; ++b) {
             *(double2 *)(a.ends + ((size_t)seq * a.nchunks + k) * (2 * MST_MAX_BANDS) + 2 * b) = double2{z1[b], z2[b]};
         }
-    } else if (a.out_sumsq) {
-        atomicAdd(&a.out_sumsq[item * MST_SUMSQ_SLOTS + (k & (MST_SUMSQ_SLOTS - 1))], ss);     // spread over the slots: few atomics per address
+    } else {
+        if (a.out_sumsq) atomicAdd(&a.out_sumsq[item * MST_SUMSQ_SLOTS + (k & (MST_SUMSQ_SLOTS - 1))], ss);     // spread over the slots: few atomics per address
+        if (a.out_in_sumsq) atomicAdd(&a.out_in_sumsq[item * MST_SUMSQ_SLOTS + (k & (MST_SUMSQ_SLOTS - 1))], ssx);
     }
 }
 

@@ -1393,6 +1393,7 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         a.n_bands = n_bands;
         a.in_scale = fuse ? fuse->in_scale_dev : nullptr;
         a.out_sumsq = fuse ? fuse->out_sumsq_dev : nullptr;
+        a.out_in_sumsq = fuse ? fuse->out_in_sumsq_dev : nullptr;
         biquad_coefs(coef, n_bands, a.coef);
         const size_t states = (size_t)a.n_seq * nchunks * 2 * MST_MAX_BANDS;
         double *ends = scratch, *starts = scratch + states;
@@ -1467,7 +1468,7 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         MST_CHECK_LAUNCH("fx_biquad_chunk_kernel<apply>");
         return MST_OK;
     }
-    if (fuse && (fuse->in_scale_dev || fuse->out_sumsq_dev))
+    if (fuse && (fuse->in_scale_dev || fuse->out_sumsq_dev || fuse->out_in_sumsq_dev))
         return fail(MST_ERR_UNSUPPORTED, "mst_fx_biquad_cascade: chain fusion needs the time-parallel path (scratch, more than one chunk, >= 1 band)");
     BiquadArgs a;
     a.x = x;
@@ -1585,7 +1586,8 @@ extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, 
     if (!x || !y || n_items < 1 || L < 1 || C < 1 || attack_ms <= 0 || release_ms <= 0 || ratio <= 0 || sample_rate <= 0)
         return fail(MST_ERR_ARG, "mst_fx_compressor: bad argument");
     const bool fused = fuse && (fuse->in_scale_dev || fuse->out_sumsq_dev);
-    if (fuse && fuse->post_rms) return fail(MST_ERR_UNSUPPORTED, "mst_fx_compressor: tail folding (post_rms) is the imager's");
+    if (fuse && (fuse->post_rms || fuse->out_in_sumsq_dev))
+        return fail(MST_ERR_UNSUPPORTED, "mst_fx_compressor: tail folding (post_rms) is the imager's, out_in_sumsq_dev the equaliser's");
     if (fused && (!scratch || (threshold_db == 0.0 && ratio == 1.0)))
         return fail(MST_ERR_UNSUPPORTED, "mst_fx_compressor: chain fusion needs the scratch buffer and an active compressor");
     if (threshold_db == 0.0 && ratio == 1.0) {   // bypass (common_audioeffects.py:637)
@@ -1683,6 +1685,7 @@ extern "C" int mst_fx_midside_imager(const float *x, float *y, int n_items, long
                                      void *stream) {
     if (!x || !y || !scratch || n_items < 1 || L < 1) return fail(MST_ERR_ARG, "mst_fx_midside_imager: bad argument");
     const bool fold = fuse && fuse->post_rms;
+    if (fuse && fuse->out_in_sumsq_dev) return fail(MST_ERR_UNSUPPORTED, "mst_fx_midside_imager: out_in_sumsq_dev is the equaliser's");
     if (fold && !fuse->in_sumsq_dev) return fail(MST_ERR_ARG, "mst_fx_midside_imager: post_rms needs in_sumsq_dev");
     int chunks = (int)std::min<long>(MST_SUMSQ_SLOTS, (L + 8191) / 8192);
     if (chunks < 1) chunks = 1;
@@ -1700,7 +1703,8 @@ extern "C" int mst_fx_midside_imager(const float *x, float *y, int n_items, long
 extern "C" int mst_fx_gain(const float *x, float *y, int n_items, long L, int C, double gain_db, int invert, const MstFxFuse *fuse,
                            void *stream) {
     if (!x || !y || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_gain: bad argument");
-    if (fuse && fuse->post_rms) return fail(MST_ERR_UNSUPPORTED, "mst_fx_gain: tail folding (post_rms) is the imager's");
+    if (fuse && (fuse->post_rms || fuse->out_in_sumsq_dev))
+        return fail(MST_ERR_UNSUPPORTED, "mst_fx_gain: tail folding (post_rms) is the imager's, out_in_sumsq_dev the equaliser's");
     double g = std::pow(10.0, gain_db / 20.0);
     if (invert) g = -g;
     const long per = L * C;

@@ -104,16 +104,20 @@ class _Dev:
     def scratch(self, n_doubles):
         return torch.empty(n_doubles, dtype=torch.float64, device=self.x.device)
 
-    def fuse(self, in_scale, want_sumsq, in_sumsq=None, post_gain=None):
+    def fuse(self, in_scale, want_sumsq, in_sumsq=None, post_gain=None, want_in_sumsq=False):
         """(MstFxFuse pointer or None, sumsq tensor or None) for a processor call inside a fused chain.
         in_sumsq + post_gain: tail folding (the rms-normalise behind the processor and a gain behind that in the processor's last pass)."""
-        if in_scale is None and not want_sumsq and in_sumsq is None:
+        self.last_in_sumsq = None
+        if in_scale is None and not want_sumsq and in_sumsq is None and not want_in_sumsq:
             return None, None
         sumsq = torch.empty(self.n * SUMSQ_SLOTS, dtype=torch.float64, device=self.x.device) if want_sumsq else None   # cleared by the producer
+        if want_in_sumsq:       # sum(x_raw^2) of this call's input, left behind by the processor (the equaliser's apply pass)
+            self.last_in_sumsq = torch.empty(self.n * SUMSQ_SLOTS, dtype=torch.float64, device=self.x.device)
         f = _lib.MstFxFuse(in_scale.data_ptr() if in_scale is not None else None, sumsq.data_ptr() if want_sumsq else None,
                            in_sumsq.data_ptr() if in_sumsq is not None else None, 1 if in_sumsq is not None else 0,
-                           float(post_gain) if post_gain is not None else 1.0)
-        self._keep = (f, in_scale, sumsq, in_sumsq)    # alive until the launches are queued
+                           float(post_gain) if post_gain is not None else 1.0,
+                           self.last_in_sumsq.data_ptr() if want_in_sumsq else None)
+        self._keep = (f, in_scale, sumsq, in_sumsq, self.last_in_sumsq)    # alive until the launches are queued
         return C.byref(f), sumsq
 
     def out(self, y):
@@ -203,12 +207,12 @@ class Equaliser(Processor):
     def fusable(self, d):
         return not self.hard_clip and d.L > 1024 and len(self.bands) >= 1       # the time-parallel path, output left as filtered
 
-    def _run(self, d, in_scale, want_sumsq):
+    def _run(self, d, in_scale, want_sumsq, want_in_sumsq=False):
         coef = np.ascontiguousarray(self.coefficients())
         y = torch.empty_like(d.x)
         nbytes = d.lib.mst_fx_biquad_scratch_bytes(d.n, d.L, d.C, coef.shape[0])      # time-parallel (chunked scan) path
         sc = d.scratch((nbytes + 7) // 8)
-        fuse, sumsq = d.fuse(in_scale, want_sumsq)
+        fuse, sumsq = d.fuse(in_scale, want_sumsq, want_in_sumsq=want_in_sumsq)
         d.lib.check(d.lib.mst_fx_biquad_cascade(d.x.data_ptr(), y.data_ptr(), d.n, d.L, d.C,
                                                 coef.ctypes.data_as(C.POINTER(C.c_double)), coef.shape[0],
                                                 sc.data_ptr(), nbytes, fuse, d.stream), "mst_fx_biquad_cascade")
@@ -609,10 +613,14 @@ class AugmentationChain:
         if hasattr(processor, "fusable") and processor.fusable(d):
             # the pending rms factor of the previous step is folded into this processor's loads; its output leaves sum(y^2) behind
             d.rebind(x.t)
-            y, sumsq_y = processor._run(d, x.scale, rms_normalize)
+            d.last_in_sumsq = None
+            if rms_normalize and x.sumsq is None and isinstance(processor, Equaliser):
+                y, sumsq_y = processor._run(d, x.scale, True, want_in_sumsq=True)      # the equaliser leaves sum(x^2) of its input behind too
+            else:
+                y, sumsq_y = processor._run(d, x.scale, rms_normalize)
             if not rms_normalize:
                 return _Pending(d, y, None, sumsq_y)
-            sumsq_x = x.sumsq if x.sumsq is not None else _sumsq(d, x.t)
+            sumsq_x = x.sumsq if x.sumsq is not None else (d.last_in_sumsq if d.last_in_sumsq is not None else _sumsq(d, x.t))
             if sumsq_y is None:
                 sumsq_y = _sumsq(d, y)
             scale = torch.empty(d.n, dtype=torch.float64, device=y.device)
