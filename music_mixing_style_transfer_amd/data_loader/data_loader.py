@@ -97,12 +97,27 @@ class Song_Dataset_Inference:
         return torch.stack(inputs, 0), torch.stack(refs, 0), dir_name
 
     def __iter__(self):
-        if self.workers <= 0 or len(self) < 2:
+        # Multi-rank runs prepare their songs INLINE whatever args.workers says: __getitem__ issues collectives (the broadcast of the
+        # normalised stems) and a prefetch thread would enqueue them on the default process group concurrently with the consumer's
+        # all_gather / barrier of the previous song - in a different order on different ranks, which neither RCCL nor gloo allows.
+        if self.workers <= 0 or len(self) < 2 or self.dist is not None:
             for i in range(len(self)):
                 yield self[i]
             return
-        # one song ahead: a daemon thread decodes + normalises song i + 1 (its kernels run on its own stream) while song i is converted
+        # one song ahead: a thread decodes + normalises song i + 1 (its kernels run on its own stream) while song i is converted.  The
+        # consumer may stop early (an exception in inference(), a break): the generator's finally sets `stop`, drains the queue so that a
+        # blocked put returns, and joins the thread - no thread is left holding a song of device tensors.
         q = queue.Queue(maxsize=1)
+        stop = threading.Event()
+
+        def put(msg):
+            while not stop.is_set():
+                try:
+                    q.put(msg, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def produce():
             try:
@@ -110,25 +125,38 @@ class Song_Dataset_Inference:
                     torch.cuda.set_device(self.device)
                     stream = torch.cuda.Stream(self.device)
                 for i in range(len(self)):
+                    if stop.is_set():
+                        return
                     if self.device is not None:
                         with torch.cuda.stream(stream):
                             item = self[i]
                         stream.synchronize()
                     else:
                         item = self[i]
-                    q.put(("item", item))
-                q.put(("done", None))
+                    if not put(("item", item)):
+                        return
+                put(("done", None))
             except BaseException as e:          # surfaces in the consumer
-                q.put(("error", e))
-        threading.Thread(target=produce, daemon=True).start()
-        while True:
-            kind, payload = q.get()
-            if kind == "done":
-                return
-            if kind == "error":
-                raise payload
-            if self.device is not None:         # made on the producer's stream, used on the consumer's: tell the caching allocator
-                for t in payload:
-                    if isinstance(t, torch.Tensor) and t.is_cuda:
-                        t.record_stream(torch.cuda.current_stream(self.device))
-            yield payload
+                put(("error", e))
+        worker = threading.Thread(target=produce, daemon=True, name="mst-prefetch")
+        worker.start()
+        try:
+            while True:
+                kind, payload = q.get()
+                if kind == "done":
+                    return
+                if kind == "error":
+                    raise payload
+                if self.device is not None:         # made on the producer's stream, used on the consumer's: tell the caching allocator
+                    for t in payload:
+                        if isinstance(t, torch.Tensor) and t.is_cuda:
+                            t.record_stream(torch.cuda.current_stream(self.device))
+                yield payload
+        finally:
+            stop.set()
+            try:
+                while True:
+                    q.get_nowait()
+            except queue.Empty:
+                pass
+            worker.join(timeout=60)

@@ -345,6 +345,18 @@ class TCNModel(_DeviceState, nn.Module):
             rf += (hp.kernel_size - 1) * hp.dilation_growth ** (n % hp.stack_size)
         return rf
 
+    @staticmethod
+    def add_model_specific_args(parent_parser):
+        """The model's hyper-parameters as command-line flags (reference architectures.py:158-174: same names, types and defaults)."""
+        from argparse import ArgumentParser
+        parser = ArgumentParser(parents=[parent_parser], add_help=False)
+        for name, default in (("ninputs", 1), ("noutputs", 1), ("nblocks", 4), ("kernel_size", 5), ("dilation_growth", 10),
+                              ("channel_growth", 1), ("channel_width", 32), ("stack_size", 10)):
+            parser.add_argument("--" + name, type=int, default=default)
+        for name in ("grouped", "causal", "skip_connections"):
+            parser.add_argument("--" + name, default=False, action="store_true")
+        return parser
+
     # ---- gfx950 plumbing -----------------------------------------------------------------------
     def _ensure(self, b):
         sig = _signature(self)

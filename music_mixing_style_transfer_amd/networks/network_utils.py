@@ -198,9 +198,26 @@ class FiLM(nn.Module):
         self.film_fc = nn.Linear(condition_len, feature_len * 2)
         self.feat_len = feature_len
 
-    def forward(self, feature, condition):
-        """feature [B, feat_len, L] (a 1-d conv feature map) or [B, feat_len] (linear), condition [1|B, condition_len]."""
+    def _sefa_shift(self, condition, sefa):
+        """SeFA edit of the condition (reference network_utils.py:164-178): sefa = (eigen index, scale).  The reference calls torch.eig,
+        which current torch no longer has; torch.linalg.eig is the same LAPACK geev (eigenvalue order included).  A once-per-condition
+        2048 x 2048 host-side decomposition - control plane, not the hot path; parity unpinned (the reference's call cannot run here).
+        Like the reference, `condition` is modified IN PLACE and row `index` (not column) of the eigenvector matrix is used."""
+        weight = self.film_fc.weight.detach().to("cpu", torch.float32).T
+        weight = weight / torch.linalg.norm(weight + 1e-07, dim=0, keepdims=True)
+        values, vectors = torch.linalg.eig(torch.matmul(weight, weight.T))
+        chosen = sefa[0]
+        alpha = values.real[chosen] * sefa[1]
+        shift = (alpha * vectors.real[chosen]).to(condition.device, condition.dtype)
+        condition += shift.repeat(condition.shape[0], 1)
+        return condition
+
+    def forward(self, feature, condition, sefa=None):
+        """feature [B, feat_len, L] (a 1-d conv feature map) or [B, feat_len] (linear), condition [1|B, condition_len];
+        sefa: None or (eigen index, scale) - see _sefa_shift."""
         b = _device_input(feature, "FiLM.forward")
+        if sefa:
+            condition = self._sefa_shift(condition, sefa)
         if feature.dim() not in (2, 3) or feature.shape[1] != self.feat_len:
             raise ValueError(f"FiLM.forward: expected a [B, {self.feat_len}(, L)] feature, got {tuple(feature.shape)}")
         x = feature.contiguous()

@@ -27,9 +27,9 @@ def _models(nblocks=3, enc_cfg=None):
     return enc.eval(), tcn.eval()
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, pass_samples=None):
     sys.path.insert(0, REPO)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MST_EMU_THREADS="2")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MST_EMU_THREADS="2" if world <= 2 else "1")
     torch.set_num_threads(1)
     from music_mixing_style_transfer_amd import _lib
     from music_mixing_style_transfer_amd.inference import StyleTransferEngine
@@ -41,7 +41,7 @@ def _worker(rank, world, port, out_path):
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     enc, tcn = _models()
-    eng = StyleTransferEngine(enc, tcn)
+    eng = StyleTransferEngine(enc, tcn) if pass_samples is None else StyleTransferEngine(enc, tcn, pass_samples=pass_samples)
     x_in = synth.synth_audio((2, L_IN), seed=5)
     x_ref = synth.synth_audio((2, L_REF), seed=6)
     res = eng.transfer_stem(x_in, x_ref, SEG, SEG)
@@ -73,6 +73,41 @@ def test_two_ranks_equal_one(tmp_path, emu):
     assert res["ranges"] == [(0, 2 * SEG), (2 * SEG, L_IN)]
     assert res["full"].shape == full.shape == (2, L_IN)
     assert torch.equal(res["full"], full)
+
+
+def test_eight_ranks_three_of_them_without_segments(tmp_path, emu):
+    """world size 8 over 5 input / 6 reference segments: shards floor(r S / 8) .. floor((r + 1) S / 8) leave three ranks without an input
+    segment and two without a reference segment - the empty-rows path of mean_embedding, the ragged branch of gather_embeddings and
+    zero-length time ranges in gather_stem; the result is the single-process one bit for bit."""
+    from music_mixing_style_transfer_amd import _lib
+    from music_mixing_style_transfer_amd.inference import segmentation as seg
+    one, eight = str(tmp_path / "one.pt"), str(tmp_path / "eight.pt")
+    prev = _lib._default
+    try:
+        _worker(0, 1, 0, one)
+    finally:
+        _lib.set_default_binding(prev)
+    mp.spawn(_worker, args=(8, 29683, eight), nprocs=8, join=True)
+    full = torch.load(one)["full"]
+    res = torch.load(eight, weights_only=False)
+    shards = [seg.shard_range(5, r, 8) for r in range(8)]
+    assert sum(1 for lo, hi in shards if lo == hi) == 3
+    assert res["ranges"] == [(min(L_IN, lo * SEG), min(L_IN, hi * SEG)) for lo, hi in shards]
+    assert torch.equal(res["full"], full)
+
+
+def test_two_ranks_with_passes_smaller_than_a_shard(tmp_path, emu):
+    """pass_samples = one segment: every rank walks its shard (2 and 3 input segments, 3 and 3 reference segments) in several network
+    passes; bit-equal to the single process that runs everything in one pass."""
+    from music_mixing_style_transfer_amd import _lib
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    prev = _lib._default
+    try:
+        _worker(0, 1, 0, one)
+    finally:
+        _lib.set_default_binding(prev)
+    mp.spawn(_worker, args=(2, 29689, two, SEG), nprocs=2, join=True)
+    assert torch.equal(torch.load(two, weights_only=False)["full"], torch.load(one)["full"])
 
 
 def _cli_worker(rank, world, port, out_path):
@@ -133,7 +168,7 @@ def _norm_features():
             "imager": {"drums": 0.8, "bass": 0.9}, "loudness": {"drums": -20.0, "bass": -22.0}}
 
 
-def _cli_files_worker(rank, world, port, root):
+def _cli_files_worker(rank, world, port, root, workers=0):
     """The runner over FILES with --normalize_input True: Song_Dataset_Inference decodes the wavs and normalises the input stems -
     on two ranks stem j is normalised by rank j % 2 only and broadcast, every rank writes its time range of the output files."""
     import types
@@ -159,10 +194,10 @@ def _cli_files_worker(rank, world, port, root):
                               save_each_inst=True, sample_rate=44100, target_dir=os.path.join(root, "data") + "/", interpolation=False,
                               input_file_name="input", reference_file_name="reference", stem_level_directory_name="separated",
                               do_not_separate=True, precomputed_normalization_feature=_norm_features(),
-                              normalization_order=["loudness", "eq", "imager", "loudness"], workers=0)      # (compression matching: a minute on the emulator; test_normalizer.py)
+                              normalization_order=["loudness", "eq", "imager", "loudness"], workers=workers)      # (compression matching: a minute on the emulator; test_normalizer.py)
     runner = object.__new__(st.Mixing_Style_Transfer_Inference)
     runner.args, runner.device = a, torch.device("cpu")
-    runner.target_dir, runner.output_dir = a.target_dir, os.path.join(root, f"out{world}") + "/"
+    runner.target_dir, runner.output_dir = a.target_dir, os.path.join(root, f"out{world}{'w' if workers else ''}") + "/"
     runner.models = {"effects_encoder": enc, "mixing_converter": tcn}
     runner.data_loader = Song_Dataset_Inference(a)
     runner.data_loader.dist = runner._world()
@@ -172,28 +207,34 @@ def _cli_files_worker(rank, world, port, root):
         dist.destroy_process_group()
 
 
-def test_cli_files_with_normalize_input_sharded_by_stems(tmp_path, emu):
-    """--normalize_input True on two ranks: byte-identical output files, and each rank ran the normaliser on ONE of the two input stems."""
+def _write_songs(root, songs):
     import wave
     import numpy as np
-    from music_mixing_style_transfer_amd import _lib
     from music_mixing_style_transfer_amd.utils import synth
-    root = str(tmp_path)
     L = 20000
     t = np.arange(L)
-    for kind, seed in (("input", 50), ("reference", 60)):
-        d = os.path.join(root, "data", "song", "separated", kind)
-        os.makedirs(d)
-        for k, s in enumerate(("drums", "bass")):
-            base = synth.synth_music(2, L, seed=seed + k).numpy().T
-            hits = sum(a * np.exp(-np.maximum(0, t - n0) / 1200.0) * (t >= n0) * np.sin(2 * np.pi * (90.0 + 40 * k) * t / 44100.0)
-                       for n0, a in ((1500, 0.9), (7000, 0.6), (12500, 0.8)))
-            x = np.clip(0.3 * base + np.stack([hits, 0.8 * hits], 1), -1, 1)
-            with wave.open(os.path.join(d, s + ".wav"), "w") as w:
-                w.setnchannels(2)
-                w.setsampwidth(2)
-                w.setframerate(44100)
-                w.writeframes(np.clip(np.rint(x * 32767), -32768, 32767).astype("<i2").tobytes())
+    for si, song in enumerate(songs):
+        for kind, seed in (("input", 50 + 100 * si), ("reference", 60 + 100 * si)):
+            d = os.path.join(root, "data", song, "separated", kind)
+            os.makedirs(d)
+            for k, s in enumerate(("drums", "bass")):
+                base = synth.synth_music(2, L, seed=seed + k).numpy().T
+                hits = sum(a * np.exp(-np.maximum(0, t - n0) / 1200.0) * (t >= n0) * np.sin(2 * np.pi * (90.0 + 40 * k) * t / 44100.0)
+                           for n0, a in ((1500, 0.9), (7000, 0.6), (12500, 0.8)))
+                x = np.clip(0.3 * base + np.stack([hits, 0.8 * hits], 1), -1, 1)
+                with wave.open(os.path.join(d, s + ".wav"), "w") as w:
+                    w.setnchannels(2)
+                    w.setsampwidth(2)
+                    w.setframerate(44100)
+                    w.writeframes(np.clip(np.rint(x * 32767), -32768, 32767).astype("<i2").tobytes())
+
+
+def test_cli_files_with_normalize_input_sharded_by_stems(tmp_path, emu):
+    """--normalize_input True on two ranks: byte-identical output files, and each rank ran the normaliser on ONE of the two input stems."""
+    import numpy as np
+    from music_mixing_style_transfer_amd import _lib
+    root = str(tmp_path)
+    _write_songs(root, ["song"])
     prev = _lib._default
     try:
         _cli_files_worker(0, 1, 0, root)
@@ -206,6 +247,30 @@ def test_cli_files_with_normalize_input_sharded_by_stems(tmp_path, emu):
         assert open(a, "rb").read() == open(b, "rb").read(), k
     assert list(np.load(os.path.join(root, "calls_w1_r0.npy"))) == ["drums", "bass"]
     assert list(np.load(os.path.join(root, "calls_w2_r0.npy"))) == ["drums"] and list(np.load(os.path.join(root, "calls_w2_r1.npy"))) == ["bass"]
+
+
+def test_two_songs_two_ranks_with_prefetch_worker_requested(tmp_path, emu):
+    """The reference CLI's defaults (--workers 1, --normalize_input True) under two ranks and TWO songs: the loader's broadcasts of song
+    i + 1 must not run on a prefetch thread beside the engine's all-gather / the runner's barrier of song i (collectives of two threads
+    on one process group pair up differently on different ranks) - multi-rank runs prepare their songs inline.  Byte-identical to the
+    single process without prefetch; the single process WITH the prefetch thread gives the same files too."""
+    from music_mixing_style_transfer_amd import _lib
+    root = str(tmp_path)
+    _write_songs(root, ["song_a", "song_b"])
+    prev = _lib._default
+    try:
+        _cli_files_worker(0, 1, 0, root)
+        _cli_files_worker(0, 1, 0, root, 1)          # one process, prefetch thread active (and joined when the loop ends)
+    finally:
+        _lib.set_default_binding(prev)
+    mp.spawn(_cli_files_worker, args=(2, 29671, root, 1), nprocs=2, join=True)
+    import threading
+    assert not [t for t in threading.enumerate() if t.name.startswith("mst-prefetch")]
+    for song in ("song_a", "song_b"):
+        for k in ["bass_output.wav", "drums_output.wav", "mixture_output.wav"]:
+            a = open(os.path.join(root, "out1", song, k), "rb").read()
+            assert a == open(os.path.join(root, "out1w", song, k), "rb").read(), (song, k)
+            assert a == open(os.path.join(root, "out2w", song, k), "rb").read(), (song, k)
 
 
 def _interp_worker(rank, world, port, out_path):
