@@ -10,7 +10,9 @@ resident in HBM before the timed region.  Weak scaling: every rank owns 32 segme
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0).  Objects carried by the line:
+Prints ONE JSON line (rank 0), kept under 4 KB so that it survives any log tail: per leg only value / ms / frac / max_abs_vs_oracle.
+Everything else (per-block times, thread sweeps, workload prose, the normaliser's per-effect times) goes to the DETAILS file the line names
+("details": gpurun_out/bench_details.json, also copied to profiles/ by tools/gpu_round.sh).  Objects carried by the line:
   "roofline"      dominant kernel = the dilated 128x128x15 TCN block conv, timed with HIP events on its stream inside
                   the timed region;
   "track60"       BASELINE configs[4]: ONE 60-minute stereo stem (158 760 000 samples = 1212 segments of 131072 for the
@@ -46,6 +48,73 @@ TCN_FLOP_PER_SAMPLE_BLOCK = 2 * 128 * 128 * 15          # one dense TCN block, p
 PEAK = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0}     # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 MFMA_PER_FLOP = {"bf16": 1, "fp32": 1, "bf16x3": 3}         # bf16x3 issues three bf16 MFMAs per algorithmic product
 HBM_PEAK_GBPS = 8000.0
+
+
+DETAILS_PATH = os.path.join(REPO, "gpurun_out", "bench_details.json")
+
+
+class BoxSampler:
+    """Shader clock and socket power of the GPU while a timed region runs: a thread polls the amdgpu hwmon files of the device
+    (freq1_input in Hz, power1_input in microwatts) every few milliseconds.  None when the files cannot be found."""
+
+    def __init__(self, dev_index, period_s=0.004):
+        import glob
+        self.files = None
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            hw = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            if hw and os.path.exists(os.path.join(hw[0], "freq1_input")):
+                self.files = (os.path.join(hw[0], "freq1_input"), os.path.join(hw[0], "power1_input"))
+        except Exception:
+            self.files = None
+        self.period, self.sclk, self.power, self._stop, self._thr = period_s, [], [], None, None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except Exception:
+            return None
+
+    def __enter__(self):
+        if self.files is None:
+            return self
+        import threading
+        self._stop = threading.Event()
+
+        def poll():
+            while not self._stop.is_set():
+                f, p = self._read(self.files[0]), self._read(self.files[1])
+                if f:
+                    self.sclk.append(f / 1e6)
+                if p:
+                    self.power.append(p / 1e6)
+                time.sleep(self.period)
+        self._thr = threading.Thread(target=poll, daemon=True)
+        self._thr.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thr is not None:
+            self._stop.set()
+            self._thr.join(timeout=1.0)
+
+    def summary(self):
+        if not self.sclk:
+            return {"sclk_mhz": None, "power_w": None}
+        return {"sclk_mhz": round(statistics.median(self.sclk)), "sclk_mhz_min": round(min(self.sclk)), "samples": len(self.sclk),
+                "power_w": round(statistics.fmean(self.power)) if self.power else None}
+
+
+def calibrate(lib, dev, launches=24):
+    """The bare main loop of the bf16 block kernel on this box (mst_calib_mainloop): (ms per launch-equivalent, shader MHz inside it)."""
+    ms, mhz = C.c_float(0), C.c_float(0)
+    with torch.cuda.device(dev):
+        lib.check(lib.mst_calib_mainloop(launches, C.byref(ms), C.byref(mhz), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                  "mst_calib_mainloop")
+    return float(ms.value), float(mhz.value)
 
 
 def load_cfg():
@@ -95,22 +164,36 @@ def cpu_baseline(enc_cfg, enc_sd, tcn_sd):
 
 
 # ------------------------------------------------------------------------------------------------ configs[1] step
-def bench_configs1(engine, tcn, lib, ref, inp, steps, warmup, world, dist, dev):
-    """K timed steps between barriers; returns (seconds max over ranks, per-block kernel ms, forwards timed)."""
+def bench_configs1(engine, tcn, lib, ref, inp, steps, warmup, world, dist, dev, stats=None):
+    """K timed steps between barriers; returns (seconds max over ranks, per-block kernel ms, forwards timed).  stats (a dict) also
+    receives the per-step durations (HIP events on the stream the steps run on) and the clock / power samples of the region."""
     for _ in range(warmup):
         engine.step(ref, inp)
     torch.cuda.synchronize()
     lib.check(lib.mst_tcn_timing_begin(tcn._handle, steps), "timing_begin")
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if stats is not None else None
+    sampler = BoxSampler(dev.index if dev.index is not None else 0) if stats is not None else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if sampler is not None:
+        sampler.__enter__()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for k in range(steps):
+        if marks is not None:
+            marks[k].record()
         engine.step(ref, inp)
+    if marks is not None:
+        marks[steps].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if sampler is not None:
+        sampler.__exit__()
+        per = [marks[k].elapsed_time(marks[k + 1]) for k in range(steps)]
+        stats["step_ms"] = {"median": statistics.median(per), "min": min(per), "max": max(per)}
+        stats["box"] = sampler.summary()
     nb = tcn.hparams.nblocks
     ms = (C.c_float * (nb + 1))()
     nf = C.c_int(0)
@@ -135,6 +218,20 @@ def roofline(block_ms, nb, B, precision, traffic=None):
     if MFMA_PER_FLOP[precision] > 1:      # `achieved` / `frac` count ALGORITHMIC flops; the matrix pipe executes three times as many
         out["mfma_flop_per_algorithmic_flop"] = MFMA_PER_FLOP[precision]
         out["mfma_pipe_frac"] = MFMA_PER_FLOP[precision] * achieved / PEAK[precision]
+    return out
+
+
+def slim_roofline(rl):
+    """The roofline object of the printed line: numbers only (kernel names shortened, per-block times in the details file)."""
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_step", "calib_ms", "frac_of_box_mainloop",
+            "calib_sclk_mhz", "sclk_mhz", "power_w", "traffic_source")
+    out = {"kernel": rl["kernel"].split(" (")[0]}
+    for k in keep:
+        if k in rl and rl[k] is not None:
+            v = rl[k]
+            out[k] = round(v, 4) if isinstance(v, float) and k not in ("traffic",) else v
+    if "traffic" not in out:
+        out["traffic"] = None
     return out
 
 
@@ -258,14 +355,24 @@ def bench_fx_chain(dev, steps=5):
     ref = F.fx_chain(x[17].cpu().numpy(), compressor_fn=_oracle_c_compressor())
     dev_max = float(np.abs(out[17].cpu().numpy() - ref).max())
     alg = 144 * L * n                       # unfused per-processor read + write bytes of the chain
+    # what the chain REALLY moves: FETCH_SIZE / WRITE_SIZE counter passes over its kernels (tools/gpu_fx_pmc.sh -> profiles/*fx_chain_traffic.json;
+    # offline: counters need their own rocprofv3 passes).  `achieved` / `frac` stay on the ALGORITHMIC basis (one read + one write of the audio,
+    # 16 L per segment - what a perfectly fused chain would move); `frac_on_traffic` is the measured bytes over the same time.
+    traffic, tsrc = None, None
+    for name in ("r04_fx_chain_traffic.json", "r04_fx_chain_traffic_before.json"):
+        tpath = os.path.join(REPO, "profiles", name)
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic, tsrc = json.load(f).get("traffic_bytes"), "profiles/" + name
+            break
     return {"workload": "configs[3]: EQ -> rms -> compressor -> rms -> imager -> rms -> gain on 64 segments of [131072, 2]",
             "value": n / dt, "unit": "segments/s", "ms_per_chain": dt * 1e3,
-            # the chain runs FUSED (MstFxFuse: no separate energy / scale passes), so the bytes that must cross HBM are one read and one
-            # write of the float32 stereo audio (16 L per segment); SURVEY 8d's 144 L is what the reference's seven separate passes
-            # move - quoted as the equivalent unfused throughput, not as a fraction of the roofline
             "roofline": {"bound": "hbm", "achieved": 16 * L * n / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": 16 * L * n / dt / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": 16 * L * n,
-                         "bytes_basis": "fused chain: one read + one write of [n, L, 2] float32",
+                         "bytes_basis": "one read + one write of [n, L, 2] float32 (a perfectly fused chain)",
+                         "traffic": traffic, "traffic_source": tsrc,
+                         "traffic_over_algorithmic": round(traffic / (16 * L * n), 2) if traffic else None,
+                         "frac_on_traffic": round(traffic / dt / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
                          "equivalent_unfused_GBps": alg / dt / 1e9, "unfused_bytes_survey_8d": alg},
             "max_abs_vs_oracle": dev_max, "probe": "item 17 vs oracle/fx_ref.py chain (EQ parity unpinned, see DESIGN.md)",
             "tolerance": "2e-6 * max|ref|"}
@@ -297,7 +404,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--workload", default="all", choices=["all", "configs1", "track60"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--x3-large-tiles", action="store_true", help="bf16x3: 256-time tiles, one workgroup per CU (mst_tcn_set_tuning 0)")
+    ap.add_argument("--x3-large-tiles", action="store_true", help="bf16x3: 256-time tiles, one workgroup per CU (mst_tcn_set_tuning bit 0 off)")
     ap.add_argument("--enc-schedule", type=int, default=None, help="mst_enc_set_schedule flags (bit 0: weight-major workgroup order of the weight-heavy encoder layers, bit 1: 2 x 2 wave tiling of the 128-channel conv kernel)")
     ap.add_argument("--enc-rows-min-tiles", type=int, default=None, help="mst_enc_set_tuning: tiles from which a layer keeps its rows resident in LDS (-1 never)")
     ap.add_argument("--tcn-tuning", type=int, default=None, help="mst_tcn_set_tuning flags (bit 0: bf16x3 small tiles, bits 1-2: form of the bf16 block kernel, include/mst_hip.h)")
@@ -342,7 +449,7 @@ def main():
     if args.enc_rows_min_tiles is not None:
         lib.check(lib.mst_enc_set_tuning(enc._get_runner().handle, args.enc_rows_min_tiles), "mst_enc_set_tuning")
     if args.x3_large_tiles:
-        lib.check(lib.mst_tcn_set_tuning(tcn._handle, 0), "mst_tcn_set_tuning")
+        lib.check(lib.mst_tcn_set_tuning(tcn._handle, _lib.TCN_TUNING_DEFAULT & ~1), "mst_tcn_set_tuning")      # bit 0 off, the bf16 form unchanged
     if args.tcn_tuning is not None:
         lib.check(lib.mst_tcn_set_tuning(tcn._handle, args.tcn_tuning), "mst_tcn_set_tuning")
     nb = tcn.hparams.nblocks
@@ -365,45 +472,85 @@ def main():
 
     ref = synth.synth_audio((B, 2, SEG_LEN), seed=100 + rank).to(dev)      # resident in HBM before timing
     inp = synth.synth_audio((B, 2, SEG_LEN), seed=200 + rank).to(dev)
-    dt, block_ms, nf = bench_configs1(engine, tcn, lib, ref, inp, args.steps, args.warmup, world, dist, dev)
+    stats = {}
+    dt, block_ms, nf = bench_configs1(engine, tcn, lib, ref, inp, args.steps, args.warmup, world, dist, dev, stats)
+    calib_ms, calib_mhz = calibrate(lib, dev) if args.precision == "bf16" else (None, None)      # right behind the timed region: the chip is warm
     track = None
     if args.workload == "all" and args.precision == "bf16":
         track = bench_track60(enc, tcn, world, rank, dist, dev, 2, 1)
 
     if rank == 0:
-        traffic = None      # HBM bytes per launch of the dominant kernel: offline rocprofv3 --pmc passes (tools/pmc_traffic.py)
-        for name in ("r03_tcn_block_bf16_traffic.json", "r02_tcn_block_bf16_traffic.json", "r01_tcn_block_bf16_traffic.json"):
+        traffic, tname = None, None      # HBM bytes per launch of the dominant kernel: offline rocprofv3 --pmc passes (tools/pmc_traffic.py)
+        for name in ("r04_tcn_block_bf16_traffic.json", "r03_tcn_block_bf16_traffic.json"):
             tpath = os.path.join(REPO, "profiles", name)
             if args.precision == "bf16" and B == BATCH and os.path.exists(tpath):
                 with open(tpath) as f:
-                    traffic = json.load(f).get("traffic_bytes")
+                    traffic, tname = json.load(f).get("traffic_bytes"), name
                 break
         rl = roofline(block_ms, nb, B, args.precision, traffic)
         rl["timed_forwards"] = nf
         if traffic is not None:      # not measured in this run: PMC counters need their own rocprofv3 passes
-            rl["traffic_source"] = "offline: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel (profiles/%s, tools/pmc_traffic.py)" % name
+            rl["traffic_source"] = "profiles/" + tname
+        if calib_ms is not None:
+            # the box: the bare main loop of the block kernel (same arithmetic as one dense launch) timed in this process, the shader
+            # clock inside it, and clock / power sampled from the driver while the timed steps ran
+            rl["calib_ms"] = calib_ms
+            rl["frac_of_box_mainloop"] = calib_ms / rl["avg_launch_ms"]
+            rl["calib_sclk_mhz"] = round(calib_mhz)
+        rl.update(stats.get("box", {}))
+        details = {"headline": {"roofline": dict(rl), "step_ms": stats.get("step_ms")}}
+        workload = (f"configs[1]: batch={B} segments of 2x{SEG_LEN} per GPU, FXencoder+MixFXcloner fwd, default configs.yaml nets, "
+                    f"synthetic weights, {args.precision} MFMA (fp32 accumulate)")
         out = dict(base, metric="stereo 44.1 kHz segments/sec (FXencoder+MixFXcloner fwd)",
                    value=world * B * args.steps / dt, unit="segments/s", ms_per_step=dt / args.steps * 1e3, scaling="weak",
-                   config={"workload": f"configs[1]: batch={B} segments of 2x{SEG_LEN} per GPU, FXencoder+MixFXcloner forward, "
-                                       f"default configs.yaml nets, synthetic weights; TCN dense blocks {args.precision} MFMA "
-                                       f"(fp32 accumulate), FXencoder convs {args.precision} MFMA",
-                           "segments_per_gpu": B, "segment_length": SEG_LEN,
+                   config={"workload": workload, "segments_per_gpu": B, "segment_length": SEG_LEN,
                            "parallelism": f"segment-sharded x{world}, all-gather of embeddings"},
-                   roofline=rl)
+                   step_ms={k: round(v, 3) for k, v in (stats.get("step_ms") or {}).items()},
+                   roofline=slim_roofline(rl))
         if track is not None:
-            out["track60"] = track
+            details["track60"] = track
+            out["track60"] = {"value": round(track["value"], 1), "ms": round(track["t_ms"], 1), "segments": track["segments"], "scaling": "strong"}
+            if "pcie_inclusive" in track:
+                out["track60"]["pcie_value"] = round(track["pcie_inclusive"]["value"], 1)
+            for k in ("t1_ms_same_job", "efficiency_t1_over_n_tn"):
+                if k in track:
+                    out["track60"][k] = round(track[k], 4)
         if world == 1 and args.workload == "all" and args.precision == "bf16" and B == BATCH:
-            out["parity_mode"] = bench_parity_mode(engine, enc, tcn, lib, ref, inp, dev, enc_cfg, enc_sd, tcn_sd)
-            out["bf16x3_mode"] = bench_parity_mode(engine, enc, tcn, lib, ref, inp, dev, enc_cfg, enc_sd, tcn_sd, "bf16x3")
-            out["fx_chain"] = bench_fx_chain(dev)
-            out["input_normalizer"] = bench_input_normalizer()
+            for key, prec in (("parity_mode", "fp32"), ("bf16x3_mode", "bf16x3")):
+                leg = bench_parity_mode(engine, enc, tcn, lib, ref, inp, dev, enc_cfg, enc_sd, tcn_sd, prec)
+                details[key] = leg
+                out[key] = {"dtype": "f32" if prec == "fp32" else "bf16x3", "value": round(leg["value"], 1), "ms": round(leg["ms_per_step"], 2),
+                            "frac": round(leg["roofline"]["frac"], 4), "max_abs_vs_oracle": leg["max_abs_vs_oracle"], "tolerance": 1e-4}
+                if "mfma_pipe_frac" in leg["roofline"]:
+                    out[key]["pipe_frac"] = round(leg["roofline"]["mfma_pipe_frac"], 4)
+            fx = bench_fx_chain(dev)
+            details["fx_chain"] = fx
+            out["fx_chain"] = {"value": round(fx["value"]), "ms": round(fx["ms_per_chain"], 4), "frac": round(fx["roofline"]["frac"], 4),
+                               "max_abs_vs_oracle": fx["max_abs_vs_oracle"], "traffic": fx["roofline"]["traffic"],
+                               "traffic_over_algorithmic": fx["roofline"]["traffic_over_algorithmic"],
+                               "frac_on_traffic": fx["roofline"]["frac_on_traffic"]}
+            nz = bench_input_normalizer()
+            details["input_normalizer"] = nz
+            out["input_normalizer"] = {"value": round(nz["value"], 1), "unit": nz["unit"]}
             sys.path.insert(0, os.path.join(REPO, "tools"))
             import bench_cli
             import contextlib
             with contextlib.redirect_stdout(sys.stderr):      # the runner prints its progress like the reference CLI: keep stdout to the ONE line
-                out["file_to_file"] = bench_cli.run(180.0, "bf16", songs=2)      # wav to wav, second pass over two 3-minute songs
+                f2f = bench_cli.run(180.0, "bf16", songs=2)      # wav to wav, second pass over two 3-minute songs
+            details["file_to_file"] = f2f
+            out["file_to_file"] = {"value": round(f2f["value"], 4), "unit": f2f.get("unit", "s/song")}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(enc_cfg, enc_sd, tcn_sd)
+            cb = cpu_baseline(enc_cfg, enc_sd, tcn_sd)
+            details["cpu_baseline"] = cb
+            out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                   "sample": f"oracle/networks_ref.py (torch-CPU fp32), 1 segment of 2x{SEG_LEN}, warm median of 3 at {cb['cores']} threads"}
+        try:
+            os.makedirs(os.path.dirname(DETAILS_PATH), exist_ok=True)
+            with open(DETAILS_PATH, "w") as f:
+                json.dump(dict(out, details=details), f, indent=1)
+            out["details"] = os.path.relpath(DETAILS_PATH, REPO)
+        except OSError:
+            out["details"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

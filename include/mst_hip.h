@@ -41,9 +41,11 @@ typedef enum {
 typedef enum {
     MST_PREC_F32 = 0,   /* v_mfma_f32_32x32x2_f32, fp32 activations in HBM: the parity mode */
     MST_PREC_BF16 = 1,  /* bf16 operands / fp32 accumulate (TCN blocks: v_mfma_f32_16x16x32_bf16, FXencoder: v_mfma_f32_32x32x16_bf16), bf16 activations in HBM */
-    MST_PREC_BF16X3 = 2 /* TCN: every fp32 operand split x = hi + lo into two bf16 values, three bf16 MFMAs per product
-                         * (hi*hi + hi*lo + lo*hi), fp32 activations in HBM: fp32-class accuracy (<= 1e-4 on the waveform)
-                         * at a third of the bf16 rate.  FXencoder: same as MST_PREC_F32. */
+    MST_PREC_BF16X3 = 2 /* every fp32 operand split x = hi + lo into two bf16 values, three bf16 MFMAs per product
+                         * (hi*hi + hi*lo + lo*hi): fp32-class accuracy at a third of the bf16 rate.  TCN: fp32 activations in HBM,
+                         * <= 1e-4 on the waveform (measured 4e-6).  FXencoder: the channel-minor bf16 pipeline in the same split
+                         * arithmetic (two bf16 planes per activation), <= 1e-4 * max|embedding| (measured 6e-6) - NOT the exact
+                         * MST_PREC_F32 kernels: use MST_PREC_F32 where bit-level parity with the fp32 reference order matters. */
 } MstPrecision;
 
 #define MST_MAX_BLOCKS 32
@@ -129,6 +131,14 @@ int mst_tcn_set_tuning(MstTcn *tcn, int flags);
  * forwards seen into *n_forwards. */
 int mst_tcn_timing_begin(MstTcn *tcn, int max_forwards);
 int mst_tcn_timing_end(MstTcn *tcn, float *ms_out, int *n_forwards);
+
+/* Calibration of the box (measurement infrastructure, bench.py "roofline.calib_ms"): runs the BARE main loop of the bf16 TCN block
+ * kernel (csrc/tcn_kernels.h::tcn_calib_mainloop_kernel: the MFMAs, weight stream and LDS reads of one dense 32 x 131072 block launch =
+ * 2.06 TFLOP; no staging, no epilogue, no store) `launches` times back to back on `stream` on synthetic operands with realistic
+ * statistics; the first half settles the power controller, the second half is timed with HIP events.  *ms_per_launch = average duration
+ * of a timed launch, *sclk_mhz = the shader clock the last launch ran at (s_memtime / s_memrealtime inside the kernel).  Allocates and
+ * frees 1.1 MB of device memory; blocks until done.  No reference counterpart. */
+int mst_calib_mainloop(int launches, float *ms_per_launch, float *sclk_mhz, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * FXencoder (networks/architectures.py:26-70) = Res_ConvBlock x N (network_utils.py:96-119), each two

@@ -58,6 +58,7 @@ SIGNATURES = {
     "mst_tcn_set_tuning": (C.c_int, [_P, C.c_int]),
     "mst_tcn_timing_begin": (C.c_int, [_P, C.c_int]),
     "mst_tcn_timing_end": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "mst_calib_mainloop": (C.c_int, [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "mst_enc_create": (C.c_int, [C.POINTER(MstEncDesc), C.POINTER(_P)]),
     "mst_enc_destroy": (C.c_int, [_P]),
     "mst_enc_load_conv": (C.c_int, [_P, C.c_int, C.c_int, _F, _F, _F, _F, _F, _F, C.c_float, _P]),

@@ -16,9 +16,12 @@
 #pragma once
 #include "mst_dev.h"
 
-// the encoder's activation (Conv1d_layer, network_utils.py:76-80): ReLU (slope 0), LeakyReLU(0.01) or none (slope 1) as
-// max(v, 0) + slope * min(v, 0); with slope 0 the second term is a signed zero and the sum is exactly max(v, 0)
-__device__ __forceinline__ float enc_act(float v, float slope) { return fmaxf(v, 0.0f) + slope * fminf(v, 0.0f); }
+// the encoder's activation (Conv1d_layer, network_utils.py:76-80): ReLU (slope 0), LeakyReLU(0.01) or none (slope 1): v > 0 ? v : slope * v,
+// with torch's results for non-finite values too - ReLU(-inf) = 0 (slope * v would be 0 * -inf = NaN), NaN propagates in every mode
+__device__ __forceinline__ float enc_act(float v, float slope) {
+    const float neg = slope == 0.0f ? (v != v ? v : 0.0f) : v * slope;
+    return v > 0.0f ? v : neg;
+}
 
 struct EncConvArgs {
     const float *x;      // [B][Cin][Lin]

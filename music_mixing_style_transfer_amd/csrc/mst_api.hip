@@ -715,6 +715,51 @@ extern "C" int mst_tcn_timing_end(MstTcn *t, float *ms_out, int *n_forwards) {
     return MST_OK;
 }
 
+extern "C" int mst_calib_mainloop(int launches, float *ms_per_launch, float *sclk_mhz, void *stream) {
+    if (launches < 2 || !ms_per_launch || !sclk_mhz) return fail(MST_ERR_ARG, "mst_calib_mainloop: bad argument");
+    constexpr int WG = 512, REP = 32;                      // 512 x 32 tiles of 256 times = 32 x 131072 output steps
+    const size_t wbytes = (size_t)120 * 256 * 16;          // 60 k-steps x 2 row tiles x 4 waves x 64 lanes x 16 B
+    void *w = nullptr;
+    float *out = nullptr;
+    long long *clk = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = MST_OK;
+    auto cleanup = [&]() {
+        if (w) (void)hipFree(w);
+        if (out) (void)hipFree(out);
+        if (clk) (void)hipFree(clk);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+#define MST_CALIB_TRY(x)                                                        \
+    if ((x) != hipSuccess) {                                                    \
+        rc = fail(MST_ERR_HIP, "mst_calib_mainloop: HIP call failed");          \
+        cleanup();                                                              \
+        return rc;                                                              \
+    }
+    MST_CALIB_TRY(hipMalloc(&w, wbytes));
+    MST_CALIB_TRY(hipMalloc((void **)&out, (size_t)WG * 256 * sizeof(float)));
+    MST_CALIB_TRY(hipMalloc((void **)&clk, 2 * sizeof(long long)));
+    MST_CALIB_TRY(hipEventCreate(&e0));
+    MST_CALIB_TRY(hipEventCreate(&e1));
+    MST_LAUNCH(tcn_calib_fill_kernel, dim3((unsigned)(wbytes / 4 + 255) / 256), dim3(256), stream, (unsigned *)w, (int)(wbytes / 4));
+    const int warm = launches / 2, timed = launches - warm;
+    for (int i = 0; i < warm; ++i) MST_LAUNCH(tcn_calib_mainloop_kernel, dim3(WG), dim3(256), stream, (const void *)w, out, clk, REP);
+    MST_CALIB_TRY(hipEventRecord(e0, (hipStream_t)stream));
+    for (int i = 0; i < timed; ++i) MST_LAUNCH(tcn_calib_mainloop_kernel, dim3(WG), dim3(256), stream, (const void *)w, out, clk, REP);
+    MST_CALIB_TRY(hipEventRecord(e1, (hipStream_t)stream));
+    MST_CALIB_TRY(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    MST_CALIB_TRY(hipEventElapsedTime(&ms, e0, e1));
+    long long c[2] = {0, 0};
+    MST_CALIB_TRY(hipMemcpy(c, clk, sizeof(c), hipMemcpyDeviceToHost));
+#undef MST_CALIB_TRY
+    *ms_per_launch = ms / (float)timed;
+    *sclk_mhz = c[1] > 0 ? (float)((double)c[0] / ((double)c[1] / 100.0)) : 0.0f;      // shader clocks per microsecond
+    cleanup();
+    return MST_OK;
+}
+
 extern "C" size_t mst_tcn_workspace_bytes(const MstTcn *t, int B, int L, int precision) {
     if (B < 1 || L < 1) return 0;
     if (t && t->generic) return 2 * align_up((size_t)B * L * t->d.channels * sizeof(float), 256);

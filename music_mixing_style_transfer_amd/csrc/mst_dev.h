@@ -39,7 +39,7 @@ __device__ __forceinline__ bf16x4 tcn_epilogue4(const float *v, f32x4 fr, f32x4 
     return out;
 }
 
-__device__ __forceinline__ long long mst_clock() { return (long long)__builtin_readcyclecounter(); }
+__device__ __forceinline__ long long mst_clock() { return (long long)__builtin_readcyclecounter(); }      // s_memtime: shader clocks
 
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll

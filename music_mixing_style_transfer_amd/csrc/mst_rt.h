@@ -72,6 +72,8 @@ __device__ __forceinline__ mst_u32x4 mst_stream_load16(MstStream16 s, unsigned v
 __device__ __forceinline__ unsigned mst_stream_load4(MstStream16 s, unsigned voffset, unsigned soffset) {      // one dword, zeros beyond the descriptor
     return __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, (int)voffset, (int)soffset, 0);
 }
+// the constant 100 MHz real-time counter (s_memrealtime) - against mst_clock() (shader clocks) it gives the clock a kernel ran at
+__device__ __forceinline__ long long mst_realtime() { return (long long)__builtin_amdgcn_s_memrealtime(); }
 // a * b for operands known to fit 24 bits: one full-rate instruction (v_mul_lo_u32 runs at a quarter of the rate)
 __device__ __forceinline__ int mst_mul24(int a, int b) { return __mul24(a, b); }
 // the device the calling thread is bound to (per-device constants), -1 on error

@@ -57,6 +57,7 @@ struct TcnBlockArgs {
 // B fragment feeds two MFMAs) - and under the chip's power limit it runs 15 % faster: on realistic operands the bare instruction
 // stream sustains 1934-1982 TFLOP/s against 1666-1685, the whole main loop 1570-1585 against 1367-1377
 // (tools/micro/tcn_mainloop_variants.hip, profiles/r02_micro_tcn_mainloop_variants.txt).
+constexpr int TCN_LIVE_MIN_P = 8;      // phases per tile from which all-padding (column tile, tap) pairs are skipped
 template <int P, bool FUSE_OUT, int NQ>
 __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1))) void tcn_block_bf16_kernel(TcnBlockArgs a) {
     constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NC = 2 * NQ;
@@ -155,14 +156,15 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
 #pragma unroll
             for (int q = 0; q < RB; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 4096);
         }
-        // P = 16 tiles (largest dilation on a short segment) cover steps far outside the segment: a (column tile q, tap j)
-        // pair whose 16 input rows are all zero padding contributes nothing and its MFMAs are skipped (wave-uniform).
+        // P >= 8 tiles (large dilations: a segment has only a few steps per phase) cover steps outside the segment: a (column tile q, tap j)
+        // pair whose 16 input rows are all zero padding contributes nothing and its MFMAs are skipped (wave-uniform).  At L = 131072 that
+        // is 20 % of the MFMAs of the d = 8192 block (16 steps per phase) and 10 % of the d = 4096 block.
         const int nsteps = (int)(((long)a.L + a.d - 1) / a.d);
         for (int j = 0; j < 15; ++j) {
             const int jn = j < 14 ? j + 1 : 14;
             const int rb0 = j * P + l16, rb1 = jn * P + l16;
             unsigned live = 0xffffu;
-            if constexpr (P >= 16) {
+            if constexpr (P >= TCN_LIVE_MIN_P) {
                 live = 0;
 #pragma unroll
                 for (int q = 0; q < NC; ++q) {
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
                 const unsigned char *np = smem + rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
 #pragma unroll
                 for (int q = 0; q < NC; ++q) {
-                    if (P < 16 || ((live >> q) & 1u)) {
+                    if (P < TCN_LIVE_MIN_P || ((live >> q) & 1u)) {
                         acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][kk], bf[q % RB], acc[0][q], 0, 0, 0);
                         acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][kk], bf[q % RB], acc[1][q], 0, 0, 0);
                     }
@@ -1170,9 +1172,18 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16x3_half_kernel(TcnBlockA
                 bl[q] = *(const bf16x8 *)(sm_lo + o0 + q * 2048);
             }
         }
+        // a (column tile q, tap j) pair whose 16 input rows all lie outside the segment (zero padding) contributes nothing: skipped,
+        // wave-uniform (20 % of the MFMAs of the d = 8192 block at L = 131072, 10 % of the d = 4096 block)
+        const int nsteps = (int)(((long)a.L + a.d - 1) / a.d);
         for (int j = 0; j < 15; ++j) {
             const int jn = j < 14 ? j + 1 : 14;
             const int rb0 = j * P + l16, rb1 = jn * P + l16;
+            unsigned live = 0;
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int s_lo = m0 + (16 * q) / P + j - 7, s_hi = m0 + (16 * q + 15) / P + j - 7;
+                if (!(s_hi < 0 || s_lo >= nsteps)) live |= 1u << q;
+            }
 #pragma unroll
             for (int kl = 0; kl < 2; ++kl) {
                 const int rbn = kl ? rb1 : rb0;
@@ -1180,12 +1191,14 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16x3_half_kernel(TcnBlockA
                 const int on = rbn * 128 + (((4 * kn + g) ^ ((rbn >> 1) & 7)) << 4);
 #pragma unroll
                 for (int q = 0; q < NC; ++q) {
+                    if ((live >> q) & 1u) {
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[kl][m], bh[q], acc[m][q], 0, 0, 0);
+                        for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[kl][m], bh[q], acc[m][q], 0, 0, 0);
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kl][m], bl[q], acc[m][q], 0, 0, 0);
+                        for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kl][m], bl[q], acc[m][q], 0, 0, 0);
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kl][m], bh[q], acc[m][q], 0, 0, 0);
+                        for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[kl][m], bh[q], acc[m][q], 0, 0, 0);
+                    }
                     bh[q] = *(const bf16x8 *)(sm_hi + on + q * 2048);
                     bl[q] = *(const bf16x8 *)(sm_lo + on + q * 2048);
                     __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
@@ -1678,4 +1691,87 @@ __global__ void tcn_unpack_kernel(const void *x, float *y, int B, int L, int Lp)
     const int t = bt % L;
     const int b = bt / L;
     y[((size_t)b * 128 + c) * L + t] = (float)((const InT *)x)[((size_t)b * Lp + t) * 128 + c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Calibration of the box (bench.py "roofline.calib_ms"): the BARE MAIN LOOP of tcn_block_bf16_kernel - v_mfma_f32_16x16x32_bf16 with the
+// product loop's operand traffic (two weight fragments from L2 and sixteen B fragments from LDS per 32 MFMAs), no staging, no epilogue,
+// no store - on synthetic operands with realistic statistics (activations ~ N(0, 0.5^2), weights ~ N(0, 0.05^2): the chip's power limit
+// depends on the operand bits).  512 workgroups x `rep` tiles of 256 times: rep = 32 is exactly the arithmetic of one dense TCN block
+// launch at 32 x 131072 (2.06 TFLOP), so its duration is what this box lets the block kernel's main loop run at - boxes of the pool
+// differ by +-4 %, the block kernel divided by THIS is comparable across boxes.  Thread 0 of workgroup 0 also reports the shader clock
+// it ran at (s_memtime counts shader clocks, s_memrealtime 100 MHz).  tools/micro/tcn_mainloop_variants.hip::k_base16<0>, unchanged.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned calib_normalish_bf16(unsigned z, float sigma) {      // sum of four uniform bytes: ~ N(0, sigma^2), as bf16 bits
+    z ^= z >> 16; z *= 0x7feb352du; z ^= z >> 15; z *= 0x846ca68bu; z ^= z >> 16;
+    const float u = ((z & 0xff) + ((z >> 8) & 0xff) + ((z >> 16) & 0xff) + (z >> 24)) / 255.0f - 2.0f;
+    return (unsigned)(__builtin_bit_cast(unsigned, u * sigma * 1.74f) >> 16);
+}
+__global__ void tcn_calib_fill_kernel(unsigned *w, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) w[i] = calib_normalish_bf16((unsigned)i * 2654435761u + 777u, 0.05f) | (calib_normalish_bf16((unsigned)i * 747796405u + 2891336453u, 0.05f) << 16);
+}
+__global__ __launch_bounds__(256, 2) void tcn_calib_mainloop_kernel(const void *wpk, float *out, long long *clocks, int rep) {
+    constexpr int P = 4, T = 256, R = T + 14 * P;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    long long c0 = 0, r0 = 0;
+    if (blockIdx.x == 0 && tid == 0) {
+        c0 = mst_clock();
+        r0 = mst_realtime();
+    }
+    for (int i = tid; i < R * 64; i += 256) {
+        const unsigned r = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+        ((unsigned *)smem)[i] = calib_normalish_bf16(r, 0.5f) | (calib_normalish_bf16(r * 747796405u + 2891336453u, 0.5f) << 16);
+    }
+    __syncthreads();
+    f32x4 acc[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[m][q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const bf16x8 *wp = (const bf16x8 *)wpk + (w * 64 + lane);                     // [k32-step (4 per tap)][row tile][wave][lane]
+    for (int r = 0; r < rep; ++r) {
+        bf16x8 af[2][4], bf[16];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            af[0][kk] = wp[(kk * 2) * 256];
+            af[1][kk] = wp[(kk * 2 + 1) * 256];
+        }
+        {
+            const unsigned char *rp0 = smem + l16 * 256 + ((g ^ l16) << 4);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 4096);
+        }
+        for (int j = 0; j < 15; ++j) {
+            const int jn = j < 14 ? j + 1 : 14;
+            const int rb0 = j * P + l16, rb1 = jn * P + l16;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int rbn = (kk == 3) ? rb1 : rb0;
+                const int kn = (kk + 1) & 3;
+                const unsigned char *np = smem + rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][kk], bf[q], acc[0][q], 0, 0, 0);
+                    acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][kk], bf[q], acc[1][q], 0, 0, 0);
+                    bf[q] = *(const bf16x8 *)(np + q * 4096);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                af[0][kk] = wp[((jn * 4 + kk) * 2) * 256];
+                af[1][kk] = wp[((jn * 4 + kk) * 2 + 1) * 256];
+            }
+        }
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += acc[m][q][0] + acc[m][q][1] + acc[m][q][2] + acc[m][q][3];
+    out[(size_t)blockIdx.x * 256 + tid] = s;
+    if (blockIdx.x == 0 && tid == 0) {
+        clocks[0] = mst_clock() - c0;
+        clocks[1] = mst_realtime() - r0;
+    }
 }

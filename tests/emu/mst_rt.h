@@ -217,6 +217,7 @@ static inline unsigned mst_stream_load4(MstStream16 s, unsigned voffset, unsigne
     return v;
 }
 static inline int mst_mul24(int a, int b) { return a * b; }
+static inline long long mst_realtime() { return (long long)(emu_now_ms() * 1e5); }      // 100 MHz ticks
 static inline int mst_current_device() { return 0; }
 static inline int mst_num_cus() { return 4; }      // a small persistent grid: every workgroup walks several tiles
 #define __builtin_amdgcn_readfirstlane(v) emu_shfl((v), 0)

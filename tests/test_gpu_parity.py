@@ -377,6 +377,38 @@ def test_fx_processors_vs_oracle(oracle_fx_lib):
         assert np.abs(out[i] - F.rms_normalize(xn[i], F.gain(xn[i], 5.0))).max() <= 1e-5
 
 
+def test_compressor_reference_cases_and_parameter_extremes_on_gpu(oracle_fx_lib):
+    """The compressor cases the reference itself was run on (tests/golden/fx.npz::comp_cases: ratio 4, ratio 40, the expander ratio 0.5 and
+    the `ratio == 1` quirk - neither branch assigns y_g, common_audioeffects.py:564-573) against the REFERENCE's outputs, then the corners
+    of the parameter ranges (:615-618: threshold -80 / -5 dB, ratio 4 / 40, attack 1 / 20 ms, release 50 / 500 ms) against the oracle, on
+    the time-parallel kernels of the MI355X (4096 samples = 128 chunks: map / chain / apply path) and on a segment-sized signal."""
+    import ctypes as C
+    from music_mixing_style_transfer_amd.mixing_manipulator import Compressor
+    g = np.load(os.path.join(GOLD, "fx.npz"))
+    x = torch.from_numpy(g["x"].astype(np.float32))
+    c = Compressor(44100)
+    for k, (th, at, rt, ra) in enumerate(g["comp_cases"]):
+        c.parameters.threshold.value, c.parameters.attack_time.value = float(th), float(at)
+        c.parameters.release_time.value, c.parameters.ratio.value = float(rt), float(ra)
+        y = c.process(x.cuda()).cpu().numpy()
+        ref = g[f"comp_f32in_{k}"]
+        assert y.dtype == np.float32 and np.abs(y - ref).max() <= 2e-6 * max(1e-3, np.abs(ref).max()), (k, np.abs(y - ref).max())
+    assert any(float(ra) == 1.0 for _, _, _, ra in g["comp_cases"]) and any(float(ra) == 40.0 for _, _, _, ra in g["comp_cases"])
+    fp = C.POINTER(C.c_float)
+    L = 131072
+    xs = (0.2 * torch.randn(L, 2, generator=torch.Generator().manual_seed(3))).clamp_(-1, 1)
+    xs[5000:5200] = 0.0                                   # |x| < 1e-6 -> the -120 dB floor (:559-560)
+    xn = xs.numpy()
+    for th, at, rt, ra in ((-80.0, 1.0, 50.0, 40.0), (-5.0, 20.0, 500.0, 4.0), (-80.0, 20.0, 50.0, 4.0), (-5.0, 1.0, 500.0, 40.0)):
+        c.parameters.threshold.value, c.parameters.attack_time.value = th, at
+        c.parameters.release_time.value, c.parameters.ratio.value = rt, ra
+        y = c.process(xs.cuda()).cpu().numpy()
+        ref = np.empty_like(xn)
+        oracle_fx_lib.ref_compressor(xn.ctypes.data_as(fp), ref.ctypes.data_as(fp), C.c_long(L), 2, C.c_double(th), C.c_double(at),
+                                     C.c_double(rt), C.c_double(ra), C.c_double(0.0), C.c_double(44100.0))
+        assert np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max(), (th, at, rt, ra, np.abs(y - ref).max())
+
+
 def test_time_parallel_fx_ragged_shapes(oracle_fx_lib):
     """Compressor (chunk maps / chain / fill) and equaliser (chunk scan) on the device at a ragged length, with more sequences
     than one wave and mono audio, against the oracle (compressor: its C restatement)."""
@@ -1169,3 +1201,26 @@ def test_fx_manipulator_chains_and_algorithmic_reverb_on_gpu(tmp_path):
     y = rv.process(x.cuda()).cpu().numpy()
     ref = F.algorithmic_reverb(x[5].numpy(), room_size=0.8, wet_mix=0.5)
     assert np.abs(y[5] - ref).max() <= 2e-6 * np.abs(ref).max()
+
+
+def test_bench_two_ranks_gloo_prints_the_strong_scaling_efficiency():
+    """`bench.py --gpus 2` through torch.distributed.run, two ranks sharing this box's one GPU over gloo (the N > 1 code path of the bench:
+    sharded track, all-gather, max over ranks, T1 of the same job on rank 0): the line carries t1_ms_same_job and
+    efficiency_t1_over_n_tn = T1 / (N * TN).  Two ranks on ONE GPU cannot exceed 0.5 by construction - this checks the plumbing, not the
+    scaling; no multi-GPU curve has been measured on hardware (README)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MST_BENCH_SHARE_GPU="1", MST_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--workload", "track60"], env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["track60"]["segments"] == 1212
+    assert out["track60"]["segments_rank0"] == 606
+    eff = out["track60"]["efficiency_t1_over_n_tn"]
+    assert 0.2 < eff <= 0.6, eff
+    assert abs(eff - out["track60"]["t1_ms_same_job"] / (2 * out["track60"]["t_ms"])) < 1e-9

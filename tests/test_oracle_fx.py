@@ -75,3 +75,43 @@ def test_conv_reverb_matches_reference():
     assert np.abs(y - g["y_mono_fade_predelay_mix"]).max() <= 2e-6 * np.abs(g["y_mono_fade_predelay_mix"]).max()
     y = F.conv_reverb(x[:, :1], hf, dry=0.3, wet=0.7, pre_delay_ms=3)
     assert np.abs(y - g["y_mono_input"]).max() <= 2e-6 * np.abs(g["y_mono_input"]).max()
+
+
+def test_equaliser_coefficients_against_an_independent_scipy_design():
+    """The Equaliser's arithmetic lives in pymixconsole (absent: parity unpinned) and both the product's `rbj_coefficients` and the oracle's
+    were written from the RBJ cookbook by the same hand.  Independent check: the cookbook filters ARE the bilinear transforms (pre-warped at
+    the centre / corner frequency) of the analog prototypes
+        peaking     H(s) = (s^2 + s A / Q + 1) / (s^2 + s / (A Q) + 1)
+        low shelf   H(s) = A (s^2 + s sqrt(A) / Q + A) / (A s^2 + s sqrt(A) / Q + 1)
+        high shelf  H(s) = A (A s^2 + s sqrt(A) / Q + 1) / (s^2 + s sqrt(A) / Q + A),            s in units of the warped frequency,
+    so scipy.signal.bilinear of those prototypes must reproduce the normalised coefficients; the magnitude landmarks (gain at the centre,
+    half the gain at a shelf's corner, 0 dB / full gain at DC and Nyquist) are checked from scipy.signal.freqz as well."""
+    import math
+    from scipy import signal
+    from music_mixing_style_transfer_amd.mixing_manipulator.common_audioeffects import rbj_coefficients
+    fs = 44100.0
+    for kind, gain_db, q, fc in (("peaking", 6.0, 0.7, 400.0), ("peaking", -9.5, 2.0, 4000.0), ("low_shelf", 4.0, 0.707, 80.0),
+                                 ("low_shelf", -12.0, 0.707, 200.0), ("high_shelf", 7.5, 0.707, 8000.0), ("high_shelf", -3.0, 0.707, 5000.0)):
+        A = 10.0 ** (gain_db / 40.0)
+        w = 2.0 * fs * math.tan(math.pi * fc / fs)           # the analog frequency the bilinear transform maps onto fc
+        if kind == "peaking":
+            b, a = [1.0, w * A / q, w * w], [1.0, w / (A * q), w * w]
+        elif kind == "low_shelf":
+            b, a = [A, A * math.sqrt(A) / q * w, A * A * w * w], [A, math.sqrt(A) / q * w, w * w]
+        else:
+            b, a = [A * A, A * math.sqrt(A) / q * w, A * w * w], [1.0, math.sqrt(A) / q * w, A * w * w]
+        bz, az = signal.bilinear(b, a, fs)
+        for name, c in (("product", rbj_coefficients(kind, gain_db, q, fc, fs)),
+                        ("oracle", np.concatenate(F.rbj_biquad(kind, gain_db, q, fc, fs)))):
+            c = np.asarray(c, dtype=np.float64)
+            got = np.concatenate([c[:3] / c[3], c[3:] / c[3]])
+            assert np.abs(got - np.concatenate([bz / az[0], az / az[0]])).max() <= 1e-9, (name, kind, gain_db, fc)
+        c = np.asarray(rbj_coefficients(kind, gain_db, q, fc, fs))
+        _, h = signal.freqz(c[:3], c[3:], worN=[1e-6, fc, fs / 2 - 1e-6], fs=fs)
+        db = 20.0 * np.log10(np.abs(h))
+        if kind == "peaking":
+            assert abs(db[0]) < 1e-6 and abs(db[1] - gain_db) < 1e-9 and abs(db[2]) < 1e-6
+        elif kind == "low_shelf":
+            assert abs(db[0] - gain_db) < 1e-6 and abs(db[1] - gain_db / 2) < 1e-9 and abs(db[2]) < 1e-6
+        else:
+            assert abs(db[0]) < 1e-6 and abs(db[1] - gain_db / 2) < 1e-9 and abs(db[2] - gain_db) < 1e-6

@@ -56,6 +56,11 @@ def main():
     fused = AugmentationChain(fxs=[(eq, 1.0, True), (comp, 1.0, True), (im, 1.0, True), (gn, 1.0, False)], randomize_param_value=False)
     out = fused([x])[0]
     torch.cuda.synchronize()
+    if "--chain-only" in sys.argv:           # counter passes (tools/gpu_fx_pmc.sh): N chains and nothing else after the warm-up chain
+        for _ in range(int(sys.argv[sys.argv.index("--chain-only") + 1])):
+            out = fused([x])[0]
+        torch.cuda.synchronize()
+        return
     steps = 5
     t0 = time.perf_counter()
     for _ in range(steps):
