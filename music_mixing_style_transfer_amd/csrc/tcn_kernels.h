@@ -57,7 +57,10 @@ struct TcnBlockArgs {
 // B fragment feeds two MFMAs) - and under the chip's power limit it runs 15 % faster: on realistic operands the bare instruction
 // stream sustains 1934-1982 TFLOP/s against 1666-1685, the whole main loop 1570-1585 against 1367-1377
 // (tools/micro/tcn_mainloop_variants.hip, profiles/r02_micro_tcn_mainloop_variants.txt).
-constexpr int TCN_LIVE_MIN_P = 8;      // phases per tile from which all-padding (column tile, tap) pairs are skipped
+// phases per tile from which all-padding (column tile, tap) pairs are skipped.  8 was measured and dropped for this kernel (round 4, same-box
+// A/B at 32 x 131072): the d = 4096 / 8192 blocks skip 10 % / 20 % of their MFMAs but run 1.58 -> 1.85 / 1.57 -> 1.74 ms - the wave-uniform
+// branches around the MFMA pairs break the (mfma, mfma, ds_read) software pipeline; the split-bf16 kernel (6 MFMAs per branch) gains 3-5 %
+constexpr int TCN_LIVE_MIN_P = 16;
 template <int P, bool FUSE_OUT, int NQ>
 __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1))) void tcn_block_bf16_kernel(TcnBlockArgs a) {
     constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NC = 2 * NQ;
@@ -156,9 +159,8 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
 #pragma unroll
             for (int q = 0; q < RB; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 4096);
         }
-        // P >= 8 tiles (large dilations: a segment has only a few steps per phase) cover steps outside the segment: a (column tile q, tap j)
-        // pair whose 16 input rows are all zero padding contributes nothing and its MFMAs are skipped (wave-uniform).  At L = 131072 that
-        // is 20 % of the MFMAs of the d = 8192 block (16 steps per phase) and 10 % of the d = 4096 block.
+        // P = 16 tiles (largest dilation on a short segment) cover steps far outside the segment: a (column tile q, tap j)
+        // pair whose 16 input rows are all zero padding contributes nothing and its MFMAs are skipped (wave-uniform).
         const int nsteps = (int)(((long)a.L + a.d - 1) / a.d);
         for (int j = 0; j < 15; ++j) {
             const int jn = j < 14 ? j + 1 : 14;

@@ -36,8 +36,13 @@ def biquad(x, b, a):
     return y
 
 
+_MAX_SPLIT = 1 << 15      # samples per workgroup of a max-reduction (fx_range_reduce_kernel runs ONE workgroup per range)
+
+
 def range_reduce(x, items, lo, hi, channel=0, mode="sumsq"):
-    """x device [n, L, C] (or [L, C]); float64 numpy [n_ranges]: sum of squares / max |x| over x[items[r], lo[r]:hi[r], channel]."""
+    """x device [n, L, C] (or [L, C]); float64 numpy [n_ranges]: sum of squares / max |x| over x[items[r], lo[r]:hi[r], channel].
+    A max over a long range (the peak of a whole stem: 16 M samples on one workgroup took 17 ms) is cut into pieces of 2^15 samples
+    that run as separate ranges and are combined on the host - a maximum does not depend on the order, the result is the same bits."""
     lib = _lib.lib()
     if x.dim() == 2:
         x = x[None]
@@ -45,14 +50,31 @@ def range_reduce(x, items, lo, hi, channel=0, mode="sumsq"):
     r = len(lo)
     if r == 0:
         return np.zeros(0)
+    owner = None
+    if mode != "sumsq" and any(min(int(b), L) - max(int(a), 0) > _MAX_SPLIT for a, b in zip(lo, hi)):
+        items2, lo2, hi2, owner = [], [], [], []
+        for k, (it, a, b) in enumerate(zip(items, lo, hi)):
+            a, b = max(int(a), 0), min(int(b), L)
+            starts = range(a, b, _MAX_SPLIT) if b > a else [a]
+            for s0 in starts:
+                items2.append(it)
+                lo2.append(s0)
+                hi2.append(min(b, s0 + _MAX_SPLIT))
+                owner.append(k)
+        items, lo, hi = items2, lo2, hi2
     dev = x.device
     it = torch.tensor(items, dtype=torch.int32, device=dev)
-    out = torch.empty(r, dtype=torch.float64, device=dev)
+    out = torch.empty(len(lo), dtype=torch.float64, device=dev)
     lo_t, hi_t = _i64(lo, dev), _i64(hi, dev)
     with lib.device_ctx(x):
-        lib.check(lib.mst_fx_range_reduce(x.data_ptr(), L, Cn, channel, it.data_ptr(), lo_t.data_ptr(), hi_t.data_ptr(), r,
+        lib.check(lib.mst_fx_range_reduce(x.data_ptr(), L, Cn, channel, it.data_ptr(), lo_t.data_ptr(), hi_t.data_ptr(), len(lo),
                                           0 if mode == "sumsq" else 1, out.data_ptr(), lib.stream_ptr(x)), "mst_fx_range_reduce")
-    return out.cpu().numpy()
+    res = out.cpu().numpy()
+    if owner is None:
+        return res
+    full = np.zeros(r)
+    np.maximum.at(full, np.asarray(owner), res)
+    return full
 
 
 class StftMeanMagnitude:

@@ -171,6 +171,22 @@ def test_product_loudness_and_onset_kernels_emulated(emu_default, gold):
     assert len(N.onset_times(xc, 44100)) >= 4
 
 
+def test_range_reduce_splits_long_maxima(emu_default):
+    """The peak of a whole stem is ONE range: it is cut into pieces of 2^15 samples (one workgroup each) and combined on the host - the same
+    value as numpy's, next to short ranges and a sum of squares over the same long range (which is never split: its order is the kernel's)."""
+    import torch
+    from music_mixing_style_transfer_amd.mixing_manipulator import _device_ops as D
+    rng = np.random.default_rng(11)
+    x = (0.3 * rng.standard_normal((2, 100001, 2))).astype(np.float32)
+    x[1, 77777, 1] = -3.5
+    t = torch.from_numpy(x)
+    got = D.range_reduce(t, [1, 0, 1, 0], [0, 10, 77000, 5], [100001, 20, 100001, 5], channel=1, mode="max")
+    want = [np.abs(x[1, :, 1]).max(), np.abs(x[0, 10:20, 1]).max(), np.abs(x[1, 77000:, 1]).max(), 0.0]
+    assert np.array_equal(got, np.asarray(want, dtype=np.float64))
+    ss = D.range_reduce(t, [0], [0], [100001], channel=0, mode="sumsq")
+    assert abs(ss[0] - np.sum(x[0, :, 0].astype(np.float64) ** 2)) <= 1e-9 * ss[0]
+
+
 def test_product_eq_matching_emulated(emu_default, gold):
     from music_mixing_style_transfer_amd.mixing_manipulator.utils_data_normalization import get_eq_matching
     nfft, hop, ntaps = (int(v) for v in gold["eq_cfg"])

@@ -164,7 +164,10 @@ def main():
     for N, V in ((32, 16), (32, 18), (64, 48), (64, 50)):
         for act, fmt in (('f', 'xxx'), ('b', 'bbb'), ('b', 'xbx'), ('f', 'xbx'), ('b', 'xxx')):
             cases.append((f"fft N={N} V={V} act={act} fwd/bin/inv={fmt}", act, lambda h, w, d, N=N, V=V, fmt=fmt: block_fft(h, w, d, N, V, fmt)))
+    only = sys.argv[3].split(",") if len(sys.argv) > 3 else None      # substrings of the case names to run
     for name, act, conv in cases:
+        if only and not any(o in name for o in only):
+            continue
         y = run(sd, x, cond, act, conv)
         print(f"{name:55s} max|y - oracle| = {float((y - ref).abs().max()):.3e}   rms = {float(((y - ref) ** 2).mean().sqrt()):.3e}", flush=True)
 
