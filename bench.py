@@ -359,7 +359,7 @@ def bench_fx_chain(dev, steps=5):
     # offline: counters need their own rocprofv3 passes).  `achieved` / `frac` stay on the ALGORITHMIC basis (one read + one write of the audio,
     # 16 L per segment - what a perfectly fused chain would move); `frac_on_traffic` is the measured bytes over the same time.
     traffic, tsrc = None, None
-    for name in ("r04_fx_chain_traffic.json", "r04_fx_chain_traffic_before.json"):
+    for name in ("r04_fx_chain_traffic.json",):
         tpath = os.path.join(REPO, "profiles", name)
         if os.path.exists(tpath):
             with open(tpath) as f:

@@ -134,6 +134,7 @@ struct MstTcn {
     bool out_loaded = false;
     void *zero_row = nullptr;     // 1 KB of zeros: what the block kernels stage for time steps outside the segment
     int x3_small_tiles = 1;       // bf16x3 mode: 128-time tiles of <= 2 phases, two workgroups per CU (mst_tcn_set_tuning; measured 5.13 vs 5.45 ms)
+    int x3_duo = 1;               // bf16x3 mode: the persistent double-tile form of the 128-time-tile kernel (mst_tcn_set_tuning bit 3)
     int bf16_form = 2;            // bf16 mode, form of the block kernel (mst_tcn_set_tuning bits 1-2): 0 one tile per workgroup, 1 stream, 2 duo (default)
     std::vector<hipEvent_t> ev;   // timing hook: (nblocks + 2) events per recorded forward
     int ev_max = 0, ev_used = 0;
@@ -413,7 +414,25 @@ template <int P, int NQ> int launch_block_duo(TcnBlockArgs a, void *stream) {
     return MST_OK;
 }
 
-template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream, int x3_small = 0, int bf16_form = 0) {
+// the persistent double-tile split-bf16 kernel (128-time tiles): one workgroup per CU
+template <int P> int launch_block_x3_duo(TcnBlockArgs a, void *stream) {
+    const long nsteps = ((long)a.L + a.d - 1) / a.d;
+    a.tiles_step = (int)((nsteps + 128 / P - 1) / (128 / P));
+    const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
+    if (ntiles > 0x7fffffffL) return fail(MST_ERR_ARG, "tcn_block_bf16x3_duo_kernel: more than 2^31 tiles");
+    long grid = mst_num_cus();
+    if (grid > ntiles) grid = ntiles;
+    a.xcd_tiles = 0;
+    if (grid >= 8) {
+        grid -= grid % 8;
+        a.xcd_tiles = (int)((ntiles + 7) / 8);
+    }
+    MST_LAUNCH((tcn_block_bf16x3_duo_kernel<P, 4>), dim3((unsigned)grid), dim3(512), stream, a);
+    MST_CHECK_LAUNCH("tcn_block_bf16x3_duo_kernel");
+    return MST_OK;
+}
+
+template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream, int x3_small = 0, int bf16_form = 0, int x3_duo = 0) {
     TcnBlockArgs a = a0;
     if (precision == MST_PREC_BF16 && bf16_form == 2) {
         // 256-time tiles only: at P = 8 (128-time tiles: half the work per tile for the same two barriers) the duo form measured
@@ -426,6 +445,7 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
     if (precision == MST_PREC_BF16 && bf16_form == 1) return launch_block_stream<P, (P == 8 ? 4 : 8)>(a, stream);
     if (precision == MST_PREC_BF16X3) {
         if constexpr (P <= 2) {
+            if (x3_small && x3_duo && !a.y_out) return launch_block_x3_duo<P>(a, stream);
             if (x3_small) {          // 128-time tiles: 2 x 39 KB of LDS, two workgroups (8 waves) per CU
                 const long nsteps = ((long)a.L + a.d - 1) / a.d;
                 a.tiles_step = (int)((nsteps + 128 / P - 1) / (128 / P));
@@ -629,10 +649,10 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         if (grid > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_tcn_forward: grid too large");
         int rc;
         switch (P) {
-            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small, t->bf16_form); break;
-            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_form); break;
-            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_form); break;
-            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_form); break;
+            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo); break;
+            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo); break;
+            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo); break;
+            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo); break;
             default: rc = launch_block<16>(precision, a, (int)grid, stream, 0, t->bf16_form); break;
         }
         if (rc) return rc;
@@ -678,9 +698,10 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
 
 extern "C" int mst_tcn_set_tuning(MstTcn *t, int flags) {
     if (!t) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: null handle");
-    if (flags < 0 || flags > 5) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: unknown flag bits");
+    if (flags < 0 || flags > 15 || ((flags >> 1) & 3) > 2) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: unknown flag bits");
     t->x3_small_tiles = flags & 1;
-    t->bf16_form = flags >> 1;
+    t->bf16_form = (flags >> 1) & 3;
+    t->x3_duo = (flags >> 3) & 1;
     return MST_OK;
 }
 

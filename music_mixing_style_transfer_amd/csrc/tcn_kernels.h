@@ -1088,6 +1088,252 @@ __global__ __launch_bounds__(256, (NQ == 4 && P <= 2) ? 2 : 1) void tcn_block_bf
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16x3: the PERSISTENT DOUBLE-TILE form of tcn_block_bf16x3_kernel<P, 4> (round 4; the split mode's twin of tcn_block_bf16_duo_kernel) -
+// same 128-time tiles, same LDS images, same main loop and epilogue arithmetic, bit-identical results; what changes is who does what:
+//   * ONE workgroup of EIGHT waves per CU, persistent, walking its share of the tiles of one XCD's contiguous tile range;
+//   * waves 0-3 (one per SIMD, s_setprio 2) are the MATRIX waves: main loop (three MFMAs per product) and the LeakyReLU / FiLM part of the
+//     epilogue in the accumulator layout, written as fp32 rows into the tile buffer they have just finished reading;
+//   * waves 4-7 (one per SIMD) are the LOADER waves: while the matrix waves work on tile i (buffer i & 1) they fetch the fp32 rows of tile
+//     i + 1, split them x = hi + lo and write the two bf16 images into the other buffer; behind barrier 2 they finish tile i: whole-row pass
+//     z + res * x_in (the residual re-read from global memory, L2-hot), coalesced 16-byte stores.
+//   * two workgroup barriers per tile: (1) the matrix waves are done reading tile i AND tile i + 1 is staged, (2) the fp32 rows of tile i are
+//     complete.  No third one: loader wave W owns the input rows r with (r >> 1) & 3 == W and the output rows o with o & 3 == W, and the lo
+//     image starts 80 output rows (40960 B) into the buffer - so the bytes a loader wave overwrites when it refills a buffer are exactly bytes
+//     of output rows it has read itself (hi row r lies in output row r / 2, lo row r in output row 80 + r / 2; 80 = 0 mod 4).
+// Why: the one-tile kernel (two workgroups per CU) runs at 4.58 ms per launch against 3 x 1.23 ms for its MFMAs at the rate the box sustains
+// (bench.py roofline.calib_ms): staging with its fp32 -> (hi, lo) conversion, the transposing epilogue and the row pass are exposed, the two
+// co-resident workgroups run in lock-step.
+// ------------------------------------------------------------------------------------------------
+template <int P, int NQ>
+__global__ __launch_bounds__(512, 1) void tcn_block_bf16x3_duo_kernel(TcnBlockArgs a) {
+    constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NC = 2 * NQ;
+    constexpr int LO_OFF = 40960, BUF = LO_OFF + ((R * 256 + 1023) / 1024) * 1024;
+    static_assert(NQ == 4 && R * 256 <= LO_OFF && T * 512 <= BUF, "128-time tiles: the (hi | lo) images and the fp32 output tile share a buffer");
+    static_assert((LO_OFF / 512) % 4 == 0, "a lo row lies in an output row of the same loader wave as its hi row");
+    static_assert(2 * BUF + 1536 <= 160 * 1024, "two buffers + parameters fit the CU's LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
+    __shared__ __attribute__((aligned(16))) float par[3 * 128];     // BN shift | FiLM r | FiLM b of the current batch item
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wv >= 4;
+    const int w = wv & 3;
+    const int l16 = lane & 15, g = lane >> 4;
+
+    const unsigned ntiles = (unsigned)a.B * (unsigned)a.tiles_phase * (unsigned)a.tiles_step;
+    unsigned tile, tstep, tend;
+    if (a.xcd_tiles > 0) {
+        tile = (blockIdx.x & 7) * (unsigned)a.xcd_tiles + (blockIdx.x >> 3);
+        tstep = gridDim.x >> 3;
+        tend = ((blockIdx.x & 7) + 1) * (unsigned)a.xcd_tiles;
+        if (tend > ntiles) tend = ntiles;
+    } else {
+        tile = blockIdx.x;
+        tstep = gridDim.x;
+        tend = ntiles;
+    }
+    if (tile >= tend) return;       // uniform
+
+    auto tile_geometry = [&](unsigned tl, int &b, int &m0, int &phi0) {
+        const unsigned r = tl / (unsigned)a.tiles_step, mg = tl - r * (unsigned)a.tiles_step;
+        const unsigned bb = r / (unsigned)a.tiles_phase;
+        phi0 = (int)(r - bb * (unsigned)a.tiles_phase) * P;
+        b = (int)bb;
+        m0 = (int)mg * MT;
+    };
+    // loader wave W stages the input rows r with (r >> 1) & 3 == W: a lane owns one 16-byte slot (8 channels) of rows rr0, rr0 + 16, ...
+    auto stage_tile = [&](int b, int m0, int phi0, int buf) {
+        const int slot = lane & 15, rr0 = 2 * w + ((lane >> 4) & 1) + 8 * (lane >> 5);      // rows rr0, rr0 + 16, ... : (row >> 1) & 3 == w
+        const float *xb = (const float *)a.x + (size_t)b * a.Lp * 128;
+        unsigned char *hi = smem + buf * BUF, *lo = hi + LO_OFF;
+        constexpr int NP = (R + 15) / 16;
+        f32x4 v0[NP], v1[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int row = rr0 + 16 * i;
+            const long t = (long)(m0 + row / P - 7) * a.d + phi0 + (row % P);
+            const float *p = (row < R && t >= 0 && t < a.L) ? xb + t * 128 + slot * 8 : (const float *)a.zeros + slot * 8;      // never a predicated load
+            v0[i] = *(const f32x4 *)p;
+            v1[i] = *(const f32x4 *)(p + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int row = rr0 + 16 * i;
+            if (row < R) {
+                bf16x8 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h[e] = (__bf16)v0[i][e];
+                    l[e] = (__bf16)(v0[i][e] - (float)h[e]);
+                    h[4 + e] = (__bf16)v1[i][e];
+                    l[4 + e] = (__bf16)(v1[i][e] - (float)h[4 + e]);
+                }
+                const int off = row * 256 + ((slot ^ (row & 15)) << 4);
+                *(bf16x8 *)(hi + off) = h;
+                *(bf16x8 *)(lo + off) = l;
+            }
+        }
+    };
+    auto stage_film = [&](int b) {          // matrix waves only
+        if (tid < 128) {
+            const float *frow0 = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+            par[128 + tid] = frow0[tid];
+            par[256 + tid] = frow0[128 + tid];
+        }
+    };
+
+    int tb, tm0, tphi0;
+    tile_geometry(tile, tb, tm0, tphi0);
+    if (loader) {
+        stage_tile(tb, tm0, tphi0, 0);
+    } else {
+        if (tid < 128) par[tid] = a.shift[tid];
+        stage_film(tb);
+    }
+    mst_dma_wait_barrier<0>();
+
+    if (loader) {
+        // =================================================================== loader waves
+        int cur = 0;
+        const int lt = tid - 256;
+        const int s4 = lt & 31;                                    // this thread's 4 channels in the row pass
+        const f32x4 rs = *(const f32x4 *)(a.res + 4 * s4);
+        for (;;) {
+            const int b = tb, m0 = tm0, phi0 = tphi0;
+            const unsigned tnext = tile + tstep;
+            const bool has_next = tnext < tend;
+            if (has_next) {
+                tile_geometry(tnext, tb, tm0, tphi0);
+                stage_tile(tb, tm0, tphi0, cur ^ 1);       // bytes of output rows this wave read itself one iteration ago
+            }
+            mst_dma_wait_barrier<63>();                    // (1) the next tile is staged (this wave's LDS writes have landed; its row stores stay in flight), the matrix waves are done reading this one
+            mst_dma_wait_barrier<63>();                    // (2) the fp32 rows of this tile are complete
+            {
+                const float *st = (const float *)(smem + cur * BUF);
+                const float *xb = (const float *)a.x + (size_t)b * a.Lp * 128;
+                float *yb = (float *)a.y + (size_t)b * a.Lp * 128;
+                // output rows o = w + 4 ((lt >> 5) & 1) + 8 i ... : o & 3 == w; 32 lanes per row
+                const int o0 = w + 4 * ((lane >> 5) & 1);
+#pragma unroll
+                for (int i = 0; i < T / 8; ++i) {
+                    const int o = o0 + 8 * i;
+                    const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
+                    if (t < a.L) {
+                        const f32x4 z = *(const f32x4 *)(st + o * 128 + ((s4 ^ (o & 31)) << 2));
+                        const f32x4 xin = *(const f32x4 *)(xb + t * 128 + 4 * s4);
+                        f32x4 out;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) out[k] = z[k] + rs[k] * xin[k];
+                        *(f32x4 *)(yb + t * 128 + 4 * s4) = out;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();           // every lane of this wave has read its rows before any lane refills them (lock-step on the GPU)
+            }
+            if (!has_next) break;
+            tile = tnext;
+            cur ^= 1;
+        }
+        return;
+    }
+
+    // ======================================================================= matrix waves
+    __builtin_amdgcn_s_setprio(2);
+    const unsigned char *wbase = (const unsigned char *)a.wpk;
+    const unsigned aoff = (unsigned)(w * 64 + lane) * 16u;
+    constexpr size_t LO_IMG = (size_t)120 * 4096;
+    constexpr int RB = 8;
+    static_assert(NC % RB == 0, "the ring divides the column tiles");
+    int cur = 0, bprev = tb;
+    for (;;) {
+        const int b = tb;
+        const unsigned tnext = tile + tstep;
+        const bool has_next = tnext < tend;
+        if (has_next) tile_geometry(tnext, tb, tm0, tphi0);
+        unsigned char *const sm_hi = smem + cur * BUF, *const sm_lo = sm_hi + LO_OFF;
+        if (b != bprev) {              // a new batch item: its FiLM row (every matrix wave is past the previous tile's epilogue: barrier 2)
+            stage_film(b);
+            bprev = b;
+        }
+        f32x4 acc[2][NC];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {          // accumulators start from the BN shift of their channel
+            const f32x4 sh = *(const f32x4 *)(par + 32 * w + 16 * m + 4 * g);
+#pragma unroll
+            for (int q = 0; q < NC; ++q) acc[m][q] = sh;
+        }
+        bf16x8 ah[2][2], al[2][2], bh[RB], bl[RB];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ah[kk][m] = *(const bf16x8 *)(wbase + (size_t)(kk * 2 + m) * 4096 + aoff);
+                al[kk][m] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)(kk * 2 + m) * 4096 + aoff);
+            }
+        {
+            const int o0 = l16 * 256 + ((g ^ l16) << 4);
+#pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                bh[q] = *(const bf16x8 *)(sm_hi + o0 + q * 4096);
+                bl[q] = *(const bf16x8 *)(sm_lo + o0 + q * 4096);
+            }
+        }
+#pragma unroll 1
+        for (int j = 0; j < 15; ++j) {
+            const int jn = j < 14 ? j + 1 : 14;
+            const int rb0 = j * P + l16, rb1 = jn * P + l16;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int rbn = (kk == 3) ? rb1 : rb0;
+                const int kn = (kk + 1) & 3;
+                const int oc = rb0 * 256 + (((4 * kk + g) ^ (rb0 & 15)) << 4);
+                const int on = rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
+                const int s = kk & 1;
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s][m], bh[q % RB], acc[m][q], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][m], bl[q % RB], acc[m][q], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][m], bh[q % RB], acc[m][q], 0, 0, 0);
+                    const int ofs = (q + RB < NC) ? oc + (q + RB) * 4096 : on + (q + RB - NC) * 4096;
+                    bh[q % RB] = *(const bf16x8 *)(sm_hi + ofs);
+                    bl[q % RB] = *(const bf16x8 *)(sm_lo + ofs);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                int ksn = j * 4 + kk + 2;
+                ksn = ksn < 60 ? ksn : 59;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    ah[s][m] = *(const bf16x8 *)(wbase + (size_t)(ksn * 2 + m) * 4096 + aoff);
+                    al[s][m] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)(ksn * 2 + m) * 4096 + aoff);
+                }
+            }
+        }
+        mst_dma_wait_barrier<63>();            // (1) every matrix wave is done reading this tile (the weight fragments in flight stay in flight)
+        float *st = (float *)sm_hi;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int co0 = 32 * w + 16 * m + 4 * g;
+            const f32x4 fr = *(const f32x4 *)(par + 128 + co0);
+            const f32x4 fb = *(const f32x4 *)(par + 256 + co0);
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int o = 16 * q + l16;
+                f32x4 z;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) z[i] = fr[i] * leaky_relu(acc[m][q][i]) + fb[i];
+                *(f32x4 *)(st + o * 128 + (((co0 >> 2) ^ (o & 31)) << 2)) = z;
+            }
+        }
+        mst_dma_wait_barrier<63>();            // (2) the fp32 rows are complete: the loader waves finish and store them
+        if (!has_next) break;
+        tile = tnext;
+        cur ^= 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // bf16x3, large dilations: the same kernel with the input staged in TWO HALVES of 64 channels (round 3).  The 8-phase tiles the
 // d >= 4096 blocks need (few steps per phase: 32 / 16 at L = 131072) have 240 rows; two whole (hi, lo) tiles are 120 KB of LDS = one
 // workgroup per CU (measured 6.4 ms per launch against 4.76 ms for the blocks that run two per CU).  Staged as [240 rows][64 channels]

@@ -93,6 +93,30 @@ def test_tcn_bf16_stream_and_duo_kernels_emulated(emu_default):
         emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 6), "tuning")
 
 
+def test_tcn_bf16x3_duo_kernel_emulated(emu_default):
+    """The persistent double-tile form of the split-bf16 block kernel (mst_tcn_set_tuning bit 3, the default): 4 matrix + 4 loader waves
+    per CU, the loader waves fetch / split the next tile and finish / store the previous one.  Same bits as the one-tile kernel (bit 3
+    off), and the oracle at the split mode's tolerance: several tiles per workgroup (the emulated device has 4 CUs), P = 1 and P = 2
+    tiles, ragged lengths (rows past the segment), several batch items with one FiLM row each, buffers refilled three and more times."""
+    cases = [(3, 2, (2, 2, 777), synth.synth_audio((1, 64), seed=2)),          # d = 2, 4: P = 2; 2 x 7 tiles
+             (3, 3, (1, 2, 1300), synth.synth_audio((1, 64), seed=3)),         # d = 3, 9: P = 1; 11 tiles on 4 workgroups
+             (2, 2, (3, 2, 2500), synth.synth_audio((3, 64), seed=11))]        # 3 x 20 tiles, one FiLM row per item
+    for nb, growth, shape, cnd in cases:
+        m, sd = _tcn(nb, growth=growth)
+        m.precision = "bf16x3"
+        x = synth.synth_audio(shape, seed=1)
+        col = []
+        y_ref = R.tcn_forward(sd, x, cnd, nblocks=nb, dilation_growth=growth, collect=col)
+        m._ensure(emu_default)
+        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 5), "tuning")            # one tile per workgroup
+        y0, a0 = m(x, cnd), m.forward_blocks(x, cnd, nb)
+        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 13), "tuning")           # the duo form
+        y1, a1 = m(x, cnd), m.forward_blocks(x, cnd, nb)
+        assert float((y1 - y_ref).abs().max()) <= 3e-5
+        assert float((a1 - col[nb - 1]).abs().max()) <= 3e-5 * float(col[nb - 1].abs().max())
+        assert torch.equal(y1, y0) and torch.equal(a1, a0)
+
+
 def test_tcn_condition_forms_emulated(emu_default):
     m, sd = _tcn(2)
     x = synth.synth_audio((2, 2, 260), seed=7)
