@@ -1100,9 +1100,12 @@ __global__ __launch_bounds__(256, (NQ == 4 && P <= 2) ? 2 : 1) void tcn_block_bf
 //     complete.  No third one: loader wave W owns the input rows r with (r >> 1) & 3 == W and the output rows o with o & 3 == W, and the lo
 //     image starts 80 output rows (40960 B) into the buffer - so the bytes a loader wave overwrites when it refills a buffer are exactly bytes
 //     of output rows it has read itself (hi row r lies in output row r / 2, lo row r in output row 80 + r / 2; 80 = 0 mod 4).
-// Why: the one-tile kernel (two workgroups per CU) runs at 4.58 ms per launch against 3 x 1.23 ms for its MFMAs at the rate the box sustains
-// (bench.py roofline.calib_ms): staging with its fp32 -> (hi, lo) conversion, the transposing epilogue and the row pass are exposed, the two
-// co-resident workgroups run in lock-step.
+// Why it was built: the one-tile kernel (two workgroups per CU) runs at 4.55 ms per launch against 3 x 1.23 ms for its MFMAs at the rate the box
+// sustains (bench.py roofline.calib_ms).  MEASURED (round 4, same-box A/B at 32 x 131072, profiles/r04_x3_duo_ab.txt): 5.45-5.6 ms per launch -
+// SLOWER than the one-tile kernel, whatever the wave priorities, with the accumulators' MFMAs two or four instructions apart and with the
+// residual rows requested in front of barrier 2.  One MFMA-issuing wave per SIMD is enough for the bf16 main loop (no two MFMAs of a k-step
+// share an accumulator) but not for the split loop, whose three terms per product are dependent accumulations: the second workgroup of the
+// one-tile form is what fills those slots.  Not the default (mst_tcn_set_tuning bit 3); kept because it is bit-identical and tested.
 // ------------------------------------------------------------------------------------------------
 template <int P, int NQ>
 __global__ __launch_bounds__(512, 1) void tcn_block_bf16x3_duo_kernel(TcnBlockArgs a) {
@@ -1206,24 +1209,50 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16x3_duo_kernel(TcnBlockAr
                 stage_tile(tb, tm0, tphi0, cur ^ 1);       // bytes of output rows this wave read itself one iteration ago
             }
             mst_dma_wait_barrier<63>();                    // (1) the next tile is staged (this wave's LDS writes have landed; its row stores stay in flight), the matrix waves are done reading this one
-            mst_dma_wait_barrier<63>();                    // (2) the fp32 rows of this tile are complete
-            {
-                const float *st = (const float *)(smem + cur * BUF);
-                const float *xb = (const float *)a.x + (size_t)b * a.Lp * 128;
-                float *yb = (float *)a.y + (size_t)b * a.Lp * 128;
-                // output rows o = w + 4 ((lt >> 5) & 1) + 8 i ... : o & 3 == w; 32 lanes per row
-                const int o0 = w + 4 * ((lane >> 5) & 1);
+            // the residual rows of THIS tile are requested here, in front of barrier 2: they do not depend on the matrix waves' epilogue and
+            // have landed when it is over.  (A tile that lies inside the segment - all but the last of a phase group - needs no bounds
+            // test; a load under `if (t < L)` is a branch per row and hipcc waits for each before the next: sixteen L2 round trips per tile
+            // made the loader waves the critical path, 5.45 instead of 4.1 ms per launch.)
+            const float *xb = (const float *)a.x + (size_t)b * a.Lp * 128;
+            float *yb = (float *)a.y + (size_t)b * a.Lp * 128;
+            const int o0 = w + 4 * ((lane >> 5) & 1);      // output rows o0 + 8 i: o & 3 == w; 32 lanes (4 channels each) per row
+            const bool inside = (long)(m0 + (T - 1) / P) * a.d + phi0 + (P - 1) < a.L;      // uniform
+            f32x4 xin[T / 8];
+            if (inside) {
 #pragma unroll
                 for (int i = 0; i < T / 8; ++i) {
                     const int o = o0 + 8 * i;
                     const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
-                    if (t < a.L) {
+                    xin[i] = *(const f32x4 *)(xb + t * 128 + 4 * s4);
+                }
+            }
+            mst_dma_wait_barrier<63>();                    // (2) the fp32 rows of this tile are complete
+            {
+                const float *st = (const float *)(smem + cur * BUF);
+                if (inside) {
+#pragma unroll
+                    for (int i = 0; i < T / 8; ++i) {
+                        const int o = o0 + 8 * i;
+                        const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
                         const f32x4 z = *(const f32x4 *)(st + o * 128 + ((s4 ^ (o & 31)) << 2));
-                        const f32x4 xin = *(const f32x4 *)(xb + t * 128 + 4 * s4);
                         f32x4 out;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) out[k] = z[k] + rs[k] * xin[k];
+                        for (int k = 0; k < 4; ++k) out[k] = z[k] + rs[k] * xin[i][k];
                         *(f32x4 *)(yb + t * 128 + 4 * s4) = out;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < T / 8; ++i) {
+                        const int o = o0 + 8 * i;
+                        const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
+                        if (t < a.L) {
+                            const f32x4 z = *(const f32x4 *)(st + o * 128 + ((s4 ^ (o & 31)) << 2));
+                            const f32x4 xv = *(const f32x4 *)(xb + t * 128 + 4 * s4);
+                            f32x4 out;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) out[k] = z[k] + rs[k] * xv[k];
+                            *(f32x4 *)(yb + t * 128 + 4 * s4) = out;
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();           // every lane of this wave has read its rows before any lane refills them (lock-step on the GPU)
@@ -1287,19 +1316,30 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16x3_duo_kernel(TcnBlockAr
                 const int oc = rb0 * 256 + (((4 * kk + g) ^ (rb0 & 15)) << 4);
                 const int on = rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
                 const int s = kk & 1;
+                // column tiles in PAIRS, term-major: an accumulator's three MFMAs (lo*hi, hi*lo, hi*hi - the one-tile kernel's order, same
+                // bits) are four instructions apart instead of two - with ONE matrix wave per SIMD nothing else hides a dependent MFMA's latency
 #pragma unroll
-                for (int q = 0; q < NC; ++q) {
+                for (int q = 0; q < NC; q += 2) {
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s][m], bh[q % RB], acc[m][q], 0, 0, 0);
+                    for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][m], bl[q % RB], acc[m][q], 0, 0, 0);
+                        for (int m = 0; m < 2; ++m) acc[m][q + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s][m], bh[(q + u) % RB], acc[m][q + u], 0, 0, 0);
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][m], bh[q % RB], acc[m][q], 0, 0, 0);
-                    const int ofs = (q + RB < NC) ? oc + (q + RB) * 4096 : on + (q + RB - NC) * 4096;
-                    bh[q % RB] = *(const bf16x8 *)(sm_hi + ofs);
-                    bl[q % RB] = *(const bf16x8 *)(sm_lo + ofs);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) acc[m][q + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][m], bl[(q + u) % RB], acc[m][q + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) acc[m][q + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][m], bh[(q + u) % RB], acc[m][q + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int ofs = (q + u + RB < NC) ? oc + (q + u + RB) * 4096 : on + (q + u + RB - NC) * 4096;
+                        bh[(q + u) % RB] = *(const bf16x8 *)(sm_hi + ofs);
+                        bl[(q + u) % RB] = *(const bf16x8 *)(sm_lo + ofs);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 }
                 int ksn = j * 4 + kk + 2;
                 ksn = ksn < 60 ? ksn : 59;

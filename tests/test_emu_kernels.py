@@ -94,7 +94,7 @@ def test_tcn_bf16_stream_and_duo_kernels_emulated(emu_default):
 
 
 def test_tcn_bf16x3_duo_kernel_emulated(emu_default):
-    """The persistent double-tile form of the split-bf16 block kernel (mst_tcn_set_tuning bit 3, the default): 4 matrix + 4 loader waves
+    """The persistent double-tile form of the split-bf16 block kernel (mst_tcn_set_tuning bit 3; not the default - measured slower): 4 matrix + 4 loader waves
     per CU, the loader waves fetch / split the next tile and finish / store the previous one.  Same bits as the one-tile kernel (bit 3
     off), and the oracle at the split mode's tolerance: several tiles per workgroup (the emulated device has 4 CUs), P = 1 and P = 2
     tiles, ragged lengths (rows past the segment), several batch items with one FiLM row each, buffers refilled three and more times."""
