@@ -182,6 +182,11 @@ int mst_enc_set_schedule(MstEnc *enc, int flags);
 /* nn.AdaptiveAvgPool1d(1) on its own (architectures.py:63,67; FXencoder(conv_block='conv') runs its ConvBlocks one by one through
  * mst_enc_forward_conv and pools here): x_dev fp32 [rows, L] -> y_dev[rows] = mean over L. */
 int mst_global_avgpool(const float *x_dev, float *y_dev, long rows, int L, void *stream);
+/* Conv1d_layer(mode="deconv") (network_utils.py:24-26,38-42, nn.ConvTranspose1d): the zero-stuffed input of the equivalent stride-1
+ * convolution - y_dev[row][pad_left + i * stride] = x_dev[row][i], zeros elsewhere; x_dev fp32 [rows, L] -> y_dev fp32 [rows, Lu],
+ * Lu >= pad_left + (L - 1) * stride + 1.  The convolution itself is mst_enc_forward_conv of a handle loaded with the tap-reversed,
+ * channel-transposed weights and VALID padding (networks/network_utils.py does both). */
+int mst_enc_zero_stuff(const float *x_dev, float *y_dev, long rows, long L, int stride, long pad_left, long Lu, void *stream);
 size_t mst_enc_workspace_bytes(const MstEnc *enc, int B, int L);
 /* replaces FXencoder.forward (architectures.py:65-70): x_dev fp32 [B, 2, L] -> emb_dev fp32 [B, C_last].
  * precision: MST_PREC_F32 (exact fp32 MFMA, parity mode) or MST_PREC_BF16 (bf16 operands, fp32 accumulate;

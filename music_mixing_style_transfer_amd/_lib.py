@@ -65,6 +65,7 @@ SIGNATURES = {
     "mst_enc_set_tuning": (C.c_int, [_P, C.c_long]),
     "mst_enc_set_schedule": (C.c_int, [_P, C.c_int]),
     "mst_global_avgpool": (C.c_int, [_F, _F, C.c_long, C.c_int, _P]),
+    "mst_enc_zero_stuff": (C.c_int, [_F, _F, C.c_long, C.c_long, C.c_int, C.c_long, C.c_long, _P]),
     "mst_enc_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int]),
     "mst_enc_forward": (C.c_int, [_P, _F, _F, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "mst_enc_forward_blocks": (C.c_int, [_P, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),

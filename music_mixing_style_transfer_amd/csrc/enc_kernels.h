@@ -991,3 +991,19 @@ __global__ void embedding_mean_kernel(const float *emb, int n_rows, int dim, flo
     for (int r = 0; r < n_rows; ++r) s += emb[(size_t)r * dim + d];
     out[d] = s / (float)n_rows;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Conv1d_layer(mode="deconv") (reference network_utils.py:24-26,38-42: nn.ConvTranspose1d with padding = dilation * (k - 1) / 2 and
+// output_padding = stride > 1): a transposed convolution IS the stride-1 convolution of the zero-stuffed input (x[i] at position
+// pad_left + i * stride of a zero row of length Lu) with the tap-reversed, channel-transposed kernel - the conv kernels above then do the
+// arithmetic (VALID padding).  This kernel writes the zero-stuffed rows: y[row][u] = x[row][(u - pad_left) / stride] where that is a
+// sample, 0 elsewhere.  rows = B * C.  HBM-bound copy; training-only mode of the reference, provided for API completeness.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void enc_zero_stuff_kernel(const float *x, float *y, long rows, long L, int stride, long pad_left, long Lu) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * Lu) return;
+    const long row = i / Lu, u = i - row * Lu, v = u - pad_left;
+    float out = 0.0f;
+    if (v >= 0 && v % stride == 0 && v / stride < L) out = x[row * L + v / stride];
+    y[i] = out;
+}

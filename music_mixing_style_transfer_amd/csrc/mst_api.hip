@@ -953,6 +953,16 @@ extern "C" int mst_global_avgpool(const float *x, float *y, long rows, int L, vo
     return MST_OK;
 }
 
+extern "C" int mst_enc_zero_stuff(const float *x, float *y, long rows, long L, int stride, long pad_left, long Lu, void *stream) {
+    if (!x || !y || rows < 1 || L < 1 || stride < 1 || pad_left < 0 || Lu < pad_left + (L - 1) * stride + 1)
+        return fail(MST_ERR_ARG, "mst_enc_zero_stuff: bad argument");
+    const long total = rows * Lu;
+    if ((total + 255) / 256 > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_enc_zero_stuff: too large");
+    MST_LAUNCH(enc_zero_stuff_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, x, y, rows, L, stride, pad_left, Lu);
+    MST_CHECK_LAUNCH("enc_zero_stuff_kernel");
+    return MST_OK;
+}
+
 extern "C" int mst_enc_set_schedule(MstEnc *e, int flags) {
     if (!e || flags < 0 || flags > 7) return fail(MST_ERR_ARG, "mst_enc_set_schedule: flags 0..7");
     e->schedule = flags;

@@ -54,25 +54,38 @@ def _device_input(t, what):
 
 
 class Conv1d_layer(_DeviceState, nn.Module):
-    """ReflectionPad1d -> Conv1d -> BatchNorm1d -> ReLU (reference order conv -> norm -> activation)."""
+    """mode "conv": ReflectionPad1d -> Conv1d -> BatchNorm1d -> ReLU (reference order conv -> norm -> activation);
+    mode "deconv" (reference :24-26,38-42; not used by the inference path, provided for the module API): ConvTranspose1d with
+    padding = dilation * (k - 1) / 2 and output_padding = (stride > 1) -> BatchNorm1d -> activation, computed as the stride-1 VALID
+    convolution of the zero-stuffed input (mst_enc_zero_stuff) with the tap-reversed, channel-transposed kernel.
+    The "alias_free_*" modes need torchaudio's resampler and stay unavailable."""
     _DEVICE_STATE = (("_handle", None), ("_sig", None), ("_hlib", None))
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding="SAME", dilation=1, bias=True,
                  norm="batch", activation="relu", mode="conv"):
         super().__init__()
-        if mode != "conv":
+        if mode not in ("conv", "deconv"):
             raise NotImplementedError(f"Conv1d_layer mode '{mode}' is not part of the inference hot path")
-        if padding not in ("SAME", "VALID"):
+        if mode == "conv" and padding not in ("SAME", "VALID"):
             raise ValueError("padding must be 'SAME' or 'VALID'")
+        self.mode = mode
         self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size, self.stride, self.dilation = kernel_size, stride, dilation
-        self.padding_area = same_padding(kernel_size, dilation) if padding == "SAME" else (0, 0)
         self.norm, self.activation = norm, activation
         self._handle = self._sig = self._hlib = None
         self.conv1d = nn.Sequential()
-        self.conv1d.add_module("conv1d_pad", nn.ReflectionPad1d(self.padding_area))
-        self.conv1d.add_module("conv1d", nn.Conv1d(in_channels, out_channels, kernel_size, stride=stride, padding=0,
-                                                   dilation=dilation, bias=bias))
+        if mode == "deconv":
+            self.deconv_padding = int(dilation * (kernel_size - 1) / 2)
+            self.output_padding = 0 if stride == 1 else 1
+            self.padding_area = (0, 0)
+            self.conv1d.add_module("deconv1d", nn.ConvTranspose1d(in_channels, out_channels, kernel_size, stride=stride,
+                                                                  padding=self.deconv_padding, output_padding=self.output_padding,
+                                                                  dilation=dilation, bias=bias))
+        else:
+            self.padding_area = same_padding(kernel_size, dilation) if padding == "SAME" else (0, 0)
+            self.conv1d.add_module("conv1d_pad", nn.ReflectionPad1d(self.padding_area))
+            self.conv1d.add_module("conv1d", nn.Conv1d(in_channels, out_channels, kernel_size, stride=stride, padding=0,
+                                                       dilation=dilation, bias=bias))
         if norm == "batch":
             self.conv1d.add_module("batch_norm", nn.BatchNorm1d(out_channels))
         if activation == "relu":
@@ -86,7 +99,7 @@ class Conv1d_layer(_DeviceState, nn.Module):
 
     def hip_supported(self):
         """Usable inside an encoder handle (Res_ConvBlock stack): SAME padding; any norm / activation the reference's layer accepts."""
-        return self.padding_area == same_padding(self.kernel_size, self.dilation)
+        return self.mode == "conv" and self.padding_area == same_padding(self.kernel_size, self.dilation)
 
     # ---- the layer on its own (reference :86-89) ------------------------------------------------
     def _ensure(self, b):
@@ -98,7 +111,7 @@ class Conv1d_layer(_DeviceState, nn.Module):
         d.act_slope = self.act_slope()
         d.nblocks = 1
         d.channels[0], d.channels[1] = self.in_channels, self.out_channels
-        d.kernels[0], d.strides[0], d.dilations[0] = self.kernel_size, self.stride, self.dilation
+        d.kernels[0], d.strides[0], d.dilations[0] = self.kernel_size, (1 if self.mode == "deconv" else self.stride), self.dilation
         d.valid_padding = 1 if self.padding_area == (0, 0) and self.kernel_size > 1 else 0
         h = C.c_void_p()
         b.check(b.mst_enc_create(C.byref(d), C.byref(h)), "mst_enc_create")
@@ -128,6 +141,15 @@ class Conv1d_layer(_DeviceState, nn.Module):
             self._ensure(b)
             x = input.contiguous()
             B, _, L = x.shape
+            if self.mode == "deconv":          # the zero-stuffed input of the equivalent stride-1 VALID convolution
+                edge = self.dilation * (self.kernel_size - 1) - self.deconv_padding
+                if edge < 0:
+                    raise RuntimeError("Conv1d_layer(mode='deconv'): padding larger than the kernel's reach")
+                Lu = edge + (L - 1) * self.stride + 1 + edge + self.output_padding
+                xu = torch.empty(B, self.in_channels, Lu, dtype=torch.float32, device=x.device)
+                b.check(b.mst_enc_zero_stuff(x.data_ptr(), xu.data_ptr(), B * self.in_channels, L, self.stride, edge, Lu, b.stream_ptr(x)),
+                        "mst_enc_zero_stuff")
+                x, L = xu, Lu
             lout = b.mst_enc_conv_length(self._handle, 0, 1, L)
             if lout < 1 or L <= max(self.padding_area):
                 raise RuntimeError("Conv1d_layer.forward: the input is too short for this kernel / reflection padding")
@@ -137,8 +159,13 @@ class Conv1d_layer(_DeviceState, nn.Module):
 
     def export_arrays(self):
         """Host fp32 arrays in the reference's layouts for mst_enc_load_conv."""
-        conv = self.conv1d.conv1d
         f = lambda t: None if t is None else t.detach().to("cpu", torch.float32).contiguous()
+        if self.mode == "deconv":      # ConvTranspose1d weight [Cin, Cout, k] -> the equivalent convolution's [Cout, Cin, k], taps reversed
+            import types
+            dc = self.conv1d.deconv1d
+            conv = types.SimpleNamespace(weight=dc.weight.detach().permute(1, 0, 2).flip(-1), bias=dc.bias)
+        else:
+            conv = self.conv1d.conv1d
         if self.norm != "batch":        # no normalisation layer (network_utils.py:70-73): the identity in BatchNorm form, folded exactly
             one, zero = torch.ones(self.out_channels), torch.zeros(self.out_channels)
             return dict(w=f(conv.weight), bias=f(conv.bias), bn_w=one, bn_b=zero, bn_mean=zero.clone(), bn_var=one.clone(), eps=0.0)

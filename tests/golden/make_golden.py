@@ -637,6 +637,11 @@ def modules_goldens():
                            cond_dim=16, **kw), 10, xt, cond)
     run("tcn_growth2", TCNModel(nparams=16, ninputs=2, noutputs=2, nblocks=3, dilation_growth=2, kernel_size=5, channel_growth=2, stack_size=15,
                                 cond_dim=16), 16, xt, cond)
+    # mode="deconv" (nn.ConvTranspose1d; not used at inference, part of the exported module API): stride 2 with output padding, a dilated
+    # stride-1 layer with LeakyReLU, and a ConvBlock whose last layer is transposed
+    run("deconv_k4_s2", Conv1d_layer(6, 10, 4, stride=2, mode="deconv"), 21, x)
+    run("deconv_k5_d2_lrelu", Conv1d_layer(6, 7, 5, stride=1, dilation=2, activation="lrelu", mode="deconv"), 22, x)
+    run("convblock_deconv", ConvBlock(1, 2, 6, 9, 3, stride=3, mode="deconv"), 23, x)
     np.savez_compressed(os.path.join(HERE, "modules.npz"), **out)
     print("modules.npz", os.path.getsize(os.path.join(HERE, "modules.npz")), len(out), "arrays")
 

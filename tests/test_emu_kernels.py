@@ -100,7 +100,7 @@ def test_tcn_bf16x3_duo_kernel_emulated(emu_default):
     tiles, ragged lengths (rows past the segment), several batch items with one FiLM row each, buffers refilled three and more times."""
     cases = [(3, 2, (2, 2, 777), synth.synth_audio((1, 64), seed=2)),          # d = 2, 4: P = 2; 2 x 7 tiles
              (3, 3, (1, 2, 1300), synth.synth_audio((1, 64), seed=3)),         # d = 3, 9: P = 1; 11 tiles on 4 workgroups
-             (2, 2, (3, 2, 2500), synth.synth_audio((3, 64), seed=11))]        # 3 x 20 tiles, one FiLM row per item
+             (2, 2, (3, 2, 1100), synth.synth_audio((3, 64), seed=11))]        # 3 x 9 tiles, one FiLM row per item
     for nb, growth, shape, cnd in cases:
         m, sd = _tcn(nb, growth=growth)
         m.precision = "bf16x3"

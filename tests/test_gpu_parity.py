@@ -1160,7 +1160,8 @@ def test_haas_branch_and_real_features_file_on_gpu(oracle_fx_lib):
 
 
 @pytest.mark.parametrize("name", ["conv_same_k4_s2", "conv_valid_k5_d2", "convblock_valid", "conv_lrelu", "conv_nonorm_noact", "resblock_lrelu",
-                                  "fxenc_conv_lrelu", "fxenc_res_lrelu", "film_conv", "film_bcast", "tcnblock_8_8_d3",
+                                  "fxenc_conv_lrelu", "fxenc_res_lrelu", "deconv_k4_s2", "deconv_k5_d2_lrelu", "convblock_deconv", "film_conv",
+                                  "film_bcast", "tcnblock_8_8_d3",
                                   "tcnblock_2_8", "tcnblock_causal", "tcnblock_grouped", "tcn_causal", "tcn_grouped", "tcn_causal_grouped",
                                   "tcn_growth2"])
 def test_standalone_modules_on_gpu(name):
