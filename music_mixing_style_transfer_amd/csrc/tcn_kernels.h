@@ -159,41 +159,92 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
 #pragma unroll
             for (int q = 0; q < RB; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 4096);
         }
-        // P = 16 tiles (largest dilation on a short segment) cover steps far outside the segment: a (column tile q, tap j)
-        // pair whose 16 input rows are all zero padding contributes nothing and its MFMAs are skipped (wave-uniform).
+        // A (column tile q, tap j) pair whose 16 input rows are all zero padding contributes nothing.
+        //  * P = 16 tiles (largest dilation on a very short segment): skipped under a wave-uniform branch (run_taps<false, false>).
+        //  * P = 8 tiles of 16 steps that start at the first step of their phase sequence (LO) and end at its last (HI) - d = 8192 at
+        //    L = 131072, the last block: the pattern is known at COMPILE time - the tap loop is unrolled and the dead pairs are simply not
+        //    there (20 % of the tile's MFMAs).  A branch per MFMA pair instead was measured slower than not skipping at all (it breaks the
+        //    mfma / mfma / ds_read pipeline: 1.58 -> 1.85 ms, TCN_LIVE_MIN_P).  (No sched_group_barrier in the unrolled form: hipcc's
+        //    scheduler does not finish a 960-MFMA block with them in 40 minutes.)
         const int nsteps = (int)(((long)a.L + a.d - 1) / a.d);
-        for (int j = 0; j < 15; ++j) {
-            const int jn = j < 14 ? j + 1 : 14;
-            const int rb0 = j * P + l16, rb1 = jn * P + l16;
-            unsigned live = 0xffffu;
-            if constexpr (P >= TCN_LIVE_MIN_P) {
-                live = 0;
+        auto run_taps = [&](auto lo_c, auto hi_c) {
+            constexpr bool LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+            if constexpr (LO || HI) {
+                static_assert(NC == RB, "one ring turn per k-step");
+                auto dead = [](int q, int j) {          // relative to the tile's first step: rows of steps < 0 (LO) / >= MT (HI) are padding
+                    const int s_lo = (16 * q) / P + j - 7, s_hi = (16 * q + 15) / P + j - 7;
+                    return (LO && s_hi < 0) || (HI && s_lo >= MT);
+                };
 #pragma unroll
-                for (int q = 0; q < NC; ++q) {
-                    const int s_lo = m0 + (16 * q) / P + j - 7, s_hi = m0 + (16 * q + 15) / P + j - 7;
-                    if (!(s_hi < 0 || s_lo >= nsteps)) live |= 1u << q;
-                }
-            }
+                for (int j = 0; j < 15; ++j) {
+                    const int jn = j < 14 ? j + 1 : 14;
+                    const int rb0 = j * P + l16, rb1 = jn * P + l16;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int rbn = (kk == 3) ? rb1 : rb0;
-                const int kn = (kk + 1) & 3;
-                const unsigned char *cp = smem + rb0 * 256 + (((4 * kk + g) ^ (rb0 & 15)) << 4);
-                const unsigned char *np = smem + rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int rbn = (kk == 3) ? rb1 : rb0;
+                        const int kn = (kk + 1) & 3;
+                        const int jx = (kk == 3) ? j + 1 : j;          // the tap of the k-step this ring slot is read for next
+                        const unsigned char *np = smem + rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
 #pragma unroll
-                for (int q = 0; q < NC; ++q) {
-                    if (P < TCN_LIVE_MIN_P || ((live >> q) & 1u)) {
-                        acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][kk], bf[q % RB], acc[0][q], 0, 0, 0);
-                        acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][kk], bf[q % RB], acc[1][q], 0, 0, 0);
+                        for (int q = 0; q < NC; ++q) {
+                            if (!dead(q, j)) {
+                                acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][kk], bf[q], acc[0][q], 0, 0, 0);
+                                acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][kk], bf[q], acc[1][q], 0, 0, 0);
+                            }
+                            if (jx < 15 && !dead(q, jx)) {
+                                bf[q] = *(const bf16x8 *)(np + q * 4096);
+                            }
+                        }
+                        if (j < 14) {
+#pragma unroll
+                            for (int m = 0; m < 2; ++m) af[m][kk] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)(jn * 4 + kk) * 8192u));
+                        }
                     }
-                    bf[q % RB] = (q + RB < NC) ? *(const bf16x8 *)(cp + (q + RB) * 4096) : *(const bf16x8 *)(np + (q + RB - NC) * 4096);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
+            } else {
+                for (int j = 0; j < 15; ++j) {
+                    const int jn = j < 14 ? j + 1 : 14;
+                    const int rb0 = j * P + l16, rb1 = jn * P + l16;
+                    unsigned live = 0xffffu;
+                    if constexpr (P >= TCN_LIVE_MIN_P) {
+                        live = 0;
 #pragma unroll
-                for (int m = 0; m < 2; ++m) af[m][kk] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)(jn * 4 + kk) * 8192u));
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                        for (int q = 0; q < NC; ++q) {
+                            const int s_lo = m0 + (16 * q) / P + j - 7, s_hi = m0 + (16 * q + 15) / P + j - 7;
+                            if (!(s_hi < 0 || s_lo >= nsteps)) live |= 1u << q;
+                        }
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int rbn = (kk == 3) ? rb1 : rb0;
+                        const int kn = (kk + 1) & 3;
+                        const unsigned char *cp = smem + rb0 * 256 + (((4 * kk + g) ^ (rb0 & 15)) << 4);
+                        const unsigned char *np = smem + rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
+#pragma unroll
+                        for (int q = 0; q < NC; ++q) {
+                            if (P < TCN_LIVE_MIN_P || ((live >> q) & 1u)) {
+                                acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][kk], bf[q % RB], acc[0][q], 0, 0, 0);
+                                acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][kk], bf[q % RB], acc[1][q], 0, 0, 0);
+                            }
+                            bf[q % RB] = (q + RB < NC) ? *(const bf16x8 *)(cp + (q + RB) * 4096) : *(const bf16x8 *)(np + (q + RB - NC) * 4096);
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) af[m][kk] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)(jn * 4 + kk) * 8192u));
+                        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                    }
+                }
             }
+        };
+        if constexpr (P == 8 && NQ == 4) {
+            // only the tile that spans its WHOLE phase sequence (16 steps: d = 8192 at L = 131072) takes the unrolled form: measured 1.585 ->
+            // 1.405 ms per launch; the one-sided forms for the d = 4096 block's two tiles per sequence (10 % fewer MFMAs each) ran 1.60 -> 1.93 ms
+            // (two unrolled 12 KB loops alternating on a CU, hipcc's own schedule instead of the pinned mfma / mfma / ds_read one) and are not used
+            if (m0 == 0 && MT == nsteps) run_taps(std::true_type{}, std::true_type{});          // workgroup-uniform
+            else run_taps(std::false_type{}, std::false_type{});
+        } else {
+            run_taps(std::false_type{}, std::false_type{});
         }
     }
 
@@ -1460,6 +1511,10 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16x3_half_kernel(TcnBlockA
                 bl[q] = *(const bf16x8 *)(sm_lo + o0 + q * 2048);
             }
         }
+        // a (column tile q, tap j) pair whose 16 input rows all lie outside the segment (zero padding) contributes nothing: skipped,
+        // wave-uniform (20 % of the MFMAs of the d = 8192 block at L = 131072, 10 % of the d = 4096 block).  (An unrolled form with the dead
+        // pairs removed at compile time - what the bf16 kernel does for tiles that span their whole phase sequence - spills 134 registers here:
+        // hipcc hoists the unrolled loop's ~30 lane-dependent LDS addresses out of the half loop.  Not used.)
         // a (column tile q, tap j) pair whose 16 input rows all lie outside the segment (zero padding) contributes nothing: skipped,
         // wave-uniform (20 % of the MFMAs of the d = 8192 block at L = 131072, 10 % of the d = 4096 block)
         const int nsteps = (int)(((long)a.L + a.d - 1) / a.d);

@@ -59,6 +59,23 @@ def test_tcn_large_dilation_and_odd_growth_emulated(emu_default):
     assert torch.equal(m2(x5, cond), y5)
 
 
+def test_tcn_bf16_whole_sequence_tiles_emulated(emu_default):
+    """bf16 tiles of 8 phases x 16 steps that span their WHOLE phase sequence (d = 8 on 121 ... 128 samples: 16 steps per phase; at
+    L = 131072 that is the d = 8192 block) run the unrolled tap loop in which the (column tile, tap) pairs that only see zero padding do not
+    exist.  Dropping a live pair would be an O(0.1) error: checked against the oracle at the bf16 tolerance, block by block, for the plain
+    epilogue (block 3 of 5) and the fused output head (block 3 of 4), full and ragged last steps."""
+    cond = synth.synth_audio((2, 64), seed=21)
+    for nb, L in ((4, 128), (4, 123), (5, 128), (5, 121)):
+        m, sd = _tcn(nb)
+        m.precision = "bf16"
+        x = synth.synth_audio((2, 2, L), seed=30 + L)
+        col = []
+        y_ref = R.tcn_forward(sd, x, cond, nblocks=nb, collect=col)
+        assert float((m(x, cond) - y_ref).abs().max()) <= 4e-2
+        a = m.forward_blocks(x, cond, 4)
+        assert float((a - col[3]).abs().max()) <= 4e-2 * float(col[3].abs().max())
+
+
 def test_tcn_bf16_stream_and_duo_kernels_emulated(emu_default):
     """The persistent LDS-DMA-fed forms of the bf16 block kernel (mst_tcn_set_tuning bits 1-2).  Form 1 ("stream"): same arithmetic as the one-tile-per-workgroup
     kernel with the fp32 accumulation running chunk-major - against the oracle at the bf16 tolerance, and against the other form
