@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(256) void fx_panner_kernel(const float *x, float *y
 }
 
 // ---- FFT convolution (ConvolutionalReverb.process, common_audioeffects.py:727-764; the normaliser's 1001-tap FIR) ----------------
-// The two FFTs and the inverse run in hipFFT (plain library transforms); everything around them is here.  A signal that is long
+// The two FFTs and the inverse are csrc/fft_kernels.h (round 4; hipFFT before); everything around them is here.  A signal that is long
 // against the impulse response is cut into nb overlapping blocks (overlap-save): block b holds the samples b * step - shift + i,
 // i in [0, n_fft), its circular convolution with the zero-padded response is the linear convolution at the outputs b * step + j,
 // j in [0, step), found at position shift + j.  A short signal is one block with step = n_fft, shift = 0.
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(256) void fx_conv_pack_kernel(const float *x, float
     seq[(size_t)blk * n_fft + i] = (n >= 0 && n < L) ? x[((size_t)item * L + n) * C + c] : 0.0f;
 }
 
-// spectrum product X[block of sequence s][k] *= H[s % C][k] / n_fft (hipFFT's inverse is unnormalised)
+// spectrum product X[block of sequence s][k] *= H[s % C][k] / n_fft (the inverse transform is unnormalised)
 __global__ __launch_bounds__(256) void fx_conv_mul_kernel(float2 *X, const float2 *H, long nbin, int C, int nb, float scale) {
     const int blk = blockIdx.y, sq = blk / nb;
     const long k = (long)blockIdx.x * 256 + threadIdx.x;

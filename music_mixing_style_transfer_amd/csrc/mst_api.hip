@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "enc_kernels.h"
+#include "fft_kernels.h"
 #include "fx_kernels.h"
 #include "tcn_kernels.h"
 
@@ -1813,50 +1814,121 @@ extern "C" int mst_fx_panner(const float *x, float *y, int n_items, long L, int 
     return MST_OK;
 }
 
+// ---- power-of-two real FFTs (csrc/fft_kernels.h): plans for the FFT convolution and the STFT ---------------------------------------
+struct MstFftPlan {
+    long n = 0, m = 0;              // transform length, m = n / 2 complex points
+    int log2m = 0;
+    int passes = 0;                 // Stockham passes: log2(m) / 2 of radix 4, one of radix 2 in front when log2(m) is odd
+    float2 *tw_m = nullptr;         // exp(-2 pi i j / m), j < m / 2
+    float2 *tw_n = nullptr;         // exp(-2 pi i k / n), k <= m / 2
+};
+
+namespace {
+void fft_plan_destroy(MstFftPlan *p) {
+    if (!p) return;
+    (void)hipFree(p->tw_m);
+    (void)hipFree(p->tw_n);
+    delete p;
+}
+// n: a power of two >= 4.  The twiddle tables are written on the null stream and waited for: plans are made once.
+int fft_plan_create(MstFftPlan **out, long n) {
+    if (n < 4 || (n & (n - 1))) return fail(MST_ERR_UNSUPPORTED, "FFT length must be a power of two >= 4");
+    auto *p = new MstFftPlan;
+    p->n = n;
+    p->m = n / 2;
+    for (long v = p->m; v > 1; v >>= 1) p->log2m++;
+    p->passes = p->log2m / 2 + p->log2m % 2;
+    const long cm = std::max<long>(1, p->m / 2), cn = p->m / 2 + 1;
+    if (hipMalloc((void **)&p->tw_m, (size_t)cm * sizeof(float2)) != hipSuccess || hipMalloc((void **)&p->tw_n, (size_t)cn * sizeof(float2)) != hipSuccess) {
+        fft_plan_destroy(p);
+        return fail(MST_ERR_HIP, "FFT plan: hipMalloc failed");
+    }
+    MST_LAUNCH(fft_twiddle_kernel, dim3((unsigned)((cm + 255) / 256)), dim3(256), nullptr, p->tw_m, p->m, cm);
+    MST_LAUNCH(fft_twiddle_kernel, dim3((unsigned)((cn + 255) / 256)), dim3(256), nullptr, p->tw_n, p->n, cn);
+    if (hipStreamSynchronize(nullptr) != hipSuccess) {
+        fft_plan_destroy(p);
+        return fail(MST_ERR_HIP, "FFT plan: twiddle kernels failed");
+    }
+    *out = p;
+    return MST_OK;
+}
+// the size-m complex FFT of nb sequences, ping-pong between a (stride sa) and b (stride sb), starting in `a`; returns where the result is
+int fft_passes(const MstFftPlan *p, float2 *a, long sa, float2 *b, long sb, int nb, int inverse, void *stream, float2 **res, long *sres) {
+    float2 *src = a, *dst = b;
+    long ss = sa, sd = sb;
+    long Ns = 1;
+    if (p->log2m % 2) {
+        MST_LAUNCH(fft_stockham2_kernel, dim3((unsigned)((p->m / 2 + 255) / 256), (unsigned)nb), dim3(256), stream, (const float2 *)src, dst,
+                   (const float2 *)p->tw_m, p->m, Ns, ss, sd, inverse);
+        MST_CHECK_LAUNCH("fft_stockham2_kernel");
+        std::swap(src, dst);
+        std::swap(ss, sd);
+        Ns = 2;
+    }
+    for (; Ns < p->m; Ns <<= 2) {
+        MST_LAUNCH(fft_stockham4_kernel, dim3((unsigned)((p->m / 4 + 255) / 256), (unsigned)nb), dim3(256), stream, (const float2 *)src, dst,
+                   (const float2 *)p->tw_m, p->m, Ns, ss, sd, inverse);
+        MST_CHECK_LAUNCH("fft_stockham4_kernel");
+        std::swap(src, dst);
+        std::swap(ss, sd);
+    }
+    *res = src;
+    *sres = ss;
+    return MST_OK;
+}
+// hipfftExecR2C's contract: in [nb][n] reals (DESTROYED: it is one of the two work buffers), out [nb][n / 2 + 1] bins, unnormalised
+int fft_exec_r2c(const MstFftPlan *p, float *in, float2 *out, int nb, void *stream) {
+    if (nb < 1) return MST_OK;
+    if (nb > 65535) return fail(MST_ERR_UNSUPPORTED, "FFT: more than 65535 sequences per call");
+    float2 *z;
+    long sz;
+    int rc = fft_passes(p, (float2 *)in, p->m, out, p->m + 1, nb, 0, stream, &z, &sz);
+    if (rc) return rc;
+    MST_LAUNCH(fft_r2c_post_kernel, dim3((unsigned)((p->m / 2 + 1 + 255) / 256), (unsigned)nb), dim3(256), stream, (const float2 *)z, out,
+               (const float2 *)p->tw_n, p->m, sz, p->m + 1);
+    MST_CHECK_LAUNCH("fft_r2c_post_kernel");
+    return MST_OK;
+}
+// hipfftExecC2R's contract: in [nb][n / 2 + 1] bins (DESTROYED), out [nb][n] reals = n * irfft(in)
+int fft_exec_c2r(const MstFftPlan *p, float2 *in, float *out, int nb, void *stream) {
+    if (nb < 1) return MST_OK;
+    if (nb > 65535) return fail(MST_ERR_UNSUPPORTED, "FFT: more than 65535 sequences per call");
+    float2 *o = (float2 *)out;
+    // the passes alternate between the two buffers and must end in `out`: an even number starts there, an odd number starts in `in`
+    float2 *start = (p->passes % 2 == 0) ? o : in;
+    const long sstart = (p->passes % 2 == 0) ? p->m : p->m + 1;
+    MST_LAUNCH(fft_c2r_pre_kernel, dim3((unsigned)((p->m / 2 + 1 + 255) / 256), (unsigned)nb), dim3(256), stream, (const float2 *)in, start,
+               (const float2 *)p->tw_n, p->m, p->m + 1, sstart);
+    MST_CHECK_LAUNCH("fft_c2r_pre_kernel");
+    float2 *other = (start == o) ? in : o;
+    const long sother = (start == o) ? p->m + 1 : p->m;
+    float2 *z;
+    long sz;
+    int rc = fft_passes(p, start, sstart, other, sother, nb, 1, stream, &z, &sz);
+    if (rc) return rc;
+    if (z != o) return fail(MST_ERR_STATE, "FFT: inverse passes ended in the wrong buffer");
+    return MST_OK;
+}
+}  // namespace
+
 // ---- FFT convolution (ConvolutionalReverb) ---------------------------------------------------------------------------
 struct MstConvolver {
     long L = 0, Lh_max = 0, n_fft = 0;
     long step = 0, shift = 0;       // overlap-save: block b holds the samples b * step - shift + i; one block: step = n_fft, shift = 0
     int nb = 1;                     // blocks per (item, channel)
     int n_items = 0, C = 0;
-    void *plan_x = nullptr, *plan_h = nullptr, *plan_inv = nullptr;       // hipfftHandle: R2C batch n_items*C, R2C batch C, C2R
+    MstFftPlan *plan = nullptr;     // one plan serves the signal blocks, the impulse response and the inverse
 };
-
-namespace {
-// hipFFT is bound at first use (dlopen), so that the library itself has no link-time dependency on it; the SIMT emulator
-// build (tests/emu/mst_rt.h) supplies host transforms under the same five names instead.
-struct FftApi {
-    int (*plan_many)(void **, int, int *, int *, int, int, int *, int, int, int, int) = nullptr;
-    int (*set_stream)(void *, hipStream_t) = nullptr;
-    int (*exec_r2c)(void *, float *, float2 *) = nullptr;
-    int (*exec_c2r)(void *, float2 *, float *) = nullptr;
-    int (*destroy)(void *) = nullptr;
-    bool ok = false;
-};
-const FftApi &fft_api() {
-    static const FftApi api = [] {
-        FftApi a;
-        if (!mst_fft_bind((void **)&a.plan_many, (void **)&a.set_stream, (void **)&a.exec_r2c, (void **)&a.exec_c2r, (void **)&a.destroy))
-            return a;
-        a.ok = true;
-        return a;
-    }();
-    return api;
-}
-constexpr int kFftR2C = 0x2a, kFftC2R = 0x2c;       // HIPFFT_R2C / HIPFFT_C2R
-}  // namespace
 
 extern "C" int mst_fx_convolver_create(long L, long Lh_max, int n_items, int C, MstConvolver **out) {
     if (!out || L < 1 || Lh_max < 1 || n_items < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_convolver_create: bad argument");
-    const FftApi &f = fft_api();
-    if (!f.ok) return fail(MST_ERR_HIP, "mst_fx_convolver_create: cannot load hipFFT (libhipfft.so)");
-    long n = 1;
+    long n = 4;
     while (n < L + Lh_max - 1) n <<= 1;
     long step = n, shift = 0;
     int nb = 1;
     if (n > (1L << 18)) {
-        // a long signal: overlap-save blocks of max(2^16, 4 x the response rounded up to a power of two) samples - one plan (and one
-        // set of run-time-compiled transform kernels) for every signal length, float32 rounding of a 2^16..2^19-point transform
+        // a long signal: overlap-save blocks of max(2^16, 4 x the response rounded up to a power of two) samples - one plan for every
+        // signal length, float32 rounding of a 2^16..2^19-point transform
         long nh = 1;
         while (nh < Lh_max) nh <<= 1;
         const long nblk = 4 * nh > (1L << 16) ? 4 * nh : (1L << 16);
@@ -1872,12 +1944,10 @@ extern "C" int mst_fx_convolver_create(long L, long Lh_max, int n_items, int C, 
     auto *cv = new MstConvolver;
     cv->L = L; cv->Lh_max = Lh_max; cv->n_fft = n; cv->n_items = n_items; cv->C = C;
     cv->step = step; cv->shift = shift; cv->nb = nb;
-    int nn = (int)n;
-    if (f.plan_many(&cv->plan_x, 1, &nn, nullptr, 1, 0, nullptr, 1, 0, kFftR2C, n_items * C * nb) ||
-        f.plan_many(&cv->plan_h, 1, &nn, nullptr, 1, 0, nullptr, 1, 0, kFftR2C, C) ||
-        f.plan_many(&cv->plan_inv, 1, &nn, nullptr, 1, 0, nullptr, 1, 0, kFftC2R, n_items * C * nb)) {
+    const int rc = fft_plan_create(&cv->plan, n);
+    if (rc) {
         mst_fx_convolver_destroy(cv);
-        return fail(MST_ERR_HIP, "mst_fx_convolver_create: hipfftPlanMany failed");
+        return rc;
     }
     *out = cv;
     return MST_OK;
@@ -1885,12 +1955,7 @@ extern "C" int mst_fx_convolver_create(long L, long Lh_max, int n_items, int C, 
 
 extern "C" void mst_fx_convolver_destroy(MstConvolver *cv) {
     if (!cv) return;
-    const FftApi &f = fft_api();
-    if (f.ok) {
-        if (cv->plan_x) f.destroy(cv->plan_x);
-        if (cv->plan_h) f.destroy(cv->plan_h);
-        if (cv->plan_inv) f.destroy(cv->plan_inv);
-    }
+    fft_plan_destroy(cv->plan);
     delete cv;
 }
 
@@ -1906,9 +1971,9 @@ extern "C" int mst_fx_convolve(MstConvolver *cv, const float *x, const float *h,
     if (Lh < 1 || Lh > cv->Lh_max) return fail(MST_ERR_ARG, "mst_fx_convolve: impulse response longer than the convolver was created for");
     if (offset < 0 || offset > Lh - 1) return fail(MST_ERR_ARG, "mst_fx_convolve: offset outside [0, Lh-1]");
     if (ws_bytes < mst_fx_convolver_workspace_bytes(cv)) return fail(MST_ERR_WORKSPACE, "mst_fx_convolve: workspace too small");
-    const FftApi &f = fft_api();
     const long n = cv->n_fft, nbin = n / 2 + 1;
     const int nseq = cv->n_items * cv->C, C = cv->C, nb = cv->nb, nblk = nseq * nb;
+    int rc;
     float *rx = (float *)ws, *rh = rx + (size_t)nblk * n;
     float2 *cx = (float2 *)(((uintptr_t)(rh + (size_t)C * n) + 255) & ~(uintptr_t)255), *ch = cx + (size_t)nblk * nbin;
     const unsigned gb = (unsigned)((n + 255) / 256);
@@ -1916,14 +1981,11 @@ extern "C" int mst_fx_convolve(MstConvolver *cv, const float *x, const float *h,
     MST_CHECK_LAUNCH("fx_conv_pack_kernel");
     MST_LAUNCH(fx_conv_pack_kernel, dim3(gb, C), dim3(256), stream, h, rh, Lh, C, n, 1, n, 0L);       // the IR is one [Lh][C] "item"
     MST_CHECK_LAUNCH("fx_conv_pack_kernel");
-    if (f.set_stream(cv->plan_x, (hipStream_t)stream) || f.set_stream(cv->plan_h, (hipStream_t)stream) ||
-        f.set_stream(cv->plan_inv, (hipStream_t)stream))
-        return fail(MST_ERR_HIP, "mst_fx_convolve: hipfftSetStream failed");
-    if (f.exec_r2c(cv->plan_x, rx, cx) || f.exec_r2c(cv->plan_h, rh, ch)) return fail(MST_ERR_HIP, "mst_fx_convolve: hipfftExecR2C failed");
+    if ((rc = fft_exec_r2c(cv->plan, rx, cx, nblk, stream)) || (rc = fft_exec_r2c(cv->plan, rh, ch, C, stream))) return rc;
     MST_LAUNCH(fx_conv_mul_kernel, dim3((unsigned)((nbin + 255) / 256), nblk), dim3(256), stream, cx, (const float2 *)ch, nbin, C, nb,
                1.0f / (float)n);
     MST_CHECK_LAUNCH("fx_conv_mul_kernel");
-    if (f.exec_c2r(cv->plan_inv, cx, rx)) return fail(MST_ERR_HIP, "mst_fx_convolve: hipfftExecC2R failed");
+    if ((rc = fft_exec_c2r(cv->plan, cx, rx, nblk, stream))) return rc;
     const long per = cv->L * C;
     MST_LAUNCH(fx_conv_mix_kernel, dim3((unsigned)((per + 255) / 256), cv->n_items), dim3(256), stream, x, (const float *)rx, y, cv->L,
                C, n, nb, cv->step, cv->shift, offset, (float)dry, (float)wet);
@@ -1972,24 +2034,22 @@ extern "C" int mst_fx_scale_items(const float *x, float *y, int n_items, long pe
 struct MstStft {
     long n_fft = 0, hop = 0;
     int batch = 0;
-    void *plan = nullptr;           // hipfftHandle: R2C, `batch` frames of n_fft
+    MstFftPlan *plan = nullptr;     // R2C of up to `batch` frames of n_fft
     float *win = nullptr;           // [n_fft] analysis window (device)
 };
 
 extern "C" int mst_fx_stft_create(long n_fft, long hop, const float *window_host, int max_batch, MstStft **out) {
     if (!out || !window_host || n_fft < 2 || hop < 1 || max_batch < 1) return fail(MST_ERR_ARG, "mst_fx_stft_create: bad argument");
-    const FftApi &f = fft_api();
-    if (!f.ok) return fail(MST_ERR_HIP, "mst_fx_stft_create: cannot load hipFFT (libhipfft.so)");
     auto *st = new MstStft;
     st->n_fft = n_fft; st->hop = hop; st->batch = max_batch;
-    int nn = (int)n_fft;
-    if (f.plan_many(&st->plan, 1, &nn, nullptr, 1, 0, nullptr, 1, 0, kFftR2C, max_batch)) {
+    const int rcp = fft_plan_create(&st->plan, n_fft);          // frame lengths are powers of two (the reference's FFT_SIZE is 65536)
+    if (rcp) {
         delete st;
-        return fail(MST_ERR_HIP, "mst_fx_stft_create: hipfftPlanMany failed");
+        return rcp;
     }
     if (hipMalloc((void **)&st->win, (size_t)n_fft * sizeof(float)) != hipSuccess ||
         hipMemcpy(st->win, window_host, (size_t)n_fft * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
-        f.destroy(st->plan);
+        fft_plan_destroy(st->plan);
         delete st;
         return fail(MST_ERR_HIP, "mst_fx_stft_create: hipMalloc failed");
     }
@@ -1999,8 +2059,7 @@ extern "C" int mst_fx_stft_create(long n_fft, long hop, const float *window_host
 
 extern "C" void mst_fx_stft_destroy(MstStft *st) {
     if (!st) return;
-    const FftApi &f = fft_api();
-    if (f.ok && st->plan) f.destroy(st->plan);
+    fft_plan_destroy(st->plan);
     (void)hipFree(st->win);
     delete st;
 }
@@ -2015,19 +2074,18 @@ extern "C" int mst_fx_stft_mean_magnitude(MstStft *st, const float *x, long L, i
     if (!st || !x || !mean_dev || !ws || C < 1 || channel < 0 || channel >= C) return fail(MST_ERR_ARG, "mst_fx_stft_mean_magnitude: bad argument");
     if (L < st->n_fft) return fail(MST_ERR_ARG, "mst_fx_stft_mean_magnitude: signal shorter than one frame");
     if (ws_bytes < mst_fx_stft_workspace_bytes(st)) return fail(MST_ERR_WORKSPACE, "mst_fx_stft_mean_magnitude: workspace too small");
-    const FftApi &f = fft_api();
     const long n = st->n_fft, nbin = n / 2 + 1;
     const long n_frames = 1 + (L - n) / st->hop;          // common_miscellaneous.py:64
     float *frames = (float *)ws;
     float2 *spec = (float2 *)(((uintptr_t)(frames + (size_t)st->batch * n) + 255) & ~(uintptr_t)255);
     MST_HIP_TRY(hipMemsetAsync(mean_dev, 0, (size_t)nbin * sizeof(float), (hipStream_t)stream));
-    if (f.set_stream(st->plan, (hipStream_t)stream)) return fail(MST_ERR_HIP, "mst_fx_stft_mean_magnitude: hipfftSetStream failed");
     for (long f0 = 0; f0 < n_frames; f0 += st->batch) {
         const int nb = (int)std::min<long>(st->batch, n_frames - f0);
-        MST_LAUNCH(fx_stft_frame_kernel, dim3((unsigned)((n + 255) / 256), st->batch), dim3(256), stream, x, frames, (const float *)st->win, L,
+        MST_LAUNCH(fx_stft_frame_kernel, dim3((unsigned)((n + 255) / 256), nb), dim3(256), stream, x, frames, (const float *)st->win, L,
                    C, channel, n, st->hop, f0, n_frames);
         MST_CHECK_LAUNCH("fx_stft_frame_kernel");
-        if (f.exec_r2c(st->plan, frames, spec)) return fail(MST_ERR_HIP, "mst_fx_stft_mean_magnitude: hipfftExecR2C failed");
+        const int rcf = fft_exec_r2c(st->plan, frames, spec, nb, stream);          // only the frames that exist
+        if (rcf) return rcf;
         MST_LAUNCH(fx_stft_mag_accum_kernel, dim3((unsigned)((nbin + 255) / 256)), dim3(256), stream, (const float2 *)spec, mean_dev, nbin, nb);
         MST_CHECK_LAUNCH("fx_stft_mag_accum_kernel");
     }

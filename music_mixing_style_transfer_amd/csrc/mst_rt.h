@@ -92,21 +92,6 @@ static inline int mst_num_cus() {
     return n;
 }
 
-// hipFFT entry points bound at first use (no link-time dependency); returns false when the library cannot be loaded
-#include <dlfcn.h>
-static inline bool mst_fft_bind(void **plan_many, void **set_stream, void **exec_r2c, void **exec_c2r, void **destroy) {
-    void *lib = nullptr;
-    for (const char *name : {"libhipfft.so.0", "libhipfft.so", "/opt/rocm/lib/libhipfft.so"})
-        if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!lib) return false;
-    *plan_many = dlsym(lib, "hipfftPlanMany");
-    *set_stream = dlsym(lib, "hipfftSetStream");
-    *exec_r2c = dlsym(lib, "hipfftExecR2C");
-    *exec_c2r = dlsym(lib, "hipfftExecC2R");
-    *destroy = dlsym(lib, "hipfftDestroy");
-    return *plan_many && *set_stream && *exec_r2c && *exec_c2r && *destroy;
-}
-
 // a wave-uniform double as the two SGPR halves v_readlane returns (kept apart so that v_writelane can take them without a copy)
 struct MstUniformF64 {
     int lo, hi;

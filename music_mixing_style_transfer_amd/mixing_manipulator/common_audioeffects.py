@@ -325,7 +325,7 @@ class Gain(Processor):
 class ConvolutionalReverb(Processor):
     """Convolution reverb (reference common_audioeffects.py:665-764): the input is convolved (full linear convolution, per
     channel) with one of the given impulse responses, the wet signal is cut out starting at the IR's peak (+ pre-delay) and
-    mixed `dry * x + wet * y`.  The convolution runs on the device (mst_fx_convolve: hipFFT transforms + HIP kernels);
+    mixed `dry * x + wet * y`.  The convolution runs on the device (mst_fx_convolve: the library's own FFT kernels);
     IR selection, the optional decay fade and the mono/stereo adaptation are the reference's host-side steps.
 
     impulse_responses: list (one entry per RT60 group) of lists of dicts whose 'impulse_response' entry is a callable

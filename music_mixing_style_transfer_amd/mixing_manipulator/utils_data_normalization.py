@@ -3,7 +3,7 @@ get_eq_matching :65-107, get_mean_peak :284-338, compress :340-355, get_comp_mat
 
 Same function names, arguments and return values as the reference (numpy in, numpy out); the sample-rate work runs on
 the MI355X:
-  * get_eq_matching: loudness normalisation (BS.1770 meter), the mean STFT magnitude (hipFFT + HIP kernels), and the
+  * get_eq_matching: loudness normalisation (BS.1770 meter), the mean STFT magnitude (the library's own FFT kernels), and the
     zero-phase 1001-tap FIR (scipy.signal.filtfilt semantics: odd extension by 3 * ntaps, forward + backward pass from the
     steady state of the first sample) as two FFT convolutions; scipy.signal.firwin2 designs the filter on the host like the
     reference does;

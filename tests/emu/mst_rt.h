@@ -251,66 +251,3 @@ static inline double atomicAdd(double *p, double v) {
 static inline unsigned __brev(unsigned v) { unsigned r = 0; for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i); return r; }
 static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
-
-
-// ---- host stand-ins for the five hipFFT entry points the library binds (power-of-two lengths, double precision inside)
-#include <complex>
-namespace emu_fft {
-struct Plan { int n, type, batch; };
-static inline void fft(std::vector<std::complex<double>> &a, bool inv) {
-    const size_t n = a.size();
-    for (size_t i = 1, j = 0; i < n; ++i) {
-        size_t bit = n >> 1;
-        for (; j & bit; bit >>= 1) j ^= bit;
-        j ^= bit;
-        if (i < j) std::swap(a[i], a[j]);
-    }
-    for (size_t len = 2; len <= n; len <<= 1) {
-        const double ang = 2 * M_PI / (double)len * (inv ? 1 : -1);
-        for (size_t i = 0; i < n; i += len)
-            for (size_t k = 0; k < len / 2; ++k) {
-                const std::complex<double> w(std::cos(ang * (double)k), std::sin(ang * (double)k));
-                const auto u = a[i + k], v = a[i + k + len / 2] * w;
-                a[i + k] = u + v;
-                a[i + k + len / 2] = u - v;
-            }
-    }
-}
-static int plan_many(void **plan, int, int *n, int *, int, int, int *, int, int, int type, int batch) {
-    *plan = new Plan{*n, type, batch};
-    return 0;
-}
-static int set_stream(void *, hipStream_t) { return 0; }
-static int exec_r2c(void *p, float *in, float2 *out) {
-    const Plan *pl = (const Plan *)p;
-    const int n = pl->n, nb = n / 2 + 1;
-    for (int b = 0; b < pl->batch; ++b) {
-        std::vector<std::complex<double>> a(n);
-        for (int i = 0; i < n; ++i) a[i] = in[(size_t)b * n + i];
-        fft(a, false);
-        for (int k = 0; k < nb; ++k) out[(size_t)b * nb + k] = make_float2((float)a[k].real(), (float)a[k].imag());
-    }
-    return 0;
-}
-static int exec_c2r(void *p, float2 *in, float *out) {
-    const Plan *pl = (const Plan *)p;
-    const int n = pl->n, nb = n / 2 + 1;
-    for (int b = 0; b < pl->batch; ++b) {
-        std::vector<std::complex<double>> a(n);
-        for (int k = 0; k < nb; ++k) a[k] = {in[(size_t)b * nb + k].x, in[(size_t)b * nb + k].y};
-        for (int k = nb; k < n; ++k) a[k] = std::conj(a[n - k]);
-        fft(a, true);
-        for (int i = 0; i < n; ++i) out[(size_t)b * n + i] = (float)a[i].real();       // unnormalised, like hipFFT
-    }
-    return 0;
-}
-static int destroy(void *p) { delete (Plan *)p; return 0; }
-}  // namespace emu_fft
-static inline bool mst_fft_bind(void **plan_many, void **set_stream, void **exec_r2c, void **exec_c2r, void **destroy) {
-    *plan_many = (void *)&emu_fft::plan_many;
-    *set_stream = (void *)&emu_fft::set_stream;
-    *exec_r2c = (void *)&emu_fft::exec_r2c;
-    *exec_c2r = (void *)&emu_fft::exec_c2r;
-    *destroy = (void *)&emu_fft::destroy;
-    return true;
-}

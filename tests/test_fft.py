@@ -1,0 +1,44 @@
+"""The library's own power-of-two real FFTs (csrc/fft_kernels.h: Stockham radix-2 passes + the real-sequence un-mix; they replaced hipFFT in
+round 4) on the SIMT emulator against numpy.fft - through the two entry points that use them: the STFT mean magnitude (R2C) and the FFT
+convolution (R2C, spectrum product, C2R).  Lengths cover odd and even pass counts (the inverse starts in a different buffer) and the
+smallest transform."""
+import numpy as np
+import pytest
+import torch
+
+
+@pytest.mark.parametrize("n_fft", [4, 8, 64, 512, 4096])
+def test_stft_mean_magnitude_vs_numpy(emu_default, n_fft):
+    from music_mixing_style_transfer_amd.mixing_manipulator import _device_ops as D
+    rng = np.random.default_rng(n_fft)
+    hop = max(1, n_fft // 4)
+    L = n_fft + 6 * hop + 3
+    x = rng.standard_normal((L, 2)).astype(np.float32)
+    win = np.sqrt(np.hanning(n_fft + 1)[:-1]).astype(np.float32) if n_fft > 4 else np.ones(n_fft, np.float32)
+    st = D.StftMeanMagnitude(n_fft, hop, win, max_batch=4)          # 7 frames in batches of 4: a full and a ragged batch
+    for ch in (0, 1):
+        got = st(torch.from_numpy(x), ch)
+        n_frames = 1 + (L - n_fft) // hop
+        frames = np.stack([x[f * hop:f * hop + n_fft, ch] * win for f in range(n_frames)]).astype(np.float32)
+        want = np.abs(np.fft.rfft(frames.astype(np.float64), axis=1)).mean(0)
+        assert got.shape == (n_fft // 2 + 1,)
+        assert np.abs(got - want).max() <= 3e-6 * max(1.0, want.max()), (n_fft, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("L,nt", [(5, 3), (40, 9), (100, 31), (700, 101), (3000, 257), (9000, 1001)])
+def test_fft_convolution_vs_numpy(emu_default, L, nt):
+    """fir_causal = one FFT convolution (transform lengths 8 ... 16384 here: both parities of the pass count)."""
+    from music_mixing_style_transfer_amd.mixing_manipulator import _device_ops as D
+    rng = np.random.default_rng(L)
+    x = rng.standard_normal((L, 1)).astype(np.float32)
+    taps = (rng.standard_normal(nt) / nt).astype(np.float64)
+    y = D.fir_causal(torch.from_numpy(x), taps).numpy()[:, 0]
+    xe = np.concatenate([np.full(nt - 1, x[0, 0], np.float64), x[:, 0].astype(np.float64)])
+    want = np.convolve(xe, taps.astype(np.float32).astype(np.float64))[nt - 1:nt - 1 + L]
+    assert np.abs(y - want).max() <= 5e-6 * max(1.0, np.abs(want).max()), (L, nt, np.abs(y - want).max())
+
+
+def test_fft_lengths_must_be_powers_of_two(emu_default):
+    from music_mixing_style_transfer_amd.mixing_manipulator import _device_ops as D
+    with pytest.raises(NotImplementedError):
+        D.StftMeanMagnitude(1000, 250, np.ones(1000, np.float32), max_batch=2)
