@@ -279,7 +279,7 @@ int mst_fx_panner(const float *x_dev, float *y_dev, int n_items, long L, int c_i
                   void *stream);
 /* ConvolutionalReverb.process (:727-764): y = dry * x + wet * (x (*) h)[offset : offset + L] per channel, x (*) h the FULL
  * linear convolution (scipy.signal.oaconvolve(x, h, mode='full', axes=0) in the reference).  Computed as one FFT convolution of
- * n_fft = next power of two >= L + Lh_max - 1 per (item, channel) with hipFFT (loaded on first use) + three HIP kernels.
+ * n_fft = next power of two >= L + Lh_max - 1 per (item, channel): the library's own FFT kernels (csrc/fft_kernels.h) + three HIP kernels.
  * The caller resolves what the reference does on the host: IR choice / decay fade (:704-725), mono <-> stereo IR (:739-742),
  * offset = argmax_t max_c |h| + pre-delay samples, clipped to [0, Lh-1] (:757-761).  x/y: [n_items, L, C]; h: [Lh, C] device
  * float32, one impulse response for all items (apply_same_processor, :150-154).  All L + Lh - 1 samples are exact linear
@@ -324,8 +324,9 @@ int mst_fx_range_reduce(const float *x_dev, long L, int C, int channel, const in
  * hanningz-windowed frame's spectrum.  win in {256, 512, 1024, 2048}.  The peak picking over this short sequence is host code. */
 int mst_fx_onset_hfc(const float *x_dev, int n_items, long L, int C, int channel, int win, float *out_dev, void *stream);
 /* Mean STFT magnitude of get_eq_matching (utils_data_normalization.py:74-79: librosa.stft(center=False) with the given window,
- * |.|, mean over frames): mean_dev[k], k = 0 .. n_fft/2, of channel `channel` of x_dev [L, C].  hipFFT transforms in batches
- * of at most max_batch frames; the analysis window is host float32 [n_fft]. */
+ * |.|, mean over frames): mean_dev[k], k = 0 .. n_fft/2, of channel `channel` of x_dev [L, C].  Transforms in batches
+ * of at most max_batch frames (csrc/fft_kernels.h: n_fft must be a power of two >= 4 - the reference's FFT_SIZE is 65536 - otherwise
+ * MST_ERR_UNSUPPORTED); the analysis window is host float32 [n_fft]. */
 typedef struct MstStft MstStft;
 int mst_fx_stft_create(long n_fft, long hop, const float *window_host, int max_batch, MstStft **out);
 void mst_fx_stft_destroy(MstStft *st);
