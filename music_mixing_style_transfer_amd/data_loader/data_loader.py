@@ -8,13 +8,11 @@ When args.normalize_input is set (the reference CLI's default) the INPUT stems g
 args.precomputed_normalization_feature and the effect order args.normalization_order (reference :559-563, :586-587).
 """
 import os
-import queue
-import threading
 from glob import glob
 
 import torch
 
-from .loader_utils import load_wav_device, load_wav_segment
+from .loader_utils import load_wav_device, load_wav_segment, read_wav_raw
 
 
 class Song_Dataset_Inference:
@@ -36,10 +34,12 @@ class Song_Dataset_Inference:
                                                                 STEMS=args.instruments, EFFECTS=args.normalization_order)
         # device: set by the runner (Mixing_Style_Transfer_Inference) to the GPU the stems are converted on - the stems are then decoded,
         # normalised and clamped THERE and returned as device tensors (the file's PCM bytes are what crosses PCIe); None = host arrays
-        # like the reference.  workers (args.workers, the reference's DataLoader(num_workers=...)): > 0 = songs are prepared by a
-        # background thread one song ahead of the consumer.
+        # like the reference.  workers (args.workers, the reference's DataLoader(num_workers=...)): > 0 = a background thread READS the next
+        # song's wav files into memory while the current song is converted (file I/O only: decoding, normalising and everything else that
+        # launches kernels stays on the consumer's thread and stream - see __iter__).
         self.device = None
         self.workers = int(getattr(args, "workers", 0) or 0)
+        self._preread = None
         # dist (set by the runner when it runs on several ranks): the stems that need host / normaliser work are prepared by ONE rank each
         # (stem j by rank j % world) and broadcast - the normaliser, the expensive part of a song's preparation, is sharded by stems
         self.dist = None
@@ -70,7 +70,7 @@ class Song_Dataset_Inference:
         path = os.path.join(self.data_dir_paths[idx], self.stem_level_directory_name, which, inst + ".wav")
         if self.device is not None:
             try:
-                wav = load_wav_device(path, self.device, sample_rate=self.args.sample_rate)            # float32 [2, L] on the device
+                wav = load_wav_device(path, self.device, sample_rate=self.args.sample_rate, preread=self._preread)      # float32 [2, L] on the device
             except ValueError as e:
                 if "stereo files only" not in str(e):
                     raise
@@ -79,7 +79,7 @@ class Song_Dataset_Inference:
                 if normalize:
                     wav = self.normalization_chain.normalize_audio(wav.t().contiguous(), src=inst).t().contiguous()
                 return torch.clamp(wav.float(), min=-1, max=1)
-        wav = load_wav_segment(path, axis=0, sample_rate=self.args.sample_rate)
+        wav = load_wav_segment(path, axis=0, sample_rate=self.args.sample_rate, preread=self._preread)
         if normalize:           # only the input stems are normalised (:586-587)
             wav = self.normalization_chain.normalize_audio(wav.transpose(), src=inst).transpose()
         return torch.clamp(torch.from_numpy(wav).float(), min=-1, max=1)
@@ -96,67 +96,39 @@ class Song_Dataset_Inference:
             return torch.stack(inputs, 0), torch.stack(refs, 0), torch.stack(refs_b, 0), dir_name
         return torch.stack(inputs, 0), torch.stack(refs, 0), dir_name
 
+    def _song_paths(self, idx):
+        kinds = [self.input_name, self.reference_name] + ([self.reference_name_B] if self.interpolate else [])
+        return [os.path.join(self.data_dir_paths[idx], self.stem_level_directory_name, k, inst + ".wav") for k in kinds for inst in self.instruments]
+
+    def _read_song(self, idx):
+        out = {}
+        for p in self._song_paths(idx):
+            try:
+                out[p] = read_wav_raw(p)
+            except Exception:           # a missing / malformed file raises where the reference raises: in __getitem__, on the consumer's thread
+                pass
+        return out
+
     def __iter__(self):
-        # Multi-rank runs prepare their songs INLINE whatever args.workers says: __getitem__ issues collectives (the broadcast of the
-        # normalised stems) and a prefetch thread would enqueue them on the default process group concurrently with the consumer's
-        # all_gather / barrier of the previous song - in a different order on different ranks, which neither RCCL nor gloo allows.
+        # Multi-rank runs prepare their songs INLINE whatever args.workers says (the loader's broadcasts must stay on the consumer's thread, in
+        # its order: collectives of two threads on one process group pair up differently on different ranks).
         if self.workers <= 0 or len(self) < 2 or self.dist is not None:
             for i in range(len(self)):
                 yield self[i]
             return
-        # one song ahead: a thread decodes + normalises song i + 1 (its kernels run on its own stream) while song i is converted.  The
-        # consumer may stop early (an exception in inference(), a break): the generator's finally sets `stop`, drains the queue so that a
-        # blocked put returns, and joins the thread - no thread is left holding a song of device tensors.
-        q = queue.Queue(maxsize=1)
-        stop = threading.Event()
-
-        def put(msg):
-            while not stop.is_set():
+        # One song ahead, FILE I/O ONLY: a thread reads song i + 1's wav files into memory while song i is converted; decoding, the
+        # normaliser and the stacking run here, on the consumer's thread and stream.  (Round 3 prepared the whole next song on a thread
+        # with its own stream: its ~150 small kernels and ~70 host round trips per song queue behind the converter's 1.5 ms launches, the
+        # prepared song arrived later than preparing it inline takes - measured 0.342 s per song against 0.324 s without the thread.)
+        # The executor's context joins the thread when the generator is closed early (an exception in inference(), a break).
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=1, thread_name_prefix="mst-prefetch") as pool:
+            nxt = pool.submit(self._read_song, 0)
+            for i in range(len(self)):
+                self._preread = nxt.result()
+                nxt = pool.submit(self._read_song, i + 1) if i + 1 < len(self) else None
                 try:
-                    q.put(msg, timeout=0.1)
-                    return True
-                except queue.Full:
-                    pass
-            return False
-
-        def produce():
-            try:
-                if self.device is not None:
-                    torch.cuda.set_device(self.device)
-                    stream = torch.cuda.Stream(self.device)
-                for i in range(len(self)):
-                    if stop.is_set():
-                        return
-                    if self.device is not None:
-                        with torch.cuda.stream(stream):
-                            item = self[i]
-                        stream.synchronize()
-                    else:
-                        item = self[i]
-                    if not put(("item", item)):
-                        return
-                put(("done", None))
-            except BaseException as e:          # surfaces in the consumer
-                put(("error", e))
-        worker = threading.Thread(target=produce, daemon=True, name="mst-prefetch")
-        worker.start()
-        try:
-            while True:
-                kind, payload = q.get()
-                if kind == "done":
-                    return
-                if kind == "error":
-                    raise payload
-                if self.device is not None:         # made on the producer's stream, used on the consumer's: tell the caching allocator
-                    for t in payload:
-                        if isinstance(t, torch.Tensor) and t.is_cuda:
-                            t.record_stream(torch.cuda.current_stream(self.device))
-                yield payload
-        finally:
-            stop.set()
-            try:
-                while True:
-                    q.get_nowait()
-            except queue.Empty:
-                pass
-            worker.join(timeout=60)
+                    item = self[i]
+                finally:
+                    self._preread = None
+                yield item

@@ -17,15 +17,32 @@ def load_wav_length(audio_path):
         return w.getnframes()
 
 
-def load_wav_segment(audio_path, start_point=None, duration=None, axis=1, sample_rate=44100):
-    start_point = 0 if start_point is None else start_point
+def read_wav_raw(audio_path):
+    """(frame rate, bytes per sample, channels, frames, the raw PCM frames) of a wav file - the part of loading that is pure file I/O, which
+    the dataset's prefetch thread does one song ahead (data_loader.py)."""
     with wave.open(audio_path, "r") as w:
-        duration = w.getnframes() if duration is None else duration
-        if w.getframerate() != sample_rate:
+        rate, width, nch, n = w.getframerate(), w.getsampwidth(), w.getnchannels(), w.getnframes()
+        raw = w.readframes(n)
+    return rate, width, nch, n, raw
+
+
+def load_wav_segment(audio_path, start_point=None, duration=None, axis=1, sample_rate=44100, preread=None):
+    start_point = 0 if start_point is None else start_point
+    if preread is not None and audio_path in preread:          # the whole file is in memory already
+        rate, width, nch, n, raw = preread[audio_path]
+        duration = n if duration is None else duration
+        if rate != sample_rate:
             raise ValueError(f"ValueError: input audio's sample rate should be {sample_rate}")
-        w.setpos(start_point)
-        raw = w.readframes(duration)
-        width, nch = w.getsampwidth(), w.getnchannels()
+        a, b = min(max(0, start_point), n), min(n, max(0, start_point) + duration)
+        raw = raw[a * width * nch:b * width * nch]
+    else:
+        with wave.open(audio_path, "r") as w:
+            duration = w.getnframes() if duration is None else duration
+            if w.getframerate() != sample_rate:
+                raise ValueError(f"ValueError: input audio's sample rate should be {sample_rate}")
+            w.setpos(start_point)
+            raw = w.readframes(duration)
+            width, nch = w.getsampwidth(), w.getnchannels()
     if width == 2:
         X = np.frombuffer(raw, dtype=np.int16) / float(2 ** 15)
     elif width == 4:
@@ -37,17 +54,15 @@ def load_wav_segment(audio_path, start_point=None, duration=None, axis=1, sample
     return X
 
 
-def load_wav_device(audio_path, device, sample_rate=44100):
+def load_wav_device(audio_path, device, sample_rate=44100, preread=None):
     """The whole file as a float32 DEVICE tensor [2, L] (load_wav_segment(path, axis=0) followed by the dataset's `.float()`): the raw
     PCM frames are uploaded as they are (2 or 4 bytes per sample instead of a float64 array made on the host) and de-interleaved /
     scaled on the device - int / 2**15 (2**31) in float64, then rounded to float32, exactly the reference's two steps.  Stereo only
-    (what the stems are); other channel counts go through load_wav_segment."""
+    (what the stems are); other channel counts go through load_wav_segment.  preread: {path: read_wav_raw(path)} of files already in memory."""
     import torch
-    with wave.open(audio_path, "r") as w:
-        if w.getframerate() != sample_rate:
-            raise ValueError(f"ValueError: input audio's sample rate should be {sample_rate}")
-        width, nch, n = w.getsampwidth(), w.getnchannels(), w.getnframes()
-        raw = w.readframes(n)
+    rate, width, nch, n, raw = preread[audio_path] if (preread is not None and audio_path in preread) else read_wav_raw(audio_path)
+    if rate != sample_rate:
+        raise ValueError(f"ValueError: input audio's sample rate should be {sample_rate}")
     if width not in (2, 4):
         raise ValueError("ValueError: input audio's bit depth should be 16 or 32-bit")
     if nch != 2:

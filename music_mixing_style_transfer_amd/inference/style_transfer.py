@@ -145,6 +145,9 @@ class Mixing_Style_Transfer_Inference:
                 dist.barrier()
             else:
                 os.makedirs(out_dir, exist_ok=True)
+            # all stems are ENQUEUED first, the files are written afterwards: converting a device-resident stem never waits for the host, so
+            # the GPU works on stem i + 1 while stem i's PCM travels back and its file is written (written stem by stem the GPU idled
+            # through five file writes per song)
             inst_outputs, t_range = [], (0, L)
             for i, inst in enumerate(a.instruments):
                 print(f"\t{inst}...")
@@ -153,9 +156,11 @@ class Mixing_Style_Transfer_Inference:
                                         a.segment_length_ref, dir_name)
                 stem_out, t_range = (res, (0, L)) if dist is None else res
                 inst_outputs.append(stem_out)
-                if a.save_each_inst:
+            mixture = sum(inst_outputs)
+            if a.save_each_inst:
+                for inst, stem_out in zip(a.instruments, inst_outputs):
                     self._write(dist, writers[f"{inst}_{tag}.wav"], t_range[0], stem_out)
-            self._write(dist, writers[f"mixture_{tag}.wav"], t_range[0], sum(inst_outputs))
+            self._write(dist, writers[f"mixture_{tag}.wav"], t_range[0], mixture)
             if dist is not None:
                 dist.barrier()
 

@@ -587,8 +587,8 @@ def test_style_transfer_cli_end_to_end(tmp_path):
 
 
 def test_song_prefetch_thread_and_host_path_give_the_same_files(tmp_path):
-    """Three songs through the runner with --normalize_input True: (a) songs prepared one ahead by the background thread (--workers 1:
-    decode + normaliser on their own stream while the previous song converts), (b) inline (--workers 0), (c) the dataset's host path
+    """Three songs through the runner with --normalize_input True: (a) the next song's wav files read into memory by the background thread
+    while the previous song converts (--workers 1; decode and normaliser on the consumer's thread), (b) inline (--workers 0), (c) the dataset's host path
     (numpy arrays like the reference, `data_loader.device = None`) - byte-identical output files in all three."""
     from music_mixing_style_transfer_amd.inference import style_transfer as st
     from music_mixing_style_transfer_amd.utils import synth
