@@ -168,10 +168,13 @@ def test_tcn_bf16x3_vs_oracle(nets):
     y_ref = R.tcn_forward(nets["tcn_sd"], x, cond, collect=col)
     tcn.precision = "bf16x3"
     try:
+        a_10 = None
         for n in (1, 2, 5, 10, 13, 14):
             a = tcn.forward_blocks(x.cuda(), cond.cuda(), n).cpu()
             err = float((a - col[n - 1]).abs().max())
             assert err <= 2e-4 * float(col[n - 1].abs().max()), f"block {n}: {err}"
+            if n == 10:
+                a_10 = a
         y = tcn(x.cuda(), cond.cuda()).cpu()
         print(f"bf16x3 @ 3 x 2x20011: max|y - oracle| = {float((y - y_ref).abs().max()):.2e}")
         assert float((y - y_ref).abs().max()) <= 1e-4
@@ -179,6 +182,15 @@ def test_tcn_bf16x3_vs_oracle(nets):
         yB = tcn(x.cuda(), condB.cuda()).cpu()
         assert float((yB - R.tcn_forward(nets["tcn_sd"], x, condB)).abs().max()) <= 1e-4
         assert torch.equal(tcn(x[1:2].cuda(), condB[1:2].cuda()).cpu()[0], yB[1])
+        # the persistent double-tile form of the split-bf16 block kernel (mst_tcn_set_tuning bit 3; measured slower, not the default): same bits
+        from music_mixing_style_transfer_amd import _lib
+        lib = _lib.lib()
+        try:
+            lib.check(lib.mst_tcn_set_tuning(tcn._handle, _lib.TCN_TUNING_DEFAULT | 8), "mst_tcn_set_tuning")
+            assert torch.equal(tcn(x.cuda(), condB.cuda()).cpu(), yB)
+            assert torch.equal(tcn.forward_blocks(x.cuda(), cond.cuda(), 10).cpu(), a_10)
+        finally:
+            lib.check(lib.mst_tcn_set_tuning(tcn._handle, _lib.TCN_TUNING_DEFAULT), "mst_tcn_set_tuning")
     finally:
         tcn.precision = "fp32"
 
