@@ -433,8 +433,23 @@ template <int P> int launch_block_x3_duo(TcnBlockArgs a, void *stream) {
     return MST_OK;
 }
 
-template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream, int x3_small = 0, int bf16_form = 0, int x3_duo = 0) {
+template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream, int x3_small = 0, int bf16_form = 0, int x3_duo = 0,
+                                  int bf16_small4 = 0) {
     TcnBlockArgs a = a0;
+    if constexpr (P == 4) {
+        if (precision == MST_PREC_BF16 && bf16_small4) {          // 128-time tiles of 4 phases (one-tile kernel, three workgroups per CU)
+            const long nsteps = ((long)a.L + a.d - 1) / a.d;
+            a.tiles_step = (int)((nsteps + 128 / P - 1) / (128 / P));
+            const long g2 = (long)a.B * a.tiles_phase * a.tiles_step;
+            if (g2 % 8 == 0) a.xcd_tiles = (int)(g2 / 8);
+            if (a.y_out)
+                MST_LAUNCH((tcn_block_bf16_kernel<P, true, 4>), dim3((unsigned)g2), dim3(256), stream, a);
+            else
+                MST_LAUNCH((tcn_block_bf16_kernel<P, false, 4>), dim3((unsigned)g2), dim3(256), stream, a);
+            MST_CHECK_LAUNCH("tcn_block_bf16_kernel");
+            return MST_OK;
+        }
+    }
     if (precision == MST_PREC_BF16 && bf16_form == 2) {
         // 256-time tiles only: at P = 8 (128-time tiles: half the work per tile for the same two barriers) the duo form measured
         // 1.62-1.82 ms against 1.50 ms, those blocks run the one-tile-per-workgroup kernel
@@ -618,8 +633,18 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
     bool fused_head = false;
     for (int n = 1; n < n_run; ++n) {
         const int d = t->d.dilations[n];
-        const int P = choose_phases(d, L, (precision == MST_PREC_BF16X3 && t->x3_small_tiles) ? MST_PREC_BF16X3 + 100 : precision);
+        int P = choose_phases(d, L, (precision == MST_PREC_BF16X3 && t->x3_small_tiles) ? MST_PREC_BF16X3 + 100 : precision);
         const int x3_small = (precision == MST_PREC_BF16X3 && t->x3_small_tiles && P <= 2) ? 1 : 0;
+        // bf16, 17 ... 32 steps per phase (d = 4096 at L = 131072): 128-time tiles of FOUR phases x 32 steps (184 rows staged per 128
+        // outputs, three workgroups per CU) instead of eight phases x 16 steps (240 rows, two workgroups per CU)
+        int bf16_small4 = 0;
+        if (precision == MST_PREC_BF16 && P == 8) {
+            const long ns = ((long)L + d - 1) / d;
+            if (ns > 16 && ns <= 32) {
+                P = 4;
+                bf16_small4 = 1;
+            }
+        }
         TcnBlockArgs a;
         a.x = buf[cur];
         a.y = buf[cur ^ 1];
@@ -650,10 +675,10 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         if (grid > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_tcn_forward: grid too large");
         int rc;
         switch (P) {
-            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo); break;
-            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo); break;
-            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo); break;
-            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo); break;
+            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4); break;
+            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4); break;
+            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4); break;
+            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4); break;
             default: rc = launch_block<16>(precision, a, (int)grid, stream, 0, t->bf16_form); break;
         }
         if (rc) return rc;

@@ -85,7 +85,7 @@ def test_tcn_bf16_stream_and_duo_kernels_emulated(emu_default):
     cases = [(4, 2, (2, 2, 777), cond),                                   # P = 2, 4, 8; 2 x 8 tiles over 8 workgroups
              (4, 3, (1, 2, 300), cond),                                   # odd dilations: P = 1
              (6, 2, (1, 2, 200), cond),                                   # short segment: P = 8 / 16 tiles, zero rows, skipped column tiles
-             (3, 2, (3, 2, 2500), synth.synth_audio((3, 64), seed=11))]   # 3 x 10 tiles: uneven walks, one FiLM row per item
+             (3, 2, (3, 2, 1500), synth.synth_audio((3, 64), seed=11))]   # 3 x 6 tiles: uneven walks, one FiLM row per item
     for nb, growth, shape, cnd in cases:
         m, sd = _tcn(nb, growth=growth)
         m.precision = "bf16"
