@@ -437,6 +437,8 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
                                   int bf16_small4 = 0) {
     TcnBlockArgs a = a0;
     if constexpr (P == 4) {
+        // (the same 128-time form for EVERY block - three workgroups per CU instead of the duo kernel - measured 1.53-1.58 ms per launch
+        //  against 1.48-1.53: it only wins where the eight-phase tiles' halo is the alternative)
         if (precision == MST_PREC_BF16 && bf16_small4) {          // 128-time tiles of 4 phases (one-tile kernel, three workgroups per CU)
             const long nsteps = ((long)a.L + a.d - 1) / a.d;
             a.tiles_step = (int)((nsteps + 128 / P - 1) / (128 / P));
