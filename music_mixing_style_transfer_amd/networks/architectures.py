@@ -82,7 +82,8 @@ class _EncoderRunner:
         slopes = {c.act_slope() for blk in self.blocks for c in (blk.conv1, blk.conv2)}
         for blk in self.blocks:
             if not (blk.conv1.hip_supported() and blk.conv2.hip_supported()):
-                raise NotImplementedError("Res_ConvBlock stack: padding='SAME' blocks only on gfx950")
+                raise NotImplementedError("Res_ConvBlock stack: mode='conv' layers with padding='SAME' only on gfx950 (Conv1d_layer and ConvBlock "
+                                          "run mode='deconv' / padding='VALID' layer by layer)")
         if len(slopes) != 1:
             raise NotImplementedError("Res_ConvBlock stack: one activation for all layers (activation == last_activation, as FXencoder "
                                       "builds them) on gfx950")
