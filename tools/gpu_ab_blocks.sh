@@ -5,8 +5,7 @@ O=gpurun_out/ab; mkdir -p $O
 one() { python bench.py --precision bf16 --workload configs1 --steps 10 --warmup 2 --no-cpu-baseline 2>$O/err.txt | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); x=json.load(open('gpurun_out/bench_details.json'))['details']['headline']['roofline']
-print(round(d['value'],1), round(d['ms_per_step'],3), d['roofline'].get('calib_ms'), [round(v,3) for v in x['per_block_ms'][10:14]])"; }
+print(round(d['value'],1), round(d['ms_per_step'],3), d['roofline'].get('calib_ms'), [round(v,3) for v in x['per_block_ms']])"; }
 for r in 1 2; do for v in old new; do cp tools/_ab/$v.so music_mixing_style_transfer_amd/csrc/libmst_hip.so; echo "$v bf16: $(one)" >> $O/ab.txt; done; done
 cat $O/ab.txt
 cp tools/_ab/new.so music_mixing_style_transfer_amd/csrc/libmst_hip.so
-timeout 600 python -m pytest tests -m gpu -q -x -k "bf16 and not x3" 2>&1 | tail -3
