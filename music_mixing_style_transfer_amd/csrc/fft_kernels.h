@@ -72,6 +72,87 @@ __global__ __launch_bounds__(256) void fft_stockham4_kernel(const float2 *in, fl
     dst[j0 + 3 * Ns] = make_float2(d02.x - r.x, d02.y - r.y);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Four-step form for m >= 256 (m = m1 * m2, m1 = 2^ceil(k/2) <= 1024, m2 = 2^floor(k/2) >= 16): two kernels instead of log4(m) global passes -
+//   fft_cols_kernel   for 16 consecutive columns n2: the m1-point FFTs over n1 of X[n1][n2] = z[n1 m2 + n2] in LDS (in-place radix-2 on
+//                     bit-reversed positions), times W_m^(n2 k1), stored as T[k1][n2];
+//   fft_rows_kernel   for 16 consecutive rows k1: the m2-point FFTs over n2 in LDS, stored transposed: Z[k1 + m1 k2].
+// Every global access is a run of 16 complex numbers (128 B) or longer; the array is read and written twice in all (a 2^17-point transform
+// took nine global passes in the Stockham form).  Sub-FFT twiddles come from the size-m table: W_m1^j = T[j m2], W_m2^j = T[j m1].
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned fft_bitrev(unsigned v, int bits) { return bits ? (__brev(v) >> (32 - bits)) : 0u; }
+
+// the in-LDS transform of 16 sequences of len = 2^lg points, sequence c at buf + c * pitch (bit-reversed order on entry); wl[j] = W_len^j,
+// j < len / 2, in LDS too (a global twiddle load per butterfly is an exposed L2 round trip per loop iteration: measured 4 x the kernel time)
+__device__ __forceinline__ void fft_lds16(float2 *buf, int pitch, int lg, const float2 *wl, int inverse, int tid) {
+    const int len = 1 << lg, half = len >> 1;
+    for (int h = 1; h < len; h <<= 1) {
+        const int ws = half / h;
+#pragma unroll 4
+        for (int e = tid; e < 16 * half; e += 256) {
+            const int c = e & 15, b = e >> 4;
+            const int k = b & (h - 1);
+            const int p0 = ((b - k) << 1) + k, p1 = p0 + h;
+            float2 w = wl[k * ws];
+            if (inverse) w.y = -w.y;
+            float2 *q = buf + c * pitch;
+            const float2 u = q[p0], v = fft_cmul(w, q[p1]);
+            q[p0] = make_float2(u.x + v.x, u.y + v.y);
+            q[p1] = make_float2(u.x - v.x, u.y - v.y);
+        }
+        __syncthreads();
+    }
+}
+
+template <int LOGMAX>
+__global__ __launch_bounds__(256) void fft_cols_kernel(const float2 *in, float2 *out, const float2 *tw, long m, int l1, int l2, long stride_in,
+                                                       long stride_out, int inverse) {
+    __shared__ float2 buf[16 * ((1 << LOGMAX) + 1)];
+    __shared__ float2 wl[(1 << LOGMAX) / 2];
+    const int tid = threadIdx.x, m1 = 1 << l1, pitch = m1 + 1;
+    const long m2 = 1L << l2, n2base = (long)blockIdx.x * 16;
+    const float2 *src = in + (size_t)blockIdx.y * stride_in;
+    float2 *dst = out + (size_t)blockIdx.y * stride_out;
+    for (int j = tid; j < m1 / 2; j += 256) wl[j] = tw[(long)j * m2];          // W_m1^j = T[j m2]
+#pragma unroll 8
+    for (int e = tid; e < 16 * m1; e += 256) {
+        const int c = e & 15, n1 = e >> 4;
+        buf[c * pitch + fft_bitrev((unsigned)n1, l1)] = src[(long)n1 * m2 + n2base + c];
+    }
+    __syncthreads();
+    fft_lds16(buf, pitch, l1, wl, inverse, tid);
+#pragma unroll 8
+    for (int e = tid; e < 16 * m1; e += 256) {
+        const int c = e & 15, k1 = e >> 4;
+        const long idx = ((n2base + c) * (long)k1) & (m - 1);
+        dst[(long)k1 * m2 + n2base + c] = fft_cmul(fft_tw(tw, idx, m / 2, inverse), buf[c * pitch + k1]);
+    }
+}
+
+template <int LOGMAX>
+__global__ __launch_bounds__(256) void fft_rows_kernel(const float2 *in, float2 *out, const float2 *tw, long m, int l1, int l2, long stride_in,
+                                                       long stride_out, int inverse) {
+    __shared__ float2 buf[16 * ((1 << LOGMAX) + 1)];
+    __shared__ float2 wl[(1 << LOGMAX) / 2];
+    const int tid = threadIdx.x, m2 = 1 << l2, pitch = m2 + 1;
+    const long m1 = 1L << l1, k1base = (long)blockIdx.x * 16;
+    const float2 *src = in + (size_t)blockIdx.y * stride_in;
+    float2 *dst = out + (size_t)blockIdx.y * stride_out;
+    for (int j = tid; j < m2 / 2; j += 256) wl[j] = tw[(long)j * m1];          // W_m2^j = T[j m1]
+#pragma unroll 8
+    for (int e = tid; e < 16 * m2; e += 256) {
+        const int rr = e >> l2, n2 = e & (m2 - 1);                  // consecutive threads read consecutive elements of a row
+        buf[rr * pitch + fft_bitrev((unsigned)n2, l2)] = src[(k1base + rr) * m2 + n2];
+    }
+    __syncthreads();
+    fft_lds16(buf, pitch, l2, wl, inverse, tid);
+#pragma unroll 8
+    for (int e = tid; e < 16 * m2; e += 256) {
+        const int c = e & 15, k2 = e >> 4;                           // 16 consecutive k1 of one k2: a 128-byte run
+        dst[k1base + c + m1 * (long)k2] = buf[c * pitch + k2];
+    }
+}
+
 // R2C un-mix: Z (m complex per sequence, stride sz) -> X (m + 1 bins per sequence, stride sx); thread k <= m / 2 handles the pair (k, m - k),
 // so Z and X may be the same buffer (sz == sx).  twn[k] = exp(-2 pi i k / n), k <= m / 2.
 __global__ __launch_bounds__(256) void fft_r2c_post_kernel(const float2 *Z, float2 *X, const float2 *twn, long m, long sz, long sx) {

@@ -1859,12 +1859,12 @@ void fft_plan_destroy(MstFftPlan *p) {
 }
 // n: a power of two >= 4.  The twiddle tables are written on the null stream and waited for: plans are made once.
 int fft_plan_create(MstFftPlan **out, long n) {
-    if (n < 4 || (n & (n - 1))) return fail(MST_ERR_UNSUPPORTED, "FFT length must be a power of two >= 4");
+    if (n < 4 || (n & (n - 1)) || n > (1L << 21)) return fail(MST_ERR_UNSUPPORTED, "FFT length must be a power of two in 4 ... 2^21");
     auto *p = new MstFftPlan;
     p->n = n;
     p->m = n / 2;
     for (long v = p->m; v > 1; v >>= 1) p->log2m++;
-    p->passes = p->log2m / 2 + p->log2m % 2;
+    p->passes = p->log2m >= 8 ? 2 : p->log2m / 2 + p->log2m % 2;          // four-step form (two kernels) from 256 complex points on
     const long cm = std::max<long>(1, p->m / 2), cn = p->m / 2 + 1;
     if (hipMalloc((void **)&p->tw_m, (size_t)cm * sizeof(float2)) != hipSuccess || hipMalloc((void **)&p->tw_n, (size_t)cn * sizeof(float2)) != hipSuccess) {
         fft_plan_destroy(p);
@@ -1883,6 +1883,27 @@ int fft_plan_create(MstFftPlan **out, long n) {
 int fft_passes(const MstFftPlan *p, float2 *a, long sa, float2 *b, long sb, int nb, int inverse, void *stream, float2 **res, long *sres) {
     float2 *src = a, *dst = b;
     long ss = sa, sd = sb;
+    if (p->log2m >= 8) {          // four-step: columns (a -> b), rows (b -> a)
+        const int l1 = (p->log2m + 1) / 2, l2 = p->log2m - l1;
+        const dim3 ga((unsigned)((1L << l2) / 16), (unsigned)nb), gb((unsigned)((1L << l1) / 16), (unsigned)nb);
+#define MST_FFT_STEP(KERN, GRID, LG)                                                                                                         \
+    if ((LG) <= 6) MST_LAUNCH((KERN<6>), GRID, dim3(256), stream, (const float2 *)src, dst, (const float2 *)p->tw_m, p->m, l1, l2, ss, sd, inverse); \
+    else if ((LG) <= 8) MST_LAUNCH((KERN<8>), GRID, dim3(256), stream, (const float2 *)src, dst, (const float2 *)p->tw_m, p->m, l1, l2, ss, sd, inverse); \
+    else if ((LG) <= 9) MST_LAUNCH((KERN<9>), GRID, dim3(256), stream, (const float2 *)src, dst, (const float2 *)p->tw_m, p->m, l1, l2, ss, sd, inverse); \
+    else MST_LAUNCH((KERN<10>), GRID, dim3(256), stream, (const float2 *)src, dst, (const float2 *)p->tw_m, p->m, l1, l2, ss, sd, inverse);
+        MST_FFT_STEP(fft_cols_kernel, ga, l1)
+        MST_CHECK_LAUNCH("fft_cols_kernel");
+        std::swap(src, dst);
+        std::swap(ss, sd);
+        MST_FFT_STEP(fft_rows_kernel, gb, l2)
+        MST_CHECK_LAUNCH("fft_rows_kernel");
+#undef MST_FFT_STEP
+        std::swap(src, dst);
+        std::swap(ss, sd);
+        *res = src;
+        *sres = ss;
+        return MST_OK;
+    }
     long Ns = 1;
     if (p->log2m % 2) {
         MST_LAUNCH(fft_stockham2_kernel, dim3((unsigned)((p->m / 2 + 255) / 256), (unsigned)nb), dim3(256), stream, (const float2 *)src, dst,

@@ -397,16 +397,22 @@ class ConvolutionalReverb(Processor):
             return d.out(d.x.clone())
         if self.h.shape[1] != d.C:
             raise ValueError(f"impulse response has {self.h.shape[1]} channels, audio has {d.C}")
-        h32 = np.ascontiguousarray(self.h, dtype=np.float32)
-        idx = int(np.argmax(np.max(np.abs(self.h), axis=1), axis=0))
-        idx += int(0.001 * np.abs(self.parameters.pre_delay.value) * self.sample_rate)
-        idx = int(np.clip(idx, 0, h32.shape[0] - 1))
-        hd = torch.from_numpy(h32).to(d.x.device)
-        cv = self._convolver(d.lib, d.L, h32.shape[0], d.n, d.C, d.x.device)
+        # the response on the device and its peak position are kept until update() (or the channel adaptation above) replaces self.h:
+        # the float32 copy, the peak search and a 0.5 MB pageable upload cost as much per call as the transforms themselves
+        key = (id(self.h), self.h.shape, self.parameters.pre_delay.value, str(d.x.device))
+        cached = getattr(self, "_h_cache", None)
+        if cached is None or cached[0] != key:
+            h32 = np.ascontiguousarray(self.h, dtype=np.float32)
+            idx = int(np.argmax(np.max(np.abs(self.h), axis=1), axis=0))
+            idx += int(0.001 * np.abs(self.parameters.pre_delay.value) * self.sample_rate)
+            idx = int(np.clip(idx, 0, h32.shape[0] - 1))
+            cached = self._h_cache = (key, torch.from_numpy(h32).to(d.x.device), idx, h32.shape[0], self.h)      # self.h kept alive: its id is the key
+        _, hd, idx, lh = cached
+        cv = self._convolver(d.lib, d.L, lh, d.n, d.C, d.x.device)
         nbytes = d.lib.mst_fx_convolver_workspace_bytes(cv)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=d.x.device)
         y = torch.empty_like(d.x)
-        d.lib.check(d.lib.mst_fx_convolve(cv, d.x.data_ptr(), hd.data_ptr(), h32.shape[0], y.data_ptr(), idx,
+        d.lib.check(d.lib.mst_fx_convolve(cv, d.x.data_ptr(), hd.data_ptr(), lh, y.data_ptr(), idx,
                                           float(self.parameters.dry.value), float(self.parameters.wet.value), ws.data_ptr(),
                                           nbytes, d.stream), "mst_fx_convolve")
         return d.out(y)

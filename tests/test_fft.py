@@ -1,13 +1,14 @@
 """The library's own power-of-two real FFTs (csrc/fft_kernels.h: Stockham radix-2 passes + the real-sequence un-mix; they replaced hipFFT in
 round 4) on the SIMT emulator against numpy.fft - through the two entry points that use them: the STFT mean magnitude (R2C) and the FFT
-convolution (R2C, spectrum product, C2R).  Lengths cover odd and even pass counts (the inverse starts in a different buffer) and the
-smallest transform."""
+convolution (R2C, spectrum product, C2R).  Lengths cover the global Stockham passes (up to 256 points: odd and even pass counts - the inverse
+starts in a different buffer - and the smallest transform) and the four-step form with in-LDS sub-transforms (from 512 points on: square and
+2:1 splits, up to 2^17 points)."""
 import numpy as np
 import pytest
 import torch
 
 
-@pytest.mark.parametrize("n_fft", [4, 8, 64, 512, 4096])
+@pytest.mark.parametrize("n_fft", [4, 8, 64, 256, 512, 1024, 4096, 32768])
 def test_stft_mean_magnitude_vs_numpy(emu_default, n_fft):
     from music_mixing_style_transfer_amd.mixing_manipulator import _device_ops as D
     rng = np.random.default_rng(n_fft)
@@ -25,9 +26,9 @@ def test_stft_mean_magnitude_vs_numpy(emu_default, n_fft):
         assert np.abs(got - want).max() <= 3e-6 * max(1.0, want.max()), (n_fft, np.abs(got - want).max())
 
 
-@pytest.mark.parametrize("L,nt", [(5, 3), (40, 9), (100, 31), (700, 101), (3000, 257), (9000, 1001)])
+@pytest.mark.parametrize("L,nt", [(5, 3), (40, 9), (100, 31), (200, 57), (400, 101), (700, 101), (3000, 257), (9000, 1001), (40000, 1001), (100000, 2001)])
 def test_fft_convolution_vs_numpy(emu_default, L, nt):
-    """fir_causal = one FFT convolution (transform lengths 8 ... 16384 here: both parities of the pass count)."""
+    """fir_causal = one FFT convolution (transform lengths 8 ... 131072 here)."""
     from music_mixing_style_transfer_amd.mixing_manipulator import _device_ops as D
     rng = np.random.default_rng(L)
     x = rng.standard_normal((L, 1)).astype(np.float32)
