@@ -407,7 +407,7 @@ class ConvolutionalReverb(Processor):
             idx += int(0.001 * np.abs(self.parameters.pre_delay.value) * self.sample_rate)
             idx = int(np.clip(idx, 0, h32.shape[0] - 1))
             cached = self._h_cache = (key, torch.from_numpy(h32).to(d.x.device), idx, h32.shape[0], self.h)      # self.h kept alive: its id is the key
-        _, hd, idx, lh = cached
+        _, hd, idx, lh, _ = cached
         cv = self._convolver(d.lib, d.L, lh, d.n, d.C, d.x.device)
         nbytes = d.lib.mst_fx_convolver_workspace_bytes(cv)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=d.x.device)
