@@ -67,7 +67,10 @@ def load_wav_device(audio_path, device, sample_rate=44100, preread=None):
         raise ValueError("ValueError: input audio's bit depth should be 16 or 32-bit")
     if nch != 2:
         raise ValueError("load_wav_device: stereo files only")
-    host = torch.frombuffer(bytearray(raw), dtype=torch.int16 if width == 2 else torch.int32)
+    import warnings
+    with warnings.catch_warnings():          # the frames are only read (uploaded): no writable copy of the file's 30 MB
+        warnings.simplefilter("ignore")
+        host = torch.frombuffer(raw, dtype=torch.int16 if width == 2 else torch.int32)
     dev = host.to(device, non_blocking=False).view(-1, 2)
     x = dev.to(torch.float64) / float(2 ** 15 if width == 2 else 2 ** 31)
     return x.to(torch.float32).t().contiguous()

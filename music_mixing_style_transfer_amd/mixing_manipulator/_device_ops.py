@@ -18,7 +18,22 @@ def to_device(x):
 
 
 def _i64(values, device):
-    return torch.tensor(values, dtype=torch.int64, device=device)
+    return torch.from_numpy(np.asarray(values, dtype=np.int64)).to(device)
+
+
+class RangeIndex:
+    """(item, lo, hi) arrays of a set of ranges, uploaded once per device: pass it as `items` of range_reduce (with the same lo / hi lists)
+    when the same ranges are reduced again and again - the BS.1770 gating blocks of a stem are measured four times per normalisation."""
+
+    def __init__(self, items, lo, hi):
+        self.items, self.lo, self.hi = np.asarray(items, dtype=np.int32), np.asarray(lo, dtype=np.int64), np.asarray(hi, dtype=np.int64)
+        self._dev = {}
+
+    def on(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = tuple(torch.from_numpy(a).to(device) for a in (self.items, self.lo, self.hi))
+        return self._dev[key]
 
 
 def biquad(x, b, a):
@@ -51,7 +66,7 @@ def range_reduce(x, items, lo, hi, channel=0, mode="sumsq"):
     if r == 0:
         return np.zeros(0)
     owner = None
-    if mode != "sumsq" and any(min(int(b), L) - max(int(a), 0) > _MAX_SPLIT for a, b in zip(lo, hi)):
+    if mode != "sumsq" and not isinstance(items, RangeIndex) and any(min(int(b), L) - max(int(a), 0) > _MAX_SPLIT for a, b in zip(lo, hi)):
         items2, lo2, hi2, owner = [], [], [], []
         for k, (it, a, b) in enumerate(zip(items, lo, hi)):
             a, b = max(int(a), 0), min(int(b), L)
@@ -63,9 +78,12 @@ def range_reduce(x, items, lo, hi, channel=0, mode="sumsq"):
                 owner.append(k)
         items, lo, hi = items2, lo2, hi2
     dev = x.device
-    it = torch.tensor(items, dtype=torch.int32, device=dev)
+    if isinstance(items, RangeIndex):          # index arrays that already live on the device (the loudness meter's gating blocks)
+        it, lo_t, hi_t = items.on(dev)
+    else:
+        it = torch.from_numpy(np.asarray(items, dtype=np.int32)).to(dev)
+        lo_t, hi_t = _i64(lo, dev), _i64(hi, dev)
     out = torch.empty(len(lo), dtype=torch.float64, device=dev)
-    lo_t, hi_t = _i64(lo, dev), _i64(hi, dev)
     with lib.device_ctx(x):
         lib.check(lib.mst_fx_range_reduce(x.data_ptr(), L, Cn, channel, it.data_ptr(), lo_t.data_ptr(), hi_t.data_ptr(), len(lo),
                                           0 if mode == "sumsq" else 1, out.data_ptr(), lib.stream_ptr(x)), "mst_fx_range_reduce")

@@ -69,6 +69,9 @@ class _quiet:
         return self._w.__exit__(*a)
 
 
+_block_index = {}
+
+
 class Meter:
     """BS.1770 loudness meter with pyloudnorm.Meter's interface (rate, block_size=0.400)."""
 
@@ -96,10 +99,16 @@ class Meter:
             raise ValueError("Audio must have length greater than the block size.")
         for b, a in self._filters:                       # each stage rounds to float32 like the reference's in-place filtering
             x = D.biquad(x, b, a)
-        lo, hi = self.block_bounds(L)
+        key = (L, self.rate, self.block_size)
+        if key not in _block_index:          # the gating blocks of a signal length: built and uploaded once (four measurements per stem)
+            if len(_block_index) > 8:
+                _block_index.clear()
+            lo, hi = self.block_bounds(L)
+            _block_index[key] = (lo, hi, D.RangeIndex([0] * len(lo), lo, hi))
+        lo, hi, index = _block_index[key]
         z = np.zeros((Cn, len(lo)))
         for c in range(Cn):
-            z[c] = D.range_reduce(x, [0] * len(lo), lo, hi, channel=c, mode="sumsq") / (self.block_size * self.rate)
+            z[c] = D.range_reduce(x, index, lo, hi, channel=c, mode="sumsq") / (self.block_size * self.rate)
         return gated_loudness(z)
 
 
