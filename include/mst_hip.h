@@ -112,7 +112,8 @@ int mst_tcn_forward(MstTcn *tcn, const float *x_dev, float *y_dev, int B, int L,
 int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int B, int L, int precision, int n_run,
                            void *workspace, size_t workspace_bytes, void *stream);
 
-/* tuning flags (choose between forms of the block kernels; flags = x3_small_tiles | bf16_form << 1 | x3_duo << 3, default 5):
+/* tuning flags (choose between forms of the block kernels; flags = x3_small_tiles | bf16_form << 1 | x3_duo << 3 | bf16_reuse << 4,
+ * default 21):
  * bit 0 (bf16x3 mode; default 1, measured 5.13 instead of 5.45 ms per launch at 32 x 131072): the split-bf16 block kernel on 128-time
  *   tiles of <= 2 phases (two workgroups per CU) wherever the segment has at least 64 steps per phase, 0 = 256-time tiles (one
  *   workgroup per CU); identical results.
@@ -125,7 +126,11 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
  *     the previous tile's row stores during the main loop; bit-identical to form 0                                       1.47-1.48 ms
  * bit 3 (bf16x3 mode; default 0): the 128-time-tile blocks run tcn_block_bf16x3_duo_kernel - persistent, one workgroup of 4 matrix waves
  *   + 4 loader waves per CU, two tile buffers; the loader waves fetch and split (hi + lo) the next tile and finish / store the previous
- *   one during the main loop; bit-identical to the one-tile kernel.  Measured 5.45-5.6 ms per launch against 4.55 ms (round 4): off. */
+ *   one during the main loop; bit-identical to the one-tile kernel.  Measured 5.45-5.6 ms per launch against 4.55 ms (round 4): off.
+ * bit 4 (bf16 mode, form 2; default 1): the duo kernel's main loop runs class-major - taps grouped by j mod (16 / phases), every B
+ *   fragment read from LDS once per class and k-step and fed to up to eight MFMAs (304 instead of 960 LDS reads per tile at four phases).
+ *   Same products, another fp32 summation order: agrees with bit 4 off to accumulation rounding (not bit-identical).  Measured at
+ *   32 x 131072, same box, d = 4 ... 2048: 1.40 ms per launch against 1.46 (profiles/r04_tcn_forms_reuse.log). */
 int mst_tcn_set_tuning(MstTcn *tcn, int flags);
 
 /* measurement hook (bench.py's roofline leg): between _begin and _end every mst_tcn_forward records HIP events

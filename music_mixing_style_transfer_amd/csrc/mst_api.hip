@@ -136,6 +136,7 @@ struct MstTcn {
     void *zero_row = nullptr;     // 1 KB of zeros: what the block kernels stage for time steps outside the segment
     int x3_small_tiles = 1;       // bf16x3 mode: 128-time tiles of <= 2 phases, two workgroups per CU (mst_tcn_set_tuning; measured 5.13 vs 5.45 ms)
     int x3_duo = 0;               // bf16x3 mode: the persistent double-tile form of the 128-time-tile kernel (mst_tcn_set_tuning bit 3; measured slower: 5.45 vs 4.55 ms)
+    int bf16_reuse = 1;           // bf16 mode, duo kernel: the class-major main loop (mst_tcn_set_tuning bit 4; measured 1.40 vs 1.46 ms per launch)
     int bf16_form = 2;            // bf16 mode, form of the block kernel (mst_tcn_set_tuning bits 1-2): 0 one tile per workgroup, 1 stream, 2 duo (default)
     std::vector<hipEvent_t> ev;   // timing hook: (nblocks + 2) events per recorded forward
     int ev_max = 0, ev_used = 0;
@@ -398,7 +399,7 @@ template <int P, int NQ> int launch_block_stream(TcnBlockArgs a, void *stream) {
 }
 
 // the persistent double-tile bf16 kernel: one workgroup per CU
-template <int P, int NQ> int launch_block_duo(TcnBlockArgs a, void *stream) {
+template <int P, int NQ> int launch_block_duo(TcnBlockArgs a, void *stream, int reuse = 0) {
     const long nsteps = ((long)a.L + a.d - 1) / a.d;
     a.tiles_step = (int)((nsteps + (32 * NQ) / P - 1) / ((32 * NQ) / P));
     const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
@@ -409,6 +410,13 @@ template <int P, int NQ> int launch_block_duo(TcnBlockArgs a, void *stream) {
     if (grid >= 8) {
         grid -= grid % 8;
         a.xcd_tiles = (int)((ntiles + 7) / 8);
+    }
+    if constexpr ((P == 4 || P == 2) && NQ == 8) {
+        if (reuse) {          // the class-major main loop (B fragments reused across the taps of a class)
+            MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ, true>), dim3((unsigned)grid), dim3(512), stream, a);
+            MST_CHECK_LAUNCH("tcn_block_bf16_duo_kernel");
+            return MST_OK;
+        }
     }
     MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ>), dim3((unsigned)grid), dim3(512), stream, a);
     MST_CHECK_LAUNCH("tcn_block_bf16_duo_kernel");
@@ -434,7 +442,7 @@ template <int P> int launch_block_x3_duo(TcnBlockArgs a, void *stream) {
 }
 
 template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream, int x3_small = 0, int bf16_form = 0, int x3_duo = 0,
-                                  int bf16_small4 = 0) {
+                                  int bf16_small4 = 0, int bf16_reuse = 0) {
     TcnBlockArgs a = a0;
     if constexpr (P == 4) {
         // (the same 128-time form for EVERY block - three workgroups per CU instead of the duo kernel - measured 1.53-1.58 ms per launch
@@ -457,7 +465,7 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
         // 1.62-1.82 ms against 1.50 ms, those blocks run the one-tile-per-workgroup kernel
         // (the last block - fused output head, 32 more live registers - spills in the duo form and runs the one-tile kernel too)
         if constexpr (P <= 4) {
-            if (!a.y_out) return launch_block_duo<P, 8>(a, stream);
+            if (!a.y_out) return launch_block_duo<P, 8>(a, stream, bf16_reuse);
         }
     }
     if (precision == MST_PREC_BF16 && bf16_form == 1) return launch_block_stream<P, (P == 8 ? 4 : 8)>(a, stream);
@@ -677,10 +685,10 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         if (grid > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_tcn_forward: grid too large");
         int rc;
         switch (P) {
-            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4); break;
-            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4); break;
-            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4); break;
-            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4); break;
+            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4, t->bf16_reuse); break;
+            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4, t->bf16_reuse); break;
+            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4, t->bf16_reuse); break;
+            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4, t->bf16_reuse); break;
             default: rc = launch_block<16>(precision, a, (int)grid, stream, 0, t->bf16_form); break;
         }
         if (rc) return rc;
@@ -726,10 +734,11 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
 
 extern "C" int mst_tcn_set_tuning(MstTcn *t, int flags) {
     if (!t) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: null handle");
-    if (flags < 0 || flags > 15 || ((flags >> 1) & 3) > 2) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: unknown flag bits");
+    if (flags < 0 || flags > 31 || ((flags >> 1) & 3) > 2) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: unknown flag bits");
     t->x3_small_tiles = flags & 1;
     t->bf16_form = (flags >> 1) & 3;
     t->x3_duo = (flags >> 3) & 1;
+    t->bf16_reuse = (flags >> 4) & 1;
     return MST_OK;
 }
 

@@ -623,6 +623,62 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16_stream_kernel(TcnBlockA
 }
 
 // ------------------------------------------------------------------------------------------------
+// Main loop of the 256-time tile with B-FRAGMENT REUSE ACROSS TAPS (round 4, REUSE form of the duo kernel).  With P phases per tile the
+// B fragment of (tap j, column tile q) is rows P j + 16 q .. + 15 of the LDS image - the same rows as (tap j + 16 / P, column tile q - 1):
+// at P = 4 the tap-major loop reads each of the 75 x 4 distinct fragments up to four times (960 ds_read_b128 per tile and wave, one per
+// MFMA pair).  Class-major order: taps fall into NCLS = 16 / P classes c = j mod NCLS; for one class and one k-step kk the wave holds the
+// A fragments of the class's NU taps x 2 row tiles (double-buffered over the k-steps: A0 / A1, fetched a whole phase ahead) and walks the
+// class's 16 + NU - 1 row windows once; window i feeds tap c + NCLS u into column tile i - u.  P = 4: 304 LDS reads per tile instead of
+// 960, up to eight MFMAs per read (P = 2: 544, up to four), the weight stream unchanged (128 fragments per tile against 120).  Same
+// products, summed class by class instead of tap by tap (fp32 accumulation: results differ from the tap-major loop by rounding only).
+// Measured, same box: the bare main loop on realistic operands 1.145 ms against 1.230 (tools/micro/tcn_mainloop_variants.hip reuse16x16 /
+// base16x16, profiles/r04_micro_mainloop_reuse.txt); the block kernel at d = 4 ... 2048 1.40 ms against 1.46 (profiles/r04_tcn_forms_reuse.log).
+// On entry ring[0..3] = windows 0..3 of (c, kk = 0) and A0 = the fragments of (c, kk = 0); on exit the same for class cn (LAST: the
+// next tile's image may not have landed yet - no window of it is read here; A0 is the next tile's first phase: the same weights).
+// ------------------------------------------------------------------------------------------------
+template <int P, int NU, bool LAST, int NUMAX>
+__device__ __forceinline__ void tcn_reuse_class(f32x4 (&acc)[2][16], bf16x8 (&A0)[NUMAX][2], bf16x8 (&A1)[NUMAX][2], bf16x8 (&ring)[4],
+                                                const unsigned char *sm, const MstStream16 &wst, unsigned aoff, int c, int cn, int l16, int g) {
+    constexpr int NW = 15 + NU, NCLS = 16 / P;
+    static_assert(NW >= 4, "the ring is four windows deep");
+    const int rsw = (P * c + l16) & 15, rswn = (P * cn + l16) & 15;
+    const unsigned char *rowb = sm + (P * c + l16) * 256, *rowbn = sm + (P * cn + l16) * 256;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 (&cur)[NUMAX][2] = (kk & 1) ? A1 : A0;
+        bf16x8 (&nxt)[NUMAX][2] = (kk & 1) ? A0 : A1;
+#pragma unroll
+        for (int u = 0; u < NUMAX; ++u) {
+            if (kk < 3 && u >= NU) continue;
+            int j = (kk < 3 ? c : cn) + NCLS * u;
+            j = j < 15 ? j : 14;                                   // the last class has one tap less: that slot holds a fragment nobody uses
+            const unsigned so = (unsigned)(j * 4 + (kk < 3 ? kk + 1 : 0)) * 8192u;
+            nxt[u][0] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff, so));
+            nxt[u][1] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + 4096u, so));
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int n = kk * NW + i;
+            const bf16x8 b = ring[n & 3];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int q = i - u;
+                if (q >= 0 && q < 16) {
+                    acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u][0], b, acc[0][q], 0, 0, 0);
+                    acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u][1], b, acc[1][q], 0, 0, 0);
+                }
+            }
+            const int n2 = n + 4, k2 = n2 / NW, i2 = n2 % NW;      // the window four ahead: this class, or the first k-step of the next
+            if (k2 < 4)
+                ring[n & 3] = *(const bf16x8 *)(rowb + (((4 * k2 + g) ^ rsw) << 4) + i2 * 4096);
+            else if (!LAST)
+                ring[n & 3] = *(const bf16x8 *)(rowbn + ((g ^ rswn) << 4) + i2 * 4096);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // blocks 1..n-1, bf16: the PERSISTENT DOUBLE-TILE form of tcn_block_bf16_kernel ("duo" kernel, round 3) - same tiles, same LDS image, same
 // main loop and epilogue arithmetic, bit-identical results; what changes is who does what:
 //   * ONE workgroup of EIGHT waves per CU, persistent, walking its share of the tiles of one XCD's contiguous tile range;
@@ -638,8 +694,9 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16_stream_kernel(TcnBlockA
 // 1.27 ms per launch at one wave per SIMD as at two; the one-tile-per-workgroup kernel 1.50-1.53 ms; a first persistent double-tile
 // form whose four waves did everything themselves 1.60 ms (0.2 ms for issuing the copy, 0.2 ms for the epilogue).
 // ------------------------------------------------------------------------------------------------
-template <int P, bool FUSE_OUT, int NQ>
+template <int P, bool FUSE_OUT, int NQ, bool REUSE = false>
 __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs a) {
+    static_assert(!REUSE || ((P == 4 || P == 2) && NQ == 8), "the class-major main loop is written for 256-time tiles of two / four phases");
     constexpr int T = 32 * NQ, R = T + 14 * P, R4 = (R + 3) / 4 * 4, MT = T / P, NC = 2 * NQ;
     constexpr int NK = R4 / 4;                   // 1 KB DMA pieces (4 rows x 256 B) per tile
     constexpr int NI = (NK + 3) / 4;             // pieces per loader wave
@@ -784,11 +841,21 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
     constexpr int RB = 8;
     static_assert(NC % RB == 0, "the ring divides the column tiles");
     bf16x8 af[2][4], bf[RB];
+    constexpr int NCLS = 16 / P, NUMAX = (15 + NCLS - 1) / NCLS;      // REUSE: tap classes, taps per class (the last class: 15 / NCLS)
+    bf16x8 A0[NUMAX][2], A1[NUMAX][2], ring[4];                      // REUSE: the class-major loop's operands (tcn_reuse_class)
+    if constexpr (REUSE) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+        for (int u = 0; u < NUMAX; ++u) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) af[m][kk] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)kk * 8192u));
-        __builtin_amdgcn_sched_barrier(0);
+            for (int m = 0; m < 2; ++m) A0[u][m] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)(4 * NCLS * u) * 8192u));
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) af[m][kk] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)kk * 8192u));
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     int cur = 0, bprev = tb;
@@ -810,6 +877,16 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
 #pragma unroll
             for (int q = 0; q < NC; ++q) acc[m][q] = sh;
         }
+        if constexpr (REUSE) {
+            {
+                const unsigned char *rp0 = sm + l16 * 256 + ((g ^ l16) << 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ring[i] = *(const bf16x8 *)(rp0 + i * 4096);
+            }
+#pragma unroll 1
+            for (int c = 0; c < NCLS - 1; ++c) tcn_reuse_class<P, NUMAX, false, NUMAX>(acc, A0, A1, ring, sm, wst, aoff, c, c + 1, l16, g);
+            tcn_reuse_class<P, 15 / NCLS, true, NUMAX>(acc, A0, A1, ring, sm, wst, aoff, NCLS - 1, 0, l16, g);
+        } else {
         {
             const unsigned char *rp0 = sm + l16 * 256 + ((g ^ l16) << 4);
 #pragma unroll
@@ -837,6 +914,7 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
                 for (int m = 0; m < 2; ++m) af[m][kk] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)(jn * 4 + kk) * 8192u));
                 __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
             }
+        }
         }
 
         // ---- epilogue arithmetic (the one of tcn_block_bf16_kernel): residual rows -> registers, barrier, transposed tile -> LDS, barrier

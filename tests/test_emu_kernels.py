@@ -110,6 +110,33 @@ def test_tcn_bf16_stream_and_duo_kernels_emulated(emu_default):
         emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 6), "tuning")
 
 
+def test_tcn_bf16_duo_reuse_main_loop_emulated(emu_default):
+    """The class-major main loop of the duo kernel's four-phase tiles (mst_tcn_set_tuning bit 4): every B fragment is read from LDS once per
+    class of taps (j mod 4) and feeds up to eight MFMAs; same products as the tap-major loop, summed in another order - against the oracle at
+    the bf16 tolerance, against the tap-major form to accumulation rounding.  d = 4 ... 32 at lengths that give four-phase tiles: several
+    tiles per workgroup, ragged last tiles (zero rows), tiles of more than one phase group, one FiLM row per item."""
+    cases = [(3, 2, (3, 2, 1500), synth.synth_audio((3, 64), seed=11)),        # d = 2, 4: 3 x 6 four-phase tiles
+             (5, 2, (1, 2, 2100), synth.synth_audio((1, 64), seed=2)),         # d = 2 ... 16: phase groups 1, 2, 4
+             (3, 2, (2, 2, 777), synth.synth_audio((1, 64), seed=3))]
+    differs = 0
+    for nb, growth, shape, cnd in cases:
+        m, sd = _tcn(nb, growth=growth)
+        m.precision = "bf16"
+        x = synth.synth_audio(shape, seed=1)
+        col = []
+        y_ref = R.tcn_forward(sd, x, cnd, nblocks=nb, dilation_growth=growth, collect=col)
+        m._ensure(emu_default)
+        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 5), "tuning")            # tap-major
+        y0, a0 = m(x, cnd), m.forward_blocks(x, cnd, nb)
+        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 21), "tuning")           # class-major
+        y1, a1 = m(x, cnd), m.forward_blocks(x, cnd, nb)
+        assert float((y1 - y_ref).abs().max()) <= 4e-2
+        assert float((a1 - col[nb - 1]).abs().max()) <= 4e-2 * float(col[nb - 1].abs().max())
+        assert float((y1 - y0).abs().max()) <= 5e-3 and float((a1 - a0).abs().max()) <= 5e-2
+        differs += int(not torch.equal(a1, a0))
+    assert differs > 0          # the other summation order did run (bit-identical activations everywhere would mean the flag was ignored)
+
+
 def test_tcn_bf16x3_duo_kernel_emulated(emu_default):
     """The persistent double-tile form of the split-bf16 block kernel (mst_tcn_set_tuning bit 3; not the default - measured slower): 4 matrix + 4 loader waves
     per CU, the loader waves fetch / split the next tile and finish / store the previous one.  Same bits as the one-tile kernel (bit 3

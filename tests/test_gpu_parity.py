@@ -102,11 +102,12 @@ def test_tcn_bf16_vs_oracle(nets):
         tcn.precision = "fp32"
 
 
-@pytest.mark.parametrize("form", [1, 3, 5])
+@pytest.mark.parametrize("form", [1, 3, 5, 21])
 def test_tcn_bf16_block_kernel_forms_vs_oracle(nets, form):
     """The three forms of the bf16 block kernel (mst_tcn_set_tuning bits 1-2: 0 = one tile per workgroup, 1 = "stream", 2 = "duo";
     the two persistent forms get their input rows by LDS-DMA) against the oracle - per block and on the waveform, ragged length (tiles that end outside the segment), per-item
-    FiLM rows, a batch larger than the persistent grid's first wave of tiles."""
+    FiLM rows, a batch larger than the persistent grid's first wave of tiles.  21 = the duo form with the class-major main loop (bit 4, the
+    default): the same products in another fp32 summation order - agrees with 5 to accumulation rounding, not bit by bit."""
     from music_mixing_style_transfer_amd import _lib
     from music_mixing_style_transfer_amd.utils import synth
     from oracle import networks_ref as R
@@ -130,9 +131,13 @@ def test_tcn_bf16_block_kernel_forms_vs_oracle(nets, form):
         assert err <= 1e-2
         assert torch.equal(tcn(x.cuda(), cond.cuda()).cpu(), y)          # deterministic
         assert torch.equal(tcn(x[1:2].cuda(), cond[1:2].cuda()).cpu()[0], y[1])      # segments are independent, whatever tile walks them
-        if form == 5:          # the duo form runs the default form's arithmetic in the default form's order
+        if form == 5:          # the duo form runs the one-tile form's arithmetic in the one-tile form's order
             lib.check(lib.mst_tcn_set_tuning(tcn._handle, 1), "mst_tcn_set_tuning")
             assert torch.equal(tcn(x.cuda(), cond.cuda()).cpu(), y)
+        if form == 21:         # class-major: another summation order
+            lib.check(lib.mst_tcn_set_tuning(tcn._handle, 5), "mst_tcn_set_tuning")
+            y5 = tcn(x.cuda(), cond.cuda()).cpu()
+            assert not torch.equal(y5, y) and float((y5 - y).abs().max()) <= 1e-2
     finally:
         lib.check(lib.mst_tcn_set_tuning(tcn._handle, _lib.TCN_TUNING_DEFAULT), "mst_tcn_set_tuning")
         tcn.precision = "fp32"

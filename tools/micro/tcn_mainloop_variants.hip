@@ -269,6 +269,92 @@ __global__ __launch_bounds__(256, 2) void k_w64_16(const bf16x8 *wpk, float *out
     out[(size_t)blockIdx.x * 256 + tid] = s;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// round 4: B-FRAGMENT REUSE ACROSS TAPS.  With P = 4 phases per tile the B fragment of (tap j, column tile q) is rows 4 j + 16 q ..+15 of
+// the LDS image - the same rows as (tap j + 4, column tile q - 1).  The product loop reads each of the 75 x 4 distinct fragments up to four
+// times (960 ds_read_b128 per tile).  Class-major order: the taps fall into four classes c = j mod 4; for one class and one k-step (kk)
+// the wave holds the A fragments of its <= 4 taps x 2 row tiles (double-buffered: 64 registers) and walks the 16 + 3 row windows
+// i of that class once - window i feeds tap c + 4 u into column tile i - u: 304 reads per tile, up to 8 MFMAs per read.
+// The A stream is unchanged (128 fragments per tile against 120).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned ru32x4;
+struct RStream { __amdgpu_buffer_rsrc_t rsrc; unsigned voff; };
+__device__ __forceinline__ bf16x8 rs_load(const RStream &s, unsigned soffset) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, (int)s.voff, (int)soffset, 0));
+}
+template <int NU>
+__device__ __forceinline__ void reuse_class(f32x4 (&acc)[2][16], bf16x8 (&A0)[4][2], bf16x8 (&A1)[4][2], bf16x8 (&ring)[4],
+                                            const unsigned char *smem, const RStream &wp, int c, int cn, int l16, int g) {
+    constexpr int NW = 15 + NU;                                   // row windows of a class: column tile 0 of tap c .. tile 15 of its last tap
+    const int rsw = (4 * c + l16) & 15, rswn = (4 * cn + l16) & 15;
+    const unsigned char *rowb = smem + (4 * c + l16) * 256, *rowbn = smem + (4 * cn + l16) * 256;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 (&cur)[4][2] = (kk & 1) ? A1 : A0;
+        bf16x8 (&nxt)[4][2] = (kk & 1) ? A0 : A1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                             // the next phase's A fragments: a whole phase (~120 MFMAs) ahead
+            const int cc = kk < 3 ? c : cn, kn = kk < 3 ? kk + 1 : 0;
+            int j = cc + 4 * u;
+            j = j < 15 ? j : 14;                                   // class 3 has three taps: the fourth slot loads a fragment nobody uses
+            if (kk < 3 && u >= NU) continue;
+            const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((j * 4 + kn) * 8192);
+            nxt[u][0] = rs_load(wp, so);
+            nxt[u][1] = rs_load(wp, so + 4096u);
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int n = kk * NW + i;
+            const bf16x8 b = ring[n & 3];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int q = i - u;
+                if (q >= 0 && q < 16) {
+                    acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u][0], b, acc[0][q], 0, 0, 0);
+                    acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u][1], b, acc[1][q], 0, 0, 0);
+                }
+            }
+            const int n2 = n + 4, k2 = n2 / NW, i2 = n2 % NW;      // the window four ahead: this class, or the next one's first k-step
+            if (k2 < 4)
+                ring[n & 3] = *(const bf16x8 *)(rowb + (((4 * k2 + g) ^ rsw) << 4) + i2 * 4096);
+            else
+                ring[n & 3] = *(const bf16x8 *)(rowbn + ((g ^ rswn) << 4) + i2 * 4096);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+__global__ __launch_bounds__(256, 2) void k_reuse16(const bf16x8 *wpk, float *out, int rep) {
+    constexpr int P = 4, T = 256, R = T + 14 * P;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l16 = lane & 15, g = lane >> 4;
+    fill_lds(smem, R * 256, tid);
+    __syncthreads();
+    f32x4 acc[2][16];
+    for (int m = 0; m < 2; ++m)
+        for (int q = 0; q < 16; ++q)
+            for (int i = 0; i < 4; ++i) acc[m][q][i] = 0.0f;
+    const RStream wp{__builtin_amdgcn_make_buffer_rsrc((void *)wpk, 0, 120 * 4096, 0x00020000), (unsigned)(w * 64 + lane) * 16u};
+    bf16x8 A0[4][2], A1[4][2], ring[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        A0[u][0] = rs_load(wp, (unsigned)(4 * u * 4) * 8192u);
+        A0[u][1] = rs_load(wp, (unsigned)(4 * u * 4) * 8192u + 4096u);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ring[i] = *(const bf16x8 *)(smem + l16 * 256 + ((g ^ l16) << 4) + i * 4096);
+    for (int r = 0; r < rep; ++r) {
+#pragma unroll 1
+        for (int c = 0; c < 3; ++c) reuse_class<4>(acc, A0, A1, ring, smem, wp, c, c + 1, l16, g);
+        reuse_class<3>(acc, A0, A1, ring, smem, wp, 3, 0, l16, g);
+    }
+    float s = 0.0f;
+    for (int m = 0; m < 2; ++m)
+        for (int q = 0; q < 16; ++q)
+            for (int i = 0; i < 4; ++i) s += acc[m][q][i];
+    out[(size_t)blockIdx.x * 256 + tid] = s;
+}
+
 // sustained rate: NL launches back to back (~0.15 s), the second half timed - the chip's power controller needs tens of milliseconds
 // to settle, a pair of launches measures the transient (1277 vs 1480 TFLOP/s for the same kernel in two consecutive pairs)
 template <typename F> static void run(const char *name, F launch, int rep) {
@@ -314,6 +400,9 @@ int main() {
         run("noA16x16", [&] { k_base16<1><<<512, 256>>>(wa, out, rep); }, rep);
         run("noB16x16", [&] { k_base16<2><<<512, 256>>>(wa, out, rep); }, rep);
         run("w64_16x16", [&] { k_w64_16<<<512, 256>>>(wa, out, rep); }, rep);
+        run("reuse16x16", [&] { k_reuse16<<<512, 256>>>(wa, out, rep); }, rep);
+        run("base16x16", [&] { k_base16<0><<<512, 256>>>(wa, out, rep); }, rep);
+        run("reuse16x16", [&] { k_reuse16<<<512, 256>>>(wa, out, rep); }, rep);
     }
     return 0;
 }
