@@ -47,6 +47,68 @@ struct TcnBlockArgs {
 };
 
 // ------------------------------------------------------------------------------------------------
+// The class-major main loop (B fragments reused across taps, tcn_reuse_class below) for the one-tile kernel's 128-time tiles that span their
+// WHOLE phase sequence: four phases x 32 steps (d = 4096 at L = 131072) and eight phases x 16 steps (d = 8192, the last block).
+// Fully unrolled - every index is a compile-time constant - so that the (column tile, tap) pairs that only see zero padding are simply not
+// there (P = 4: 8 of 120, P = 8: 24 of 120).  Taps of one residue class mod S = 16 / P share their B fragments (tap j + S, column tile
+// q - 1 = the rows of tap j, column tile q); a class is walked in groups of <= 4 taps ("pseudo-classes": 4 + 4 + 4 + 3 taps at both P)
+// so that a group's A fragments are 32 registers, double-buffered over the 16 phases (pseudo-class x k-step).
+// ------------------------------------------------------------------------------------------------
+template <int P, int NC>
+__device__ __forceinline__ void tcn_class_major_whole_tile(f32x4 (&acc)[2][NC], const unsigned char *smem, const MstStream16 &wst, unsigned aoff,
+                                                           int l16, int g) {
+    static_assert((P == 4 || P == 8) && NC == 8, "128-time tiles of four / eight phases");
+    constexpr int S = 16 / P, MT = 16 * NC / P, NW4 = NC + 3, NW3 = NC + 2, NWIN = 12 * NW4 + 4 * NW3;
+    auto j0_of = [](int pc) { return pc % S + 4 * S * (pc / S); };          // first tap of pseudo-class pc
+    auto nu_of = [](int pc) { return pc < 3 ? 4 : 3; };
+    auto dead = [](int q, int j) {          // rows of steps < 0 / >= MT are padding (the tile starts at the first step and ends at the last)
+        const int s_lo = (16 * q) / P + j - 7, s_hi = (16 * q + 15) / P + j - 7;
+        return s_hi < 0 || s_lo >= MT;
+    };
+    auto window = [&](int n) -> const unsigned char * {                      // LDS address of this lane's 16 bytes of window n
+        const int ph = n < 12 * NW4 ? n / NW4 : 12 + (n - 12 * NW4) / NW3, i = n < 12 * NW4 ? n % NW4 : (n - 12 * NW4) % NW3;
+        const int row0 = P * j0_of(ph >> 2), kk = ph & 3;
+        return smem + (row0 + 16 * i + l16) * 256 + (((4 * kk + g) ^ ((row0 + l16) & 15)) << 4);
+    };
+    auto load_a = [&](bf16x8 (&A)[4][2], int ph) {
+        const int pc = ph >> 2, kk = ph & 3;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (u >= nu_of(pc)) continue;
+            const unsigned so = (unsigned)((j0_of(pc) + S * u) * 4 + kk) * 8192u;
+            A[u][0] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff, so));
+            A[u][1] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + 4096u, so));
+        }
+    };
+    bf16x8 A0[4][2], A1[4][2], ring[4];
+    load_a(A0, 0);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) ring[n] = *(const bf16x8 *)window(n);
+#pragma unroll
+    for (int ph = 0; ph < 16; ++ph) {
+        bf16x8 (&cur)[4][2] = (ph & 1) ? A1 : A0;
+        bf16x8 (&nxt)[4][2] = (ph & 1) ? A0 : A1;
+        if (ph < 15) load_a(nxt, ph + 1);
+        const int pc = ph >> 2, nw = pc < 3 ? NW4 : NW3, n0 = pc < 3 ? ph * NW4 : 12 * NW4 + (ph - 12) * NW3;
+#pragma unroll
+        for (int i = 0; i < nw; ++i) {
+            const int n = n0 + i;
+            const bf16x8 b = ring[n & 3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = i - u, j = j0_of(pc) + S * u;
+                if (u < nu_of(pc) && q >= 0 && q < NC && !dead(q, j)) {
+                    acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u][0], b, acc[0][q], 0, 0, 0);
+                    acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u][1], b, acc[1][q], 0, 0, 0);
+                }
+            }
+            if (n + 4 < NWIN) ring[n & 3] = *(const bf16x8 *)window(n + 4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // blocks 1..n-1, bf16 MFMA (v_mfma_f32_16x16x32_bf16), bf16 activations.  MFMA-bound:
 // 2*128*1920 = 491 520 FLOP per output time step against 512 B of HBM traffic.
 // ------------------------------------------------------------------------------------------------
@@ -147,104 +209,67 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
         const unsigned aoff = (unsigned)(w * 64 + lane) * 16u;
         constexpr int RB = 8;
         static_assert(NC % RB == 0, "the ring divides the column tiles");
-        bf16x8 af[2][4], bf[RB];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) af[m][kk] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)kk * 8192u));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        {
-            const unsigned char *rp0 = smem + l16 * 256 + ((g ^ l16) << 4);
-#pragma unroll
-            for (int q = 0; q < RB; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 4096);
-        }
         // A (column tile q, tap j) pair whose 16 input rows are all zero padding contributes nothing.
-        //  * P = 16 tiles (largest dilation on a very short segment): skipped under a wave-uniform branch (run_taps<false, false>).
-        //  * P = 8 tiles of 16 steps that start at the first step of their phase sequence (LO) and end at its last (HI) - d = 8192 at
-        //    L = 131072, the last block: the pattern is known at COMPILE time - the tap loop is unrolled and the dead pairs are simply not
-        //    there (20 % of the tile's MFMAs).  A branch per MFMA pair instead was measured slower than not skipping at all (it breaks the
-        //    mfma / mfma / ds_read pipeline: 1.58 -> 1.85 ms, TCN_LIVE_MIN_P).  (No sched_group_barrier in the unrolled form: hipcc's
-        //    scheduler does not finish a 960-MFMA block with them in 40 minutes.)
+        //  * P = 16 tiles (largest dilation on a very short segment): skipped under a wave-uniform branch.
+        //  * 128-time tiles of four / eight phases that span their WHOLE phase sequence (d = 4096 / 8192 at L = 131072, the last two
+        //    blocks): the pattern is known at COMPILE time - tcn_class_major_whole_tile is unrolled and the dead pairs are simply not there
+        //    (7 % / 20 % of the tile's MFMAs).  A branch per MFMA pair instead was measured slower than not skipping at all (it breaks
+        //    the mfma / mfma / ds_read pipeline: 1.58 -> 1.85 ms, TCN_LIVE_MIN_P).
         const int nsteps = (int)(((long)a.L + a.d - 1) / a.d);
-        auto run_taps = [&](auto lo_c, auto hi_c) {
-            constexpr bool LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-            if constexpr (LO || HI) {
-                static_assert(NC == RB, "one ring turn per k-step");
-                auto dead = [](int q, int j) {          // relative to the tile's first step: rows of steps < 0 (LO) / >= MT (HI) are padding
-                    const int s_lo = (16 * q) / P + j - 7, s_hi = (16 * q + 15) / P + j - 7;
-                    return (LO && s_hi < 0) || (HI && s_lo >= MT);
-                };
+        auto tap_major = [&]() {
+            bf16x8 af[2][4], bf[RB];
 #pragma unroll
-                for (int j = 0; j < 15; ++j) {
-                    const int jn = j < 14 ? j + 1 : 14;
-                    const int rb0 = j * P + l16, rb1 = jn * P + l16;
+            for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const int rbn = (kk == 3) ? rb1 : rb0;
-                        const int kn = (kk + 1) & 3;
-                        const int jx = (kk == 3) ? j + 1 : j;          // the tap of the k-step this ring slot is read for next
-                        const unsigned char *np = smem + rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
+                for (int m = 0; m < 2; ++m) af[m][kk] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)kk * 8192u));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            {
+                const unsigned char *rp0 = smem + l16 * 256 + ((g ^ l16) << 4);
 #pragma unroll
-                        for (int q = 0; q < NC; ++q) {
-                            if (!dead(q, j)) {
-                                acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][kk], bf[q], acc[0][q], 0, 0, 0);
-                                acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][kk], bf[q], acc[1][q], 0, 0, 0);
-                            }
-                            if (jx < 15 && !dead(q, jx)) {
-                                bf[q] = *(const bf16x8 *)(np + q * 4096);
-                            }
-                        }
-                        if (j < 14) {
+                for (int q = 0; q < RB; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 4096);
+            }
+            for (int j = 0; j < 15; ++j) {
+                const int jn = j < 14 ? j + 1 : 14;
+                const int rb0 = j * P + l16, rb1 = jn * P + l16;
+                unsigned live = 0xffffu;
+                if constexpr (P >= TCN_LIVE_MIN_P) {
+                    live = 0;
 #pragma unroll
-                            for (int m = 0; m < 2; ++m) af[m][kk] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)(jn * 4 + kk) * 8192u));
-                        }
+                    for (int q = 0; q < NC; ++q) {
+                        const int s_lo = m0 + (16 * q) / P + j - 7, s_hi = m0 + (16 * q + 15) / P + j - 7;
+                        if (!(s_hi < 0 || s_lo >= nsteps)) live |= 1u << q;
                     }
                 }
-            } else {
-                for (int j = 0; j < 15; ++j) {
-                    const int jn = j < 14 ? j + 1 : 14;
-                    const int rb0 = j * P + l16, rb1 = jn * P + l16;
-                    unsigned live = 0xffffu;
-                    if constexpr (P >= TCN_LIVE_MIN_P) {
-                        live = 0;
 #pragma unroll
-                        for (int q = 0; q < NC; ++q) {
-                            const int s_lo = m0 + (16 * q) / P + j - 7, s_hi = m0 + (16 * q + 15) / P + j - 7;
-                            if (!(s_hi < 0 || s_lo >= nsteps)) live |= 1u << q;
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int rbn = (kk == 3) ? rb1 : rb0;
+                    const int kn = (kk + 1) & 3;
+                    const unsigned char *cp = smem + rb0 * 256 + (((4 * kk + g) ^ (rb0 & 15)) << 4);
+                    const unsigned char *np = smem + rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) {
+                        if (P < TCN_LIVE_MIN_P || ((live >> q) & 1u)) {
+                            acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][kk], bf[q % RB], acc[0][q], 0, 0, 0);
+                            acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][kk], bf[q % RB], acc[1][q], 0, 0, 0);
                         }
+                        bf[q % RB] = (q + RB < NC) ? *(const bf16x8 *)(cp + (q + RB) * 4096) : *(const bf16x8 *)(np + (q + RB - NC) * 4096);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const int rbn = (kk == 3) ? rb1 : rb0;
-                        const int kn = (kk + 1) & 3;
-                        const unsigned char *cp = smem + rb0 * 256 + (((4 * kk + g) ^ (rb0 & 15)) << 4);
-                        const unsigned char *np = smem + rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
-#pragma unroll
-                        for (int q = 0; q < NC; ++q) {
-                            if (P < TCN_LIVE_MIN_P || ((live >> q) & 1u)) {
-                                acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][kk], bf[q % RB], acc[0][q], 0, 0, 0);
-                                acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][kk], bf[q % RB], acc[1][q], 0, 0, 0);
-                            }
-                            bf[q % RB] = (q + RB < NC) ? *(const bf16x8 *)(cp + (q + RB) * 4096) : *(const bf16x8 *)(np + (q + RB - NC) * 4096);
-                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        }
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) af[m][kk] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)(jn * 4 + kk) * 8192u));
-                        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-                    }
+                    for (int m = 0; m < 2; ++m) af[m][kk] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)(jn * 4 + kk) * 8192u));
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
                 }
             }
         };
-        if constexpr (P == 8 && NQ == 4) {
-            // only the tile that spans its WHOLE phase sequence (16 steps: d = 8192 at L = 131072) takes the unrolled form: measured 1.585 ->
-            // 1.405 ms per launch; the one-sided forms for the d = 4096 block's two tiles per sequence (10 % fewer MFMAs each) ran 1.60 -> 1.93 ms
-            // (two unrolled 12 KB loops alternating on a CU, hipcc's own schedule instead of the pinned mfma / mfma / ds_read one) and are not used
-            if (m0 == 0 && MT == nsteps) run_taps(std::true_type{}, std::true_type{});          // workgroup-uniform
-            else run_taps(std::false_type{}, std::false_type{});
+        if constexpr ((P == 8 || P == 4) && NQ == 4) {
+            // only the tile that spans its WHOLE phase sequence takes the unrolled class-major form (the one-sided forms for a sequence of two
+            // tiles - 10 % fewer MFMAs each - were measured slower in the tap-major order: two unrolled 12 KB loops alternating on a CU)
+            if (m0 == 0 && MT == nsteps) tcn_class_major_whole_tile<P, NC>(acc, smem, wst, aoff, l16, g);          // workgroup-uniform
+            else tap_major();
         } else {
-            run_taps(std::false_type{}, std::false_type{});
+            tap_major();
         }
     }
 

@@ -61,11 +61,13 @@ def test_tcn_large_dilation_and_odd_growth_emulated(emu_default):
 
 def test_tcn_bf16_whole_sequence_tiles_emulated(emu_default):
     """bf16 tiles of 8 phases x 16 steps that span their WHOLE phase sequence (d = 8 on 121 ... 128 samples: 16 steps per phase; at
-    L = 131072 that is the d = 8192 block) run the unrolled tap loop in which the (column tile, tap) pairs that only see zero padding do not
+    L = 131072 that is the d = 8192 block) run the unrolled class-major loop in which the (column tile, tap) pairs that only see zero padding do not
     exist.  Dropping a live pair would be an O(0.1) error: checked against the oracle at the bf16 tolerance, block by block, for the plain
     epilogue (block 3 of 5) and the fused output head (block 3 of 4), full and ragged last steps."""
     cond = synth.synth_audio((2, 64), seed=21)
-    for nb, L in ((4, 128), (4, 123), (5, 128), (5, 121)):
+    # (d = 8 on 249 ... 256 samples: 32 steps per phase = four-phase 128-time tiles that span their sequence: the d = 4096 block at L = 131072;
+    #  200 samples: the same tiles not spanning it - the tap-major loop)
+    for nb, L in ((4, 128), (4, 123), (5, 128), (5, 121), (4, 256), (5, 250), (5, 200)):
         m, sd = _tcn(nb)
         m.precision = "bf16"
         x = synth.synth_audio((2, 2, L), seed=30 + L)
