@@ -2140,13 +2140,14 @@ __global__ void tcn_unpack_kernel(const void *x, float *y, int B, int L, int Lp)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Calibration of the box (bench.py "roofline.calib_ms"): the BARE MAIN LOOP of tcn_block_bf16_kernel - v_mfma_f32_16x16x32_bf16 with the
-// product loop's operand traffic (two weight fragments from L2 and sixteen B fragments from LDS per 32 MFMAs), no staging, no epilogue,
-// no store - on synthetic operands with realistic statistics (activations ~ N(0, 0.5^2), weights ~ N(0, 0.05^2): the chip's power limit
+// Calibration of the box (bench.py "roofline.calib_ms"): the BARE MAIN LOOP of tcn_block_bf16_duo_kernel - v_mfma_f32_16x16x32_bf16 with the
+// product loop's operand traffic (class-major since round 4's last third: 128 weight fragments from L2 and 304 B fragments from LDS per
+// 1920 MFMAs; before: 120 and 960 - the tap-major loop; same box 1.230 -> 1.145 ms, profiles/r04_micro_mainloop_reuse.txt, so calib_ms
+// values of earlier records are 7 % higher for the same box), no staging, no epilogue, no store - on synthetic operands with realistic statistics (activations ~ N(0, 0.5^2), weights ~ N(0, 0.05^2): the chip's power limit
 // depends on the operand bits).  512 workgroups x `rep` tiles of 256 times: rep = 32 is exactly the arithmetic of one dense TCN block
 // launch at 32 x 131072 (2.06 TFLOP), so its duration is what this box lets the block kernel's main loop run at - boxes of the pool
 // differ by +-4 %, the block kernel divided by THIS is comparable across boxes.  Thread 0 of workgroup 0 also reports the shader clock
-// it ran at (s_memtime counts shader clocks, s_memrealtime 100 MHz).  tools/micro/tcn_mainloop_variants.hip::k_base16<0>, unchanged.
+// it ran at (s_memtime counts shader clocks, s_memrealtime 100 MHz).  tools/micro/tcn_mainloop_variants.hip::k_reuse16.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned calib_normalish_bf16(unsigned z, float sigma) {      // sum of four uniform bytes: ~ N(0, sigma^2), as bf16 bits
     z ^= z >> 16; z *= 0x7feb352du; z ^= z >> 15; z *= 0x846ca68bu; z ^= z >> 16;
@@ -2176,39 +2177,21 @@ __global__ __launch_bounds__(256, 2) void tcn_calib_mainloop_kernel(const void *
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[m][q] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    const bf16x8 *wp = (const bf16x8 *)wpk + (w * 64 + lane);                     // [k32-step (4 per tap)][row tile][wave][lane]
+    // the class-major loop of the duo kernel's four-phase tiles (tcn_reuse_class), tile after tile on the same LDS image
+    const MstStream16 wst = mst_stream16(wpk, 60u * 2u * 4096u);
+    const unsigned aoff = (unsigned)(w * 64 + lane) * 16u;
+    bf16x8 A0[4][2], A1[4][2], ring[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) A0[u][m] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)(16 * u) * 8192u));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ring[i] = *(const bf16x8 *)(smem + l16 * 256 + ((g ^ l16) << 4) + i * 4096);
     for (int r = 0; r < rep; ++r) {
-        bf16x8 af[2][4], bf[16];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            af[0][kk] = wp[(kk * 2) * 256];
-            af[1][kk] = wp[(kk * 2 + 1) * 256];
-        }
-        {
-            const unsigned char *rp0 = smem + l16 * 256 + ((g ^ l16) << 4);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 4096);
-        }
-        for (int j = 0; j < 15; ++j) {
-            const int jn = j < 14 ? j + 1 : 14;
-            const int rb0 = j * P + l16, rb1 = jn * P + l16;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int rbn = (kk == 3) ? rb1 : rb0;
-                const int kn = (kk + 1) & 3;
-                const unsigned char *np = smem + rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][kk], bf[q], acc[0][q], 0, 0, 0);
-                    acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][kk], bf[q], acc[1][q], 0, 0, 0);
-                    bf[q] = *(const bf16x8 *)(np + q * 4096);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                af[0][kk] = wp[((jn * 4 + kk) * 2) * 256];
-                af[1][kk] = wp[((jn * 4 + kk) * 2 + 1) * 256];
-            }
-        }
+#pragma unroll 1
+        for (int c = 0; c < 3; ++c) tcn_reuse_class<P, 4, false, 4>(acc, A0, A1, ring, smem, wst, aoff, c, c + 1, l16, g);
+        tcn_reuse_class<P, 3, false, 4>(acc, A0, A1, ring, smem, wst, aoff, 3, 0, l16, g);
     }
     float s = 0.0f;
 #pragma unroll
