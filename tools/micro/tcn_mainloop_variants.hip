@@ -283,7 +283,9 @@ struct RStream { __amdgpu_buffer_rsrc_t rsrc; unsigned voff; };
 __device__ __forceinline__ bf16x8 rs_load(const RStream &s, unsigned soffset) {
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, (int)s.voff, (int)soffset, 0));
 }
-template <int NU>
+// MODE 0: the loop as built into the kernels; 1: the A fragments are not re-fetched (as if the weight stream were free); 2: no
+// sched_barrier behind the windows (the compiler's own schedule)
+template <int NU, int MODE>
 __device__ __forceinline__ void reuse_class(f32x4 (&acc)[2][16], bf16x8 (&A0)[4][2], bf16x8 (&A1)[4][2], bf16x8 (&ring)[4],
                                             const unsigned char *smem, const RStream &wp, int c, int cn, int l16, int g) {
     constexpr int NW = 15 + NU;                                   // row windows of a class: column tile 0 of tap c .. tile 15 of its last tap
@@ -299,6 +301,7 @@ __device__ __forceinline__ void reuse_class(f32x4 (&acc)[2][16], bf16x8 (&A0)[4]
             int j = cc + 4 * u;
             j = j < 15 ? j : 14;                                   // class 3 has three taps: the fourth slot loads a fragment nobody uses
             if (kk < 3 && u >= NU) continue;
+            if (MODE == 1) continue;
             const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((j * 4 + kn) * 8192);
             nxt[u][0] = rs_load(wp, so);
             nxt[u][1] = rs_load(wp, so + 4096u);
@@ -320,10 +323,11 @@ __device__ __forceinline__ void reuse_class(f32x4 (&acc)[2][16], bf16x8 (&A0)[4]
                 ring[n & 3] = *(const bf16x8 *)(rowb + (((4 * k2 + g) ^ rsw) << 4) + i2 * 4096);
             else
                 ring[n & 3] = *(const bf16x8 *)(rowbn + ((g ^ rswn) << 4) + i2 * 4096);
-            __builtin_amdgcn_sched_barrier(0);
+            if (MODE != 2) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_reuse16(const bf16x8 *wpk, float *out, int rep) {
     constexpr int P = 4, T = 256, R = T + 14 * P;
     __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
@@ -342,11 +346,16 @@ __global__ __launch_bounds__(256, 2) void k_reuse16(const bf16x8 *wpk, float *ou
         A0[u][1] = rs_load(wp, (unsigned)(4 * u * 4) * 8192u + 4096u);
     }
 #pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        A1[u][0] = A0[(u + 1) & 3][1];
+        A1[u][1] = A0[(u + 2) & 3][0];
+    }
+#pragma unroll
     for (int i = 0; i < 4; ++i) ring[i] = *(const bf16x8 *)(smem + l16 * 256 + ((g ^ l16) << 4) + i * 4096);
     for (int r = 0; r < rep; ++r) {
 #pragma unroll 1
-        for (int c = 0; c < 3; ++c) reuse_class<4>(acc, A0, A1, ring, smem, wp, c, c + 1, l16, g);
-        reuse_class<3>(acc, A0, A1, ring, smem, wp, 3, 0, l16, g);
+        for (int c = 0; c < 3; ++c) reuse_class<4, MODE>(acc, A0, A1, ring, smem, wp, c, c + 1, l16, g);
+        reuse_class<3, MODE>(acc, A0, A1, ring, smem, wp, 3, 0, l16, g);
     }
     float s = 0.0f;
     for (int m = 0; m < 2; ++m)
@@ -400,9 +409,11 @@ int main() {
         run("noA16x16", [&] { k_base16<1><<<512, 256>>>(wa, out, rep); }, rep);
         run("noB16x16", [&] { k_base16<2><<<512, 256>>>(wa, out, rep); }, rep);
         run("w64_16x16", [&] { k_w64_16<<<512, 256>>>(wa, out, rep); }, rep);
-        run("reuse16x16", [&] { k_reuse16<<<512, 256>>>(wa, out, rep); }, rep);
+        run("reuse16x16", [&] { k_reuse16<0><<<512, 256>>>(wa, out, rep); }, rep);
         run("base16x16", [&] { k_base16<0><<<512, 256>>>(wa, out, rep); }, rep);
-        run("reuse16x16", [&] { k_reuse16<<<512, 256>>>(wa, out, rep); }, rep);
+        run("reuse16x16", [&] { k_reuse16<0><<<512, 256>>>(wa, out, rep); }, rep);
+        run("reuse_noA", [&] { k_reuse16<1><<<512, 256>>>(wa, out, rep); }, rep);
+        // (k_reuse16<2>, no sched_barrier behind the windows: hipcc hoists the LDS reads and spills 391 registers - not worth a run)
     }
     return 0;
 }
