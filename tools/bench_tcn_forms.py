@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""A/B of the bf16 TCN block kernel forms on the MI355X (mst_tcn_set_tuning flags 1 / 3 / 5): the one-tile-per-workgroup kernel
-against the two persistent LDS-DMA-fed kernels ("stream", "duo").  Per-block kernel times from HIP events on the launch stream (mst_tcn_timing_*), the forms
+"""A/B of the bf16 TCN block kernel forms on the MI355X (mst_tcn_set_tuning flags 1 / 3 / 5 / 21): the one-tile-per-workgroup kernel
+against the two persistent LDS-DMA-fed kernels ("stream", "duo"; 21 = duo with the class-major main loop, the default).  Per-block kernel times from HIP events on the launch stream (mst_tcn_timing_*), the forms
 alternating so that both see the same clock / thermal state; parity of the two forms against each other at full size and against
 the oracle on a short segment.
 
