@@ -116,7 +116,8 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
  * default 21):
  * bit 0 (bf16x3 mode; default 1, measured 5.13 instead of 5.45 ms per launch at 32 x 131072): the split-bf16 block kernel on 128-time
  *   tiles of <= 2 phases (two workgroups per CU) wherever the segment has at least 64 steps per phase, 0 = 256-time tiles (one
- *   workgroup per CU); identical results.
+ *   workgroup per CU); the two-phase 128-time tiles run the class-major loop (B fragment pairs reused by the two taps of a class: 4.62 ->
+ *   4.09 ms per launch, round 4), the 256-time tiles the tap-major one: results agree to fp32 accumulation rounding (~1e-6).
  * bits 1-2 (bf16 mode), form of the dense block kernel - measured at 32 x 131072, profiles/r03_tcn_block_forms_summary.md:
  *   0 tcn_block_bf16_kernel: one tile per workgroup, two workgroups per CU                                              1.49-1.51 ms
  *   1 tcn_block_bf16_stream_kernel: persistent, input rows by LDS-DMA one 32-channel chunk ahead of the matrix cores,
@@ -126,7 +127,8 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
  *     the previous tile's row stores during the main loop; bit-identical to form 0                                       1.47-1.48 ms
  * bit 3 (bf16x3 mode; default 0): the 128-time-tile blocks run tcn_block_bf16x3_duo_kernel - persistent, one workgroup of 4 matrix waves
  *   + 4 loader waves per CU, two tile buffers; the loader waves fetch and split (hi + lo) the next tile and finish / store the previous
- *   one during the main loop; bit-identical to the one-tile kernel.  Measured 5.45-5.6 ms per launch against 4.55 ms (round 4): off.
+ *   one during the main loop; tap-major like the 256-time tiles (the one-tile kernel's results to accumulation rounding).  Measured
+ *   5.45-5.6 ms per launch against 4.55 ms tap-major / 4.09 class-major (round 4): off.
  * bit 4 (bf16 mode, form 2; default 1): the duo kernel's main loop runs class-major - taps grouped by j mod (16 / phases), every B
  *   fragment read from LDS once per class and k-step and fed to up to eight MFMAs (304 instead of 960 LDS reads per tile at four phases).
  *   Same products, another fp32 summation order: agrees with bit 4 off to accumulation rounding (not bit-identical).  Measured at

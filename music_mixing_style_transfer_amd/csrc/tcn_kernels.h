@@ -1039,6 +1039,69 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
 // max-abs on the output waveform (exact-fp32 mode: 9e-7; plain bf16 mode: 4e-3) at three MFMAs per bf16-mode MFMA.
 // Same polyphase tiling, LDS swizzle and fragment order as tcn_block_bf16_kernel; one workgroup per CU (two 78 KB tiles).
 // ------------------------------------------------------------------------------------------------
+// The class-major loop (tcn_reuse_class) in split arithmetic: per window one hi and one lo B fragment, per tap of the class three MFMAs per
+// row tile (W_lo x_hi, W_hi x_lo, W_hi x_hi: the small terms first, like the tap-major loop).  Two phases per tile (P = 2): eight classes of
+// two taps (the last: one) - every B fragment pair is read once per class instead of once per tap.
+template <int P, int NU, bool LASTC, int NUMAX, int NC>
+__device__ __forceinline__ void tcn_reuse_class_x3(f32x4 (&acc)[2][NC], bf16x8 (&H0)[NUMAX][2], bf16x8 (&L0)[NUMAX][2], bf16x8 (&H1)[NUMAX][2],
+                                                   bf16x8 (&L1)[NUMAX][2], bf16x8 (&rh)[4], bf16x8 (&rl)[4], const unsigned char *sm_hi,
+                                                   const unsigned char *sm_lo, const unsigned char *wbase, size_t lo_img, unsigned aoff, int c, int cn,
+                                                   int l16, int g) {
+    constexpr int NW = NC - 1 + NU, NCLS = 16 / P;
+    static_assert(NW >= 4, "the ring is four windows deep");
+    const int rsw = (P * c + l16) & 15, rswn = (P * cn + l16) & 15;
+    const int rowb = (P * c + l16) * 256, rowbn = (P * cn + l16) * 256;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 (&ch)[NUMAX][2] = (kk & 1) ? H1 : H0;
+        bf16x8 (&cl)[NUMAX][2] = (kk & 1) ? L1 : L0;
+        bf16x8 (&nh)[NUMAX][2] = (kk & 1) ? H0 : H1;
+        bf16x8 (&nl)[NUMAX][2] = (kk & 1) ? L0 : L1;
+        if (!(LASTC && kk == 3)) {          // behind the tile's last phase nothing is fetched (one tile per workgroup)
+#pragma unroll
+            for (int u = 0; u < NUMAX; ++u) {
+                if (kk < 3 && u >= NU) continue;
+                int j = (kk < 3 ? c : cn) + NCLS * u;
+                j = j < 15 ? j : 14;
+                const size_t so = (size_t)((j * 4 + (kk < 3 ? kk + 1 : 0)) * 2) * 4096 + aoff;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    nh[u][m] = *(const bf16x8 *)(wbase + so + (size_t)m * 4096);
+                    nl[u][m] = *(const bf16x8 *)(wbase + lo_img + so + (size_t)m * 4096);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int n = kk * NW + i;
+            const bf16x8 bh = rh[n & 3], bl = rl[n & 3];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int q = i - u;
+                if (q >= 0 && q < NC) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cl[u][m], bh, acc[m][q], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch[u][m], bl, acc[m][q], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch[u][m], bh, acc[m][q], 0, 0, 0);
+                }
+            }
+            const int n2 = n + 4, k2 = n2 / NW, i2 = n2 % NW;
+            if (k2 < 4) {
+                const int ofs = rowb + (((4 * k2 + g) ^ rsw) << 4) + i2 * 4096;
+                rh[n & 3] = *(const bf16x8 *)(sm_hi + ofs);
+                rl[n & 3] = *(const bf16x8 *)(sm_lo + ofs);
+            } else if (!LASTC) {
+                const int ofs = rowbn + ((g ^ rswn) << 4) + i2 * 4096;
+                rh[n & 3] = *(const bf16x8 *)(sm_hi + ofs);
+                rl[n & 3] = *(const bf16x8 *)(sm_lo + ofs);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 template <int P, int NQ>
 __global__ __launch_bounds__(256, (NQ == 4 && P <= 2) ? 2 : 1) void tcn_block_bf16x3_kernel(TcnBlockArgs a) {
     constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P;
@@ -1115,56 +1178,81 @@ __global__ __launch_bounds__(256, (NQ == 4 && P <= 2) ? 2 : 1) void tcn_block_bf
     constexpr size_t LO_IMG = (size_t)120 * 4096;
     // ring of 2 k-steps of A fragments (hi and lo, two row tiles): the set of k-step ks + 2 is requested from L2 when ks has been consumed;
     // ring of 8 column tiles of B fragments (hi and lo)
-    constexpr int RB = 8;
-    static_assert(NC % RB == 0, "the ring divides the column tiles");
-    bf16x8 ah[2][2], al[2][2], bh[RB], bl[RB];
+    if constexpr (P == 2 && NQ == 4) {
+        // class-major (round 4): B fragment pairs reused by the two taps of a class (j mod 8) - 576 instead of 960 LDS reads per tile
+        constexpr int NCLS = 16 / P, NUMAX = 2;
+        bf16x8 H0[NUMAX][2], L0[NUMAX][2], H1[NUMAX][2], L1[NUMAX][2], rh[4], rl[4];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            ah[kk][m] = *(const bf16x8 *)(wbase + (size_t)(kk * 2 + m) * 4096 + aoff);
-            al[kk][m] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)(kk * 2 + m) * 4096 + aoff);
-        }
-    {
-        const int o0 = l16 * 256 + ((g ^ l16) << 4);
-#pragma unroll
-        for (int q = 0; q < RB; ++q) {
-            bh[q] = *(const bf16x8 *)(sm_hi + o0 + q * 4096);
-            bl[q] = *(const bf16x8 *)(sm_lo + o0 + q * 4096);
-        }
-    }
-    for (int j = 0; j < 15; ++j) {
-        const int jn = j < 14 ? j + 1 : 14;
-        const int rb0 = j * P + l16, rb1 = jn * P + l16;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int rbn = (kk == 3) ? rb1 : rb0;
-            const int kn = (kk + 1) & 3;
-            const int oc = rb0 * 256 + (((4 * kk + g) ^ (rb0 & 15)) << 4);
-            const int on = rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
-            const int s = kk & 1;
-            // per column tile six MFMAs (two row tiles x three terms, the small terms first): consecutive MFMAs alternate between the two
-            // accumulators; the fragment pair eight column tiles ahead is requested behind them
-#pragma unroll
-            for (int q = 0; q < NC; ++q) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s][m], bh[q % RB], acc[m][q], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][m], bl[q % RB], acc[m][q], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][m], bh[q % RB], acc[m][q], 0, 0, 0);
-                const int ofs = (q + RB < NC) ? oc + (q + RB) * 4096 : on + (q + RB - NC) * 4096;
-                bh[q % RB] = *(const bf16x8 *)(sm_hi + ofs);
-                bl[q % RB] = *(const bf16x8 *)(sm_lo + ofs);
-                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            }
-            int ksn = j * 4 + kk + 2;
-            ksn = ksn < 60 ? ksn : 59;
+        for (int u = 0; u < NUMAX; ++u)
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                ah[s][m] = *(const bf16x8 *)(wbase + (size_t)(ksn * 2 + m) * 4096 + aoff);
-                al[s][m] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)(ksn * 2 + m) * 4096 + aoff);
+                H0[u][m] = *(const bf16x8 *)(wbase + (size_t)((NCLS * u * 4) * 2 + m) * 4096 + aoff);
+                L0[u][m] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)((NCLS * u * 4) * 2 + m) * 4096 + aoff);
+            }
+        {
+            const int o0 = l16 * 256 + ((g ^ l16) << 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rh[i] = *(const bf16x8 *)(sm_hi + o0 + i * 4096);
+                rl[i] = *(const bf16x8 *)(sm_lo + o0 + i * 4096);
+            }
+        }
+#pragma unroll 1
+        for (int c = 0; c < NCLS - 1; ++c)
+            tcn_reuse_class_x3<P, NUMAX, false, NUMAX, NC>(acc, H0, L0, H1, L1, rh, rl, sm_hi, sm_lo, wbase, LO_IMG, aoff, c, c + 1, l16, g);
+        tcn_reuse_class_x3<P, 15 / NCLS, true, NUMAX, NC>(acc, H0, L0, H1, L1, rh, rl, sm_hi, sm_lo, wbase, LO_IMG, aoff, NCLS - 1, 0, l16, g);
+    } else {
+        constexpr int RB = 8;
+        static_assert(NC % RB == 0, "the ring divides the column tiles");
+        bf16x8 ah[2][2], al[2][2], bh[RB], bl[RB];
+    #pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+    #pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                ah[kk][m] = *(const bf16x8 *)(wbase + (size_t)(kk * 2 + m) * 4096 + aoff);
+                al[kk][m] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)(kk * 2 + m) * 4096 + aoff);
+            }
+        {
+            const int o0 = l16 * 256 + ((g ^ l16) << 4);
+    #pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                bh[q] = *(const bf16x8 *)(sm_hi + o0 + q * 4096);
+                bl[q] = *(const bf16x8 *)(sm_lo + o0 + q * 4096);
+            }
+        }
+        for (int j = 0; j < 15; ++j) {
+            const int jn = j < 14 ? j + 1 : 14;
+            const int rb0 = j * P + l16, rb1 = jn * P + l16;
+    #pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int rbn = (kk == 3) ? rb1 : rb0;
+                const int kn = (kk + 1) & 3;
+                const int oc = rb0 * 256 + (((4 * kk + g) ^ (rb0 & 15)) << 4);
+                const int on = rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
+                const int s = kk & 1;
+                // per column tile six MFMAs (two row tiles x three terms, the small terms first): consecutive MFMAs alternate between the two
+                // accumulators; the fragment pair eight column tiles ahead is requested behind them
+    #pragma unroll
+                for (int q = 0; q < NC; ++q) {
+    #pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s][m], bh[q % RB], acc[m][q], 0, 0, 0);
+    #pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][m], bl[q % RB], acc[m][q], 0, 0, 0);
+    #pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][m], bh[q % RB], acc[m][q], 0, 0, 0);
+                    const int ofs = (q + RB < NC) ? oc + (q + RB) * 4096 : on + (q + RB - NC) * 4096;
+                    bh[q % RB] = *(const bf16x8 *)(sm_hi + ofs);
+                    bl[q % RB] = *(const bf16x8 *)(sm_lo + ofs);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                int ksn = j * 4 + kk + 2;
+                ksn = ksn < 60 ? ksn : 59;
+    #pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    ah[s][m] = *(const bf16x8 *)(wbase + (size_t)(ksn * 2 + m) * 4096 + aoff);
+                    al[s][m] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)(ksn * 2 + m) * 4096 + aoff);
+                }
             }
         }
     }

@@ -51,12 +51,17 @@ def test_tcn_large_dilation_and_odd_growth_emulated(emu_default):
     m2.precision = "bf16x3"          # split-bf16 mode: 8-phase tiles of 128 times for the large dilations
     y3 = m2(x, cond)
     assert float((y3 - y_ref).abs().max()) <= 3e-5
-    emu_default.check(emu_default.mst_tcn_set_tuning(m2._handle, 0), "tuning")      # 256-time tiles instead of 128-time ones: same bits
-    assert torch.equal(m2(x, cond), y3)
+    # 256-time tiles instead of 128-time ones: the same products; the two-phase 128-time tiles sum them class-major (B fragments reused by the
+    # two taps of a class), the 256-time tiles tap-major - equal to fp32 accumulation rounding
+    emu_default.check(emu_default.mst_tcn_set_tuning(m2._handle, 0), "tuning")
+    assert float((m2(x, cond) - y3).abs().max()) <= 1e-5
     x5 = synth.synth_audio((2, 2, 700), seed=16)
     y5 = m2(x5, cond)
+    y5_ref = R.tcn_forward(sd2, x5, cond, nblocks=6)
+    assert float((y5 - y5_ref).abs().max()) <= 3e-5
     emu_default.check(emu_default.mst_tcn_set_tuning(m2._handle, 1), "tuning")
-    assert torch.equal(m2(x5, cond), y5)
+    y5s = m2(x5, cond)
+    assert float((y5s - y5).abs().max()) <= 1e-5 and float((y5s - y5_ref).abs().max()) <= 3e-5
 
 
 def test_tcn_bf16_whole_sequence_tiles_emulated(emu_default):
@@ -141,8 +146,8 @@ def test_tcn_bf16_duo_reuse_main_loop_emulated(emu_default):
 
 def test_tcn_bf16x3_duo_kernel_emulated(emu_default):
     """The persistent double-tile form of the split-bf16 block kernel (mst_tcn_set_tuning bit 3; not the default - measured slower): 4 matrix + 4 loader waves
-    per CU, the loader waves fetch / split the next tile and finish / store the previous one.  Same bits as the one-tile kernel (bit 3
-    off), and the oracle at the split mode's tolerance: several tiles per workgroup (the emulated device has 4 CUs), P = 1 and P = 2
+    per CU, the loader waves fetch / split the next tile and finish / store the previous one.  The one-tile kernel's results (bit 3
+    off) to accumulation rounding, and the oracle at the split mode's tolerance: several tiles per workgroup (the emulated device has 4 CUs), P = 1 and P = 2
     tiles, ragged lengths (rows past the segment), several batch items with one FiLM row each, buffers refilled three and more times."""
     cases = [(3, 2, (2, 2, 777), synth.synth_audio((1, 64), seed=2)),          # d = 2, 4: P = 2; 2 x 7 tiles
              (3, 3, (1, 2, 1300), synth.synth_audio((1, 64), seed=3)),         # d = 3, 9: P = 1; 11 tiles on 4 workgroups
@@ -160,7 +165,11 @@ def test_tcn_bf16x3_duo_kernel_emulated(emu_default):
         y1, a1 = m(x, cnd), m.forward_blocks(x, cnd, nb)
         assert float((y1 - y_ref).abs().max()) <= 3e-5
         assert float((a1 - col[nb - 1]).abs().max()) <= 3e-5 * float(col[nb - 1].abs().max())
-        assert torch.equal(y1, y0) and torch.equal(a1, a0)
+        # the duo form sums tap-major; the one-tile kernel's two-phase tiles class-major since round 4: equal to accumulation rounding there,
+        # bit for bit on the one-phase tiles (odd dilations)
+        assert float((y1 - y0).abs().max()) <= 1e-5 and float((a1 - a0).abs().max()) <= 1e-5 * float(a0.abs().max())
+        if growth == 3:
+            assert torch.equal(y1, y0) and torch.equal(a1, a0)
 
 
 def test_tcn_condition_forms_emulated(emu_default):

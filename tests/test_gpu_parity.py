@@ -187,13 +187,16 @@ def test_tcn_bf16x3_vs_oracle(nets):
         yB = tcn(x.cuda(), condB.cuda()).cpu()
         assert float((yB - R.tcn_forward(nets["tcn_sd"], x, condB)).abs().max()) <= 1e-4
         assert torch.equal(tcn(x[1:2].cuda(), condB[1:2].cuda()).cpu()[0], yB[1])
-        # the persistent double-tile form of the split-bf16 block kernel (mst_tcn_set_tuning bit 3; measured slower, not the default): same bits
+        # the persistent double-tile form of the split-bf16 block kernel (mst_tcn_set_tuning bit 3; measured slower, not the default): the same
+        # products summed tap-major (the one-tile kernel's two-phase tiles: class-major) - equal to fp32 accumulation rounding
         from music_mixing_style_transfer_amd import _lib
         lib = _lib.lib()
         try:
             lib.check(lib.mst_tcn_set_tuning(tcn._handle, _lib.TCN_TUNING_DEFAULT | 8), "mst_tcn_set_tuning")
-            assert torch.equal(tcn(x.cuda(), condB.cuda()).cpu(), yB)
-            assert torch.equal(tcn.forward_blocks(x.cuda(), cond.cuda(), 10).cpu(), a_10)
+            yD = tcn(x.cuda(), condB.cuda()).cpu()
+            assert float((yD - yB).abs().max()) <= 1e-5 and float((yD - R.tcn_forward(nets["tcn_sd"], x, condB)).abs().max()) <= 1e-4
+            aD = tcn.forward_blocks(x.cuda(), cond.cuda(), 10).cpu()
+            assert float((aD - a_10).abs().max()) <= 2e-5 * float(a_10.abs().max())
         finally:
             lib.check(lib.mst_tcn_set_tuning(tcn._handle, _lib.TCN_TUNING_DEFAULT), "mst_tcn_set_tuning")
     finally:
