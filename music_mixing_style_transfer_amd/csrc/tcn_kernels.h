@@ -118,8 +118,10 @@ __device__ __forceinline__ void tcn_class_major_whole_tile(f32x4 (&acc)[2][NC], 
 // tiles of 16, a k-step is 32 input channels of one tap.  Per FLOP it moves exactly the operands the 32 x 32 x 16 form moved (every
 // B fragment feeds two MFMAs) - and under the chip's power limit it runs 15 % faster: on realistic operands the bare instruction
 // stream sustains 1934-1982 TFLOP/s against 1666-1685, the whole main loop 1570-1585 against 1367-1377
-// (tools/micro/tcn_mainloop_variants.hip, profiles/r02_micro_tcn_mainloop_variants.txt).
-// phases per tile from which all-padding (column tile, tap) pairs are skipped.  8 was measured and dropped for this kernel (round 4, same-box
+// (tools/micro/tcn_mainloop_variants.hip, profiles/archive/r02_micro_tcn_mainloop_variants_16x16.txt).
+// The tap-major loop below serves the tiles that do not span their phase sequence; whole-sequence 128-time tiles run
+// tcn_class_major_whole_tile, the duo kernel's 256-time tiles tcn_reuse_class (B fragments reused across taps).
+// TCN_LIVE_MIN_P: phases per tile from which all-padding (column tile, tap) pairs are skipped under a branch.  8 was measured and dropped for this kernel (round 4, same-box
 // A/B at 32 x 131072): the d = 4096 / 8192 blocks skip 10 % / 20 % of their MFMAs but run 1.58 -> 1.85 / 1.57 -> 1.74 ms - the wave-uniform
 // branches around the MFMA pairs break the (mfma, mfma, ds_read) software pipeline; the split-bf16 kernel (6 MFMAs per branch) gains 3-5 %
 constexpr int TCN_LIVE_MIN_P = 16;
