@@ -55,9 +55,10 @@ DETAILS_PATH = os.path.join(REPO, "gpurun_out", "bench_details.json")
 
 class BoxSampler:
     """Shader clock and socket power of the GPU while a timed region runs: a thread polls the amdgpu hwmon files of the device
-    (freq1_input in Hz, power1_input in microwatts) every few milliseconds.  None when the files cannot be found."""
+    (freq1_input in Hz, power1_input in microwatts) every 20 ms (~20 samples per timed region: the poll shares the
+    interpreter lock with the thread that enqueues the steps, so it is kept rare).  None when the files cannot be found."""
 
-    def __init__(self, dev_index, period_s=0.004):
+    def __init__(self, dev_index, period_s=0.02):
         import glob
         self.files = None
         try:
