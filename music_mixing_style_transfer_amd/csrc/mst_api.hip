@@ -136,6 +136,8 @@ struct MstTcn {
     void *zero_row = nullptr;     // 1 KB of zeros: what the block kernels stage for time steps outside the segment
     int x3_small_tiles = 1;       // bf16x3 mode: 128-time tiles of <= 2 phases, two workgroups per CU (mst_tcn_set_tuning; measured 5.13 vs 5.45 ms)
     int x3_duo = 0;               // bf16x3 mode: the persistent double-tile form of the 128-time-tile kernel (mst_tcn_set_tuning bit 3; measured slower: 5.45 vs 4.55 ms)
+    int bf16_fuse0 = 0;           // bf16 mode: block 0 computed by the loader waves of block 1's duo kernel (mst_tcn_set_tuning bit 5; measured -0.2 ms
+                                  // per forward, bit-identical at 32 x 131072 - not yet run through the GPU test suite: off)
     int bf16_reuse = 1;           // bf16 mode, duo kernel: the class-major main loop (mst_tcn_set_tuning bit 4; measured 1.40 vs 1.46 ms per launch)
     int bf16_form = 2;            // bf16 mode, form of the block kernel (mst_tcn_set_tuning bits 1-2): 0 one tile per workgroup, 1 stream, 2 duo (default)
     std::vector<hipEvent_t> ev;   // timing hook: (nblocks + 2) events per recorded forward
@@ -400,6 +402,7 @@ template <int P, int NQ> int launch_block_stream(TcnBlockArgs a, void *stream) {
 
 // the persistent double-tile bf16 kernel: one workgroup per CU
 template <int P, int NQ> int launch_block_duo(TcnBlockArgs a, void *stream, int reuse = 0) {
+    if (a.x0 && !(P == 2 && NQ == 8 && reuse)) return fail(MST_ERR_STATE, "tcn_block_bf16_duo_kernel: block 0 can only be fused into two-phase class-major tiles");
     const long nsteps = ((long)a.L + a.d - 1) / a.d;
     a.tiles_step = (int)((nsteps + (32 * NQ) / P - 1) / ((32 * NQ) / P));
     const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
@@ -410,6 +413,13 @@ template <int P, int NQ> int launch_block_duo(TcnBlockArgs a, void *stream, int 
     if (grid >= 8) {
         grid -= grid % 8;
         a.xcd_tiles = (int)((ntiles + 7) / 8);
+    }
+    if constexpr (P == 2 && NQ == 8) {
+        if (reuse && a.x0) {          // block 0 computed by the loader waves (mst_tcn_set_tuning bit 5)
+            MST_LAUNCH((tcn_block_bf16_duo_kernel<P, false, NQ, true, true>), dim3((unsigned)grid), dim3(512), stream, a);
+            MST_CHECK_LAUNCH("tcn_block_bf16_duo_kernel");
+            return MST_OK;
+        }
     }
     if constexpr ((P == 4 || P == 2) && NQ == 8) {
         if (reuse) {          // the class-major main loop (B fragments reused across the taps of a class)
@@ -616,7 +626,13 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         MST_HIP_TRY(hipEventRecord(ev[0], (hipStream_t)stream));
     }
 
-    {
+    // block 0 inside block 1's launch (bf16, tuning bit 5): block 1 must be the d = 2 block on the duo kernel's two-phase class-major tiles
+    // and not the last block; the probes of block 0 itself (n_run == 1) always run the separate kernel
+    const bool fuse0 = precision == MST_PREC_BF16 && t->bf16_fuse0 && t->bf16_reuse && t->bf16_form == 2 && t->blk[0].w_bf16 && n_run >= 2 &&
+                       t->d.nblocks > 2 && t->d.dilations[0] == 1 && t->d.dilations[1] == 2 && choose_phases(2, L, precision) == 2;
+    if (fuse0) {
+        if (ev) MST_HIP_TRY(hipEventRecord(ev[1], (hipStream_t)stream));
+    } else {
         TcnBlock0Args a;
         a.x = x;
         a.y = buf[0];
@@ -682,6 +698,13 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         a.nout = t->d.noutputs;
         a.xcd_tiles = 0;
         a.zeros = t->zero_row;
+        if (fuse0 && n == 1) {
+            a.x0 = x;
+            a.w0pk = t->blk[0].w_bf16;
+            a.shift0 = t->blk[0].shift;
+            a.film0 = t->film;
+            a.res0 = t->blk[0].res;
+        }
         if (grid > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_tcn_forward: grid too large");
         int rc;
         switch (P) {
@@ -734,11 +757,12 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
 
 extern "C" int mst_tcn_set_tuning(MstTcn *t, int flags) {
     if (!t) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: null handle");
-    if (flags < 0 || flags > 31 || ((flags >> 1) & 3) > 2) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: unknown flag bits");
+    if (flags < 0 || flags > 63 || ((flags >> 1) & 3) > 2) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: unknown flag bits");
     t->x3_small_tiles = flags & 1;
     t->bf16_form = (flags >> 1) & 3;
     t->x3_duo = (flags >> 3) & 1;
     t->bf16_reuse = (flags >> 4) & 1;
+    t->bf16_fuse0 = (flags >> 5) & 1;
     return MST_OK;
 }
 

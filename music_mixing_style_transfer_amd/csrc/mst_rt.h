@@ -50,6 +50,11 @@ template <int N> __device__ __forceinline__ void mst_dma_wait_barrier() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
+// this wave's LDS stores have completed and all its lanes have passed this point: what one lane wrote, another lane of the wave may read
+__device__ __forceinline__ void mst_wave_lds_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 // v_permlane16_swap_b32: rows (16 lanes) 1 and 3 of `a` trade places with rows 0 and 2 of `b`
 typedef __attribute__((ext_vector_type(2))) unsigned mst_u32x2;
 __device__ __forceinline__ void mst_row_swap(unsigned &a, unsigned &b) {

@@ -44,7 +44,33 @@ struct TcnBlockArgs {
     const void *zeros;    // >= 256 bytes of zeros in device memory: the row staged for time steps outside the segment
     int xcd_tiles;        // > 0: tiles per XCD; workgroup i (dispatched to XCD i % 8) takes tile (i % 8) * xcd_tiles + i / 8, so that
                           // neighbouring time tiles (which share their halo rows) run on the same XCD and meet in its L2
+    // block 0 fused into this launch (duo kernel with FUSE0, d = P = 2: a tile's rows are consecutive samples): the loader waves compute
+    // the tile's input rows from the waveform with block 0's weights instead of fetching them (x is not read)
+    const float *x0 = nullptr;         // waveform [B][2][L]
+    const void *w0pk = nullptr;        // block 0's A fragments (TcnBlock0Args::wpk16)
+    const float *shift0 = nullptr, *film0 = nullptr, *res0 = nullptr;      // block 0's BN shift, FiLM rows (film_rows of them), residual scale
 };
+
+// ------------------------------------------------------------------------------------------------
+// Block 0's arithmetic in the bf16 mode, shared by tcn_block0_mfma_kernel and the duo kernel's FUSE0 loader so that both produce the same
+// bits: the B fragments of one k-step (16 of the 32 k = ci * 15 + j; k >= 30 is padding) for the 32 output times o0 .. o0 + 31 of a
+// waveform window xs[ci][k] = x[ci][t_first - 7 + k], split hi + lo; and one output element.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tcn_block0_bfrag(const float *xs0, const float *xs1, int o, int sI, int h, bf16x8 &hi, bf16x8 &lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 16 * sI + 8 * h + e;               // ci = k / 15, tap j = k % 15
+        const int ci = k >= 15 ? 1 : 0, j = k - 15 * ci;
+        const float v = k < 30 ? (ci ? xs1 : xs0)[o + j] : 0.0f;
+        const __bf16 vh = (__bf16)v;
+        hi[e] = vh;
+        lo[e] = (__bf16)(v - (float)vh);
+    }
+}
+__device__ __forceinline__ __bf16 tcn_block0_out(float v, float fr, float fb, float rs, float xres) {
+    // explicit fused multiply-adds: the two call sites must not be contracted differently (measured: they were - 1 ulp of bf16 apart)
+    return (__bf16)fmaf(fr, mst_fmax(v, MST_LEAKY * v), fmaf(rs, xres, fb));
+}
 
 // ------------------------------------------------------------------------------------------------
 // The class-major main loop (B fragments reused across taps, tcn_reuse_class below) for the one-tile kernel's 128-time tiles that span their
@@ -721,9 +747,10 @@ __device__ __forceinline__ void tcn_reuse_class(f32x4 (&acc)[2][16], bf16x8 (&A0
 // 1.27 ms per launch at one wave per SIMD as at two; the one-tile-per-workgroup kernel 1.50-1.53 ms; a first persistent double-tile
 // form whose four waves did everything themselves 1.60 ms (0.2 ms for issuing the copy, 0.2 ms for the epilogue).
 // ------------------------------------------------------------------------------------------------
-template <int P, bool FUSE_OUT, int NQ, bool REUSE = false>
+template <int P, bool FUSE_OUT, int NQ, bool REUSE = false, bool FUSE0 = false>
 __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs a) {
     static_assert(!REUSE || ((P == 4 || P == 2) && NQ == 8), "the class-major main loop is written for 256-time tiles of two / four phases");
+    static_assert(!FUSE0 || (P == 2 && NQ == 8 && !FUSE_OUT), "block 0 is fused into the d = 2 block's two-phase tiles (consecutive samples)");
     constexpr int T = 32 * NQ, R = T + 14 * P, R4 = (R + 3) / 4 * 4, MT = T / P, NC = 2 * NQ;
     constexpr int NK = R4 / 4;                   // 1 KB DMA pieces (4 rows x 256 B) per tile
     constexpr int NI = (NK + 3) / 4;             // pieces per loader wave
@@ -731,6 +758,9 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
     static_assert(2 * BUF + 2048 <= 160 * 1024, "two tiles + parameters fit the CU's LDS");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
     __shared__ __attribute__((aligned(16))) float par[4 * 128];     // shift | FiLM r | FiLM b | res
+    constexpr int XWP = 304;                                         // FUSE0: waveform samples per channel a tile needs (R + 14 = 298), padded
+    __shared__ float xs0[FUSE0 ? 4 * 2 * XWP : 1];                   // FUSE0: one private waveform window per loader wave
+    __shared__ __attribute__((aligned(16))) float par0[FUSE0 ? 4 * 128 : 4];          // FUSE0: block 0's shift | FiLM r | FiLM b | res for the loader waves
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wv >= 4;
@@ -790,6 +820,85 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
             }
         }
     };
+    // FUSE0, loader waves: the rows of tile (b, m0) are block 0's outputs at the consecutive times t_first + r (d = P = 2, one phase group) -
+    // computed here exactly like tcn_block0_mfma_kernel computes them (same fragments, same MFMA order, same epilogue: the same bits) and
+    // written where the DMA would have put them; rows outside the segment are zero rows (this block's padding).  Loader wave w owns the
+    // 32-row column tiles q = w, w + 4, w + 8 of the image - ALL 128 channels of them, and (see the store phase) the same rows of the
+    // output tile: a wave only overwrites rows it has stored out itself, no barrier between the loader waves.  Its waveform window is its own.
+    auto compute_tile0 = [&](int b, int m0, int phi0, int buf) {
+        if constexpr (FUSE0) {
+            const int ln = lane & 31, h = lane >> 5;
+            float *xw0 = xs0 + w * 2 * XWP, *xw1 = xw0 + XWP;
+            const long t_first = (long)(m0 - 7) * a.d + phi0;           // time of row 0
+            __builtin_amdgcn_wave_barrier();          // every lane is past its reads of the rows / the window this call overwrites
+            for (int i = lane; i < 2 * XWP; i += 64) {
+                const int ci = i >= XWP ? 1 : 0, k = i - ci * XWP;
+                const long t = t_first - 7 + k;
+                (ci ? xw1 : xw0)[k] = (t >= 0 && t < a.L) ? a.x0[((size_t)b * 2 + ci) * a.L + t] : 0.0f;
+            }
+            unsigned char *img = smem + buf * BUF;
+            // block 0's parameters with the FiLM row of item b: ONE copy that every loader wave writes in full - they fill the same tile between the
+            // same two workgroup barriers, so concurrent writers write the same values, and a wave reads behind its own fence
+            float *pw = par0;
+            {
+                const float *frow0 = a.film0 + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+                for (int i = lane; i < 128; i += 64) {
+                    pw[i] = a.shift0[i];
+                    pw[128 + i] = frow0[i];
+                    pw[256 + i] = frow0[128 + i];
+                    pw[384 + i] = a.res0[i];
+                }
+            }
+            mst_wave_lds_fence();                                       // the window and the parameters are in LDS
+            const bf16x8 *const w0p = (const bf16x8 *)a.w0pk + lane;
+            // rows 0 .. 255 (the rows the store phase reads): 32-row groups w and w + 4, all four channel quarters; the halo group 8 (rows 256 ..
+            // 283, never stored) is shared: every wave computes ITS quarter of it - nine (group, quarter) units per wave
+            static_assert((R + 31) / 32 == 9, "eight stored row groups + one halo group");
+#pragma unroll 1
+            for (int q = w; q < 12; q += 4) {
+                const bool halo = q >= 8;                                  // third trip: group 8, one quarter
+                if (halo) q = 8;
+                bf16x8 bh[2], bl[2];
+#pragma unroll
+                for (int sI = 0; sI < 2; ++sI) tcn_block0_bfrag(xw0, xw1, 32 * q + ln, sI, h, bh[sI], bl[sI]);
+                const int o = 32 * q + ln;
+                const long t = t_first + o;
+                const bool inside = t >= 0 && t < a.L;
+#pragma unroll 1
+                for (int cw = halo ? w : 0; cw < (halo ? w + 1 : 4); ++cw) {      // channel quarters (what the four waves of the block-0 kernel do)
+                    f32x16 acc;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const f32x4 sh = *(const f32x4 *)(pw + 32 * cw + 8 * gq + 4 * h);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[4 * gq + i] = sh[i];
+                    }
+#pragma unroll
+                    for (int sI = 0; sI < 2; ++sI) {
+                        const bf16x8 af = w0p[(sI ? 256 : 0) + 64 * cw];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bh[sI], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bl[sI], acc, 0, 0, 0);
+                    }
+                    const float xres = ((cw >> 1) ? xw1 : xw0)[o + 7];      // grouped residual: channels 0..63 read input 0, 64..127 input 1
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int co0 = 32 * cw + 8 * gq + 4 * h;
+                        const f32x4 fr = *(const f32x4 *)(pw + 128 + co0);
+                        const f32x4 fb = *(const f32x4 *)(pw + 256 + co0);
+                        const f32x4 rs = *(const f32x4 *)(pw + 384 + co0);
+                        bf16x4 out;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) out[i] = inside ? tcn_block0_out(acc[4 * gq + i], fr[i], fb[i], rs[i], xres) : (__bf16)0.0f;
+                        if (o < R) *(bf16x4 *)(img + o * 256 + (((co0 >> 3) ^ (o & 15)) << 4) + 8 * h) = out;
+                    }
+                }
+            }
+        }
+    };
+    auto fill_tile = [&](int b, int m0, int phi0, int buf) {
+        if constexpr (FUSE0) compute_tile0(b, m0, phi0, buf);
+        else dma_tile(b, m0, phi0, buf);
+    };
     auto stage_film = [&](int b) {          // matrix waves only (tid < 256)
         if (tid < 128) {
             const float *frow0 = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
@@ -801,7 +910,7 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
     int tb, tm0, tphi0;
     tile_geometry(tile, tb, tm0, tphi0);
     if (loader) {
-        dma_tile(tb, tm0, tphi0, 0);
+        fill_tile(tb, tm0, tphi0, 0);
     } else {
         if (tid < 128) {
             par[tid] = a.shift[tid];
@@ -822,7 +931,7 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
             const bool has_next = tnext < tend;
             if (has_next) {
                 tile_geometry(tnext, tb, tm0, tphi0);
-                dma_tile(tb, tm0, tphi0, cur ^ 1);      // the buffer whose rows this wave stored out itself one iteration ago
+                fill_tile(tb, tm0, tphi0, cur ^ 1);     // the buffer whose rows this wave stored out itself one iteration ago
             }
             mst_dma_wait_barrier<0>();                  // (1) the next tile has landed (and this wave's stores have left)
             if constexpr (FUSE_OUT) {
@@ -832,6 +941,18 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
                 mst_dma_wait_barrier<63>();             // (2) the transposed output tile is complete
                 const unsigned char *sm = smem + cur * BUF;
                 __bf16 *yb = (__bf16 *)a.y + (size_t)b * a.Lp * 128;
+                if constexpr (FUSE0) {
+                    // loader wave w stores the rows it will overwrite with the next tile: the 32-row groups q = w, w + 4 (d = P = 2: row o is time 2 m0 + o)
+                    const int slot = lane & 15, rsub = lane >> 4;
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int o = 32 * (w + 4 * qq) + rsub + 4 * i;
+                            const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
+                            if (t < a.L) *(bf16x8 *)(yb + t * 128 + slot * 8) = *(const bf16x8 *)(sm + o * 256 + ((slot ^ (o & 15)) << 4));
+                        }
+                } else {
                 const int slot = lt & 15, prow = lt >> 4;
                 const long dt = (long)(16 / P) * a.d;
                 long t = (long)(m0 + prow / P) * a.d + phi0 + (prow % P);
@@ -850,6 +971,7 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
                         t += dt;
                         dstp += dt * 128;
                     }
+                }
                 }
             }
             if (!has_next) break;
@@ -1971,15 +2093,7 @@ __global__ __launch_bounds__(256, 2) void tcn_block0_mfma_kernel(TcnBlock0Args a
 #pragma unroll
         for (int sI = 0; sI < 2; ++sI) {
             bf16x8 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int k = 16 * sI + 8 * h + e;               // ci = k / 15, tap j = k % 15; k >= 30 is padding
-                const int ci = k >= 15 ? 1 : 0, j = k - 15 * ci;
-                const float v = k < 30 ? xs[ci][32 * q + ln + j] : 0.0f;
-                const __bf16 vh = (__bf16)v;
-                hi[e] = vh;
-                lo[e] = (__bf16)(v - (float)vh);
-            }
+            tcn_block0_bfrag(xs[0], xs[1], 32 * q + ln, sI, h, hi, lo);
             *(bf16x8 *)(buf + (((q * 2 + sI) * 2 + 0) * 64 + lane) * 16) = hi;
             *(bf16x8 *)(buf + (((q * 2 + sI) * 2 + 1) * 64 + lane) * 16) = lo;
         }
@@ -2019,10 +2133,7 @@ __global__ __launch_bounds__(256, 2) void tcn_block0_mfma_kernel(TcnBlock0Args a
             const float xres = xs[cin][o + 7];
             bf16x4 out;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float v = acc[q][4 * g + i];
-                out[i] = (__bf16)(fr[i] * mst_fmax(v, MST_LEAKY * v) + (fb[i] + rs[i] * xres));
-            }
+            for (int i = 0; i < 4; ++i) out[i] = tcn_block0_out(acc[q][4 * g + i], fr[i], fb[i], rs[i], xres);
             *(bf16x4 *)(buf + o * 256 + (((co0 >> 3) ^ (o & 15)) << 4) + 8 * h) = out;
         }
     }

@@ -194,6 +194,7 @@ static inline void mst_dma16(const void *gsrc, void *lds_wave_base) {
     memcpy((unsigned char *)lds_wave_base + 16 * emu::lane_id(), gsrc, 16);
 }
 template <int N> static inline void mst_dma_wait_barrier() { __syncthreads(); }
+static inline void mst_wave_lds_fence() { (void)emu_shfl(0, 0); }      // the lanes of the wave meet
 static inline void mst_row_swap(unsigned &a, unsigned &b) {      // v_permlane16_swap_b32: rows 1, 3 of a <-> rows 0, 2 of b
     struct AB { unsigned a, b; } me = {a, b};
     const unsigned char *base = emu::wave_publish(&me, sizeof(me));

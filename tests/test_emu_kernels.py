@@ -144,6 +144,37 @@ def test_tcn_bf16_duo_reuse_main_loop_emulated(emu_default):
     assert differs > 0          # the other summation order did run (bit-identical activations everywhere would mean the flag was ignored)
 
 
+def test_tcn_bf16_block0_fused_into_block1_emulated(emu_default):
+    """mst_tcn_set_tuning bit 5 (experimental, off by default): block 0 is not launched, the loader waves of the d = 2 block's duo kernel
+    compute its outputs into the LDS image with tcn_block0_mfma_kernel's arithmetic - the same bits as the separate kernel on every
+    activation and on the waveform.  Several tiles per workgroup (the buffers are refilled), ragged lengths (zero rows on both sides, a last
+    tile mostly outside the segment), segments shorter than a tile, per-item FiLM rows; probes of block 0 alone stay on the separate kernel."""
+    cases = [(4, (2, 2, 777), synth.synth_audio((1, 64), seed=2)),
+             (3, (3, 2, 1500), synth.synth_audio((3, 64), seed=11)),
+             (5, (1, 2, 300), synth.synth_audio((1, 64), seed=3)),
+             (3, (2, 2, 41), synth.synth_audio((2, 64), seed=4)),
+             (3, (1, 2, 2600), synth.synth_audio((1, 64), seed=5))]
+    for nb, shape, cnd in cases:
+        m, sd = _tcn(nb)
+        m.precision = "bf16"
+        x = synth.synth_audio(shape, seed=1)
+        m._ensure(emu_default)
+        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 21), "tuning")
+        y0 = m(x, cnd)
+        a0 = [m.forward_blocks(x, cnd, n) for n in (1, 2, nb)]
+        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 21 | 32), "tuning")
+        y1 = m(x, cnd)
+        a1 = [m.forward_blocks(x, cnd, n) for n in (1, 2, nb)]
+        assert torch.equal(y1, y0), shape
+        for u, v in zip(a0, a1):
+            assert torch.equal(u, v), shape
+        y_ref = R.tcn_forward(sd, x, cnd, nblocks=nb)
+        assert float((y1 - y_ref).abs().max()) <= 4e-2
+    # without the class-major duo form there is nothing to fuse into: the flag is ignored, block 0 runs on its own
+    emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 1 | 32), "tuning")
+    assert float((m(x, cnd) - y_ref).abs().max()) <= 4e-2
+
+
 def test_tcn_bf16x3_duo_kernel_emulated(emu_default):
     """The persistent double-tile form of the split-bf16 block kernel (mst_tcn_set_tuning bit 3; not the default - measured slower): 4 matrix + 4 loader waves
     per CU, the loader waves fetch / split the next tile and finish / store the previous one.  The one-tile kernel's results (bit 3

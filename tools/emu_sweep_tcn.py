@@ -24,6 +24,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--fuse0", action="store_true", help="bf16 cases only: also run with mst_tcn_set_tuning bit 5 (block 0 computed by block 1's loader "
+                                                          "waves) and require the same bits")
     args = ap.parse_args()
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     from emu_binding import bind_emulator
@@ -44,7 +46,7 @@ def main():
         L = rng.choice([rng.randint(30, 400), rng.randint(400, 2500), 64 * dmax + rng.randint(-3, 3), 32 * dmax + rng.randint(-2, 2),
                         16 * dmax + rng.randint(-2, 2), 256 * rng.randint(1, 6) + rng.randint(-1, 1)])
         L = max(L, 20)
-        prec = rng.choice(["bf16", "bf16", "bf16x3", "bf16x3", "fp32"])
+        prec = "bf16" if args.fuse0 else rng.choice(["bf16", "bf16", "bf16x3", "bf16x3", "fp32"])
         per_item = rng.random() < 0.4
         sd = synth.tcn_state_dict(nblocks=nb, cond_dim=64, seed=case)
         m = TCNModel(nparams=64, ninputs=2, noutputs=2, nblocks=nb, dilation_growth=growth, kernel_size=15, channel_width=128, stack_size=15,
@@ -61,6 +63,10 @@ def main():
         a = m.forward_blocks(x, cond, n_probe)
         erra = float((a - col[n_probe - 1]).abs().max()) / max(1e-9, float(col[n_probe - 1].abs().max()))
         ok = err <= TOL[prec] and erra <= TOL[prec]
+        if args.fuse0:
+            emu.check(emu.mst_tcn_set_tuning(m._handle, _lib.TCN_TUNING_DEFAULT | 32), "tuning")
+            ok = ok and torch.equal(m(x, cond), y) and torch.equal(m.forward_blocks(x, cond, n_probe), a)
+            emu.check(emu.mst_tcn_set_tuning(m._handle, _lib.TCN_TUNING_DEFAULT), "tuning")
         worst[prec] = max(worst.get(prec, 0.0), err)
         print(f"case {case:3d} nb={nb} g={growth} B={B} L={L:5d} {prec:6s} film_rows={'B' if per_item else '1'}: waveform {err:.2e}, block {n_probe} rel {erra:.2e} "
               f"{'ok' if ok else 'FAIL'}", flush=True)
