@@ -113,7 +113,7 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* tuning flags (choose between forms of the block kernels; flags = x3_small_tiles | bf16_form << 1 | x3_duo << 3 | bf16_reuse << 4 |
- * bf16_fuse0 << 5, default 21):
+ * bf16_fuse0 << 5 | x3_half_cm << 6, default 21):
  * bit 0 (bf16x3 mode; default 1, measured 5.13 instead of 5.45 ms per launch at 32 x 131072): the split-bf16 block kernel on 128-time
  *   tiles of <= 2 phases (two workgroups per CU) wherever the segment has at least 64 steps per phase, 0 = 256-time tiles (one
  *   workgroup per CU); the two-phase 128-time tiles run the class-major loop (B fragment pairs reused by the two taps of a class: 4.62 ->
@@ -137,7 +137,10 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
  *   duo kernel compute its outputs straight into the LDS image (same arithmetic as tcn_block0_mfma_kernel: bit-identical results, checked
  *   on the MI355X at 32 x 131072; no 1.07 GB store and re-read).  Measured, same box, alternating (profiles/r04_tcn_forms_fuse0.log):
  *   the fused launch 1.58 ms against 0.31 + 1.44 for the two kernels, -0.2 ms per forward (1 % of the step).  Built in the last hour of
- *   round 4: covered by emulator tests (bit identity over random shapes) and that one GPU run, NOT by the GPU test suite yet - off. */
+ *   round 4: covered by emulator tests (bit identity over random shapes) and that one GPU run, NOT by the GPU test suite yet - off.
+ * bit 6 (bf16x3 mode; default 0): the eight-phase half-tile kernel (d >= 4096 at L = 131072: 2 of that mode's 13 launches) runs a class-major
+ *   loop too (pseudo-classes of two taps of one parity); results agree with bit 6 off to accumulation rounding.  Validated on the SIMT
+ *   emulator, NOT yet run on the GPU (round 4 was out of GPU time): EXPERIMENTAL, off. */
 int mst_tcn_set_tuning(MstTcn *tcn, int flags);
 
 /* measurement hook (bench.py's roofline leg): between _begin and _end every mst_tcn_forward records HIP events

@@ -136,6 +136,8 @@ struct MstTcn {
     void *zero_row = nullptr;     // 1 KB of zeros: what the block kernels stage for time steps outside the segment
     int x3_small_tiles = 1;       // bf16x3 mode: 128-time tiles of <= 2 phases, two workgroups per CU (mst_tcn_set_tuning; measured 5.13 vs 5.45 ms)
     int x3_duo = 0;               // bf16x3 mode: the persistent double-tile form of the 128-time-tile kernel (mst_tcn_set_tuning bit 3; measured slower: 5.45 vs 4.55 ms)
+    int x3_half_cm = 0;           // bf16x3 mode: class-major loop in the eight-phase half-tile kernel (mst_tcn_set_tuning bit 6; emulator-validated, not
+                                  // measured yet: off)
     int bf16_fuse0 = 0;           // bf16 mode: block 0 computed by the loader waves of block 1's duo kernel (mst_tcn_set_tuning bit 5; measured -0.2 ms
                                   // per forward, bit-identical at 32 x 131072 - not yet run through the GPU test suite: off)
     int bf16_reuse = 1;           // bf16 mode, duo kernel: the class-major main loop (mst_tcn_set_tuning bit 4; measured 1.40 vs 1.46 ms per launch)
@@ -452,7 +454,7 @@ template <int P> int launch_block_x3_duo(TcnBlockArgs a, void *stream) {
 }
 
 template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream, int x3_small = 0, int bf16_form = 0, int x3_duo = 0,
-                                  int bf16_small4 = 0, int bf16_reuse = 0) {
+                                  int bf16_small4 = 0, int bf16_reuse = 0, int x3_half_cm = 0) {
     TcnBlockArgs a = a0;
     if constexpr (P == 4) {
         // (the same 128-time form for EVERY block - three workgroups per CU instead of the duo kernel - measured 1.53-1.58 ms per launch
@@ -498,9 +500,12 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
             a.tiles_step = (int)((nsteps + (32 * NQ) / P - 1) / ((32 * NQ) / P));
             const long g2 = (long)a.B * a.tiles_phase * a.tiles_step;
             if (g2 % 8 == 0) a.xcd_tiles = (int)(g2 / 8);
-            if constexpr (P == 8)      // 8-phase tiles: the input staged in two halves of 64 channels (60 KB of LDS, two workgroups per CU)
-                MST_LAUNCH((tcn_block_bf16x3_half_kernel<P, NQ>), dim3((unsigned)g2), dim3(256), stream, a);
-            else
+            if constexpr (P == 8) {    // 8-phase tiles: the input staged in two halves of 64 channels (60 KB of LDS, two workgroups per CU)
+                if (x3_half_cm)
+                    MST_LAUNCH((tcn_block_bf16x3_half_kernel<P, NQ, true>), dim3((unsigned)g2), dim3(256), stream, a);
+                else
+                    MST_LAUNCH((tcn_block_bf16x3_half_kernel<P, NQ>), dim3((unsigned)g2), dim3(256), stream, a);
+            } else
             MST_LAUNCH((tcn_block_bf16x3_kernel<P, NQ>), dim3((unsigned)g2), dim3(256), stream, a);
             MST_CHECK_LAUNCH("tcn_block_bf16x3_kernel");
             return MST_OK;
@@ -708,10 +713,10 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         if (grid > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_tcn_forward: grid too large");
         int rc;
         switch (P) {
-            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4, t->bf16_reuse); break;
-            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4, t->bf16_reuse); break;
-            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4, t->bf16_reuse); break;
-            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4, t->bf16_reuse); break;
+            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4, t->bf16_reuse, t->x3_half_cm); break;
+            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4, t->bf16_reuse, t->x3_half_cm); break;
+            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4, t->bf16_reuse, t->x3_half_cm); break;
+            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4, t->bf16_reuse, t->x3_half_cm); break;
             default: rc = launch_block<16>(precision, a, (int)grid, stream, 0, t->bf16_form); break;
         }
         if (rc) return rc;
@@ -757,12 +762,13 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
 
 extern "C" int mst_tcn_set_tuning(MstTcn *t, int flags) {
     if (!t) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: null handle");
-    if (flags < 0 || flags > 63 || ((flags >> 1) & 3) > 2) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: unknown flag bits");
+    if (flags < 0 || flags > 127 || ((flags >> 1) & 3) > 2) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: unknown flag bits");
     t->x3_small_tiles = flags & 1;
     t->bf16_form = (flags >> 1) & 3;
     t->x3_duo = (flags >> 3) & 1;
     t->bf16_reuse = (flags >> 4) & 1;
     t->bf16_fuse0 = (flags >> 5) & 1;
+    t->x3_half_cm = (flags >> 6) & 1;
     return MST_OK;
 }
 

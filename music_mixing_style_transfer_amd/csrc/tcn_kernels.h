@@ -1748,8 +1748,75 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16x3_duo_kernel(TcnBlockAr
 // LDS image: 128-byte rows (8 slots of 16 B), slot ^ ((row >> 1) & 7): conflict free for ds_read_b128's lane groups at the start rows
 // that occur (multiples of 8).
 // ------------------------------------------------------------------------------------------------
-template <int P, int NQ>
+// The class-major loop for the eight-phase half-tile kernel below (128-byte rows of 64 channels, two k-steps kl per staged half): taps of one
+// parity share their B fragments (tap j + 2, column tile q - 1 = the rows of tap j, column tile q); a pseudo-class is two taps j0, j0 + 2 (the
+// last one: tap 13 alone), its A fragments (2 taps x 2 row tiles x hi / lo) double-buffered over the two k-steps, B fragment pairs in a ring
+// of two windows.  The all-padding (column tile, tap) pairs are skipped under a wave-uniform branch like in the tap-major loop (live[u]).
+template <int NU, bool LASTC, int NC>
+__device__ __forceinline__ void tcn_reuse_class_x3_half(f32x4 (&acc)[2][NC], bf16x8 (&H0)[2][2], bf16x8 (&L0)[2][2], bf16x8 (&H1)[2][2],
+                                                        bf16x8 (&L1)[2][2], bf16x8 (&rh)[2], bf16x8 (&rl)[2], const unsigned char *sm_hi,
+                                                        const unsigned char *sm_lo, const unsigned char *wbase, size_t lo_img, unsigned aoff, int half,
+                                                        int j0, int j0n, unsigned live0, unsigned live1, int l16, int g) {
+    constexpr int P = 8, NW = NC - 1 + NU;
+    static_assert((2 * NW) % 2 == 0, "the ring is two windows deep");
+    const int rowb = (P * j0 + l16) * 128, rowbn = (P * j0n + l16) * 128;
+    const int swz = (4 * (j0 & 1) + (l16 >> 1)) & 7, swzn = (4 * (j0n & 1) + (l16 >> 1)) & 7;
+#pragma unroll
+    for (int kl = 0; kl < 2; ++kl) {
+        bf16x8 (&ch)[2][2] = kl ? H1 : H0;
+        bf16x8 (&cl)[2][2] = kl ? L1 : L0;
+        bf16x8 (&nh)[2][2] = kl ? H0 : H1;
+        bf16x8 (&nl)[2][2] = kl ? L0 : L1;
+        if (!(LASTC && kl == 1)) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (kl == 0 && u >= NU) continue;
+                int j = (kl == 0 ? j0 : j0n) + 2 * u;
+                j = j < 15 ? j : 14;                               // the last pseudo-class has one tap: that slot holds a fragment nobody uses
+                const size_t so = (size_t)((j * 4 + 2 * half + (kl == 0 ? 1 : 0)) * 2) * 4096 + aoff;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    nh[u][m] = *(const bf16x8 *)(wbase + so + (size_t)m * 4096);
+                    nl[u][m] = *(const bf16x8 *)(wbase + lo_img + so + (size_t)m * 4096);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int n = kl * NW + i;
+            const bf16x8 bh = rh[n & 1], bl = rl[n & 1];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int q = i - u;
+                if (q >= 0 && q < NC) {
+                    if (((u ? live1 : live0) >> q) & 1u) {
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cl[u][m], bh, acc[m][q], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch[u][m], bl, acc[m][q], 0, 0, 0);
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ch[u][m], bh, acc[m][q], 0, 0, 0);
+                    }
+                }
+            }
+            const int n2 = n + 2, k2 = n2 / NW, i2 = n2 % NW;
+            if (k2 < 2) {
+                const int ofs = rowb + (((4 * k2 + g) ^ swz) << 4) + i2 * 2048;
+                rh[n & 1] = *(const bf16x8 *)(sm_hi + ofs);
+                rl[n & 1] = *(const bf16x8 *)(sm_lo + ofs);
+            } else if (!LASTC) {
+                const int ofs = rowbn + ((g ^ swzn) << 4) + i2 * 2048;
+                rh[n & 1] = *(const bf16x8 *)(sm_hi + ofs);
+                rl[n & 1] = *(const bf16x8 *)(sm_lo + ofs);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int P, int NQ, bool CM = false>
 __global__ __launch_bounds__(256, 2) void tcn_block_bf16x3_half_kernel(TcnBlockArgs a) {
+    static_assert(!CM || (P == 8 && NQ == 4), "the class-major loop is written for eight phases x 16 steps");
     constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NC = 2 * NQ;
     static_assert(P % 8 == 0, "the swizzle is conflict free for start rows that are multiples of 8");
     __shared__ __attribute__((aligned(16))) unsigned char smem[(2 * R * 128 > T * 512) ? 2 * R * 128 : T * 512];      // [hi | lo] half tiles; later the fp32 output tile
@@ -1809,6 +1876,44 @@ __global__ __launch_bounds__(256, 2) void tcn_block_bf16x3_half_kernel(TcnBlockA
         }
         __syncthreads();
 
+        if constexpr (CM) {
+            // class-major (mst_tcn_set_tuning bit 6): eight pseudo-classes of two taps (0, 2), (4, 6), (8, 10), (12, 14), (1, 3), (5, 7), (9, 11), (13)
+            const int nsteps_cm = (int)(((long)a.L + a.d - 1) / a.d);
+            auto live_of = [&](int j) {
+                unsigned live = 0;
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+                    const int s_lo = m0 + (16 * q) / P + j - 7, s_hi = m0 + (16 * q + 15) / P + j - 7;
+                    if (!(s_hi < 0 || s_lo >= nsteps_cm)) live |= 1u << q;
+                }
+                return live;
+            };
+            auto j0_of = [](int pc) { return 4 * (pc & 3) + (pc >> 2); };
+            bf16x8 H0[2][2], L0[2][2], H1[2][2], L1[2][2], rh[2], rl[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    H0[u][m] = *(const bf16x8 *)(wbase + (size_t)(((2 * u) * 4 + 2 * c) * 2 + m) * 4096 + aoff);
+                    L0[u][m] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)(((2 * u) * 4 + 2 * c) * 2 + m) * 4096 + aoff);
+                }
+            {
+                const int o0 = l16 * 128 + ((g ^ ((l16 >> 1) & 7)) << 4);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    rh[i] = *(const bf16x8 *)(sm_hi + o0 + i * 2048);
+                    rl[i] = *(const bf16x8 *)(sm_lo + o0 + i * 2048);
+                }
+            }
+#pragma unroll 1
+            for (int pc = 0; pc < 7; ++pc) {
+                const int j0 = j0_of(pc), j0n = j0_of(pc + 1);
+                tcn_reuse_class_x3_half<2, false, NC>(acc, H0, L0, H1, L1, rh, rl, sm_hi, sm_lo, wbase, LO_IMG, aoff, c, j0, j0n, live_of(j0),
+                                                      live_of(j0 + 2), l16, g);
+            }
+            tcn_reuse_class_x3_half<1, true, NC>(acc, H0, L0, H1, L1, rh, rl, sm_hi, sm_lo, wbase, LO_IMG, aoff, c, 13, 13, live_of(13), 0u, l16, g);
+            continue;
+        }
         // A fragments: wpk[part][ks = j*4 + kk][row tile m][wave][lane], kk = 2 c + kl; one k-step of (hi, lo) fragments in flight ahead
         bf16x8 ah[2][2], al[2][2], bh[RB], bl[RB];
 #pragma unroll

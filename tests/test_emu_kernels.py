@@ -175,6 +175,32 @@ def test_tcn_bf16_block0_fused_into_block1_emulated(emu_default):
     assert float((m(x, cnd) - y_ref).abs().max()) <= 4e-2
 
 
+def test_tcn_bf16x3_half_tile_kernel_class_major_emulated(emu_default):
+    """mst_tcn_set_tuning bit 6 (experimental, off by default): the eight-phase half-tile kernel of the split-bf16 mode (d a multiple of 8 with
+    fewer than 64 steps per phase) with the class-major loop - the oracle at the mode's tolerance, bit 6 off to accumulation rounding.  Tiles
+    that span their phase sequence, several tiles per sequence (first / last ones with all-padding tap tiles skipped), ragged lengths,
+    the fused output head (last block) and the plain epilogue, per-item FiLM rows."""
+    cases = [(6, (1, 2, 200), synth.synth_audio((1, 64), seed=5)),          # d = 8, 16, 32 on 25 / 13 / 7 steps
+             (4, (2, 2, 400), synth.synth_audio((2, 64), seed=6)),          # d = 8: 50 steps = four tiles per sequence; the last block
+             (5, (3, 2, 131), synth.synth_audio((1, 64), seed=7)),          # d = 8, 16: 17 / 9 steps
+             (5, (1, 2, 1000), synth.synth_audio((1, 64), seed=8))]         # d = 16: 63 steps
+    for nb, shape, cnd in cases:
+        m, sd = _tcn(nb)
+        m.precision = "bf16x3"
+        x = synth.synth_audio(shape, seed=3)
+        col = []
+        y_ref = R.tcn_forward(sd, x, cnd, nblocks=nb, collect=col)
+        m._ensure(emu_default)
+        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 21), "tuning")
+        y0, a0 = m(x, cnd), m.forward_blocks(x, cnd, nb)
+        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 21 | 64), "tuning")
+        y1, a1 = m(x, cnd), m.forward_blocks(x, cnd, nb)
+        assert float((y1 - y_ref).abs().max()) <= 3e-5
+        assert float((a1 - col[nb - 1]).abs().max()) <= 3e-5 * float(col[nb - 1].abs().max())
+        assert float((y1 - y0).abs().max()) <= 1e-5 and float((a1 - a0).abs().max()) <= 1e-5 * float(a0.abs().max())
+        assert not torch.equal(a1, a0)          # the other loop did run
+
+
 def test_tcn_bf16x3_duo_kernel_emulated(emu_default):
     """The persistent double-tile form of the split-bf16 block kernel (mst_tcn_set_tuning bit 3; not the default - measured slower): 4 matrix + 4 loader waves
     per CU, the loader waves fetch / split the next tile and finish / store the previous one.  The one-tile kernel's results (bit 3

@@ -24,6 +24,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--tuning", type=int, default=None, help="mst_tcn_set_tuning flags for every model (e.g. 85 = default + bit 6)")
+    ap.add_argument("--only", default=None, help="restrict the sweep to one precision")
     ap.add_argument("--fuse0", action="store_true", help="bf16 cases only: also run with mst_tcn_set_tuning bit 5 (block 0 computed by block 1's loader "
                                                           "waves) and require the same bits")
     args = ap.parse_args()
@@ -46,7 +48,7 @@ def main():
         L = rng.choice([rng.randint(30, 400), rng.randint(400, 2500), 64 * dmax + rng.randint(-3, 3), 32 * dmax + rng.randint(-2, 2),
                         16 * dmax + rng.randint(-2, 2), 256 * rng.randint(1, 6) + rng.randint(-1, 1)])
         L = max(L, 20)
-        prec = "bf16" if args.fuse0 else rng.choice(["bf16", "bf16", "bf16x3", "bf16x3", "fp32"])
+        prec = "bf16" if args.fuse0 else (args.only or rng.choice(["bf16", "bf16", "bf16x3", "bf16x3", "fp32"]))
         per_item = rng.random() < 0.4
         sd = synth.tcn_state_dict(nblocks=nb, cond_dim=64, seed=case)
         m = TCNModel(nparams=64, ninputs=2, noutputs=2, nblocks=nb, dilation_growth=growth, kernel_size=15, channel_width=128, stack_size=15,
@@ -57,6 +59,9 @@ def main():
         cond = synth.synth_audio((B if per_item else 1, 64), seed=2000 + case)
         col = []
         y_ref = R.tcn_forward(sd, x, cond, nblocks=nb, dilation_growth=growth, collect=col)
+        if args.tuning is not None:
+            m._ensure(emu)
+            emu.check(emu.mst_tcn_set_tuning(m._handle, args.tuning), "tuning")
         y = m(x, cond)
         err = float((y - y_ref).abs().max())
         n_probe = rng.randint(1, nb)
