@@ -202,13 +202,48 @@ def bench_configs1(engine, tcn, lib, ref, inp, steps, warmup, world, dist, dev, 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if stats is not None:
+        stats["fused0"] = tcn_fused_block0(lib, tcn)
     return float(tmax.item()), [float(v) for v in ms], int(nf.value)
 
 
-def roofline(block_ms, nb, B, precision, traffic=None):
+KERNEL_SOURCES = {"tcn": ("tcn_kernels.h", "mst_dev.h", "mst_rt.h"), "fx": ("fx_kernels.h", "fft_kernels.h", "mst_dev.h", "mst_rt.h")}
+
+
+def csrc_sha256(family):
+    """Fingerprint of the kernel sources of one family ("tcn": the block kernels, "fx": the FX processors).  The counter files under
+    profiles/ carry the fingerprint of the sources they were measured on (tools/pmc_traffic.py, tools/pmc_fx_traffic.py write it), and a
+    stored `traffic` figure of other kernel sources is not printed.  (Sources, not the binary: the .so is rebuilt per checkout.)"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES[family]:
+        with open(os.path.join(REPO, "music_mixing_style_transfer_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def stored_traffic(name, family):
+    """(traffic bytes, source note) from profiles/<name> if that file was measured on THESE kernel sources, else (None, why)."""
+    tpath = os.path.join(REPO, "profiles", name)
+    if not os.path.exists(tpath):
+        return None, f"profiles/{name} absent"
+    with open(tpath) as f:
+        rec = json.load(f)
+    if rec.get("csrc_sha256") != csrc_sha256(family):
+        return None, f"profiles/{name} was measured on other kernel sources (csrc_sha256 differs): not printed"
+    return rec.get("traffic_bytes"), f"profiles/{name} (offline rocprofv3 --pmc passes, same kernel sources)"
+
+
+def tcn_fused_block0(lib, tcn):
+    """Whether the handle's last forward ran block 0 inside block 1's launch (mst_tcn_get_tuning; bit 5 is a request with conditions)."""
+    fl, fused = C.c_int(0), C.c_int(0)
+    lib.check(lib.mst_tcn_get_tuning(tcn._handle, C.byref(fl), C.byref(fused)), "mst_tcn_get_tuning")
+    return bool(fused.value)
+
+
+def roofline(block_ms, nb, B, precision, traffic=None, fused0=False):
     dense = block_ms[1:nb]                                   # the 13 dilated 128->128 blocks
-    fused0 = nb > 2 and block_ms[0] < 0.1 * block_ms[1]      # mst_tcn_set_tuning bit 5: block 0 runs inside block 1's launch (no launch of its own)
-    if fused0:
+    if fused0:          # mst_tcn_set_tuning bit 5 applied: block 0 ran inside block 1's launch (no launch of its own)
         dense = block_ms[2:nb]                               # that launch also does block 0's work: not a plain dense launch
     avg_ms = sum(dense) / len(dense)
     flop = TCN_FLOP_PER_SAMPLE_BLOCK * B * SEG_LEN
@@ -303,6 +338,7 @@ def bench_parity_mode(engine, enc, tcn, lib, ref, inp, dev, enc_cfg, enc_sd, tcn
     try:
         nsteps = 2 if precision == "fp32" else 4
         dt, block_ms, _ = bench_configs1(engine, tcn, lib, ref, inp, nsteps, 2, 1, None, dev)
+        fused0 = tcn_fused_block0(lib, tcn)
         L = 16384
         pr, pi = synth.synth_audio((2, 2, L), seed=5), synth.synth_audio((2, 2, L), seed=6)
         y, _ = engine.step(pr.to(dev), pi.to(dev))
@@ -312,7 +348,7 @@ def bench_parity_mode(engine, enc, tcn, lib, ref, inp, dev, enc_cfg, enc_sd, tcn
         enc.precision = tcn.precision = "bf16"
     return {"dtype": "f32" if precision == "fp32" else "bf16x3 (fp32 operands split hi + lo, three bf16 MFMAs per product, fp32 accumulate; FXencoder and TCN)",
             "value": BATCH * nsteps / dt, "unit": "segments/s", "ms_per_step": dt / nsteps * 1e3, "steps": nsteps,
-            "roofline": roofline(block_ms, tcn.hparams.nblocks, BATCH, precision),
+            "roofline": roofline(block_ms, tcn.hparams.nblocks, BATCH, precision, fused0=fused0),
             "max_abs_vs_oracle": err, "probe": f"2 reference + 2 input segments of 2x{L} vs oracle/networks_ref.py", "tolerance": 1e-4}
 
 
@@ -379,13 +415,7 @@ def bench_fx_chain(dev, steps=5):
     # what the chain REALLY moves: FETCH_SIZE / WRITE_SIZE counter passes over its kernels (tools/gpu_fx_pmc.sh -> profiles/*fx_chain_traffic.json;
     # offline: counters need their own rocprofv3 passes).  `achieved` / `frac` stay on the ALGORITHMIC basis (one read + one write of the audio,
     # 16 L per segment - what a perfectly fused chain would move); `frac_on_traffic` is the measured bytes over the same time.
-    traffic, tsrc = None, None
-    for name in ("r04_fx_chain_traffic.json",):
-        tpath = os.path.join(REPO, "profiles", name)
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic, tsrc = json.load(f).get("traffic_bytes"), "profiles/" + name
-            break
+    traffic, tsrc = stored_traffic("r05_fx_chain_traffic.json", "fx")
     return {"workload": "configs[3]: EQ -> rms -> compressor -> rms -> imager -> rms -> gain on 64 segments of [131072, 2]",
             "value": n / dt, "unit": "segments/s", "ms_per_chain": dt * 1e3,
             "roofline": {"bound": "hbm", "achieved": 16 * L * n / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -433,12 +463,26 @@ def main():
     ap.add_argument("--tcn-tuning", type=int, default=None, help="mst_tcn_set_tuning flags (bit 0: bf16x3 small tiles, bits 1-2: form of the bf16 block kernel, include/mst_hip.h)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` typed like the N = 1 command: start the N ranks ourselves (one process per GPU through
+        # torch.distributed.run on 127.0.0.1 with a free port); rank 0 of that job prints the ONE line to our stdout
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started inside a job of WORLD_SIZE={world}: the two must agree "
+                         f"(torch.distributed.run --nproc-per-node {args.gpus}, or no launcher at all)")
     import torch.distributed as dist
     if os.environ.get("MST_BENCH_SHARE_GPU"):      # test hook: several ranks on one GPU (with MST_DIST_BACKEND=gloo)
         local_rank = 0
@@ -451,6 +495,13 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        seen = torch.ones(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")      # every rank really takes part in a collective
+        dist.all_reduce(seen)
+        ranks_seen = int(seen.item())
+        assert ranks_seen == args.gpus, (ranks_seen, args.gpus)
+    else:
+        ranks_seen = 1
 
     from music_mixing_style_transfer_amd import _lib
     from music_mixing_style_transfer_amd.inference import StyleTransferEngine, build_models
@@ -478,7 +529,7 @@ def main():
     nb = tcn.hparams.nblocks
     B = args.batch
     dtype = {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3"}[args.precision]
-    base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
+    base = {"n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
             "dtype": dtype, "data": "synthetic"}
 
     if args.workload == "track60":
@@ -503,17 +554,15 @@ def main():
         track = bench_track60(enc, tcn, world, rank, dist, dev, 2, 1)
 
     if rank == 0:
-        traffic, tname = None, None      # HBM bytes per launch of the dominant kernel: offline rocprofv3 --pmc passes (tools/pmc_traffic.py)
-        for name in ("r04_tcn_block_bf16_traffic.json", "r03_tcn_block_bf16_traffic.json"):
-            tpath = os.path.join(REPO, "profiles", name)
-            if args.precision == "bf16" and B == BATCH and os.path.exists(tpath):
-                with open(tpath) as f:
-                    traffic, tname = json.load(f).get("traffic_bytes"), name
-                break
-        rl = roofline(block_ms, nb, B, args.precision, traffic)
+        # HBM bytes per launch of the dominant kernel: PMC counters need their own rocprofv3 passes (tools/pmc_traffic.py), so the figure is a
+        # stored one - printed only when it was measured on this build of the kernels and with the default tuning flags, else null + the reason
+        traffic, tsrc = (None, "counter file covers the bf16 headline workload with the default tuning flags only")
+        if args.precision == "bf16" and B == BATCH and args.tcn_tuning in (None, _lib.TCN_TUNING_DEFAULT):
+            traffic, tsrc = stored_traffic("r05_tcn_block_bf16_traffic.json", "tcn")
+        rl = roofline(block_ms, nb, B, args.precision, traffic, fused0=stats.get("fused0", False))
         rl["timed_forwards"] = nf
-        if traffic is not None:      # not measured in this run: PMC counters need their own rocprofv3 passes
-            rl["traffic_source"] = "profiles/" + tname
+        rl["traffic_source"] = tsrc
+        rl["block0_fused_into_block1"] = stats.get("fused0", False)
         if calib_ms is not None:
             # the box: the bare main loop of the block kernel (same arithmetic as one dense launch) timed in this process, the shader
             # clock inside it, and clock / power sampled from the driver while the timed steps ran

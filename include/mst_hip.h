@@ -113,7 +113,7 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* tuning flags (choose between forms of the block kernels; flags = x3_small_tiles | bf16_form << 1 | x3_duo << 3 | bf16_reuse << 4 |
- * bf16_fuse0 << 5 | x3_half_cm << 6, default 21):
+ * bf16_fuse0 << 5 | x3_half_cm << 6, default 53):
  * bit 0 (bf16x3 mode; default 1, measured 5.13 instead of 5.45 ms per launch at 32 x 131072): the split-bf16 block kernel on 128-time
  *   tiles of <= 2 phases (two workgroups per CU) wherever the segment has at least 64 steps per phase, 0 = 256-time tiles (one
  *   workgroup per CU); the two-phase 128-time tiles run the class-major loop (B fragment pairs reused by the two taps of a class: 4.62 ->
@@ -133,15 +133,19 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
  *   fragment read from LDS once per class and k-step and fed to up to eight MFMAs (304 instead of 960 LDS reads per tile at four phases).
  *   Same products, another fp32 summation order: agrees with bit 4 off to accumulation rounding (not bit-identical).  Measured at
  *   32 x 131072, same box, d = 4 ... 2048: 1.40 ms per launch against 1.46 (profiles/r04_tcn_forms_reuse.log).
- * bit 5 (bf16 mode, with form 2 and bit 4; default 0): block 0 (2 -> 128 channels) is not launched - the loader waves of the d = 2 block's
+ * bit 5 (bf16 mode, with form 2 and bit 4; default 1 since round 5): block 0 (2 -> 128 channels) is not launched - the loader waves of the d = 2 block's
  *   duo kernel compute its outputs straight into the LDS image (same arithmetic as tcn_block0_mfma_kernel: bit-identical results, checked
  *   on the MI355X at 32 x 131072; no 1.07 GB store and re-read).  Measured, same box, alternating (profiles/r04_tcn_forms_fuse0.log):
- *   the fused launch 1.58 ms against 0.31 + 1.44 for the two kernels, -0.2 ms per forward (1 % of the step).  Built in the last hour of
- *   round 4: covered by emulator tests (bit identity over random shapes) and that one GPU run, NOT by the GPU test suite yet - off.
+ *   the fused launch 1.58 ms against 0.31 + 1.44 for the two kernels, -0.2 ms per forward (1 % of the step).  Applies only when block 1 is
+ *   the d = 2 block on two-phase class-major tiles (>= 128 steps per phase) and is not the last block; otherwise the separate block-0
+ *   kernel runs - mst_tcn_get_tuning reports which happened.  Emulator tests (bit identity over random shapes) + tests/test_gpu_parity.py form 53.
  * bit 6 (bf16x3 mode; default 0): the eight-phase half-tile kernel (d >= 4096 at L = 131072: 2 of that mode's 13 launches) runs a class-major
  *   loop too (pseudo-classes of two taps of one parity); results agree with bit 6 off to accumulation rounding.  Validated on the SIMT
  *   emulator, NOT yet run on the GPU (round 4 was out of GPU time): EXPERIMENTAL, off. */
 int mst_tcn_set_tuning(MstTcn *tcn, int flags);
+/* the flags in force and whether the handle's LAST forward ran block 0 inside block 1's launch (bit 5 is a request: see its conditions above);
+ * either pointer may be null. */
+int mst_tcn_get_tuning(const MstTcn *tcn, int *flags, int *last_forward_fused_block0);
 
 /* measurement hook (bench.py's roofline leg): between _begin and _end every mst_tcn_forward records HIP events
  * on its stream around each kernel; _end synchronises, writes the AVERAGE milliseconds per forward of

@@ -138,8 +138,9 @@ struct MstTcn {
     int x3_duo = 0;               // bf16x3 mode: the persistent double-tile form of the 128-time-tile kernel (mst_tcn_set_tuning bit 3; measured slower: 5.45 vs 4.55 ms)
     int x3_half_cm = 0;           // bf16x3 mode: class-major loop in the eight-phase half-tile kernel (mst_tcn_set_tuning bit 6; emulator-validated, not
                                   // measured yet: off)
-    int bf16_fuse0 = 0;           // bf16 mode: block 0 computed by the loader waves of block 1's duo kernel (mst_tcn_set_tuning bit 5; measured -0.2 ms
-                                  // per forward, bit-identical at 32 x 131072 - not yet run through the GPU test suite: off)
+    int bf16_fuse0 = 1;           // bf16 mode: block 0 computed by the loader waves of block 1's duo kernel (mst_tcn_set_tuning bit 5; measured -0.2 ms
+                                  // per forward, bit-identical to the separate kernel; default since round 5 - tests/test_gpu_parity.py form 53)
+    int last_fused0 = 0;          // whether the last forward of this handle really ran block 0 inside block 1's launch (mst_tcn_get_tuning)
     int bf16_reuse = 1;           // bf16 mode, duo kernel: the class-major main loop (mst_tcn_set_tuning bit 4; measured 1.40 vs 1.46 ms per launch)
     int bf16_form = 2;            // bf16 mode, form of the block kernel (mst_tcn_set_tuning bits 1-2): 0 one tile per workgroup, 1 stream, 2 duo (default)
     std::vector<hipEvent_t> ev;   // timing hook: (nblocks + 2) events per recorded forward
@@ -635,6 +636,7 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
     // and not the last block; the probes of block 0 itself (n_run == 1) always run the separate kernel
     const bool fuse0 = precision == MST_PREC_BF16 && t->bf16_fuse0 && t->bf16_reuse && t->bf16_form == 2 && t->blk[0].w_bf16 && n_run >= 2 &&
                        t->d.nblocks > 2 && t->d.dilations[0] == 1 && t->d.dilations[1] == 2 && choose_phases(2, L, precision) == 2;
+    t->last_fused0 = fuse0 ? 1 : 0;
     if (fuse0) {
         if (ev) MST_HIP_TRY(hipEventRecord(ev[1], (hipStream_t)stream));
     } else {
@@ -769,6 +771,14 @@ extern "C" int mst_tcn_set_tuning(MstTcn *t, int flags) {
     t->bf16_reuse = (flags >> 4) & 1;
     t->bf16_fuse0 = (flags >> 5) & 1;
     t->x3_half_cm = (flags >> 6) & 1;
+    return MST_OK;
+}
+
+extern "C" int mst_tcn_get_tuning(const MstTcn *t, int *flags, int *last_forward_fused_block0) {
+    if (!t) return fail(MST_ERR_ARG, "mst_tcn_get_tuning: null handle");
+    if (flags)
+        *flags = t->x3_small_tiles | t->bf16_form << 1 | t->x3_duo << 3 | t->bf16_reuse << 4 | t->bf16_fuse0 << 5 | t->x3_half_cm << 6;
+    if (last_forward_fused_block0) *last_forward_fused_block0 = t->last_fused0;
     return MST_OK;
 }
 

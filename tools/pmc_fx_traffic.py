@@ -5,7 +5,10 @@ accesses of some FX kernels make that an upper bound, stated per kernel as raw a
 usage: pmc_fx_traffic.py <fetch_dir> <write_dir> <chains incl. the warm-up> <out.json>"""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from collections import defaultdict
 
 
@@ -38,6 +41,8 @@ def main():
            "one_read_one_write_bytes": fused, "traffic_over_one_read_one_write": (2.0 * rd + wr) / fused,
            "unfused_bytes_survey_8d": 144.0 * L * n_items, "per_kernel": rows,
            "note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes); the x2 is the guide's gfx950 correction for 16-byte-per-lane streams"}
+    import bench
+    res["csrc_sha256"] = bench.csrc_sha256("fx")      # bench.py prints this figure only while the FX kernels' sources are these
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if k != "per_kernel"}))
 

@@ -4,7 +4,10 @@ with the gfx950 correction the microarch guide prescribes: FETCH_SIZE counts 64 
 coalesced streams (x2); units are KiB.   usage: pmc_traffic.py <fetch_dir> <write_dir> <kernel substring> <out.json>"""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def avg(path, counter, key):
@@ -24,6 +27,8 @@ def main():
            "read_bytes": 2.0 * f * 1024.0, "write_bytes": w * 1024.0, "traffic_bytes": (2.0 * f + w) * 1024.0,
            "note": "read = 2 x FETCH_SIZE x 1024 (gfx950 rocprofv3 tallies 128-B requests at 64 B, MI355X_MICROARCH.md HBM section); "
                    "write = WRITE_SIZE x 1024; separate --pmc passes, bench.py --steps 1 --warmup 1 --precision bf16"}
+    import bench
+    res["csrc_sha256"] = bench.csrc_sha256("tcn")      # bench.py prints this figure only while the block kernels' sources are these
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 
