@@ -113,7 +113,7 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* tuning flags (choose between forms of the block kernels; flags = x3_small_tiles | bf16_form << 1 | x3_duo << 3 | bf16_reuse << 4 |
- * bf16_fuse0 << 5 | x3_half_cm << 6, default 53):
+ * bf16_fuse0 << 5 | x3_half_cm << 6, default 117):
  * bit 0 (bf16x3 mode; default 1, measured 5.13 instead of 5.45 ms per launch at 32 x 131072): the split-bf16 block kernel on 128-time
  *   tiles of <= 2 phases (two workgroups per CU) wherever the segment has at least 64 steps per phase, 0 = 256-time tiles (one
  *   workgroup per CU); the two-phase 128-time tiles run the class-major loop (B fragment pairs reused by the two taps of a class: 4.62 ->
@@ -139,9 +139,10 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
  *   the fused launch 1.58 ms against 0.31 + 1.44 for the two kernels, -0.2 ms per forward (1 % of the step).  Applies only when block 1 is
  *   the d = 2 block on two-phase class-major tiles (>= 128 steps per phase) and is not the last block; otherwise the separate block-0
  *   kernel runs - mst_tcn_get_tuning reports which happened.  Emulator tests (bit identity over random shapes) + tests/test_gpu_parity.py form 53.
- * bit 6 (bf16x3 mode; default 0): the eight-phase half-tile kernel (d >= 4096 at L = 131072: 2 of that mode's 13 launches) runs a class-major
- *   loop too (pseudo-classes of two taps of one parity); results agree with bit 6 off to accumulation rounding.  Validated on the SIMT
- *   emulator, NOT yet run on the GPU (round 4 was out of GPU time): EXPERIMENTAL, off. */
+ * bit 6 (bf16x3 mode; default 1 since round 5): the eight-phase half-tile kernel (d >= 4096 at L = 131072: 2 of that mode's 13 launches) runs a
+ *   class-major loop too (pseudo-classes of two taps of one parity); results agree with bit 6 off to accumulation rounding (GPU test:
+ *   <= 1e-5 on the waveform, both within 1e-4 of the oracle).  Measured, same box, alternating: 571.7 / 572.1 against 566.2 segments/s for the
+ *   whole bf16x3 step at 32 x 131072 (profiles/r05_x3_ab_bit6_53_117.jsonl). */
 int mst_tcn_set_tuning(MstTcn *tcn, int flags);
 /* the flags in force and whether the handle's LAST forward ran block 0 inside block 1's launch (bit 5 is a request: see its conditions above);
  * either pointer may be null. */
@@ -276,6 +277,13 @@ int mst_fx_scale_items(const float *x_dev, float *y_dev, int n_items, long per_i
 size_t mst_fx_biquad_scratch_bytes(int n_items, long L, int C, int n_bands);
 int mst_fx_biquad_cascade(const float *x_dev, float *y_dev, int n_items, long L, int C, const double *coef_host,
                           int n_bands, double *scratch_dev, size_t scratch_bytes, const MstFxFuse *fuse, void *stream);
+/* process-wide tuning of the FX kernels (results do not depend on it).  bit 0 (default 1): the time-parallel compressor of a large batch
+ * (>= 32 chain batches of 1024 samples and >= 4e6 samples in all) is cut into four time slices whose map / apply kernels run on an internal
+ * low-priority side stream BESIDE the chain kernel of the neighbouring slice (the chain is one latency-bound walk per sequence on n_seq
+ * workgroups; events order map_i -> chain_i -> apply_i, the caller's stream joins the side stream before the call returns to it).
+ * Measured on configs[3] (64 x [131072, 2]): see DESIGN.md 3.3.  bit 1 (default 0; test / A-B hook): slices whatever the size (>= 4 batches). */
+int mst_fx_set_tuning(int flags);
+
 /* Compressor.process / compressor_process (:529-587, :637-649), makeup gain 0.  With a scratch buffer of
  * mst_fx_compressor_scratch_bytes() (about 9 bytes per sample) the gain computer and the gain application run over all samples
  * in parallel and the attack/release smoother runs parallel in time (per-chunk convex piecewise-linear maps + one walk over the

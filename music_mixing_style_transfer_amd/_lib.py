@@ -18,7 +18,7 @@ MST_PREC_F32 = 0
 MST_PREC_BF16 = 1
 MST_PREC_BF16X3 = 2
 MST_MAX_BLOCKS = 32
-TCN_TUNING_DEFAULT = 53     # mst_tcn_set_tuning flags a fresh handle starts with (csrc/mst_api.hip: x3_small_tiles = 1, bf16_form = 2, x3_duo = 0, bf16_reuse = 1, bf16_fuse0 = 1)
+TCN_TUNING_DEFAULT = 117    # mst_tcn_set_tuning flags a fresh handle starts with (csrc/mst_api.hip: x3_small_tiles = 1, bf16_form = 2, x3_duo = 0, bf16_reuse = 1, bf16_fuse0 = 1, x3_half_cm = 1)
 PRECISIONS = {"fp32": MST_PREC_F32, "f32": MST_PREC_F32, "bf16": MST_PREC_BF16, "bf16x3": MST_PREC_BF16X3}
 
 STATUS_NAMES = {0: "MST_OK", -1: "MST_ERR_ARG", -2: "MST_ERR_UNSUPPORTED", -3: "MST_ERR_HIP", -4: "MST_ERR_STATE",
@@ -80,6 +80,7 @@ SIGNATURES = {
     "mst_fx_sumsq": (C.c_int, [_F, C.c_int, C.c_long, _P, _P]),
     "mst_fx_rms_pending": (C.c_int, [_P, _P, C.c_long, _P, C.c_long, _P, C.c_int, _P]),
     "mst_fx_scale_items": (C.c_int, [_F, _F, C.c_int, C.c_long, _P, _P]),
+    "mst_fx_set_tuning": (C.c_int, [C.c_int]),
     "mst_fx_compressor_scratch_bytes": (C.c_size_t, [C.c_int, C.c_long, C.c_int]),
     "mst_fx_compressor": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                     C.c_double, _P, C.c_size_t, _P, _P]),

@@ -536,7 +536,13 @@ struct CompMapArgs {
     // slope of the piece at sorted position p and its reciprocal; [0]: a chunk of T steps, [1]: the last chunk when it is shorter
     // (0 beyond its pieces)
     double slope[2][MST_COMP_NP], inv_slope[2][MST_COMP_NP];
+    // time slices (the host pipelines map -> chain -> apply over slices of whole batches, mst_api.hip compressor_run): the map launch covers
+    // chunks chunk0 .. chunk0 + gridDim.x - 1, the chain launch batches batch0 .. batch1 - 1 (of MST_CHAIN_CB chunks); a chain launch with
+    // batch0 > 0 starts from ycarry[seq] (what the launch before it left there) instead of yL_prev = 0, and every launch leaves its last value
+    int chunk0 = 0, batch0 = 0, batch1 = 0, clear_sumsq = 1;
+    double *ycarry = nullptr;      // [n_seq]
 };
+#define MST_CHAIN_CB 32                    // chunks per batch of the chain kernel
 
 // grid (nchunks, ceil(n_seq / 64)), 64 threads: lanes = sequences of one chunk (coalesced time-major loads).  Four waves per SIMD
 // (<= 128 registers, 8.5 KB of LDS): the early steps of a chunk have few pieces and little to overlap within one wave.
@@ -545,7 +551,7 @@ __global__ __launch_bounds__(64) MST_WAVES_PER_SIMD(4) MST_HEAVY_UNROLL void fx_
     constexpr int PASS = 16;                                        // doubles of every record that cross the LDS tile at a time (128 B)
     __shared__ double tr[64 * (PASS + 1)];
     __shared__ double tab[256];
-    const int k = blockIdx.x;
+    const int k = blockIdx.x + a.chunk0;
     const int seq = blockIdx.y * 64 + threadIdx.x;
     const bool live = seq < a.n_seq;
     const size_t sq = live ? seq : a.n_seq - 1;
@@ -553,7 +559,7 @@ __global__ __launch_bounds__(64) MST_WAVES_PER_SIMD(4) MST_HEAVY_UNROLL void fx_
     // the level differences x_l are computed here from the audio (a lane walks its own sequence: 32 frames = 256 contiguous bytes that
     // it shares with the lane of the other channel), not read from a float64 scratch that a separate pass would have to write
     for (int i = threadIdx.x; i < 256; i += 64) tab[i] = a.log_tab[i];
-    if (ca.out_sumsq) {             // the first launch of a compressor call clears the energy slots its apply pass adds to
+    if (ca.out_sumsq && a.clear_sumsq) {      // the first launch of a compressor call clears the energy slots its apply passes add to
         const long nthr = (long)gridDim.x * gridDim.y * 64, me = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 64 + threadIdx.x;
         for (long i = me; i < (long)(ca.n_seq / ca.C) * MST_SUMSQ_SLOTS; i += nthr) ca.out_sumsq[i] = 0.0;
     }
@@ -626,7 +632,7 @@ __global__ __launch_bounds__(64) MST_WAVES_PER_SIMD(4) MST_HEAVY_UNROLL void fx_
 #define MST_CHAIN_HELPERS 4
 #define MST_CHAIN_THREADS 384
 __global__ __launch_bounds__(MST_CHAIN_THREADS) void fx_comp_chain_kernel(CompMapArgs a) {
-    constexpr int CB = 32, REC = MST_COMP_REC, NPE = MST_COMP_NP + 1, ENT = 2 * NPE;      // chunks per batch, doubles per record / per chunk of entries
+    constexpr int CB = MST_CHAIN_CB, REC = MST_COMP_REC, NPE = MST_COMP_NP + 1, ENT = 2 * NPE;      // chunks per batch, doubles per record / per chunk of entries
     constexpr int NH = MST_CHAIN_HELPERS, HB = CB / NH;               // helper waves; chunks per helper wave and batch
     constexpr int NLD = (HB * REC / 2 + 63) / 64;                     // 16-byte loads per helper lane per batch
     static_assert(REC % 2 == 0 && HB % 2 == 0, "records are whole 16-byte units; a helper takes its chunks two at a time");
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(MST_CHAIN_THREADS) void fx_comp_chain_kernel(CompMa
     const bool helper = wave != 0 && wave != 4;
     const double2 *m = (const double2 *)(a.maps + (size_t)seq * a.nchunks * REC);
     const size_t total = (size_t)a.nchunks * REC / 2;
-    const int nbatch = (a.nchunks + CB - 1) / CB;
+    const int nbatch = a.batch1;                                      // this launch walks batches batch0 .. batch1 - 1
     // ---- waves 1, 2: global -> registers -> raw records in LDS -> entries
     const int hp = (lane & 31) + 1;                                   // the piece this helper lane rebuilds (1 .. T)
     const double sl_full = a.slope[0][hp], isl_full = a.inv_slope[0][hp - 1], sl_last = a.slope[1][hp], isl_last = a.inv_slope[1][hp - 1];
@@ -685,15 +691,16 @@ __global__ __launch_bounds__(MST_CHAIN_THREADS) void fx_comp_chain_kernel(CompMa
             q[0] = 0.0;
             q[1] = MST_COMP_NEVER;
         }
-        load(0);
-        cook(0, 0);
+        load(a.batch0);
+        cook(0, a.batch0);
     }
     __syncthreads();
-    MstUniformF64 yu = mst_wave_read_u64(0.0, 0);                   // yL_prev = 0 on entry (common_audioeffects.py:553)
+    // yL_prev = 0 on entry (common_audioeffects.py:553); a later time slice continues from the value the slice before it left
+    MstUniformF64 yu = mst_wave_read_u64(a.batch0 > 0 ? a.ycarry[seq] : 0.0, 0);
     const int pl = lane < MST_COMP_NP ? MST_COMP_NP - 1 - lane : MST_COMP_NP;   // descending; lanes without a piece read the "never" entry
     const double a_full = pl < MST_COMP_NP ? a.slope[0][pl] : 0.0, a_last = pl < MST_COMP_NP ? a.slope[1][pl] : 0.0;
-    for (int bt = 0; bt < nbatch; ++bt) {
-        const int cur = bt & 1;
+    for (int bt = a.batch0; bt < nbatch; ++bt) {
+        const int cur = (bt - a.batch0) & 1;
         if (helper) {
             if (bt + 1 < nbatch) {
                 cook(cur ^ 1, bt + 1);
@@ -734,6 +741,7 @@ __global__ __launch_bounds__(MST_CHAIN_THREADS) void fx_comp_chain_kernel(CompMa
                 }
             }
             if (lane < nc) a.ystart[(size_t)(bt * CB + lane) * a.n_seq + seq] = keep;
+            if (bt + 1 == nbatch && lane == 0) a.ycarry[seq] = yu.value();
         }
         __syncthreads();
     }
@@ -743,9 +751,10 @@ __global__ __launch_bounds__(MST_CHAIN_THREADS) void fx_comp_chain_kernel(CompMa
 // differences from the audio (yl = the log10 table), the smoother inside each chunk from its true start value (two chunks per tile, one
 // (chunk, sequence) per thread of the first two waves), the gain application: neither x_l nor y_l ever travels to HBM.
 template <bool FILL>
-__global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const double *yl, const double *ystart, int nchunks) {
+__global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const double *yl, const double *ystart, int nchunks, int tile0) {
     __shared__ double t[64][65];
-    const long n0 = (long)blockIdx.x * 64;
+    const long tx = (long)blockIdx.x + tile0;                       // time tile (a launch covers the tiles of one time slice)
+    const long n0 = tx * 64;
     const int s0 = blockIdx.y * 64;
     float xv[16];
     if constexpr (FILL) {
@@ -780,7 +789,7 @@ __global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const do
         }
         __syncthreads();
         const int sl = threadIdx.x & 63, hh = threadIdx.x >> 6;
-        const long k = (long)blockIdx.x * 2 + hh;
+        const long k = tx * 2 + hh;
         if (hh < 2 && s0 + sl < a.n_seq && k < nchunks) {
             const double cA = 1.0 - a.alpha_att, cR = 1.0 - a.alpha_rel;
             double prev = ystart[(size_t)k * a.n_seq + s0 + sl];
@@ -822,7 +831,7 @@ __global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const do
             double cs = 0.0;
 #pragma unroll 8
             for (int nl = 0; nl < 64; ++nl) cs += t[nl][threadIdx.x];
-            atomicAdd(&a.out_sumsq[((s0 + threadIdx.x) / a.C) * MST_SUMSQ_SLOTS + (blockIdx.x & (MST_SUMSQ_SLOTS - 1))], cs);
+            atomicAdd(&a.out_sumsq[((s0 + threadIdx.x) / a.C) * MST_SUMSQ_SLOTS + (tx & (MST_SUMSQ_SLOTS - 1))], cs);
         }
     }
 }

@@ -136,8 +136,8 @@ struct MstTcn {
     void *zero_row = nullptr;     // 1 KB of zeros: what the block kernels stage for time steps outside the segment
     int x3_small_tiles = 1;       // bf16x3 mode: 128-time tiles of <= 2 phases, two workgroups per CU (mst_tcn_set_tuning; measured 5.13 vs 5.45 ms)
     int x3_duo = 0;               // bf16x3 mode: the persistent double-tile form of the 128-time-tile kernel (mst_tcn_set_tuning bit 3; measured slower: 5.45 vs 4.55 ms)
-    int x3_half_cm = 0;           // bf16x3 mode: class-major loop in the eight-phase half-tile kernel (mst_tcn_set_tuning bit 6; emulator-validated, not
-                                  // measured yet: off)
+    int x3_half_cm = 1;           // bf16x3 mode: class-major loop in the eight-phase half-tile kernel (mst_tcn_set_tuning bit 6; round 5: GPU-tested,
+                                  // 566 -> 572 segments/s at 32 x 131072, profiles/r05_x3_ab_bit6_53_117.jsonl: on)
     int bf16_fuse0 = 1;           // bf16 mode: block 0 computed by the loader waves of block 1's duo kernel (mst_tcn_set_tuning bit 5; measured -0.2 ms
                                   // per forward, bit-identical to the separate kernel; default since round 5 - tests/test_gpu_parity.py form 53)
     int last_fused0 = 0;          // whether the last forward of this handle really ran block 0 inside block 1's launch (mst_tcn_get_tuning)
@@ -1639,7 +1639,7 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
 namespace {
 // scratch = level differences [L][n_seq] (serial fallback only) | chunk maps [n_seq][nchunks][NP + 1] | chunk start values
 // [nchunks][n_seq] | log10 table [256]
-struct CompScratch { size_t xl, maps, ystart, tab, total; long nchunks; };
+struct CompScratch { size_t xl, maps, ystart, tab, carry, total; long nchunks; };
 CompScratch comp_scratch(int n_items, long L, int C) {
     CompScratch c;
     const size_t n_seq = (size_t)n_items * C;
@@ -1648,7 +1648,8 @@ CompScratch comp_scratch(int n_items, long L, int C) {
     c.maps = n_seq * (size_t)c.nchunks * MST_COMP_REC * sizeof(double);
     c.ystart = n_seq * (size_t)c.nchunks * sizeof(double);
     c.tab = 256 * sizeof(double);
-    c.total = c.xl + c.maps + c.ystart + c.tab;
+    c.carry = n_seq * sizeof(double);                                      // the smoother's value between two time slices of the chain
+    c.total = c.xl + c.maps + c.ystart + c.tab + c.carry;
     return c;
 }
 }  // namespace
@@ -1677,6 +1678,40 @@ const double *log10_table(void *stream) {
         tabs[dev] = t;
     }
     return tabs[dev];
+}
+
+// the side stream of the time-parallel FX kernels (compressor_run): one per device, non-blocking, lowest priority, with the events of one
+// fork / join; kept for the life of the process
+struct FxSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, map_done[8] = {}, chain_done[8] = {};
+    std::mutex mu;
+};
+int g_fx_pipeline = 1;          // mst_fx_set_tuning bit 0
+int g_fx_pipeline_any_size = 0; // mst_fx_set_tuning bit 1 (test / A-B hook: slices whatever the size of the batch)
+FxSide *fx_side() {
+    static std::mutex mu;
+    static FxSide *sides[64] = {};
+    const int dev = mst_current_device();
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!sides[dev]) {
+        FxSide *f = new FxSide;
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = the numerically greatest = lowest priority
+        bool ok = hipStreamCreateWithPriority(&f->stream, hipStreamNonBlocking, lo) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&f->fork, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&f->join, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 8 && ok; ++i)
+            ok = hipEventCreateWithFlags(&f->map_done[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&f->chain_done[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            delete f;
+            return nullptr;
+        }
+        sides[dev] = f;
+    }
+    return sides[dev];
 }
 
 int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size_t scratch_bytes, void *stream) {
@@ -1713,17 +1748,75 @@ int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size
                     m.inv_slope[which][p] = p <= n ? 1.0 / m.slope[which][p] : 0.0;
                 }
             }
-            const dim3 cg((unsigned)cs.nchunks, (unsigned)((a.n_seq + 63) / 64));
-            if (m.use_min) MST_LAUNCH(fx_comp_map_kernel<true>, cg, dim3(64), stream, m, a);
-            else MST_LAUNCH(fx_comp_map_kernel<false>, cg, dim3(64), stream, m, a);
-            MST_CHECK_LAUNCH("fx_comp_map_kernel");
-            MST_LAUNCH(fx_comp_chain_kernel, dim3(a.n_seq), dim3(MST_CHAIN_THREADS), stream, m);
-            MST_CHECK_LAUNCH("fx_comp_chain_kernel");
-            MST_LAUNCH((fx_comp_apply_kernel<true>), tiles, dim3(256), stream, a, tab, (const double *)m.ystart, m.nchunks);
-            MST_CHECK_LAUNCH("fx_comp_apply_kernel");
+            m.ycarry = (double *)((unsigned char *)scratch + cs.xl + cs.maps + cs.ystart + cs.tab);
+            // Time slices.  The chain is ONE dependent walk per sequence (n_seq workgroups, latency-bound: most of the chip idles beside it) while
+            // the map and apply kernels are throughput work.  The signal is cut into NS slices of whole chain batches; the caller's stream runs
+            // the chain of slice 0, 1, ... back to back, a side stream (lower priority) the maps of slice 1, 2, ... and the applies of slice
+            // 0 .. NS - 2 beside it (events order map_i -> chain_i -> apply_i); the last apply follows the last chain on the caller's stream, which
+            // then waits for the side stream.  Same arithmetic, same results (the smoother's value crosses a slice boundary as a float64 in
+            // ycarry); without concurrency (a profiler serialising the queues) the launches simply run one after the other.
+            const int nbatch = (int)((cs.nchunks + MST_CHAIN_CB - 1) / MST_CHAIN_CB);
+            const int gy = (a.n_seq + 63) / 64;
+            int ns = 1;
+            if (g_fx_pipeline && ((nbatch >= 32 && (double)a.n_seq * (double)L >= 4.0e6) || (g_fx_pipeline_any_size && nbatch >= 4))) ns = 4;
+            FxSide *side = ns > 1 ? fx_side() : nullptr;
+            if (!side) ns = 1;
+            auto launch_map = [&](int b0, int b1, void *st) -> int {
+                CompMapArgs mm = m;
+                mm.chunk0 = b0 * MST_CHAIN_CB;
+                mm.clear_sumsq = b0 == 0 ? 1 : 0;
+                const long c1 = std::min<long>((long)b1 * MST_CHAIN_CB, cs.nchunks);
+                const dim3 cg((unsigned)(c1 - mm.chunk0), (unsigned)gy);
+                if (m.use_min) MST_LAUNCH(fx_comp_map_kernel<true>, cg, dim3(64), st, mm, a);
+                else MST_LAUNCH(fx_comp_map_kernel<false>, cg, dim3(64), st, mm, a);
+                MST_CHECK_LAUNCH("fx_comp_map_kernel");
+                return MST_OK;
+            };
+            auto launch_chain = [&](int b0, int b1, void *st) -> int {
+                CompMapArgs mm = m;
+                mm.batch0 = b0;
+                mm.batch1 = b1;
+                MST_LAUNCH(fx_comp_chain_kernel, dim3(a.n_seq), dim3(MST_CHAIN_THREADS), st, mm);
+                MST_CHECK_LAUNCH("fx_comp_chain_kernel");
+                return MST_OK;
+            };
+            auto launch_apply = [&](int b0, int b1, void *st) -> int {      // a batch is 32 chunks = 16 time tiles of 64 samples
+                const long t0 = (long)b0 * (MST_CHAIN_CB / 2), t1 = std::min<long>((long)b1 * (MST_CHAIN_CB / 2), (long)tiles.x);
+                MST_LAUNCH((fx_comp_apply_kernel<true>), dim3((unsigned)(t1 - t0), tiles.y), dim3(256), st, a, tab, (const double *)m.ystart, m.nchunks, (int)t0);
+                MST_CHECK_LAUNCH("fx_comp_apply_kernel");
+                return MST_OK;
+            };
+            static_assert(MST_COMP_T == 32 && MST_CHAIN_CB % 2 == 0, "two chunks per 64-sample apply tile");
+            int rc;
+            if (ns == 1) {
+                if ((rc = launch_map(0, nbatch, stream)) || (rc = launch_chain(0, nbatch, stream)) || (rc = launch_apply(0, nbatch, stream))) return rc;
+                return MST_OK;
+            }
+            std::lock_guard<std::mutex> lock(side->mu);          // one fork / join at a time per device: the events are reused
+            hipStream_t main_s = (hipStream_t)stream, side_s = side->stream;
+            auto bound = [&](int i) { return (int)((long)nbatch * i / ns); };
+            if ((rc = launch_map(0, bound(1), stream))) return rc;          // slice 0's map: nothing to overlap it with
+            MST_HIP_TRY(hipEventRecord(side->fork, main_s));               // the side stream sees the input (and slice 0's cleared energy slots)
+            MST_HIP_TRY(hipStreamWaitEvent(side_s, side->fork, 0));
+            for (int i = 1; i < ns; ++i) {
+                if ((rc = launch_map(bound(i), bound(i + 1), side_s))) return rc;
+                MST_HIP_TRY(hipEventRecord(side->map_done[i], side_s));
+            }
+            for (int i = 0; i < ns; ++i) {
+                if (i > 0) MST_HIP_TRY(hipStreamWaitEvent(main_s, side->map_done[i], 0));
+                if ((rc = launch_chain(bound(i), bound(i + 1), stream))) return rc;
+                if (i + 1 < ns) {
+                    MST_HIP_TRY(hipEventRecord(side->chain_done[i], main_s));
+                    MST_HIP_TRY(hipStreamWaitEvent(side_s, side->chain_done[i], 0));
+                    if ((rc = launch_apply(bound(i), bound(i + 1), side_s))) return rc;
+                }
+            }
+            if ((rc = launch_apply(bound(ns - 1), nbatch, stream))) return rc;
+            MST_HIP_TRY(hipEventRecord(side->join, side_s));
+            MST_HIP_TRY(hipStreamWaitEvent(main_s, side->join, 0));
             return MST_OK;
         }
-        MST_LAUNCH((fx_comp_apply_kernel<false>), tiles, dim3(256), stream, a, (const double *)scratch, (const double *)nullptr, 0);
+        MST_LAUNCH((fx_comp_apply_kernel<false>), tiles, dim3(256), stream, a, (const double *)scratch, (const double *)nullptr, 0, 0);
         MST_CHECK_LAUNCH("fx_comp_apply_kernel");
         return MST_OK;
     }
@@ -1732,6 +1825,13 @@ int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size
     return MST_OK;
 }
 }  // namespace
+
+extern "C" int mst_fx_set_tuning(int flags) {
+    if (flags < 0 || flags > 3) return fail(MST_ERR_ARG, "mst_fx_set_tuning: unknown flag bits");
+    g_fx_pipeline = flags & 1;
+    g_fx_pipeline_any_size = (flags >> 1) & 1;
+    return MST_OK;
+}
 
 extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, int C, double threshold_db,
                                  double attack_ms, double release_ms, double ratio, double sample_rate, double *scratch,

@@ -56,6 +56,13 @@ static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emu_event{0.0}
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu_now_ms(); return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+// streams are synchronous here: a side stream is the same thing as the caller's, waiting for an event is a no-op
+#define hipStreamNonBlocking 1
+#define hipEventDisableTiming 2
+static inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return 0; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = nullptr; return 0; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new emu_event{0.0}; return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return 0; }
 
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }

@@ -580,6 +580,29 @@ def test_time_parallel_fx_shapes_emulated(emu_default, L, n_items, C):
             assert np.abs(y[i] - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (L, bands, i)
 
 
+@pytest.mark.parametrize("L,n_items,C", [(4 * 1024, 1, 2), (5 * 1024 + 517, 3, 2), (9 * 1024 + 31, 2, 1)])
+def test_compressor_time_slices_are_bit_identical_emulated(emu_default, L, n_items, C):
+    """The compressor's map / chain / apply kernels over FOUR time slices (mst_fx_set_tuning bits 0 | 1: the pipelined form the product uses
+    for large batches, here forced on a small one) against the single-slice run: the same bits - the smoother's value crosses a slice
+    boundary as a float64 - and both against the oracle.  Slices of unequal batch counts, a ragged last batch, a short last chunk."""
+    from music_mixing_style_transfer_amd.mixing_manipulator import Compressor
+    rng = np.random.default_rng(L)
+    x = (0.25 * rng.standard_normal((n_items, L, C))).astype(np.float32)
+    c = Compressor(44100)
+    c.parameters.threshold.value, c.parameters.attack_time.value = -28.0, 3.0
+    c.parameters.release_time.value, c.parameters.ratio.value = 120.0, 6.0
+    try:
+        emu_default.check(emu_default.mst_fx_set_tuning(0), "mst_fx_set_tuning")
+        y1 = c.process(x.copy())
+        emu_default.check(emu_default.mst_fx_set_tuning(3), "mst_fx_set_tuning")
+        y4 = c.process(x.copy())
+    finally:
+        emu_default.check(emu_default.mst_fx_set_tuning(1), "mst_fx_set_tuning")
+    assert np.array_equal(y1, y4)
+    ref = F.compressor(x[n_items - 1].copy(), -28.0, 3.0, 120.0, 6.0)
+    assert np.abs(y4[n_items - 1] - ref).max() <= 3e-7 * max(1.0, np.abs(ref).max())
+
+
 def test_encoder_rows_kernel_matches_im2col_emulated(emu_default):
     """bf16 FXencoder: the LDS-resident-rows convolution kernel (long early layers) against the im2col kernel it replaces -
     same operands in the same k order, so bit-identical - over strides 1 / 2 / 4, even kernels, ragged last tiles."""

@@ -148,15 +148,17 @@ def test_tcn_bf16_block_kernel_forms_vs_oracle(nets, form):
             y5 = tcn(x.cuda(), cond.cuda()).cpu()
             d = float((y5 - y).abs().max())
             print(f"class-major vs tap-major waveform: {d:.2e}")
-            assert d <= 2e-3, d          # well inside the bf16 mode's own deviation from the oracle (4e-3 .. 8e-3); a wrong tap or tile shows as >= 1e-2
+            assert d <= 1e-2, d          # both are within 1e-2 of the oracle; the TIGHT check of the class-major order is the single block below
             # before any re-rounding the two orders agree to fp32 accumulation rounding: one dense block on the SAME bf16 input, outputs one bf16 ulp apart at most
             a5 = tcn.forward_blocks(x.cuda(), cond.cuda(), 2).cpu()
             lib.check(lib.mst_tcn_set_tuning(tcn._handle, 21), "mst_tcn_set_tuning")
             a21 = tcn.forward_blocks(x.cuda(), cond.cuda(), 2).cpu()
-            assert float((a5 - a21).abs().max()) <= 2.0 ** -7 * float(a21.abs().max())
+            d2 = float((a5 - a21).abs().max()) / float(a21.abs().max())
+            print(f"class-major vs tap-major, block 2 on the same bf16 input: {d2:.2e} of max|a|")
+            assert d2 <= 2.0 ** -7, d2
         if form == 53:         # block 0 inside block 1's launch: the same arithmetic, bit for bit - and it must really have run fused
             fl, fused = tcn_tuning_state(lib, tcn)
-            assert fl == 53 and fused == 1
+            assert fl == 53 and fused == 1          # (53 = the default 117 without the bf16x3-only bit 6)
             a53 = tcn.forward_blocks(x.cuda(), cond.cuda(), 2).cpu()
             lib.check(lib.mst_tcn_set_tuning(tcn._handle, 21), "mst_tcn_set_tuning")
             assert torch.equal(tcn(x.cuda(), cond.cuda()).cpu(), y)

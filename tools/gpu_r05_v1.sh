@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$(pwd); O=$R/gpurun_out/v1; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 (rocm-smi --showproductname; lscpu | head -20; nproc) > $O/box.txt 2>&1
-timeout 1500 python -m pytest tests -m gpu -q -rA --durations=15 2>&1 | tail -150 > $O/pytest_gpu.log
+timeout 1500 python -m pytest tests -m gpu -q -rA --durations=15 2>&1 > $O/pytest_gpu_full.log; tail -150 $O/pytest_gpu_full.log > $O/pytest_gpu.log
 timeout 300 python tools/bench_tcn_forms.py --forms 21,53 --steps 10 --rounds 3 --out $O/tcn_forms_21_53.json > $O/tcn_forms_21_53.log 2>&1
 for f in 53 117 53 117; do
   timeout 300 python bench.py --precision bf16x3 --workload configs1 --steps 4 --warmup 2 --no-cpu-baseline --tcn-tuning $f >> $O/x3_ab_53_117.jsonl 2>> $O/x3_ab.err
