@@ -281,7 +281,8 @@ int mst_fx_biquad_cascade(const float *x_dev, float *y_dev, int n_items, long L,
  * (>= 32 chain batches of 1024 samples and >= 4e6 samples in all) is cut into four time slices whose map / apply kernels run on an internal
  * low-priority side stream BESIDE the chain kernel of the neighbouring slice (the chain is one latency-bound walk per sequence on n_seq
  * workgroups; events order map_i -> chain_i -> apply_i, the caller's stream joins the side stream before the call returns to it).
- * Measured on configs[3] (64 x [131072, 2]): see DESIGN.md 3.3.  bit 1 (default 0; test / A-B hook): slices whatever the size (>= 4 batches). */
+ * Measured on configs[3] (64 x [131072, 2]): see DESIGN.md 3.3.  bit 1 (default 0; test / A-B hook): slices whatever the size (>= 8 batches);
+ * bits 2-3 (A-B hook): number of slices, 0 -> 4 (default), 1 -> 2, 2 -> 3, 3 -> 8. */
 int mst_fx_set_tuning(int flags);
 
 /* Compressor.process / compressor_process (:529-587, :637-649), makeup gain 0.  With a scratch buffer of

@@ -179,6 +179,203 @@ __global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) 
     }
 }
 
+// Pass 1 without the recursion (round 5).  The zero-state end state of a chunk is LINEAR in its M input samples:
+//     e = sum_n h_(M-1-n) x[n],   h_m = A^m B = the cascade's state m steps after a unit impulse went in
+// - 2 * n_bands independent multiply-add chains per sample instead of the cascade's 5 * n_bands DEPENDENT operations (the recursion pass is
+// bound by that chain: one wave per SIMD, ~400 clocks per sample at five bands).  htab[m][S] = h_m comes from the host (float64, the same
+// recursion run on an impulse; cached per coefficient set, mst_api.hip); a workgroup stages it through LDS in segments of TS samples and every
+// lane reads its row as broadcast ds_read_b128s.  Same sum as the recursion up to float64 rounding (the terms are added in time order, not
+// nested through the states).  The last chunk of a sequence, when it is short, has no successor: its end state is not needed (zeros).
+template <int NBANDS>
+__global__ __launch_bounds__(256) void fx_biquad_ends_kernel(BiquadChunkArgs a, const double *__restrict__ htab) {
+    // FOUR lanes per (sequence, chunk), a quarter of the chunk's samples each (M is a multiple of 16): 4 x the waves of one lane per chunk - at
+    // 61 696 chunks one lane each is one wave per SIMD, whose load latency, LDS reads and multiply-adds then run one after the other (measured
+    // 49 us like the recursion pass it replaced).  Lanes: quarter fastest (the four partial sums meet by two lane exchanges), then channel, chunk, item.
+    constexpr int S = 2 * NBANDS, TS = 32, NB = 4, PARTS = 4;          // TS = samples per quarter and table segment
+    __shared__ __attribute__((aligned(16))) double tab[PARTS * TS * S];
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x, total = (long)a.n_seq * a.nchunks * PARTS;
+    if (a.out_sumsq)          // the state pass clears the energy slots the apply pass adds to (no memset launch in front of the call)
+        for (long i = gid; i < (long)(a.n_seq / a.C) * MST_SUMSQ_SLOTS; i += (long)gridDim.x * 256) a.out_sumsq[i] = 0.0;
+    if (a.out_in_sumsq)
+        for (long i = gid; i < (long)(a.n_seq / a.C) * MST_SUMSQ_SLOTS; i += (long)gridDim.x * 256) a.out_in_sumsq[i] = 0.0;
+    const bool live = gid < total;
+    const long gl = live ? gid : total - 1;                 // idle lanes of the last workgroup shadow a live one (they take part in the barriers)
+    const int part = (int)(gl % PARTS);
+    const int c = (int)((gl / PARTS) % a.C);
+    const int k = (int)((gl / ((long)a.C * PARTS)) % a.nchunks);
+    const int item = (int)(gl / ((long)a.C * PARTS * a.nchunks));
+    const int seq = item * a.C + c;
+    const int MQ = a.M / PARTS;                             // samples per quarter (a multiple of 4)
+    const long n_lo = (long)k * a.M;
+    const bool full = n_lo + a.M <= a.L;
+    const float *xp = a.x + ((size_t)item * a.L + (full ? n_lo : 0) + (size_t)part * MQ) * a.C + c;      // a short chunk reads (and ignores) the sequence's first samples
+    const float sf = a.in_scale ? (float)a.in_scale[item] : 1.0f;
+    double acc[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) acc[j] = 0.0;
+    for (int s0 = 0; s0 < MQ; s0 += TS) {
+        const int cnt = MQ - s0 < TS ? MQ - s0 : TS;        // a multiple of 4
+        __syncthreads();
+        for (int e = threadIdx.x; e < PARTS * cnt * S; e += 256) {      // rows of the four quarters' samples s0 .. s0 + cnt - 1
+            const int p = e / (cnt * S), r = e - p * cnt * S, i = r / S, j = r - i * S;
+            tab[(p * TS + i) * S + j] = htab[(size_t)(a.M - 1 - (p * MQ + s0 + i)) * S + j];
+        }
+        __syncthreads();
+        const double *mytab = tab + part * TS * S;
+        for (int i0 = 0; i0 < cnt; i0 += NB) {
+            float xin[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) xin[i] = xp[(size_t)(s0 + i0 + i) * a.C];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const double v = (double)(xin[i] * sf);
+                const double *row = mytab + (i0 + i) * S;
+#pragma unroll
+                for (int j = 0; j < S; ++j) acc[j] = fma(row[j], v, acc[j]);
+            }
+        }
+    }
+    // the four quarters of a chunk sit in four neighbouring lanes (an aligned quad: 256 and 64 are multiples of 4)
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        acc[j] += __shfl_xor(acc[j], 1);
+        acc[j] += __shfl_xor(acc[j], 2);
+    }
+    if (live && part == 0) {
+#pragma unroll
+        for (int b = 0; b < NBANDS; ++b)
+            *(double2 *)(a.ends + ((size_t)seq * a.nchunks + k) * (2 * MST_MAX_BANDS) + 2 * b) = full ? double2{acc[2 * b], acc[2 * b + 1]} : double2{0.0, 0.0};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// STEREO chunks through LDS (round 5).  One lane per (channel, chunk) walks its chunk sample by sample; read straight from global memory
+// that is 4 useful bytes per lane out of 32 different 128-byte lines per wave-instruction - measured: a state pass with next to no
+// arithmetic (fx_biquad_ends_kernel) takes the same 50 us as the recursion it replaced; the passes are bound by the vector cache's line
+// rate, not by float64.  Here a wave owns 32 consecutive chunks of stereo audio and moves them in SLABS of 16 frames: 16 stereo frames of a
+// chunk are one 128-byte run (one aligned line when L * 8 is a multiple of 128, as for power-of-two segments), eight lanes fetch it as eight 16-byte pieces (4 wave
+// loads per slab instead of 16, 8 lines per instruction instead of 32), the slab sits in LDS as 32 rows of 144 bytes and lane (c, chunk)
+// reads its 16 samples from its row.  Four slabs' loads are in flight while the current one is used.
+// Waves that hold the last chunk of a sequence (it may be short, and a line may run past the end of the buffer) guard every piece.
+// Measured at 64 x [131072, 2], five bands (profiles/r05_fx_*): the state pass 49.4 us (recursion or dot products, one lane per chunk,
+// straight from global memory) -> 49.6 (slabs, one in flight) -> 40.9 (four in flight).  The APPLY pass was built the same way (slabs in
+// and out) and measured SLOWER than fx_biquad_chunk_kernel<true> (73-78 us against 62-64: 64 unrolled samples of a 25-coefficient recursion
+// spill scalar registers): dropped, the apply pass keeps its lane-per-chunk loads.
+// ------------------------------------------------------------------------------------------------
+typedef float fx_f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // a 16-byte global access that is only dword aligned (odd L)
+constexpr int FXS_TS = 16;          // frames per slab
+constexpr int FXS_ROWB = 144;       // LDS row pitch in bytes: 128 + 16 (16-byte aligned pieces; rows 0 .. 15 start in distinct banks)
+struct FxStereoRows {
+    const float *src[4];            // frame 0 of this lane's four rows (row = (lane >> 3) + 8 i), advanced to the lane's 16-byte piece
+    long room[4];                   // frames from the row's first frame to the end of its sequence; 0: no such row
+    bool edge;                      // wave-uniform: some row may be short or absent -> guarded pieces
+};
+__device__ __forceinline__ FxStereoRows fx_stereo_rows(const float *x, long pair0, long npairs, int nchunks, int M, long L, int lane) {
+    FxStereoRows r;
+    r.edge = pair0 + 32 > npairs || (pair0 % nchunks) + 31 >= nchunks - 1;      // the wave holds the last chunk of a sequence
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long g = pair0 + (lane >> 3) + 8 * i;
+        const bool ok = g < npairs;
+        const long gg = ok ? g : npairs - 1;
+        const long item = gg / nchunks;
+        const long k = gg - item * nchunks;
+        r.src[i] = x + ((size_t)item * L + (size_t)k * M) * 2 + 4 * (lane & 7);
+        r.room[i] = ok ? L - k * M : 0;
+    }
+    return r;
+}
+__device__ __forceinline__ void fx_stereo_fetch(const FxStereoRows &r, int s, int lane, f32x4 (&v)[4]) {
+    if (!r.edge) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *(const fx_f32x4u *)(r.src[i] + (size_t)s * 2);
+    } else {
+        const long f0 = s + 2 * (lane & 7);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float *p = r.src[i] + (size_t)s * 2;
+            f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (f0 + 1 < r.room[i]) {
+                t = *(const fx_f32x4u *)p;
+            } else if (f0 < r.room[i]) {
+                t[0] = p[0];
+                t[1] = p[1];
+            }
+            v[i] = t;
+        }
+    }
+}
+__device__ __forceinline__ void fx_stereo_to_lds(unsigned char *rows_lds, int lane, const f32x4 (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *(f32x4 *)(rows_lds + ((lane >> 3) + 8 * i) * FXS_ROWB + (lane & 7) * 16) = v[i];
+}
+
+// pass 1 for stereo audio: fx_biquad_ends_kernel's dot products (e = sum_n h_(M-1-n) x[n]) on slabs.  A workgroup = four waves = 128
+// chunk pairs sharing the table segments (64 rows at a time).
+template <int NBANDS>
+__global__ __launch_bounds__(256) void fx_biquad_stereo_ends_kernel(BiquadChunkArgs a, const double *__restrict__ htab) {
+    constexpr int S = 2 * NBANDS, TT = 64;
+    __shared__ __attribute__((aligned(16))) double tab[TT * S];
+    __shared__ __attribute__((aligned(16))) unsigned char slab[4][32 * FXS_ROWB];
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (a.out_sumsq)          // the state pass clears the energy slots the apply pass adds to (no memset launch in front of the call)
+        for (long i = gid; i < (long)(a.n_seq / 2) * MST_SUMSQ_SLOTS; i += (long)gridDim.x * 256) a.out_sumsq[i] = 0.0;
+    if (a.out_in_sumsq)
+        for (long i = gid; i < (long)(a.n_seq / 2) * MST_SUMSQ_SLOTS; i += (long)gridDim.x * 256) a.out_in_sumsq[i] = 0.0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 1;
+    const long npairs = (long)(a.n_seq / 2) * a.nchunks, pair0 = (long)blockIdx.x * 128 + wave * 32;
+    const FxStereoRows rows = fx_stereo_rows(a.x, pair0, npairs, a.nchunks, a.M, a.L, lane);
+    const long g = pair0 + (lane >> 1);
+    const bool live = g < npairs;
+    const long gg = live ? g : npairs - 1, item = gg / a.nchunks, k = gg - item * a.nchunks;
+    const bool full = (k + 1) * a.M <= a.L;                  // a short last chunk has no successor: its end state is not needed
+    const float sf = a.in_scale ? (float)a.in_scale[item] : 1.0f;
+    unsigned char *my = slab[wave];
+    double acc[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) acc[j] = 0.0;
+    // FOUR slabs in flight per wave (a register ring; TT = 4 slabs): with one slab the pass is bound by memory-level parallelism - 964
+    // waves x 4 KB in flight = 1.3 TB/s, measured 50 us whatever the access pattern
+    constexpr int D = TT / FXS_TS;
+    f32x4 ring[D][4];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d * FXS_TS < a.M) fx_stereo_fetch(rows, d * FXS_TS, lane, ring[d]);
+    for (int seg = 0; seg < a.M; seg += TT) {
+        const int cnt = a.M - seg < TT ? a.M - seg : TT;    // a multiple of 16
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt * S; e += 256) {
+            const int i = e / S, j = e - i * S;
+            tab[e] = htab[(size_t)(a.M - 1 - (seg + i)) * S + j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int s = seg + d * FXS_TS;
+            if (s < a.M) {                                    // uniform
+                __builtin_amdgcn_wave_barrier();              // every lane is done with the previous slab
+                fx_stereo_to_lds(my, lane, ring[d]);
+                if (s + TT < a.M) fx_stereo_fetch(rows, s + TT, lane, ring[d]);
+                mst_wave_lds_fence();
+                const float *mine = (const float *)(my + (lane >> 1) * FXS_ROWB) + c;
+#pragma unroll
+                for (int f = 0; f < FXS_TS; ++f) {
+                    const double xv = (double)(mine[2 * f] * sf);
+                    const double *row = tab + (d * FXS_TS + f) * S;
+#pragma unroll
+                    for (int j = 0; j < S; ++j) acc[j] = fma(row[j], xv, acc[j]);
+                }
+            }
+        }
+    }
+    if (live) {
+        const int seq = (int)item * 2 + c;
+#pragma unroll
+        for (int b = 0; b < NBANDS; ++b)
+            *(double2 *)(a.ends + ((size_t)seq * a.nchunks + k) * (2 * MST_MAX_BANDS) + 2 * b) = full ? double2{acc[2 * b], acc[2 * b + 1]} : double2{0.0, 0.0};
+    }
+}
+
 // s_0 = 0 ; s_k = A^M s_{k-1} + e_{k-1}: a first-order linear recurrence over the chunks with a matrix coefficient - scanned in
 // parallel.  One workgroup of NB = 256 or 512 threads per sequence; a block of NB - 1 chunks at a time: element 0 is the carry (the
 // start state of the block's first chunk), element i > 0 the zero-state end state of chunk i - 1, and a Hillis-Steele scan

@@ -1517,6 +1517,79 @@ void biquad_coefs(const double *coef, int n_bands, double (*out)[5]) {
 }
 }  // namespace
 
+namespace {
+// Impulse-state table of a biquad cascade for fx_biquad_ends_kernel: h_m = the cascade's state m steps after a unit impulse, m = 0 .. M - 1,
+// [M][2 * n_bands] float64.  Built on the host (the kernels' own recursion) and kept on the device per (device, coefficients, M): a chain calls
+// its equaliser with the same settings again and again.  An entry owns its host copy (the asynchronous upload reads it) and its device
+// buffer; the 16 most recent entries per device are kept, evicting one waits for the device (rare: randomised parameter sweeps).
+struct BiquadTab {
+    int dev = -1, n_bands = 0, M = 0;
+    double coef[MST_MAX_BANDS][5];
+    std::vector<double> host;
+    double *devp = nullptr;
+    unsigned long stamp = 0;
+};
+const double *biquad_impulse_table(const double (*coef)[5], int n_bands, int M, void *stream) {
+    static std::mutex mu;
+    static std::vector<BiquadTab *> tabs;
+    static unsigned long clock_ = 0;
+    const int dev = mst_current_device();
+    std::lock_guard<std::mutex> lock(mu);
+    BiquadTab *oldest = nullptr;
+    int n_dev = 0;
+    for (BiquadTab *t : tabs) {
+        if (t->dev != dev) continue;
+        ++n_dev;
+        if (t->n_bands == n_bands && t->M == M && std::memcmp(t->coef, coef, sizeof(double) * 5 * n_bands) == 0) {
+            t->stamp = ++clock_;
+            return t->devp;
+        }
+        if (!oldest || t->stamp < oldest->stamp) oldest = t;
+    }
+    const int S = 2 * n_bands;
+    BiquadTab *t = nullptr;
+    if (n_dev >= 16) {
+        t = oldest;
+        if (hipDeviceSynchronize() != hipSuccess) return nullptr;      // nobody reads the evicted table any more
+        if (t->host.size() < (size_t)M * S) {
+            (void)hipFree(t->devp);
+            t->devp = nullptr;
+        }
+    } else {
+        t = new BiquadTab;
+        tabs.push_back(t);
+    }
+    t->dev = dev;
+    t->n_bands = n_bands;
+    t->M = M;
+    std::memset(t->coef, 0, sizeof(t->coef));
+    std::memcpy(t->coef, coef, sizeof(double) * 5 * n_bands);
+    t->stamp = ++clock_;
+    if (t->host.size() < (size_t)M * S) t->host.assign((size_t)M * S, 0.0);
+    std::vector<double> z(S, 0.0);
+    for (int m = 0; m < M; ++m) {
+        double v = m == 0 ? 1.0 : 0.0;
+        for (int b = 0; b < n_bands; ++b) {
+            const double yn = coef[b][0] * v + z[2 * b];
+            z[2 * b] = coef[b][1] * v - coef[b][3] * yn + z[2 * b + 1];
+            z[2 * b + 1] = coef[b][2] * v - coef[b][4] * yn;
+            v = yn;
+        }
+        for (int j = 0; j < S; ++j) t->host[(size_t)m * S + j] = z[j];
+    }
+    if (!t->devp && hipMalloc((void **)&t->devp, t->host.size() * sizeof(double)) != hipSuccess) {
+        t->dev = -1;
+        t->devp = nullptr;
+        return nullptr;
+    }
+    if (hipMemcpyAsync(t->devp, t->host.data(), (size_t)M * S * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+        t->dev = -1;
+        return nullptr;
+    }
+    return t->devp;
+}
+}  // namespace
+
 extern "C" size_t mst_fx_biquad_scratch_bytes(int n_items, long L, int C, int n_bands) {
     if (n_items < 1 || L < 1 || C < 1 || n_bands < 1) return 0;
     const int M = biquad_chunk(L, (long)n_items * C);
@@ -1585,8 +1658,36 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
                 default: MST_LAUNCH((fx_biquad_chunk_kernel<ap, 8>), cg, dim3(64), stream, a); break;
             }
         };
-        launch_chunks(std::false_type{});
-        MST_CHECK_LAUNCH("fx_biquad_chunk_kernel<state>");
+        // pass 1: zero-state end states as dot products with the cascade's impulse-state table (fx_biquad_ends_kernel)
+        const double *htab = biquad_impulse_table(a.coef, n_bands, M, stream);
+        if (!htab) return fail(MST_ERR_HIP, "mst_fx_biquad_cascade: impulse-state table");
+        const long npairs = (long)n_items * nchunks;                       // stereo: (item, chunk) pairs - 32 per wave, slabs through LDS
+        if (C == 2) {
+            const dim3 eg((unsigned)((npairs + 127) / 128));
+            switch (n_bands) {
+                case 1: MST_LAUNCH(fx_biquad_stereo_ends_kernel<1>, eg, dim3(256), stream, a, htab); break;
+                case 2: MST_LAUNCH(fx_biquad_stereo_ends_kernel<2>, eg, dim3(256), stream, a, htab); break;
+                case 3: MST_LAUNCH(fx_biquad_stereo_ends_kernel<3>, eg, dim3(256), stream, a, htab); break;
+                case 4: MST_LAUNCH(fx_biquad_stereo_ends_kernel<4>, eg, dim3(256), stream, a, htab); break;
+                case 5: MST_LAUNCH(fx_biquad_stereo_ends_kernel<5>, eg, dim3(256), stream, a, htab); break;
+                case 6: MST_LAUNCH(fx_biquad_stereo_ends_kernel<6>, eg, dim3(256), stream, a, htab); break;
+                case 7: MST_LAUNCH(fx_biquad_stereo_ends_kernel<7>, eg, dim3(256), stream, a, htab); break;
+                default: MST_LAUNCH(fx_biquad_stereo_ends_kernel<8>, eg, dim3(256), stream, a, htab); break;
+            }
+        } else {
+            const dim3 eg((unsigned)((4 * lanes + 255) / 256));          // four lanes per chunk
+            switch (n_bands) {
+                case 1: MST_LAUNCH(fx_biquad_ends_kernel<1>, eg, dim3(256), stream, a, htab); break;
+                case 2: MST_LAUNCH(fx_biquad_ends_kernel<2>, eg, dim3(256), stream, a, htab); break;
+                case 3: MST_LAUNCH(fx_biquad_ends_kernel<3>, eg, dim3(256), stream, a, htab); break;
+                case 4: MST_LAUNCH(fx_biquad_ends_kernel<4>, eg, dim3(256), stream, a, htab); break;
+                case 5: MST_LAUNCH(fx_biquad_ends_kernel<5>, eg, dim3(256), stream, a, htab); break;
+                case 6: MST_LAUNCH(fx_biquad_ends_kernel<6>, eg, dim3(256), stream, a, htab); break;
+                case 7: MST_LAUNCH(fx_biquad_ends_kernel<7>, eg, dim3(256), stream, a, htab); break;
+                default: MST_LAUNCH(fx_biquad_ends_kernel<8>, eg, dim3(256), stream, a, htab); break;
+            }
+        }
+        MST_CHECK_LAUNCH("fx_biquad_ends_kernel");
         const dim3 sg((unsigned)a.n_seq);
         double *pmat = scratch + 2 * states;          // (A^M)^(2^l), l = 0 .. 8
         switch (n_bands) {
@@ -1689,6 +1790,7 @@ struct FxSide {
 };
 int g_fx_pipeline = 1;          // mst_fx_set_tuning bit 0
 int g_fx_pipeline_any_size = 0; // mst_fx_set_tuning bit 1 (test / A-B hook: slices whatever the size of the batch)
+int g_fx_slices = 4;            // mst_fx_set_tuning bits 2-3: 0 -> 4 slices, 1 -> 2, 2 -> 3, 3 -> 8
 FxSide *fx_side() {
     static std::mutex mu;
     static FxSide *sides[64] = {};
@@ -1758,7 +1860,7 @@ int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size
             const int nbatch = (int)((cs.nchunks + MST_CHAIN_CB - 1) / MST_CHAIN_CB);
             const int gy = (a.n_seq + 63) / 64;
             int ns = 1;
-            if (g_fx_pipeline && ((nbatch >= 32 && (double)a.n_seq * (double)L >= 4.0e6) || (g_fx_pipeline_any_size && nbatch >= 4))) ns = 4;
+            if (g_fx_pipeline && ((nbatch >= 32 && (double)a.n_seq * (double)L >= 4.0e6) || (g_fx_pipeline_any_size && nbatch >= 8))) ns = g_fx_slices;
             FxSide *side = ns > 1 ? fx_side() : nullptr;
             if (!side) ns = 1;
             auto launch_map = [&](int b0, int b1, void *st) -> int {
@@ -1827,9 +1929,11 @@ int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size
 }  // namespace
 
 extern "C" int mst_fx_set_tuning(int flags) {
-    if (flags < 0 || flags > 3) return fail(MST_ERR_ARG, "mst_fx_set_tuning: unknown flag bits");
+    if (flags < 0 || flags > 15) return fail(MST_ERR_ARG, "mst_fx_set_tuning: unknown flag bits");
     g_fx_pipeline = flags & 1;
     g_fx_pipeline_any_size = (flags >> 1) & 1;
+    static const int slices[4] = {4, 2, 3, 8};
+    g_fx_slices = slices[(flags >> 2) & 3];
     return MST_OK;
 }
 

@@ -580,7 +580,7 @@ def test_time_parallel_fx_shapes_emulated(emu_default, L, n_items, C):
             assert np.abs(y[i] - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (L, bands, i)
 
 
-@pytest.mark.parametrize("L,n_items,C", [(4 * 1024, 1, 2), (5 * 1024 + 517, 3, 2), (9 * 1024 + 31, 2, 1)])
+@pytest.mark.parametrize("L,n_items,C", [(8 * 1024, 1, 2), (9 * 1024 + 517, 3, 2), (13 * 1024 + 31, 2, 1)])
 def test_compressor_time_slices_are_bit_identical_emulated(emu_default, L, n_items, C):
     """The compressor's map / chain / apply kernels over FOUR time slices (mst_fx_set_tuning bits 0 | 1: the pipelined form the product uses
     for large batches, here forced on a small one) against the single-slice run: the same bits - the smoother's value crosses a slice
@@ -596,9 +596,13 @@ def test_compressor_time_slices_are_bit_identical_emulated(emu_default, L, n_ite
         y1 = c.process(x.copy())
         emu_default.check(emu_default.mst_fx_set_tuning(3), "mst_fx_set_tuning")
         y4 = c.process(x.copy())
+        emu_default.check(emu_default.mst_fx_set_tuning(3 | 2 << 2), "mst_fx_set_tuning")      # three slices: unequal batch counts
+        y3 = c.process(x.copy())
+        emu_default.check(emu_default.mst_fx_set_tuning(3 | 3 << 2), "mst_fx_set_tuning")      # eight
+        y8 = c.process(x.copy())
     finally:
         emu_default.check(emu_default.mst_fx_set_tuning(1), "mst_fx_set_tuning")
-    assert np.array_equal(y1, y4)
+    assert np.array_equal(y1, y4) and np.array_equal(y1, y3) and np.array_equal(y1, y8)
     ref = F.compressor(x[n_items - 1].copy(), -28.0, 3.0, 120.0, 6.0)
     assert np.abs(y4[n_items - 1] - ref).max() <= 3e-7 * max(1.0, np.abs(ref).max())
 
