@@ -112,23 +112,18 @@ int mst_tcn_forward(MstTcn *tcn, const float *x_dev, float *y_dev, int B, int L,
 int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int B, int L, int precision, int n_run,
                            void *workspace, size_t workspace_bytes, void *stream);
 
-/* tuning flags (choose between forms of the block kernels; flags = x3_small_tiles | bf16_form << 1 | x3_duo << 3 | bf16_reuse << 4 |
- * bf16_fuse0 << 5 | x3_half_cm << 6, default 117):
+/* tuning flags (choose between forms of the block kernels; flags = x3_small_tiles | bf16_form << 1 | bf16_reuse << 4 | bf16_fuse0 << 5 |
+ * x3_half_cm << 6, default 117; bit 3 and form 1 named kernels that were measured slower and left the library in round 5 - they are rejected):
  * bit 0 (bf16x3 mode; default 1, measured 5.13 instead of 5.45 ms per launch at 32 x 131072): the split-bf16 block kernel on 128-time
  *   tiles of <= 2 phases (two workgroups per CU) wherever the segment has at least 64 steps per phase, 0 = 256-time tiles (one
  *   workgroup per CU); the two-phase 128-time tiles run the class-major loop (B fragment pairs reused by the two taps of a class: 4.62 ->
  *   4.09 ms per launch, round 4), the 256-time tiles the tap-major one: results agree to fp32 accumulation rounding (~1e-6).
  * bits 1-2 (bf16 mode), form of the dense block kernel - measured at 32 x 131072, profiles/r03_tcn_block_forms_summary.md:
  *   0 tcn_block_bf16_kernel: one tile per workgroup, two workgroups per CU                                              1.49-1.51 ms
- *   1 tcn_block_bf16_stream_kernel: persistent, input rows by LDS-DMA one 32-channel chunk ahead of the matrix cores,
- *     epilogue straight from / to global memory; the fp32 accumulation runs chunk-major (agrees to accumulation rounding)   1.67 ms
  *   2 (default) tcn_block_bf16_duo_kernel for the blocks with 256-time tiles of <= 4 phases (form 0 for the others and for the last
  *     block): persistent, one workgroup of 4 matrix waves + 4 loader waves per CU, two tile buffers, the next tile by LDS-DMA and
- *     the previous tile's row stores during the main loop; bit-identical to form 0                                       1.47-1.48 ms
- * bit 3 (bf16x3 mode; default 0): the 128-time-tile blocks run tcn_block_bf16x3_duo_kernel - persistent, one workgroup of 4 matrix waves
- *   + 4 loader waves per CU, two tile buffers; the loader waves fetch and split (hi + lo) the next tile and finish / store the previous
- *   one during the main loop; tap-major like the 256-time tiles (the one-tile kernel's results to accumulation rounding).  Measured
- *   5.45-5.6 ms per launch against 4.55 ms tap-major / 4.09 class-major (round 4): off.
+ *     the previous tile's row stores during the main loop; with bit 4 off bit-identical to form 0                        1.47-1.48 ms
+ *   (1 was tcn_block_bf16_stream_kernel, 1.67 ms; bit 3 tcn_block_bf16x3_duo_kernel, 5.45-5.6 ms per launch against 4.09: EXPERIMENTS.md)
  * bit 4 (bf16 mode, form 2; default 1): the duo kernel's main loop runs class-major - taps grouped by j mod (16 / phases), every B
  *   fragment read from LDS once per class and k-step and fed to up to eight MFMAs (304 instead of 960 LDS reads per tile at four phases).
  *   Same products, another fp32 summation order: agrees with bit 4 off to accumulation rounding (not bit-identical).  Measured at
@@ -197,7 +192,9 @@ int mst_enc_set_tuning(MstEnc *enc, long rows_min_tiles);
  * weight slice crosses the fabric once instead of once per XCD.  bit 1 (default off: measured 7-12 % slower): the 128-channel x
  * 128-column tile with its waves 2 x 2 (enc_conv_nlc22_kernel: two MFMAs per LDS read, every weight fragment fetched by two waves).
  * bit 2 (exact-fp32 mode, a test hook): gather through 64-bit addresses - the path that activations beyond the 32-bit offset range take
- * by themselves - instead of buffer loads.  Same bits either way. */
+ * by themselves - instead of buffer loads.  Same bits either way.  (Round 5 built and measured an in-kernel split-K finalize - tickets, last
+ * workgroup of a tile sums the partial tiles - as bit 3: correct, and 5 x SLOWER per layer (the device-scope release fence writes the
+ * whole L2 back on this part; EXPERIMENTS.md D.3): not in the library.) */
 int mst_enc_set_schedule(MstEnc *enc, int flags);
 /* nn.AdaptiveAvgPool1d(1) on its own (architectures.py:63,67; FXencoder(conv_block='conv') runs its ConvBlocks one by one through
  * mst_enc_forward_conv and pools here): x_dev fp32 [rows, L] -> y_dev[rows] = mean over L. */

@@ -135,14 +135,13 @@ struct MstTcn {
     bool out_loaded = false;
     void *zero_row = nullptr;     // 1 KB of zeros: what the block kernels stage for time steps outside the segment
     int x3_small_tiles = 1;       // bf16x3 mode: 128-time tiles of <= 2 phases, two workgroups per CU (mst_tcn_set_tuning; measured 5.13 vs 5.45 ms)
-    int x3_duo = 0;               // bf16x3 mode: the persistent double-tile form of the 128-time-tile kernel (mst_tcn_set_tuning bit 3; measured slower: 5.45 vs 4.55 ms)
     int x3_half_cm = 1;           // bf16x3 mode: class-major loop in the eight-phase half-tile kernel (mst_tcn_set_tuning bit 6; round 5: GPU-tested,
                                   // 566 -> 572 segments/s at 32 x 131072, profiles/r05_x3_ab_bit6_53_117.jsonl: on)
     int bf16_fuse0 = 1;           // bf16 mode: block 0 computed by the loader waves of block 1's duo kernel (mst_tcn_set_tuning bit 5; measured -0.2 ms
                                   // per forward, bit-identical to the separate kernel; default since round 5 - tests/test_gpu_parity.py form 53)
     int last_fused0 = 0;          // whether the last forward of this handle really ran block 0 inside block 1's launch (mst_tcn_get_tuning)
     int bf16_reuse = 1;           // bf16 mode, duo kernel: the class-major main loop (mst_tcn_set_tuning bit 4; measured 1.40 vs 1.46 ms per launch)
-    int bf16_form = 2;            // bf16 mode, form of the block kernel (mst_tcn_set_tuning bits 1-2): 0 one tile per workgroup, 1 stream, 2 duo (default)
+    int bf16_form = 2;            // bf16 mode, form of the block kernel (mst_tcn_set_tuning bits 1-2): 0 one tile per workgroup, 2 duo (default)
     std::vector<hipEvent_t> ev;   // timing hook: (nblocks + 2) events per recorded forward
     int ev_max = 0, ev_used = 0;
 };
@@ -383,26 +382,6 @@ int choose_phases(int d, int L, int precision) {
     return P;
 }
 
-// the persistent bf16 kernel: two workgroups per CU, workgroup i walks tiles of XCD i % 8's contiguous range
-template <int P, int NQ> int launch_block_stream(TcnBlockArgs a, void *stream) {
-    const long nsteps = ((long)a.L + a.d - 1) / a.d;
-    a.tiles_step = (int)((nsteps + (32 * NQ) / P - 1) / ((32 * NQ) / P));
-    const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
-    long grid = 2L * mst_num_cus();
-    if (grid > ntiles) grid = ntiles;
-    a.xcd_tiles = 0;
-    if (grid >= 8) {
-        grid -= grid % 8;
-        a.xcd_tiles = (int)((ntiles + 7) / 8);
-    }
-    if (a.y_out)
-        MST_LAUNCH((tcn_block_bf16_stream_kernel<P, true, NQ>), dim3((unsigned)grid), dim3(256), stream, a);
-    else
-        MST_LAUNCH((tcn_block_bf16_stream_kernel<P, false, NQ>), dim3((unsigned)grid), dim3(256), stream, a);
-    MST_CHECK_LAUNCH("tcn_block_bf16_stream_kernel");
-    return MST_OK;
-}
-
 // the persistent double-tile bf16 kernel: one workgroup per CU
 template <int P, int NQ> int launch_block_duo(TcnBlockArgs a, void *stream, int reuse = 0) {
     if (a.x0 && !(P == 2 && NQ == 8 && reuse)) return fail(MST_ERR_STATE, "tcn_block_bf16_duo_kernel: block 0 can only be fused into two-phase class-major tiles");
@@ -436,25 +415,7 @@ template <int P, int NQ> int launch_block_duo(TcnBlockArgs a, void *stream, int 
     return MST_OK;
 }
 
-// the persistent double-tile split-bf16 kernel (128-time tiles): one workgroup per CU
-template <int P> int launch_block_x3_duo(TcnBlockArgs a, void *stream) {
-    const long nsteps = ((long)a.L + a.d - 1) / a.d;
-    a.tiles_step = (int)((nsteps + 128 / P - 1) / (128 / P));
-    const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
-    if (ntiles > 0x7fffffffL) return fail(MST_ERR_ARG, "tcn_block_bf16x3_duo_kernel: more than 2^31 tiles");
-    long grid = mst_num_cus();
-    if (grid > ntiles) grid = ntiles;
-    a.xcd_tiles = 0;
-    if (grid >= 8) {
-        grid -= grid % 8;
-        a.xcd_tiles = (int)((ntiles + 7) / 8);
-    }
-    MST_LAUNCH((tcn_block_bf16x3_duo_kernel<P, 4>), dim3((unsigned)grid), dim3(512), stream, a);
-    MST_CHECK_LAUNCH("tcn_block_bf16x3_duo_kernel");
-    return MST_OK;
-}
-
-template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream, int x3_small = 0, int bf16_form = 0, int x3_duo = 0,
+template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream, int x3_small = 0, int bf16_form = 0,
                                   int bf16_small4 = 0, int bf16_reuse = 0, int x3_half_cm = 0) {
     TcnBlockArgs a = a0;
     if constexpr (P == 4) {
@@ -481,10 +442,8 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
             if (!a.y_out) return launch_block_duo<P, 8>(a, stream, bf16_reuse);
         }
     }
-    if (precision == MST_PREC_BF16 && bf16_form == 1) return launch_block_stream<P, (P == 8 ? 4 : 8)>(a, stream);
     if (precision == MST_PREC_BF16X3) {
         if constexpr (P <= 2) {
-            if (x3_small && x3_duo && !a.y_out) return launch_block_x3_duo<P>(a, stream);
             if (x3_small) {          // 128-time tiles: 2 x 39 KB of LDS, two workgroups (8 waves) per CU
                 const long nsteps = ((long)a.L + a.d - 1) / a.d;
                 a.tiles_step = (int)((nsteps + 128 / P - 1) / (128 / P));
@@ -715,10 +674,10 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         if (grid > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_tcn_forward: grid too large");
         int rc;
         switch (P) {
-            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4, t->bf16_reuse, t->x3_half_cm); break;
-            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4, t->bf16_reuse, t->x3_half_cm); break;
-            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4, t->bf16_reuse, t->x3_half_cm); break;
-            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_form, t->x3_duo, bf16_small4, t->bf16_reuse, t->x3_half_cm); break;
+            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm); break;
+            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm); break;
+            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm); break;
+            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm); break;
             default: rc = launch_block<16>(precision, a, (int)grid, stream, 0, t->bf16_form); break;
         }
         if (rc) return rc;
@@ -764,10 +723,10 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
 
 extern "C" int mst_tcn_set_tuning(MstTcn *t, int flags) {
     if (!t) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: null handle");
-    if (flags < 0 || flags > 127 || ((flags >> 1) & 3) > 2) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: unknown flag bits");
+    if (flags < 0 || flags > 127 || (((flags >> 1) & 3) != 0 && ((flags >> 1) & 3) != 2) || ((flags >> 3) & 1))
+        return fail(MST_ERR_ARG, "mst_tcn_set_tuning: unknown flag bits (form 1 - the stream kernel - and bit 3 - the split-bf16 duo kernel - left the library in round 5)");
     t->x3_small_tiles = flags & 1;
     t->bf16_form = (flags >> 1) & 3;
-    t->x3_duo = (flags >> 3) & 1;
     t->bf16_reuse = (flags >> 4) & 1;
     t->bf16_fuse0 = (flags >> 5) & 1;
     t->x3_half_cm = (flags >> 6) & 1;
@@ -777,7 +736,7 @@ extern "C" int mst_tcn_set_tuning(MstTcn *t, int flags) {
 extern "C" int mst_tcn_get_tuning(const MstTcn *t, int *flags, int *last_forward_fused_block0) {
     if (!t) return fail(MST_ERR_ARG, "mst_tcn_get_tuning: null handle");
     if (flags)
-        *flags = t->x3_small_tiles | t->bf16_form << 1 | t->x3_duo << 3 | t->bf16_reuse << 4 | t->bf16_fuse0 << 5 | t->x3_half_cm << 6;
+        *flags = t->x3_small_tiles | t->bf16_form << 1 | t->bf16_reuse << 4 | t->bf16_fuse0 << 5 | t->x3_half_cm << 6;
     if (last_forward_fused_block0) *last_forward_fused_block0 = t->last_fused0;
     return MST_OK;
 }
@@ -2111,8 +2070,9 @@ void fft_plan_destroy(MstFftPlan *p) {
     delete p;
 }
 // n: a power of two >= 4.  The twiddle tables are written on the null stream and waited for: plans are made once.
+constexpr long MST_FFT_MAX_N = 1L << 21;          // the four-step kernels' largest transform (fft_kernels.h: LOGMAX 10 columns x 10 rows of complex points)
 int fft_plan_create(MstFftPlan **out, long n) {
-    if (n < 4 || (n & (n - 1)) || n > (1L << 21)) return fail(MST_ERR_UNSUPPORTED, "FFT length must be a power of two in 4 ... 2^21");
+    if (n < 4 || (n & (n - 1)) || n > MST_FFT_MAX_N) return fail(MST_ERR_UNSUPPORTED, "FFT length must be a power of two in 4 ... 2^21");
     auto *p = new MstFftPlan;
     p->n = n;
     p->m = n / 2;
@@ -2232,7 +2192,8 @@ extern "C" int mst_fx_convolver_create(long L, long Lh_max, int n_items, int C, 
         // signal length, float32 rounding of a 2^16..2^19-point transform
         long nh = 1;
         while (nh < Lh_max) nh <<= 1;
-        const long nblk = 4 * nh > (1L << 16) ? 4 * nh : (1L << 16);
+        long nblk = 4 * nh > (1L << 16) ? 4 * nh : (1L << 16);
+        if (nblk > MST_FFT_MAX_N) nblk = 2 * nh;          // a response longer than 2^19 samples (11.9 s at 44.1 kHz): blocks of twice its length
         if (nblk < n) {
             n = nblk;
             shift = Lh_max - 1;
@@ -2240,7 +2201,8 @@ extern "C" int mst_fx_convolver_create(long L, long Lh_max, int n_items, int C, 
             nb = (int)((L + Lh_max - 1 + step - 1) / step);
         }
     }
-    if (n > (1L << 30)) return fail(MST_ERR_UNSUPPORTED, "mst_fx_convolver_create: transform longer than 2^30 samples");
+    if (n > MST_FFT_MAX_N)
+        return fail(MST_ERR_UNSUPPORTED, "mst_fx_convolver_create: impulse responses longer than 2^20 samples (23.8 s at 44.1 kHz) need a transform beyond 2^21 points");
     if ((long)n_items * C * nb > 65535) return fail(MST_ERR_UNSUPPORTED, "mst_fx_convolver_create: more than 65535 transform blocks (split the batch)");
     auto *cv = new MstConvolver;
     cv->L = L; cv->Lh_max = Lh_max; cv->n_fft = n; cv->n_items = n_items; cv->C = C;

@@ -389,293 +389,6 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
 }
 
 // ------------------------------------------------------------------------------------------------
-// blocks 1..n-1, bf16: the PERSISTENT, LDS-DMA-streamed form of tcn_block_bf16_kernel ("stream" kernel, round 3).
-//
-// Why: the one-tile-per-workgroup kernel above stages its 78 KB tile in a prologue and stores it in an epilogue; every resident
-// workgroup of the chip is in that phase at the same time (equal tiles, equal start), so the prologue is an HBM burst (~11 B/clk/CU:
-// ~10 k clocks per tile) during which the matrix pipe idles - 15-20 % of the launch.  Here a workgroup is persistent (2 per CU, each
-// walking its share of the tiles of ONE XCD's contiguous tile range) and the input rows arrive by LDS-DMA (global_load_lds_dwordx4: no
-// VGPRs, no ds_write) one 32-channel chunk AHEAD of the chunk the matrix cores are working on:
-//     tile = 4 chunk phases (input channels 32c .. 32c+31; MFMA k-step = one tap of one chunk, i.e. the reduction runs chunk-major);
-//     LDS   = 2 chunk buffers of ceil(R/16) KB (R = 32 NQ + 14 P rows x 64 B) + 2 KB of epilogue parameters: 42 KB at P = 4;
-//     phase c: [issue DMA of chunk c+1 (of the next tile after chunk 3) into the other buffer] [15 taps x 2 NC MFMAs on chunk c]
-//              [s_waitcnt vmcnt(10) lgkmcnt(0); s_barrier].
-// The copy of chunk c+1 has a whole phase (>= 8 k clocks) to land; what bounds it is only the in-order vmcnt: the A fragments requested
-// behind it are needed five taps later.  Nothing about a tile is exposed except the epilogue's residual read (L2 hits).
-// LDS image of a chunk buffer: 16-byte piece (row r, slot s) at 64 r + 16 (s ^ ((r >> 1) & 2)): with ds_read_b128's lane groups
-// ({0-3, 12-15, 20-27}, ...) every B fragment read (16 consecutive rows x 4 slots, any start row) is conflict free; the DMA writes
-// 1 KB = 16 rows per wave-instruction lane-linearly, the swizzle sits on the SOURCE address (lane l fetches row l / 4, slot (l & 3) ^ ((l >> 3) & 2)).
-// Epilogue without LDS: the residual rows are read from global memory (this block's input, L2-hot) and the results stored 16 bytes per
-// lane: v_permlane16_swap_b32 turns the accumulator layout (lane = 4 channels of time 16 q + l16) into 8 channels of time
-// 16 (q & ~1) + 16 (g & 1) + l16 and back.  Same arithmetic as tcn_block_bf16_kernel except the ORDER of the fp32 accumulation
-// (chunk-major instead of tap-major): results agree to accumulation rounding, not bit for bit.
-// ------------------------------------------------------------------------------------------------
-template <int P, bool FUSE_OUT, int NQ>
-__global__ __launch_bounds__(256, 2) void tcn_block_bf16_stream_kernel(TcnBlockArgs a) {
-    constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NC = 2 * NQ;
-    constexpr int NK = (R + 15) / 16;            // 1 KB DMA pieces (16 rows x 64 B) per chunk buffer
-    constexpr int NI = (NK + 3) / 4;             // pieces per wave
-    constexpr int BUF = NK * 1024;
-    constexpr int NTAP = 15, RA = 5;             // taps; depth of the A fragment ring in taps (15 = 3 x 5: static ring indices)
-    static_assert(32 % P == 0, "pairs of column tiles advance by a whole number of steps");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
-    __shared__ __attribute__((aligned(16))) float par[4 * 128];     // shift | FiLM r | FiLM b | res
-    __shared__ float part[FUSE_OUT ? 8 * T : 4];                    // FUSE_OUT: [4 waves][2 outputs][T] partial sums of the output head
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l16 = lane & 15, g = lane >> 4;
-
-    // ---- this workgroup's tiles: workgroup i runs on XCD i % 8 and walks tiles (i % 8) * xcd_tiles + i / 8 + n * gridDim.x / 8
-    const long ntiles = (long)a.B * a.tiles_phase * a.tiles_step;
-    long tile, tstep, tend;
-    if (a.xcd_tiles > 0) {
-        tile = (long)(blockIdx.x & 7) * a.xcd_tiles + (blockIdx.x >> 3);
-        tstep = gridDim.x >> 3;
-        tend = (long)((blockIdx.x & 7) + 1) * a.xcd_tiles;
-        if (tend > ntiles) tend = ntiles;
-    } else {
-        tile = blockIdx.x;
-        tstep = gridDim.x;
-        tend = ntiles;
-    }
-    if (tile >= tend) return;       // uniform
-
-    // byte offsets (from the batch item's first row) of this wave's DMA pieces of a tile, chunk 0; ~0u = a row outside the segment (zeros)
-    unsigned src[NI];
-    int tb = 0, tm0 = 0, tphi0 = 0;
-    auto tile_geometry = [&](long tl, int &b, int &m0, int &phi0) {
-        const int mg = (int)(tl % a.tiles_step);
-        const long r = tl / a.tiles_step;
-        phi0 = (int)(r % a.tiles_phase) * P;
-        b = (int)(r / a.tiles_phase);
-        m0 = mg * MT;
-    };
-    const int dsl = (lane & 3) ^ ((lane >> 3) & 2);       // the chunk slot this lane fetches (the LDS swizzle, on the source side)
-    auto dma_sources = [&](int m0, int phi0) {
-        const int rl = lane >> 2;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int row = 16 * (w + 4 * i) + rl;
-            const long t = (long)(m0 + row / P - 7) * a.d + phi0 + (row % P);
-            const bool ok = row < R && t >= 0 && t < a.L;
-            src[i] = ok ? (unsigned)t * 256u : ~0u;
-        }
-    };
-    auto dma_issue = [&](int b, int c, int buf) {
-        const unsigned char *xb = (const unsigned char *)a.x + (size_t)b * a.Lp * 256 + 64 * c + 16 * dsl;
-        const unsigned char *zb = (const unsigned char *)a.zeros + 16 * dsl;
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-            if (w + 4 * i < NK) mst_dma16(src[i] != ~0u ? xb + src[i] : zb, smem + buf * BUF + (w + 4 * i) * 1024);
-    };
-    auto stage_par = [&](int b) {
-        if (tid < 128) {
-            const float *frow0 = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
-            par[tid] = a.shift[tid];
-            par[384 + tid] = a.res[tid];
-            par[128 + tid] = frow0[tid];
-            par[256 + tid] = frow0[128 + tid];
-        }
-    };
-
-    tile_geometry(tile, tb, tm0, tphi0);
-    dma_sources(tm0, tphi0);
-    dma_issue(tb, 0, 0);
-    stage_par(tb);
-    mst_dma_wait_barrier<0>();
-
-    const MstStream16 wst = mst_stream16(a.wpk, 60u * 2u * 4096u);
-    const unsigned aoff = (unsigned)(w * 64 + lane) * 16u;
-    const int nsteps = (int)(((long)a.L + a.d - 1) / a.d);
-
-    bool first = true;
-    for (;;) {
-        const int b = tb, m0 = tm0, phi0 = tphi0;
-        const long tnext = tile + tstep;
-        const bool has_next = tnext < tend;
-
-        f32x4 acc[2][NC];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {          // the accumulators start from the BN shift of their channel
-            const f32x4 sh = *(const f32x4 *)(par + 32 * w + 16 * m + 4 * g);
-#pragma unroll
-            for (int q = 0; q < NC; ++q) acc[m][q] = sh;
-        }
-        // A fragments: wpk[ks = j*4 + c][row tile m][wave][lane] = 8 bf16 = W'[32w + 16m + (lane & 15)][32c + 8 (lane >> 4) + e][j];
-        // a ring of RA taps, the fragments of tap j + RA (of the next chunk behind tap 14) requested when tap j has been consumed
-        // (this tile's FiLM row travels to registers first: stored to LDS in phase 1, and by then long landed - a load consumed right where
-        //  it is issued would wait for everything older, the copy in flight included)
-        float pf0 = 0.0f, pf1 = 0.0f;
-        if (!first) {
-            const float *frow0 = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
-            pf0 = frow0[tid & 127];
-            pf1 = frow0[128 + (tid & 127)];
-        }
-        bf16x8 af[2][RA];
-#pragma unroll
-        for (int s = 0; s < RA; ++s) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) af[m][s] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)(s * 4 + 0) * 8192u));
-            __builtin_amdgcn_sched_barrier(0);          // in ring order, like the loop issues them (the loop's counted waits assume it)
-        }
-
-#pragma unroll 1
-        for (int c = 0; c < 4; ++c) {
-            const int buf = c & 1;
-            // the chunk behind this one travels while this one is computed on
-            if (c < 3) {
-                dma_issue(b, c + 1, buf ^ 1);
-            } else if (has_next) {
-                tile_geometry(tnext, tb, tm0, tphi0);
-                dma_sources(tm0, tphi0);
-                dma_issue(tb, 0, buf ^ 1);
-            }
-            if (c == 1 && !first && tid < 128) {       // every wave has left the previous tile's epilogue (barrier of phase 0); read behind the barrier of phase 3
-                par[128 + tid] = pf0;
-                par[256 + tid] = pf1;
-            }
-            const unsigned char *xs = smem + buf * BUF;
-            constexpr int RB = 8;
-            static_assert(NC % RB == 0, "the ring divides the column tiles");
-            bf16x8 bf[RB];
-            {
-                const unsigned char *rp0 = xs + 64 * l16 + 16 * (g ^ ((l16 >> 1) & 2));
-#pragma unroll
-                for (int q = 0; q < RB; ++q) bf[q] = *(const bf16x8 *)(rp0 + q * 1024);
-            }
-#pragma unroll 1
-            for (int it = 0; it < NTAP / RA; ++it) {
-#pragma unroll
-                for (int s = 0; s < RA; ++s) {
-                    const int j = it * RA + s;
-                    const int jn = j < NTAP - 1 ? j + 1 : NTAP - 1;      // behind the last tap: a harmless re-read (the ring restarts behind the barrier)
-                    const int rb0 = j * P + l16, rb1 = jn * P + l16;
-                    unsigned live = 0xffffu;
-                    if constexpr (P >= 16) {
-                        live = 0;
-#pragma unroll
-                        for (int q = 0; q < NC; ++q) {
-                            const int s_lo = m0 + (16 * q) / P + j - 7, s_hi = m0 + (16 * q + 15) / P + j - 7;
-                            if (!(s_hi < 0 || s_lo >= nsteps)) live |= 1u << q;
-                        }
-                    }
-                    const unsigned char *cp = xs + 64 * rb0 + 16 * (g ^ ((rb0 >> 1) & 2));
-                    const unsigned char *np = xs + 64 * rb1 + 16 * (g ^ ((rb1 >> 1) & 2));
-#pragma unroll
-                    for (int q = 0; q < NC; ++q) {
-                        if (P < 16 || ((live >> q) & 1u)) {
-                            acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][s], bf[q % RB], acc[0][q], 0, 0, 0);
-                            acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][s], bf[q % RB], acc[1][q], 0, 0, 0);
-                        }
-                        bf[q % RB] = (q + RB < NC) ? *(const bf16x8 *)(cp + (q + RB) * 1024) : *(const bf16x8 *)(np + (q + RB - NC) * 1024);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    }
-                    // tap j + RA of this chunk, or tap s of the next chunk (behind chunk 3: chunk 3 again - loaded, never used)
-                    const int ksn = it < NTAP / RA - 1 ? (j + RA) * 4 + c : s * 4 + (c < 3 ? c + 1 : 3);
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) af[m][s] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)ksn * 8192u));
-                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // the two fragment loads stay HERE (otherwise every load of the body sinks behind its last MFMA group)
-                }
-            }
-            // this wave's DMA pieces have landed (they are older than the >= 10 fragment loads that may still be in flight), every
-            // wave is done reading this chunk's buffer
-            mst_dma_wait_barrier<2 * RA>();
-        }
-
-        // ---- fused epilogue straight from / to global memory, 16 bytes per lane: the lane of accumulator row group g handles time
-        //      16 (2 pr + (g & 1)) + l16, channels 32 w + 16 m + 8 (g >> 1) .. + 7 of the pair pr of column tiles
-        {
-            const __bf16 *xb = (const __bf16 *)a.x + (size_t)b * a.Lp * 128;
-            __bf16 *yb = (__bf16 *)a.y + (size_t)b * a.Lp * 128;
-            const int og = 16 * (g & 1) + l16;
-            const long t0 = (long)(m0 + og / P) * a.d + phi0 + (og % P);
-            const long dtp = (long)(32 / P) * a.d;
-            const int ch = 32 * w + 8 * (g >> 1);
-            float hs0[NC], hs1[NC];
-#pragma unroll
-            for (int q = 0; q < NC; ++q) hs0[q] = hs1[q] = 0.0f;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int co0 = 32 * w + 16 * m + 4 * g;
-                const f32x4 fr = *(const f32x4 *)(par + 128 + co0);
-                const f32x4 fb = *(const f32x4 *)(par + 256 + co0);
-                const f32x4 rs = *(const f32x4 *)(par + 384 + co0);
-                f32x4 ow0 = {0.0f, 0.0f, 0.0f, 0.0f}, ow1 = {0.0f, 0.0f, 0.0f, 0.0f};
-                if constexpr (FUSE_OUT) {
-                    ow0 = *(const f32x4 *)(a.out_w + co0);
-                    if (a.nout > 1) ow1 = *(const f32x4 *)(a.out_w + 128 + co0);
-                }
-                u32x4 xr[NC / 2];
-#pragma unroll
-                for (int pr = 0; pr < NC / 2; ++pr) {
-                    const long t = t0 + pr * dtp;
-                    xr[pr] = *(const u32x4 *)(t < a.L ? xb + t * 128 + ch + 16 * m : (const __bf16 *)a.zeros);
-                }
-#pragma unroll
-                for (int pr = 0; pr < NC / 2; ++pr) {
-                    const long t = t0 + pr * dtp;
-                    unsigned x0 = xr[pr][0], x1 = xr[pr][1], x2 = xr[pr][2], x3 = xr[pr][3];
-                    mst_row_swap(x0, x2);          // -> (x0, x1) = this lane's 4 residual channels at column tile 2 pr, (x2, x3) at 2 pr + 1
-                    mst_row_swap(x1, x3);
-                    unsigned o[4];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int q = 2 * pr + h;
-                        const u32x2 xw = {h ? x2 : x0, h ? x3 : x1};
-                        const float v4[4] = {acc[m][q][0], acc[m][q][1], acc[m][q][2], acc[m][q][3]};
-                        const bf16x4 out = tcn_epilogue4(v4, fr, fb, rs, __builtin_bit_cast(bf16x4, xw));
-                        if constexpr (FUSE_OUT) {          // the head reads the bf16-rounded activation, like the separate output kernel
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                hs0[q] = fmaf(ow0[i], (float)out[i], hs0[q]);
-                                hs1[q] = fmaf(ow1[i], (float)out[i], hs1[q]);
-                            }
-                        }
-                        const u32x2 ov = __builtin_bit_cast(u32x2, out);
-                        o[2 * h] = ov[0];
-                        o[2 * h + 1] = ov[1];
-                    }
-                    if constexpr (!FUSE_OUT) {
-                        mst_row_swap(o[0], o[2]);      // back to 8 consecutive channels of one time step per lane
-                        mst_row_swap(o[1], o[3]);
-                        if (t < a.L) *(u32x4 *)(yb + t * 128 + ch + 16 * m) = u32x4{o[0], o[1], o[2], o[3]};
-                    }
-                }
-            }
-            if constexpr (FUSE_OUT) {
-                // last block: 1x1 output conv + bias + clamp(-1, 1) (reference architectures.py:133,145) straight from the registers
-#pragma unroll
-                for (int q = 0; q < NC; ++q) {
-                    hs0[q] += __shfl_xor(hs0[q], 16);
-                    hs1[q] += __shfl_xor(hs1[q], 16);
-                    hs0[q] += __shfl_xor(hs0[q], 32);
-                    hs1[q] += __shfl_xor(hs1[q], 32);
-                    if (g == 0) {
-                        part[(w * 2 + 0) * T + 16 * q + l16] = hs0[q];
-                        part[(w * 2 + 1) * T + 16 * q + l16] = hs1[q];
-                    }
-                }
-                mst_dma_wait_barrier<63>();          // LDS only: a copy in flight for the next tile is left alone
-#pragma unroll
-                for (int i = 0; i < 2 * T / 256; ++i) {
-                    const int idx = tid + 256 * i, co = idx / T, o = idx % T;
-                    const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
-                    if (co < a.nout && t < a.L) {
-                        const float v = part[(0 * 2 + co) * T + o] + part[(1 * 2 + co) * T + o] + part[(2 * 2 + co) * T + o] +
-                                        part[(3 * 2 + co) * T + o] + a.out_b[co];
-                        a.y_out[((size_t)b * a.nout + co) * a.L + t] = fminf(1.0f, fmaxf(-1.0f, v));
-                    }
-                }
-            }
-        }
-        if (!has_next) break;
-        tile = tnext;
-        first = false;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Main loop of the 256-time tile with B-FRAGMENT REUSE ACROSS TAPS (round 4, REUSE form of the duo kernel).  With P phases per tile the
 // B fragment of (tap j, column tile q) is rows P j + 16 q .. + 15 of the LDS image - the same rows as (tap j + 16 / P, column tile q - 1):
 // at P = 4 the tap-major loop reads each of the 75 x 4 distinct fragments up to four times (960 ds_read_b128 per tile and wave, one per
@@ -1450,292 +1163,6 @@ __global__ __launch_bounds__(256, (NQ == 4 && P <= 2) ? 2 : 1) void tcn_block_bf
                 *(f32x4 *)(yb + t * 128 + 4 * s4) = out;
             }
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// bf16x3: the PERSISTENT DOUBLE-TILE form of tcn_block_bf16x3_kernel<P, 4> (round 4; the split mode's twin of tcn_block_bf16_duo_kernel) -
-// same 128-time tiles, same LDS images, same main loop and epilogue arithmetic, bit-identical results; what changes is who does what:
-//   * ONE workgroup of EIGHT waves per CU, persistent, walking its share of the tiles of one XCD's contiguous tile range;
-//   * waves 0-3 (one per SIMD, s_setprio 2) are the MATRIX waves: main loop (three MFMAs per product) and the LeakyReLU / FiLM part of the
-//     epilogue in the accumulator layout, written as fp32 rows into the tile buffer they have just finished reading;
-//   * waves 4-7 (one per SIMD) are the LOADER waves: while the matrix waves work on tile i (buffer i & 1) they fetch the fp32 rows of tile
-//     i + 1, split them x = hi + lo and write the two bf16 images into the other buffer; behind barrier 2 they finish tile i: whole-row pass
-//     z + res * x_in (the residual re-read from global memory, L2-hot), coalesced 16-byte stores.
-//   * two workgroup barriers per tile: (1) the matrix waves are done reading tile i AND tile i + 1 is staged, (2) the fp32 rows of tile i are
-//     complete.  No third one: loader wave W owns the input rows r with (r >> 1) & 3 == W and the output rows o with o & 3 == W, and the lo
-//     image starts 80 output rows (40960 B) into the buffer - so the bytes a loader wave overwrites when it refills a buffer are exactly bytes
-//     of output rows it has read itself (hi row r lies in output row r / 2, lo row r in output row 80 + r / 2; 80 = 0 mod 4).
-// Why it was built: the one-tile kernel (two workgroups per CU) runs at 4.55 ms per launch against 3 x 1.23 ms for its MFMAs at the rate the box
-// sustains (bench.py roofline.calib_ms).  MEASURED (round 4, same-box A/B at 32 x 131072, profiles/r04_x3_duo_ab.txt): 5.45-5.6 ms per launch -
-// SLOWER than the one-tile kernel, whatever the wave priorities, with the accumulators' MFMAs two or four instructions apart and with the
-// residual rows requested in front of barrier 2.  One MFMA-issuing wave per SIMD is enough for the bf16 main loop (no two MFMAs of a k-step
-// share an accumulator) but not for the split loop, whose three terms per product are dependent accumulations: the second workgroup of the
-// one-tile form is what fills those slots.  Not the default (mst_tcn_set_tuning bit 3); kept because it is bit-identical and tested.
-// ------------------------------------------------------------------------------------------------
-template <int P, int NQ>
-__global__ __launch_bounds__(512, 1) void tcn_block_bf16x3_duo_kernel(TcnBlockArgs a) {
-    constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NC = 2 * NQ;
-    constexpr int LO_OFF = 40960, BUF = LO_OFF + ((R * 256 + 1023) / 1024) * 1024;
-    static_assert(NQ == 4 && R * 256 <= LO_OFF && T * 512 <= BUF, "128-time tiles: the (hi | lo) images and the fp32 output tile share a buffer");
-    static_assert((LO_OFF / 512) % 4 == 0, "a lo row lies in an output row of the same loader wave as its hi row");
-    static_assert(2 * BUF + 1536 <= 160 * 1024, "two buffers + parameters fit the CU's LDS");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF];
-    __shared__ __attribute__((aligned(16))) float par[3 * 128];     // BN shift | FiLM r | FiLM b of the current batch item
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wv >= 4;
-    const int w = wv & 3;
-    const int l16 = lane & 15, g = lane >> 4;
-
-    const unsigned ntiles = (unsigned)a.B * (unsigned)a.tiles_phase * (unsigned)a.tiles_step;
-    unsigned tile, tstep, tend;
-    if (a.xcd_tiles > 0) {
-        tile = (blockIdx.x & 7) * (unsigned)a.xcd_tiles + (blockIdx.x >> 3);
-        tstep = gridDim.x >> 3;
-        tend = ((blockIdx.x & 7) + 1) * (unsigned)a.xcd_tiles;
-        if (tend > ntiles) tend = ntiles;
-    } else {
-        tile = blockIdx.x;
-        tstep = gridDim.x;
-        tend = ntiles;
-    }
-    if (tile >= tend) return;       // uniform
-
-    auto tile_geometry = [&](unsigned tl, int &b, int &m0, int &phi0) {
-        const unsigned r = tl / (unsigned)a.tiles_step, mg = tl - r * (unsigned)a.tiles_step;
-        const unsigned bb = r / (unsigned)a.tiles_phase;
-        phi0 = (int)(r - bb * (unsigned)a.tiles_phase) * P;
-        b = (int)bb;
-        m0 = (int)mg * MT;
-    };
-    // loader wave W stages the input rows r with (r >> 1) & 3 == W: a lane owns one 16-byte slot (8 channels) of rows rr0, rr0 + 16, ...
-    auto stage_tile = [&](int b, int m0, int phi0, int buf) {
-        const int slot = lane & 15, rr0 = 2 * w + ((lane >> 4) & 1) + 8 * (lane >> 5);      // rows rr0, rr0 + 16, ... : (row >> 1) & 3 == w
-        const float *xb = (const float *)a.x + (size_t)b * a.Lp * 128;
-        unsigned char *hi = smem + buf * BUF, *lo = hi + LO_OFF;
-        constexpr int NP = (R + 15) / 16;
-        f32x4 v0[NP], v1[NP];
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int row = rr0 + 16 * i;
-            const long t = (long)(m0 + row / P - 7) * a.d + phi0 + (row % P);
-            const float *p = (row < R && t >= 0 && t < a.L) ? xb + t * 128 + slot * 8 : (const float *)a.zeros + slot * 8;      // never a predicated load
-            v0[i] = *(const f32x4 *)p;
-            v1[i] = *(const f32x4 *)(p + 4);
-        }
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int row = rr0 + 16 * i;
-            if (row < R) {
-                bf16x8 h, l;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    h[e] = (__bf16)v0[i][e];
-                    l[e] = (__bf16)(v0[i][e] - (float)h[e]);
-                    h[4 + e] = (__bf16)v1[i][e];
-                    l[4 + e] = (__bf16)(v1[i][e] - (float)h[4 + e]);
-                }
-                const int off = row * 256 + ((slot ^ (row & 15)) << 4);
-                *(bf16x8 *)(hi + off) = h;
-                *(bf16x8 *)(lo + off) = l;
-            }
-        }
-    };
-    auto stage_film = [&](int b) {          // matrix waves only
-        if (tid < 128) {
-            const float *frow0 = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
-            par[128 + tid] = frow0[tid];
-            par[256 + tid] = frow0[128 + tid];
-        }
-    };
-
-    int tb, tm0, tphi0;
-    tile_geometry(tile, tb, tm0, tphi0);
-    if (loader) {
-        stage_tile(tb, tm0, tphi0, 0);
-    } else {
-        if (tid < 128) par[tid] = a.shift[tid];
-        stage_film(tb);
-    }
-    mst_dma_wait_barrier<0>();
-
-    if (loader) {
-        // =================================================================== loader waves
-        int cur = 0;
-        const int lt = tid - 256;
-        const int s4 = lt & 31;                                    // this thread's 4 channels in the row pass
-        const f32x4 rs = *(const f32x4 *)(a.res + 4 * s4);
-        for (;;) {
-            const int b = tb, m0 = tm0, phi0 = tphi0;
-            const unsigned tnext = tile + tstep;
-            const bool has_next = tnext < tend;
-            if (has_next) {
-                tile_geometry(tnext, tb, tm0, tphi0);
-                stage_tile(tb, tm0, tphi0, cur ^ 1);       // bytes of output rows this wave read itself one iteration ago
-            }
-            mst_dma_wait_barrier<63>();                    // (1) the next tile is staged (this wave's LDS writes have landed; its row stores stay in flight), the matrix waves are done reading this one
-            // the residual rows of THIS tile are requested here, in front of barrier 2: they do not depend on the matrix waves' epilogue and
-            // have landed when it is over.  (A tile that lies inside the segment - all but the last of a phase group - needs no bounds
-            // test; a load under `if (t < L)` is a branch per row and hipcc waits for each before the next: sixteen L2 round trips per tile
-            // made the loader waves the critical path, 5.45 instead of 4.1 ms per launch.)
-            const float *xb = (const float *)a.x + (size_t)b * a.Lp * 128;
-            float *yb = (float *)a.y + (size_t)b * a.Lp * 128;
-            const int o0 = w + 4 * ((lane >> 5) & 1);      // output rows o0 + 8 i: o & 3 == w; 32 lanes (4 channels each) per row
-            const bool inside = (long)(m0 + (T - 1) / P) * a.d + phi0 + (P - 1) < a.L;      // uniform
-            f32x4 xin[T / 8];
-            if (inside) {
-#pragma unroll
-                for (int i = 0; i < T / 8; ++i) {
-                    const int o = o0 + 8 * i;
-                    const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
-                    xin[i] = *(const f32x4 *)(xb + t * 128 + 4 * s4);
-                }
-            }
-            mst_dma_wait_barrier<63>();                    // (2) the fp32 rows of this tile are complete
-            {
-                const float *st = (const float *)(smem + cur * BUF);
-                if (inside) {
-#pragma unroll
-                    for (int i = 0; i < T / 8; ++i) {
-                        const int o = o0 + 8 * i;
-                        const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
-                        const f32x4 z = *(const f32x4 *)(st + o * 128 + ((s4 ^ (o & 31)) << 2));
-                        f32x4 out;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) out[k] = z[k] + rs[k] * xin[i][k];
-                        *(f32x4 *)(yb + t * 128 + 4 * s4) = out;
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < T / 8; ++i) {
-                        const int o = o0 + 8 * i;
-                        const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
-                        if (t < a.L) {
-                            const f32x4 z = *(const f32x4 *)(st + o * 128 + ((s4 ^ (o & 31)) << 2));
-                            const f32x4 xv = *(const f32x4 *)(xb + t * 128 + 4 * s4);
-                            f32x4 out;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) out[k] = z[k] + rs[k] * xv[k];
-                            *(f32x4 *)(yb + t * 128 + 4 * s4) = out;
-                        }
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();           // every lane of this wave has read its rows before any lane refills them (lock-step on the GPU)
-            }
-            if (!has_next) break;
-            tile = tnext;
-            cur ^= 1;
-        }
-        return;
-    }
-
-    // ======================================================================= matrix waves
-    __builtin_amdgcn_s_setprio(2);
-    const unsigned char *wbase = (const unsigned char *)a.wpk;
-    const unsigned aoff = (unsigned)(w * 64 + lane) * 16u;
-    constexpr size_t LO_IMG = (size_t)120 * 4096;
-    constexpr int RB = 8;
-    static_assert(NC % RB == 0, "the ring divides the column tiles");
-    int cur = 0, bprev = tb;
-    for (;;) {
-        const int b = tb;
-        const unsigned tnext = tile + tstep;
-        const bool has_next = tnext < tend;
-        if (has_next) tile_geometry(tnext, tb, tm0, tphi0);
-        unsigned char *const sm_hi = smem + cur * BUF, *const sm_lo = sm_hi + LO_OFF;
-        if (b != bprev) {              // a new batch item: its FiLM row (every matrix wave is past the previous tile's epilogue: barrier 2)
-            stage_film(b);
-            bprev = b;
-        }
-        f32x4 acc[2][NC];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {          // accumulators start from the BN shift of their channel
-            const f32x4 sh = *(const f32x4 *)(par + 32 * w + 16 * m + 4 * g);
-#pragma unroll
-            for (int q = 0; q < NC; ++q) acc[m][q] = sh;
-        }
-        bf16x8 ah[2][2], al[2][2], bh[RB], bl[RB];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                ah[kk][m] = *(const bf16x8 *)(wbase + (size_t)(kk * 2 + m) * 4096 + aoff);
-                al[kk][m] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)(kk * 2 + m) * 4096 + aoff);
-            }
-        {
-            const int o0 = l16 * 256 + ((g ^ l16) << 4);
-#pragma unroll
-            for (int q = 0; q < RB; ++q) {
-                bh[q] = *(const bf16x8 *)(sm_hi + o0 + q * 4096);
-                bl[q] = *(const bf16x8 *)(sm_lo + o0 + q * 4096);
-            }
-        }
-#pragma unroll 1
-        for (int j = 0; j < 15; ++j) {
-            const int jn = j < 14 ? j + 1 : 14;
-            const int rb0 = j * P + l16, rb1 = jn * P + l16;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int rbn = (kk == 3) ? rb1 : rb0;
-                const int kn = (kk + 1) & 3;
-                const int oc = rb0 * 256 + (((4 * kk + g) ^ (rb0 & 15)) << 4);
-                const int on = rbn * 256 + (((4 * kn + g) ^ (rbn & 15)) << 4);
-                const int s = kk & 1;
-                // column tiles in PAIRS, term-major: an accumulator's three MFMAs (lo*hi, hi*lo, hi*hi - the one-tile kernel's order, same
-                // bits) are four instructions apart instead of two - with ONE matrix wave per SIMD nothing else hides a dependent MFMA's latency
-#pragma unroll
-                for (int q = 0; q < NC; q += 2) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) acc[m][q + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s][m], bh[(q + u) % RB], acc[m][q + u], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) acc[m][q + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][m], bl[(q + u) % RB], acc[m][q + u], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int m = 0; m < 2; ++m) acc[m][q + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[s][m], bh[(q + u) % RB], acc[m][q + u], 0, 0, 0);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int ofs = (q + u + RB < NC) ? oc + (q + u + RB) * 4096 : on + (q + u + RB - NC) * 4096;
-                        bh[(q + u) % RB] = *(const bf16x8 *)(sm_hi + ofs);
-                        bl[(q + u) % RB] = *(const bf16x8 *)(sm_lo + ofs);
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                }
-                int ksn = j * 4 + kk + 2;
-                ksn = ksn < 60 ? ksn : 59;
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    ah[s][m] = *(const bf16x8 *)(wbase + (size_t)(ksn * 2 + m) * 4096 + aoff);
-                    al[s][m] = *(const bf16x8 *)(wbase + LO_IMG + (size_t)(ksn * 2 + m) * 4096 + aoff);
-                }
-            }
-        }
-        mst_dma_wait_barrier<63>();            // (1) every matrix wave is done reading this tile (the weight fragments in flight stay in flight)
-        float *st = (float *)sm_hi;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int co0 = 32 * w + 16 * m + 4 * g;
-            const f32x4 fr = *(const f32x4 *)(par + 128 + co0);
-            const f32x4 fb = *(const f32x4 *)(par + 256 + co0);
-#pragma unroll
-            for (int q = 0; q < NC; ++q) {
-                const int o = 16 * q + l16;
-                f32x4 z;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) z[i] = fr[i] * leaky_relu(acc[m][q][i]) + fb[i];
-                *(f32x4 *)(st + o * 128 + (((co0 >> 2) ^ (o & 31)) << 2)) = z;
-            }
-        }
-        mst_dma_wait_barrier<63>();            // (2) the fp32 rows are complete: the loader waves finish and store them
-        if (!has_next) break;
-        tile = tnext;
-        cur ^= 1;
     }
 }
 

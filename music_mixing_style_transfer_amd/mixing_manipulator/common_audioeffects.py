@@ -399,7 +399,11 @@ class ConvolutionalReverb(Processor):
             raise ValueError(f"impulse response has {self.h.shape[1]} channels, audio has {d.C}")
         # the response on the device and its peak position are kept until update() (or the channel adaptation above) replaces self.h:
         # the float32 copy, the peak search and a 0.5 MB pageable upload cost as much per call as the transforms themselves
-        key = (id(self.h), self.h.shape, self.parameters.pre_delay.value, str(d.x.device))
+        # (an in-place edit of the public array - `rv.h *= g` - must not leave the old response on the device: the key carries a cheap
+        #  content fingerprint, 64 strided samples and the array's sum, besides its identity; the reference recomputes from self.h every call)
+        flat = self.h.reshape(-1)
+        probe = flat[::max(1, flat.shape[0] // 64)][:64]
+        key = (id(self.h), self.h.shape, self.parameters.pre_delay.value, str(d.x.device), probe.tobytes(), float(flat.sum(dtype=np.float64)))
         cached = getattr(self, "_h_cache", None)
         if cached is None or cached[0] != key:
             h32 = np.ascontiguousarray(self.h, dtype=np.float32)

@@ -87,6 +87,7 @@ int lane_id();
     emu::launch((grid), (block), [&]() { kern(__VA_ARGS__); })
 
 static inline void __syncthreads() { emu::block_barrier(); }
+static inline void __threadfence() {}          // one OS thread runs the workgroups one after the other: every store is visible to the next
 
 // ---- wave collectives ------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(16))) float emu_f32x16;

@@ -83,11 +83,11 @@ def test_tcn_bf16_whole_sequence_tiles_emulated(emu_default):
         assert float((a - col[3]).abs().max()) <= 4e-2 * float(col[3].abs().max())
 
 
-def test_tcn_bf16_stream_and_duo_kernels_emulated(emu_default):
-    """The persistent LDS-DMA-fed forms of the bf16 block kernel (mst_tcn_set_tuning bits 1-2).  Form 1 ("stream"): same arithmetic as the one-tile-per-workgroup
-    kernel with the fp32 accumulation running chunk-major - against the oracle at the bf16 tolerance, and against the other form
-    to accumulation rounding.  The emulated grid has 8 workgroups: several tiles per workgroup, XCD-ordered tile ranges, every
-    phase count P, per-item FiLM rows, the fused output head."""
+def test_tcn_bf16_duo_kernel_emulated(emu_default):
+    """The persistent LDS-DMA-fed form of the bf16 block kernel (mst_tcn_set_tuning bits 1-2 = 2, "duo") in its tap-major order (bit 4 off): the
+    one-tile-per-workgroup kernel's arithmetic in the same order - bit-identical - and the oracle at the bf16 tolerance.  The emulated grid
+    has 8 workgroups: several tiles per workgroup, XCD-ordered tile ranges, every phase count P, per-item FiLM rows, the fused output head.
+    (Form 1, the "stream" kernel, and bit 3, the split-bf16 duo kernel, left the library in round 5: the setter rejects them.)"""
     cond = synth.synth_audio((1, 64), seed=2)
     cases = [(4, 2, (2, 2, 777), cond),                                   # P = 2, 4, 8; 2 x 8 tiles over 8 workgroups
              (4, 3, (1, 2, 300), cond),                                   # odd dilations: P = 1
@@ -103,18 +103,15 @@ def test_tcn_bf16_stream_and_duo_kernels_emulated(emu_default):
         emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 1), "tuning")           # form 0: one tile per workgroup
         y0 = m(x, cnd)
         a0 = m.forward_blocks(x, cnd, nb)
-        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 3), "tuning")
-        y1 = m(x, cnd)
-        a1 = m.forward_blocks(x, cnd, nb)
-        assert float((y1 - y_ref).abs().max()) <= 4e-2
-        assert float((a1 - col[nb - 1]).abs().max()) <= 4e-2 * float(col[nb - 1].abs().max())
-        assert float((y1 - y0).abs().max()) <= 5e-3 and float((a1 - a0).abs().max()) <= 5e-2
-        # form 2, the default ("duo": 4 matrix + 4 loader waves per CU, two tile buffers, the next tile by LDS-DMA during the main loop):
+        assert float((y0 - y_ref).abs().max()) <= 4e-2
+        assert float((a0 - col[nb - 1]).abs().max()) <= 4e-2 * float(col[nb - 1].abs().max())
+        # form 2 ("duo": 4 matrix + 4 loader waves per CU, two tile buffers, the next tile by LDS-DMA during the main loop), tap-major:
         # the same bits as form 0
         emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 5), "tuning")
         assert torch.equal(m(x, cnd), y0) and torch.equal(m.forward_blocks(x, cnd, nb), a0)
-    with pytest.raises(ValueError):
-        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 6), "tuning")
+    for gone in (3, 6, 13):          # the stream kernel (form 1), form 3, the split-bf16 duo kernel (bit 3)
+        with pytest.raises(ValueError):
+            emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, gone), "tuning")
 
 
 def test_tcn_bf16_duo_reuse_main_loop_emulated(emu_default):
@@ -196,34 +193,6 @@ def test_tcn_bf16x3_half_tile_kernel_class_major_emulated(emu_default):
         assert float((a1 - col[nb - 1]).abs().max()) <= 3e-5 * float(col[nb - 1].abs().max())
         assert float((y1 - y0).abs().max()) <= 1e-5 and float((a1 - a0).abs().max()) <= 1e-5 * float(a0.abs().max())
         assert not torch.equal(a1, a0)          # the other loop did run
-
-
-def test_tcn_bf16x3_duo_kernel_emulated(emu_default):
-    """The persistent double-tile form of the split-bf16 block kernel (mst_tcn_set_tuning bit 3; not the default - measured slower): 4 matrix + 4 loader waves
-    per CU, the loader waves fetch / split the next tile and finish / store the previous one.  The one-tile kernel's results (bit 3
-    off) to accumulation rounding, and the oracle at the split mode's tolerance: several tiles per workgroup (the emulated device has 4 CUs), P = 1 and P = 2
-    tiles, ragged lengths (rows past the segment), several batch items with one FiLM row each, buffers refilled three and more times."""
-    cases = [(3, 2, (2, 2, 777), synth.synth_audio((1, 64), seed=2)),          # d = 2, 4: P = 2; 2 x 7 tiles
-             (3, 3, (1, 2, 1300), synth.synth_audio((1, 64), seed=3)),         # d = 3, 9: P = 1; 11 tiles on 4 workgroups
-             (2, 2, (3, 2, 1100), synth.synth_audio((3, 64), seed=11))]        # 3 x 9 tiles, one FiLM row per item
-    for nb, growth, shape, cnd in cases:
-        m, sd = _tcn(nb, growth=growth)
-        m.precision = "bf16x3"
-        x = synth.synth_audio(shape, seed=1)
-        col = []
-        y_ref = R.tcn_forward(sd, x, cnd, nblocks=nb, dilation_growth=growth, collect=col)
-        m._ensure(emu_default)
-        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 5), "tuning")            # one tile per workgroup
-        y0, a0 = m(x, cnd), m.forward_blocks(x, cnd, nb)
-        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 13), "tuning")           # the duo form
-        y1, a1 = m(x, cnd), m.forward_blocks(x, cnd, nb)
-        assert float((y1 - y_ref).abs().max()) <= 3e-5
-        assert float((a1 - col[nb - 1]).abs().max()) <= 3e-5 * float(col[nb - 1].abs().max())
-        # the duo form sums tap-major; the one-tile kernel's two-phase tiles class-major since round 4: equal to accumulation rounding there,
-        # bit for bit on the one-phase tiles (odd dilations)
-        assert float((y1 - y0).abs().max()) <= 1e-5 and float((a1 - a0).abs().max()) <= 1e-5 * float(a0.abs().max())
-        if growth == 3:
-            assert torch.equal(y1, y0) and torch.equal(a1, a0)
 
 
 def test_tcn_condition_forms_emulated(emu_default):
@@ -460,6 +429,12 @@ def test_conv_reverb_emulated(emu_default):
     rv2 = ConvolutionalReverb(irs, 44100)
     yb = rv2.process(xb)
     assert np.abs(yb[1] - F.conv_reverb(xb[1], h2)).max() <= 5e-6 * np.abs(yb[1]).max()
+    # the public response edited IN PLACE must not leave the old one on the device (the device copy is cached: round-4 advice)
+    rv2.parameters.dry.value, rv2.parameters.wet.value = 0.0, 1.0
+    y_a = rv2.process(x.copy())
+    rv2.h *= np.float32(0.5)
+    y_b = rv2.process(x.copy())
+    assert np.abs(y_b - 0.5 * y_a).max() <= 1e-6 * np.abs(y_a).max()
     rv2.parameters.wet.value = 0.0
     assert np.array_equal(rv2.process(x.copy()), x)
     with pytest.raises(ValueError):

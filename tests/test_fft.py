@@ -43,3 +43,29 @@ def test_fft_lengths_must_be_powers_of_two(emu_default):
     from music_mixing_style_transfer_amd.mixing_manipulator import _device_ops as D
     with pytest.raises(NotImplementedError):
         D.StftMeanMagnitude(1000, 250, np.ones(1000, np.float32), max_batch=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L,nt", [(300000, 100001), (50000, 600001), (5000000, 600001)])
+def test_long_transforms_and_long_responses_on_gpu(L, nt):
+    """The largest four-step kernels (2^18 ... 2^21 real points: LOGMAX 9 and 10 column / row kernels, no emulator test reaches them) and the
+    block choice for responses longer than 2^19 samples: (300000, 100001) is one 2^19-point transform, (50000, 600001) one 2^21-point
+    transform, (5000000, 600001) overlap-save with blocks of TWICE the response (four times would need 2^22 points: round 4 returned
+    MST_ERR_UNSUPPORTED there).  Against scipy's float64 FFT convolution; a response beyond 2^20 samples is refused with a message."""
+    import scipy.signal
+    from music_mixing_style_transfer_amd import _lib
+    from music_mixing_style_transfer_amd.mixing_manipulator import _device_ops as D
+    rng = np.random.default_rng(L + nt)
+    x = rng.standard_normal((L, 1)).astype(np.float32)
+    taps = (rng.standard_normal(nt) * np.exp(-np.arange(nt) / (0.2 * nt)) / np.sqrt(nt)).astype(np.float32)
+    y = D.fir_causal(torch.from_numpy(x).cuda(), taps.astype(np.float64)).cpu().numpy()[:, 0]
+    xe = np.concatenate([np.full(nt - 1, x[0, 0], np.float64), x[:, 0].astype(np.float64)])
+    want = scipy.signal.fftconvolve(xe, taps.astype(np.float64))[nt - 1:nt - 1 + L]
+    err = np.abs(y - want).max() / max(1.0, np.abs(want).max())
+    print(f"fir_causal L = {L}, {nt} taps: max deviation {err:.2e} of max|ref|")
+    assert err <= 2e-5, (L, nt, err)
+    import ctypes as C
+    lib = _lib.lib()
+    h = C.c_void_p()
+    assert lib.mst_fx_convolver_create(10000000, (1 << 20) + 1, 1, 1, C.byref(h)) == -2          # MST_ERR_UNSUPPORTED
+    assert b"2^20" in lib.mst_last_error()

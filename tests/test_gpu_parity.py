@@ -110,10 +110,10 @@ def test_tcn_bf16_vs_oracle(nets):
         tcn.precision = "fp32"
 
 
-@pytest.mark.parametrize("form", [1, 3, 5, 21, 53])
+@pytest.mark.parametrize("form", [1, 5, 21, 53])
 def test_tcn_bf16_block_kernel_forms_vs_oracle(nets, form):
-    """The three forms of the bf16 block kernel (mst_tcn_set_tuning bits 1-2: 0 = one tile per workgroup, 1 = "stream", 2 = "duo";
-    the two persistent forms get their input rows by LDS-DMA) against the oracle - per block and on the waveform, ragged length (tiles that end outside the segment), per-item
+    """The forms of the bf16 block kernel (mst_tcn_set_tuning bits 1-2: 0 = one tile per workgroup, 2 = "duo", persistent, input rows by
+    LDS-DMA; the "stream" form 1 left the library in round 5) against the oracle - per block and on the waveform, ragged length (tiles that end outside the segment), per-item
     FiLM rows, a batch larger than the persistent grid's first wave of tiles.  21 = the duo form with the class-major main loop (bit 4):
     the same products in another fp32 summation order - agrees with 5 to accumulation rounding.  53 = 21 + block 0 computed inside
     the d = 2 block's launch (bit 5, the default since round 5): bit-identical to 21, and `mst_tcn_get_tuning` reports that the fusion ran."""
@@ -199,13 +199,10 @@ def test_tcn_bf16x3_vs_oracle(nets):
     y_ref = R.tcn_forward(nets["tcn_sd"], x, cond, collect=col)
     tcn.precision = "bf16x3"
     try:
-        a_10 = None
         for n in (1, 2, 5, 10, 13, 14):
             a = tcn.forward_blocks(x.cuda(), cond.cuda(), n).cpu()
             err = float((a - col[n - 1]).abs().max())
             assert err <= 2e-4 * float(col[n - 1].abs().max()), f"block {n}: {err}"
-            if n == 10:
-                a_10 = a
         y = tcn(x.cuda(), cond.cuda()).cpu()
         print(f"bf16x3 @ 3 x 2x20011: max|y - oracle| = {float((y - y_ref).abs().max()):.2e}")
         assert float((y - y_ref).abs().max()) <= 1e-4
@@ -213,16 +210,9 @@ def test_tcn_bf16x3_vs_oracle(nets):
         yB = tcn(x.cuda(), condB.cuda()).cpu()
         assert float((yB - R.tcn_forward(nets["tcn_sd"], x, condB)).abs().max()) <= 1e-4
         assert torch.equal(tcn(x[1:2].cuda(), condB[1:2].cuda()).cpu()[0], yB[1])
-        # the persistent double-tile form of the split-bf16 block kernel (mst_tcn_set_tuning bit 3; measured slower, not the default): the same
-        # products summed tap-major (the one-tile kernel's two-phase tiles: class-major) - equal to fp32 accumulation rounding
         from music_mixing_style_transfer_amd import _lib
         lib = _lib.lib()
         try:
-            lib.check(lib.mst_tcn_set_tuning(tcn._handle, _lib.TCN_TUNING_DEFAULT | 8), "mst_tcn_set_tuning")
-            yD = tcn(x.cuda(), condB.cuda()).cpu()
-            assert float((yD - yB).abs().max()) <= 1e-5 and float((yD - R.tcn_forward(nets["tcn_sd"], x, condB)).abs().max()) <= 1e-4
-            aD = tcn.forward_blocks(x.cuda(), cond.cuda(), 10).cpu()
-            assert float((aD - a_10).abs().max()) <= 2e-5 * float(a_10.abs().max())
             # bit 6: the eight-phase half-tile kernel (here every block from d = 512 on: fewer than 64 steps per phase) with its loop toggled -
             # the same products in another summation order: fp32 accumulation rounding apart, both within the oracle tolerance
             lib.check(lib.mst_tcn_set_tuning(tcn._handle, _lib.TCN_TUNING_DEFAULT ^ 64), "mst_tcn_set_tuning")

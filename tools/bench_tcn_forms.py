@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""A/B of the bf16 TCN block kernel forms on the MI355X (mst_tcn_set_tuning flags 1 / 3 / 5 / 21): the one-tile-per-workgroup kernel
-against the two persistent LDS-DMA-fed kernels ("stream", "duo"; 21 = duo with the class-major main loop, the default).  Per-block kernel times from HIP events on the launch stream (mst_tcn_timing_*), the forms
+"""A/B of the bf16 TCN block kernel forms on the MI355X (mst_tcn_set_tuning flags 1 / 5 / 21 / 53): the one-tile-per-workgroup kernel
+against the persistent LDS-DMA-fed "duo" kernel (5 tap-major, 21 class-major, 53 = 21 + block 0 inside block 1's launch: the default's bf16 part).  Per-block kernel times from HIP events on the launch stream (mst_tcn_timing_*), the forms
 alternating so that both see the same clock / thermal state; parity of the two forms against each other at full size and against
 the oracle on a short segment.
 
@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=3)
-    ap.add_argument("--forms", default="1,3,5")
+    ap.add_argument("--forms", default="1,5,21,53")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     import yaml
