@@ -579,6 +579,21 @@ def main():
                            "parallelism": f"segment-sharded x{world}, all-gather of embeddings"},
                    step_ms={k: round(v, 3) for k, v in (stats.get("step_ms") or {}).items()},
                    roofline=slim_roofline(rl))
+        if world == 1 and args.precision in ("bf16", "bf16x3"):
+            # row f-1 (inference/feature_extraction.py): the FXencoder alone on the same 32 resident segments - its segments/s is the whole cost
+            # of the feature-extraction CLI's network part
+            for _ in range(2):
+                enc(ref)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                enc(ref)
+            torch.cuda.synchronize()
+            fe_ms = (time.perf_counter() - t0) / 10 * 1e3
+            out["feature_extraction"] = {"value": round(B / fe_ms * 1e3, 1), "unit": "segments/s", "ms": round(fe_ms, 3),
+                                         "what": "FXencoder forward only, same batch"}
+            details["feature_extraction"] = dict(out["feature_extraction"], flop_per_batch=457.6e9 * B / 32,
+                                                 frac_of_bf16_peak=457.6e9 * B / 32 / (fe_ms * 1e-3) / 1e12 / PEAK["bf16"] * MFMA_PER_FLOP[args.precision])
         if track is not None:
             details["track60"] = track
             out["track60"] = {"value": round(track["value"], 1), "ms": round(track["t_ms"], 1), "segments": track["segments"], "scaling": "strong"}

@@ -259,6 +259,13 @@ typedef struct {
     /* mst_fx_biquad_cascade only (the others refuse it): also leave sum(x_raw^2) of the call's raw input here
      * ([n_items][MST_SUMSQ_SLOTS], the arithmetic of mst_fx_sumsq) - the first rms-normalise of a chain then needs no energy pass over x */
     double *out_in_sumsq_dev;
+    /* mid / side energies handed from mst_fx_compressor (stereo, time-parallel path; the others refuse it) to mst_fx_midside_imager (round 5):
+     * the compressor's apply pass leaves sum((l + r)^2), sum((l - r)^2) of its raw output - float32 sums and squares per frame, float64
+     * accumulation, the arithmetic of the imager's own energy pass - as MST_SUMSQ_SLOTS pairs per item in out_ms_dev
+     * ([n_items][MST_SUMSQ_SLOTS][2]; cleared by the call), and an imager given the same array as in_ms_dev skips its energy pass over the
+     * audio (one launch and one read of the batch less per chain).  NULL: off. */
+    double *out_ms_dev;
+    const double *in_ms_dev;
 } MstFxFuse;
 int mst_fx_sumsq(const float *x_dev, int n_items, long per_item, double *out_dev, void *stream);   /* out[item][slot]: partial sums of x^2 */
 /* scale_out[item] = float32(sqrt(mean(x_true^2) / max(1e-7, mean(y^2)))), mean(x_true^2) = scale_x^2 sum_slots(sumsq_x) / per_x
@@ -275,11 +282,11 @@ size_t mst_fx_biquad_scratch_bytes(int n_items, long L, int C, int n_bands);
 int mst_fx_biquad_cascade(const float *x_dev, float *y_dev, int n_items, long L, int C, const double *coef_host,
                           int n_bands, double *scratch_dev, size_t scratch_bytes, const MstFxFuse *fuse, void *stream);
 /* process-wide tuning of the FX kernels (results do not depend on it).  bit 0 (default 1): the time-parallel compressor of a large batch
- * (>= 32 chain batches of 1024 samples and >= 4e6 samples in all) is cut into four time slices whose map / apply kernels run on an internal
+ * (>= 32 chain batches of 1024 samples and >= 4e6 samples in all) is cut into three time slices whose map / apply kernels run on an internal
  * low-priority side stream BESIDE the chain kernel of the neighbouring slice (the chain is one latency-bound walk per sequence on n_seq
  * workgroups; events order map_i -> chain_i -> apply_i, the caller's stream joins the side stream before the call returns to it).
  * Measured on configs[3] (64 x [131072, 2]): see DESIGN.md 3.3.  bit 1 (default 0; test / A-B hook): slices whatever the size (>= 8 batches);
- * bits 2-3 (A-B hook): number of slices, 0 -> 4 (default), 1 -> 2, 2 -> 3, 3 -> 8. */
+ * bits 2-3 (A-B hook): number of slices, 0 -> 3 (default), 1 -> 2, 2 -> 4, 3 -> 8. */
 int mst_fx_set_tuning(int flags);
 
 /* Compressor.process / compressor_process (:529-587, :637-649), makeup gain 0.  With a scratch buffer of

@@ -32,7 +32,7 @@ class MstTcnDesc(C.Structure):
 
 class MstFxFuse(C.Structure):
     _fields_ = [("in_scale_dev", C.c_void_p), ("out_sumsq_dev", C.c_void_p), ("in_sumsq_dev", C.c_void_p), ("post_rms", C.c_int),
-                ("post_gain", C.c_float), ("out_in_sumsq_dev", C.c_void_p)]
+                ("post_gain", C.c_float), ("out_in_sumsq_dev", C.c_void_p), ("out_ms_dev", C.c_void_p), ("in_ms_dev", C.c_void_p)]
 
 
 class MstEncDesc(C.Structure):

@@ -381,43 +381,17 @@ __global__ __launch_bounds__(256) void fx_biquad_stereo_ends_kernel(BiquadChunkA
 // start state of the block's first chunk), element i > 0 the zero-state end state of chunk i - 1, and a Hillis-Steele scan
 //     t_i += (A^M)^(2^l) t_{i - 2^l}      l = 0 .. log2(NB) - 1
 // leaves t_i = the true start state of chunk i (t_(NB-1) = the next block's carry).  The powers (A^M)^(2^l) come from
-// fx_biquad_pow_kernel (squared up from the host's A^M, float64).  128 sequences x 128 chunks: 8 matrix-vector products of depth per
+// the host (squared up from A^M, float64).  128 sequences x 128 chunks: 8 matrix-vector products of depth per
 // sequence instead of 128 (round 1's kernel ran one LANE per sequence: 2 workgroups, 88 us); a 3-minute stem (7 752 chunks) is
 // 31 blocks instead of 7 752 serial steps.  AM is [S][S] row-major with S = 2 * n_bands, state order (z1, z2) per band; ends /
 // starts are laid out [sequence][chunk][16 states]: one 128-byte record per chunk, so that the scan's element i reads / writes
 // record i (the first layout, [chunk][state][sequence], cost the scan 19 of its 39 us in 8-byte accesses 16 KB apart).
-struct BiquadPowArgs { double am[4 * MST_MAX_BANDS * MST_MAX_BANDS]; };      // A^M, [S][S] row-major, by value in the kernel arguments
 #define MST_BIQUAD_LEVELS 9                                                   // log2 of the largest scan block
 
-// pm[l] = (A^M)^(2^l), l = 0 .. 8, squared up by one workgroup into the caller's scratch: the scan kernel reads the matrix elements
-// with scalar loads (uniform addresses) and feeds them to v_fma_f64 as SGPR operands - its first version kept them in LDS and spent
-// its time on 100 broadcast ds_read_b64 per thread and level (40 us for 482 chunks of 128 sequences)
-template <int NBANDS>
-__global__ __launch_bounds__(256) void fx_biquad_pow_kernel(BiquadPowArgs pw, double *pm) {
-    constexpr int S = 2 * NBANDS;
-    __shared__ double cur[S * S];
-    const int i = threadIdx.x;
-    if (i < S * S) {
-        cur[i] = pw.am[i];
-        pm[i] = pw.am[i];
-    }
-    __syncthreads();
-    for (int l = 1; l < MST_BIQUAD_LEVELS; ++l) {
-        double acc = 0.0;
-        if (i < S * S) {
-            const int r = i / S, c = i % S;
-#pragma unroll
-            for (int j = 0; j < S; ++j) acc += cur[r * S + j] * cur[j * S + c];
-        }
-        __syncthreads();
-        if (i < S * S) {
-            cur[i] = acc;
-            pm[l * S * S + i] = acc;
-        }
-        __syncthreads();
-    }
-}
-
+// pm[l] = (A^M)^(2^l), l = 0 .. 8: the scan kernel reads the matrix elements with scalar loads (uniform addresses) and feeds them to v_fma_f64
+// as SGPR operands - its first version kept them in LDS and spent its time on 100 broadcast ds_read_b64 per thread and level (40 us for 482
+// chunks of 128 sequences).  The powers come from the host with the impulse-state table (mst_api.hip biquad_impulse_table, cached per
+// coefficient set; until round 5 a one-workgroup kernel squared them up on the device in front of every scan).
 template <int NBANDS, int NB>
 __global__ __launch_bounds__(NB) void fx_biquad_scan_kernel(const double *ends, double *starts, const double *__restrict__ pm, int n_seq,
                                                            int nchunks) {
@@ -508,6 +482,7 @@ struct CompArgs {
     // chain fusion: x is read as x * (float)in_scale[item]; the apply pass adds sum(y^2) per item to out_sumsq (both may be null)
     const double *in_scale = nullptr;
     double *out_sumsq = nullptr;
+    double *out_ms = nullptr;      // stereo: the apply pass also adds sum((l + r)^2), sum((l - r)^2) per item to [item][MST_SUMSQ_SLOTS][2] (for the imager)
 };
 
 __global__ __launch_bounds__(256) void fx_compressor_kernel(CompArgs a) {
@@ -759,6 +734,8 @@ __global__ __launch_bounds__(64) MST_WAVES_PER_SIMD(4) MST_HEAVY_UNROLL void fx_
     if (ca.out_sumsq && a.clear_sumsq) {      // the first launch of a compressor call clears the energy slots its apply passes add to
         const long nthr = (long)gridDim.x * gridDim.y * 64, me = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 64 + threadIdx.x;
         for (long i = me; i < (long)(ca.n_seq / ca.C) * MST_SUMSQ_SLOTS; i += nthr) ca.out_sumsq[i] = 0.0;
+        if (ca.out_ms)
+            for (long i = me; i < (long)(ca.n_seq / ca.C) * MST_SUMSQ_SLOTS * 2; i += nthr) ca.out_ms[i] = 0.0;
     }
     const int item = (int)(sq / ca.C);
     const FxCompCurve cv = fx_comp_curve(ca, item);
@@ -1017,12 +994,44 @@ __global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const do
             // 10^(v / 20) as exp(v ln10 / 20): the general pow() is five times the instructions for the same value to 1e-15 relative
             const float out = (float)((double)xs * exp((a.makeup - t[nl][sl]) * 0.11512925464970228420));
             a.y[e] = out;
-            if (a.out_sumsq) t[nl][sl] = (double)out * (double)out;          // this thread's own tile element: reused for the energy sum
+            if (a.out_sumsq) t[nl][sl] = a.out_ms ? (double)out : (double)out * (double)out;      // this thread's own tile element: reused for the energy sums
         } else if (a.out_sumsq) {
             t[nl][sl] = 0.0;
         }
     }
-    if (a.out_sumsq) {             // column sums of the tile: one atomic per (tile, sequence)
+    if (a.out_sumsq && a.out_ms) {
+        // stereo chain, an imager downstream: the tile holds the OUTPUT samples (exact float32 values); thread (pair p = tid & 31, frames
+        // nl = 8 (tid >> 5) .. + 7) forms l^2 + r^2 and the imager's mid / side terms - m = l + r, s = l - r and their squares in float32,
+        // sums in float64, like fx_energy_parts_kernel - then lanes p and p + 32 meet by a shuffle, the four waves through LDS, and pair p
+        // leaves three atomics per tile (C == 2: the tile's sequences 2 p, 2 p + 1 are the channels of one item)
+        __shared__ double red[4][32][3];
+        __syncthreads();
+        const int p = threadIdx.x & 31, g8 = threadIdx.x >> 5;
+        double e2 = 0.0, em = 0.0, es = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float l = (float)t[8 * g8 + i][2 * p], r = (float)t[8 * g8 + i][2 * p + 1];
+            const float m = l + r, sd = l - r;
+            e2 += (double)l * (double)l + (double)r * (double)r;
+            em += (double)(m * m);
+            es += (double)(sd * sd);
+        }
+        e2 += __shfl_xor(e2, 32);
+        em += __shfl_xor(em, 32);
+        es += __shfl_xor(es, 32);
+        if ((threadIdx.x & 63) < 32) {
+            red[threadIdx.x >> 6][p][0] = e2;
+            red[threadIdx.x >> 6][p][1] = em;
+            red[threadIdx.x >> 6][p][2] = es;
+        }
+        __syncthreads();
+        if (threadIdx.x < 32 && s0 + 2 * p < a.n_seq) {
+            const int item = (s0 + 2 * p) / 2, slot = (int)(tx & (MST_SUMSQ_SLOTS - 1));
+            atomicAdd(&a.out_sumsq[item * MST_SUMSQ_SLOTS + slot], red[0][p][0] + red[1][p][0] + red[2][p][0] + red[3][p][0]);
+            atomicAdd(&a.out_ms[(item * MST_SUMSQ_SLOTS + slot) * 2 + 0], red[0][p][1] + red[1][p][1] + red[2][p][1] + red[3][p][1]);
+            atomicAdd(&a.out_ms[(item * MST_SUMSQ_SLOTS + slot) * 2 + 1], red[0][p][2] + red[1][p][2] + red[2][p][2] + red[3][p][2]);
+        }
+    } else if (a.out_sumsq) {             // column sums of the tile: one atomic per (tile, sequence)
         __syncthreads();
         if (threadIdx.x < 64 && s0 + (int)threadIdx.x < a.n_seq) {
             double cs = 0.0;

@@ -1488,6 +1488,8 @@ struct BiquadTab {
     double *devp = nullptr;
     unsigned long stamp = 0;
 };
+// (the same entry carries the scan's matrix powers (A^M)^(2^l), l = 0 .. MST_BIQUAD_LEVELS - 1, behind the table: [M][S] | [levels][S][S];
+//  round 4 squared them up on the device with a one-workgroup launch per call - 5-8 us on the chain's critical path)
 const double *biquad_impulse_table(const double (*coef)[5], int n_bands, int M, void *stream) {
     static std::mutex mu;
     static std::vector<BiquadTab *> tabs;
@@ -1510,10 +1512,6 @@ const double *biquad_impulse_table(const double (*coef)[5], int n_bands, int M, 
     if (n_dev >= 16) {
         t = oldest;
         if (hipDeviceSynchronize() != hipSuccess) return nullptr;      // nobody reads the evicted table any more
-        if (t->host.size() < (size_t)M * S) {
-            (void)hipFree(t->devp);
-            t->devp = nullptr;
-        }
     } else {
         t = new BiquadTab;
         tabs.push_back(t);
@@ -1524,7 +1522,12 @@ const double *biquad_impulse_table(const double (*coef)[5], int n_bands, int M, 
     std::memset(t->coef, 0, sizeof(t->coef));
     std::memcpy(t->coef, coef, sizeof(double) * 5 * n_bands);
     t->stamp = ++clock_;
-    if (t->host.size() < (size_t)M * S) t->host.assign((size_t)M * S, 0.0);
+    const size_t n_tab = (size_t)M * S, n_all = n_tab + (size_t)MST_BIQUAD_LEVELS * S * S;
+    if (t->host.size() < n_all) {
+        if (t->devp) (void)hipFree(t->devp);
+        t->devp = nullptr;
+        t->host.assign(n_all, 0.0);
+    }
     std::vector<double> z(S, 0.0);
     for (int m = 0; m < M; ++m) {
         double v = m == 0 ? 1.0 : 0.0;
@@ -1536,12 +1539,39 @@ const double *biquad_impulse_table(const double (*coef)[5], int n_bands, int M, 
         }
         for (int j = 0; j < S; ++j) t->host[(size_t)m * S + j] = z[j];
     }
+    {   // A^M column by column (the cascade run M steps on zero input from each unit state), then squared up level by level
+        double *pm = t->host.data() + n_tab;
+        for (int col = 0; col < S; ++col) {
+            std::vector<double> u(S, 0.0);
+            u[col] = 1.0;
+            for (int n = 0; n < M; ++n) {
+                double v = 0.0;
+                for (int b = 0; b < n_bands; ++b) {
+                    const double yn = coef[b][0] * v + u[2 * b];
+                    u[2 * b] = coef[b][1] * v - coef[b][3] * yn + u[2 * b + 1];
+                    u[2 * b + 1] = coef[b][2] * v - coef[b][4] * yn;
+                    v = yn;
+                }
+            }
+            for (int row = 0; row < S; ++row) pm[(size_t)row * S + col] = u[row];
+        }
+        for (int l = 1; l < MST_BIQUAD_LEVELS; ++l) {
+            const double *cur = pm + (size_t)(l - 1) * S * S;
+            double *nxt = pm + (size_t)l * S * S;
+            for (int r = 0; r < S; ++r)
+                for (int c = 0; c < S; ++c) {
+                    double acc = 0.0;
+                    for (int j = 0; j < S; ++j) acc += cur[r * S + j] * cur[j * S + c];
+                    nxt[r * S + c] = acc;
+                }
+        }
+    }
     if (!t->devp && hipMalloc((void **)&t->devp, t->host.size() * sizeof(double)) != hipSuccess) {
         t->dev = -1;
         t->devp = nullptr;
         return nullptr;
     }
-    if (hipMemcpyAsync(t->devp, t->host.data(), (size_t)M * S * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+    if (hipMemcpyAsync(t->devp, t->host.data(), n_all * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
         t->dev = -1;
         return nullptr;
     }
@@ -1561,6 +1591,7 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
                                      double *scratch, size_t scratch_bytes, const MstFxFuse *fuse, void *stream) {
     if (!x || !y || !coef || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_biquad_cascade: bad argument");
     if (fuse && fuse->post_rms) return fail(MST_ERR_UNSUPPORTED, "mst_fx_biquad_cascade: tail folding (post_rms) is the imager's");
+    if (fuse && (fuse->out_ms_dev || fuse->in_ms_dev)) return fail(MST_ERR_UNSUPPORTED, "mst_fx_biquad_cascade: the mid / side energies travel from the compressor to the imager");
     if (n_bands < 0 || n_bands > MST_MAX_BANDS) return fail(MST_ERR_UNSUPPORTED, "mst_fx_biquad_cascade: at most 8 bands");
     const int M = biquad_chunk(L, (long)n_items * C);
     const long nchunks = (L + M - 1) / M;
@@ -1584,24 +1615,7 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         double *ends = scratch, *starts = scratch + states;
         a.ends = ends;
         a.starts = starts;
-        // A^M column by column: run the cascade M steps on zero input from each unit state (host, float64)
         const int S = 2 * n_bands;
-        BiquadPowArgs pw;
-        double *am = pw.am;
-        for (int col = 0; col < S; ++col) {
-            std::vector<double> z(S, 0.0);
-            z[col] = 1.0;
-            for (int n = 0; n < M; ++n) {
-                double v = 0.0;
-                for (int b = 0; b < n_bands; ++b) {
-                    const double yn = a.coef[b][0] * v + z[2 * b];
-                    z[2 * b] = a.coef[b][1] * v - a.coef[b][3] * yn + z[2 * b + 1];
-                    z[2 * b + 1] = a.coef[b][2] * v - a.coef[b][4] * yn;
-                    v = yn;
-                }
-            }
-            for (int row = 0; row < S; ++row) am[(size_t)row * S + col] = z[row];
-        }
         const long lanes = (long)a.n_seq * nchunks;
         const dim3 cg((unsigned)((lanes + 63) / 64));
         auto launch_chunks = [&](auto APPLY) {         // the band count is a template parameter: no per-band branches in the recursion
@@ -1648,18 +1662,7 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         }
         MST_CHECK_LAUNCH("fx_biquad_ends_kernel");
         const dim3 sg((unsigned)a.n_seq);
-        double *pmat = scratch + 2 * states;          // (A^M)^(2^l), l = 0 .. 8
-        switch (n_bands) {
-            case 1: MST_LAUNCH(fx_biquad_pow_kernel<1>, dim3(1), dim3(256), stream, pw, pmat); break;
-            case 2: MST_LAUNCH(fx_biquad_pow_kernel<2>, dim3(1), dim3(256), stream, pw, pmat); break;
-            case 3: MST_LAUNCH(fx_biquad_pow_kernel<3>, dim3(1), dim3(256), stream, pw, pmat); break;
-            case 4: MST_LAUNCH(fx_biquad_pow_kernel<4>, dim3(1), dim3(256), stream, pw, pmat); break;
-            case 5: MST_LAUNCH(fx_biquad_pow_kernel<5>, dim3(1), dim3(256), stream, pw, pmat); break;
-            case 6: MST_LAUNCH(fx_biquad_pow_kernel<6>, dim3(1), dim3(256), stream, pw, pmat); break;
-            case 7: MST_LAUNCH(fx_biquad_pow_kernel<7>, dim3(1), dim3(256), stream, pw, pmat); break;
-            default: MST_LAUNCH(fx_biquad_pow_kernel<8>, dim3(1), dim3(256), stream, pw, pmat); break;
-        }
-        MST_CHECK_LAUNCH("fx_biquad_pow_kernel");
+        const double *pmat = htab + (size_t)M * S;          // (A^M)^(2^l), l = 0 .. 8: behind the impulse-state table (cached per coefficient set)
         auto launch_scan = [&](auto NBv) {
             constexpr int nb = decltype(NBv)::value;
             const double *e = ends, *pmc = pmat;
@@ -1749,7 +1752,7 @@ struct FxSide {
 };
 int g_fx_pipeline = 1;          // mst_fx_set_tuning bit 0
 int g_fx_pipeline_any_size = 0; // mst_fx_set_tuning bit 1 (test / A-B hook: slices whatever the size of the batch)
-int g_fx_slices = 4;            // mst_fx_set_tuning bits 2-3: 0 -> 4 slices, 1 -> 2, 2 -> 3, 3 -> 8
+int g_fx_slices = 3;            // mst_fx_set_tuning bits 2-3: 0 -> 3 slices (default: measured 0.523-0.539 ms per chain against 0.540-0.550 with 4), 1 -> 2, 2 -> 4, 3 -> 8
 FxSide *fx_side() {
     static std::mutex mu;
     static FxSide *sides[64] = {};
@@ -1783,6 +1786,7 @@ int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size
         const CompScratch cs = comp_scratch(n_items, L, C);
         if (cs.nchunks < 4) {
             if (a.out_sumsq) MST_HIP_TRY(hipMemsetAsync(a.out_sumsq, 0, (size_t)n_items * MST_SUMSQ_SLOTS * sizeof(double), (hipStream_t)stream));
+            if (a.out_ms) MST_HIP_TRY(hipMemsetAsync(a.out_ms, 0, (size_t)n_items * MST_SUMSQ_SLOTS * 2 * sizeof(double), (hipStream_t)stream));
             MST_LAUNCH(fx_comp_gain_kernel, tiles, dim3(256), stream, a, scratch);
             MST_CHECK_LAUNCH("fx_comp_gain_kernel");
             MST_LAUNCH(fx_comp_smooth_kernel, dim3((a.n_seq + 63) / 64), dim3(64), stream, a, scratch);
@@ -1811,7 +1815,7 @@ int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size
             }
             m.ycarry = (double *)((unsigned char *)scratch + cs.xl + cs.maps + cs.ystart + cs.tab);
             // Time slices.  The chain is ONE dependent walk per sequence (n_seq workgroups, latency-bound: most of the chip idles beside it) while
-            // the map and apply kernels are throughput work.  The signal is cut into NS slices of whole chain batches; the caller's stream runs
+            // the map and apply kernels are throughput work.  The signal is cut into NS (three) slices of whole chain batches; the caller's stream runs
             // the chain of slice 0, 1, ... back to back, a side stream (lower priority) the maps of slice 1, 2, ... and the applies of slice
             // 0 .. NS - 2 beside it (events order map_i -> chain_i -> apply_i); the last apply follows the last chain on the caller's stream, which
             // then waits for the side stream.  Same arithmetic, same results (the smoother's value crosses a slice boundary as a float64 in
@@ -1891,7 +1895,7 @@ extern "C" int mst_fx_set_tuning(int flags) {
     if (flags < 0 || flags > 15) return fail(MST_ERR_ARG, "mst_fx_set_tuning: unknown flag bits");
     g_fx_pipeline = flags & 1;
     g_fx_pipeline_any_size = (flags >> 1) & 1;
-    static const int slices[4] = {4, 2, 3, 8};
+    static const int slices[4] = {3, 2, 4, 8};
     g_fx_slices = slices[(flags >> 2) & 3];
     return MST_OK;
 }
@@ -1923,6 +1927,11 @@ extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, 
     a.makeup = 0.0;
     a.in_scale = fuse ? fuse->in_scale_dev : nullptr;
     a.out_sumsq = fuse ? fuse->out_sumsq_dev : nullptr;
+    if (fuse && fuse->in_ms_dev) return fail(MST_ERR_UNSUPPORTED, "mst_fx_compressor: in_ms_dev is the imager's");
+    if (fuse && fuse->out_ms_dev) {
+        if (C != 2 || !fuse->out_sumsq_dev) return fail(MST_ERR_UNSUPPORTED, "mst_fx_compressor: out_ms_dev needs stereo audio and out_sumsq_dev");
+        a.out_ms = fuse->out_ms_dev;
+    }
     return compressor_run(a, n_items, L, C, scratch, scratch_bytes, stream);
 }
 
@@ -2003,13 +2012,20 @@ extern "C" int mst_fx_midside_imager(const float *x, float *y, int n_items, long
     const bool fold = fuse && fuse->post_rms;
     if (fuse && fuse->out_in_sumsq_dev) return fail(MST_ERR_UNSUPPORTED, "mst_fx_midside_imager: out_in_sumsq_dev is the equaliser's");
     if (fold && !fuse->in_sumsq_dev) return fail(MST_ERR_ARG, "mst_fx_midside_imager: post_rms needs in_sumsq_dev");
+    if (fuse && fuse->out_ms_dev) return fail(MST_ERR_UNSUPPORTED, "mst_fx_midside_imager: out_ms_dev is the compressor's");
     int chunks = (int)std::min<long>(MST_SUMSQ_SLOTS, (L + 8191) / 8192);
     if (chunks < 1) chunks = 1;
-    MST_LAUNCH(fx_energy_parts_kernel, dim3(n_items * chunks), dim3(256), stream, x, scratch, L, chunks);
-    MST_CHECK_LAUNCH("fx_energy_parts_kernel");
+    const double *parts = scratch;
+    if (fuse && fuse->in_ms_dev) {          // the producer of x (the compressor's apply pass) left the mid / side energies behind: no energy pass
+        parts = fuse->in_ms_dev;
+        chunks = MST_SUMSQ_SLOTS;
+    } else {
+        MST_LAUNCH(fx_energy_parts_kernel, dim3(n_items * chunks), dim3(256), stream, x, scratch, L, chunks);
+        MST_CHECK_LAUNCH("fx_energy_parts_kernel");
+    }
     const double bal_r = std::round(bal * 1000.0) / 1000.0;   // round(bal, 3) (:980)
     MST_LAUNCH(fx_imager_apply_kernel, dim3((unsigned)((L + MST_IMAGER_FRAMES - 1) / MST_IMAGER_FRAMES), n_items), dim3(256), stream, x, y,
-               (const double *)scratch, chunks, L, bal_r, fuse ? fuse->in_scale_dev : (const double *)nullptr,
+               parts, chunks, L, bal_r, fuse ? fuse->in_scale_dev : (const double *)nullptr,
                fuse ? fuse->out_sumsq_dev : (double *)nullptr, fold ? fuse->in_sumsq_dev : (const double *)nullptr,
                fold ? fuse->post_gain : 1.0f);
     MST_CHECK_LAUNCH("fx_imager_apply_kernel");
@@ -2019,8 +2035,8 @@ extern "C" int mst_fx_midside_imager(const float *x, float *y, int n_items, long
 extern "C" int mst_fx_gain(const float *x, float *y, int n_items, long L, int C, double gain_db, int invert, const MstFxFuse *fuse,
                            void *stream) {
     if (!x || !y || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_gain: bad argument");
-    if (fuse && (fuse->post_rms || fuse->out_in_sumsq_dev))
-        return fail(MST_ERR_UNSUPPORTED, "mst_fx_gain: tail folding (post_rms) is the imager's, out_in_sumsq_dev the equaliser's");
+    if (fuse && (fuse->post_rms || fuse->out_in_sumsq_dev || fuse->out_ms_dev || fuse->in_ms_dev))
+        return fail(MST_ERR_UNSUPPORTED, "mst_fx_gain: tail folding (post_rms) is the imager's, out_in_sumsq_dev the equaliser's, the mid / side energies the compressor's / imager's");
     double g = std::pow(10.0, gain_db / 20.0);
     if (invert) g = -g;
     const long per = L * C;

@@ -104,20 +104,26 @@ class _Dev:
     def scratch(self, n_doubles):
         return torch.empty(n_doubles, dtype=torch.float64, device=self.x.device)
 
-    def fuse(self, in_scale, want_sumsq, in_sumsq=None, post_gain=None, want_in_sumsq=False):
+    def fuse(self, in_scale, want_sumsq, in_sumsq=None, post_gain=None, want_in_sumsq=False, want_ms=False, in_ms=None):
         """(MstFxFuse pointer or None, sumsq tensor or None) for a processor call inside a fused chain.
-        in_sumsq + post_gain: tail folding (the rms-normalise behind the processor and a gain behind that in the processor's last pass)."""
+        in_sumsq + post_gain: tail folding (the rms-normalise behind the processor and a gain behind that in the processor's last pass).
+        want_ms (compressor): the mid / side energies of the raw output are left in self.last_ms; in_ms (imager): such an array, instead of
+        the imager's own energy pass over the audio."""
         self.last_in_sumsq = None
-        if in_scale is None and not want_sumsq and in_sumsq is None and not want_in_sumsq:
+        self.last_ms = None
+        if in_scale is None and not want_sumsq and in_sumsq is None and not want_in_sumsq and in_ms is None:
             return None, None
+        if want_ms:             # [n][SUMSQ_SLOTS][2], cleared by the producer
+            self.last_ms = torch.empty(self.n * SUMSQ_SLOTS * 2, dtype=torch.float64, device=self.x.device)
         sumsq = torch.empty(self.n * SUMSQ_SLOTS, dtype=torch.float64, device=self.x.device) if want_sumsq else None   # cleared by the producer
         if want_in_sumsq:       # sum(x_raw^2) of this call's input, left behind by the processor (the equaliser's apply pass)
             self.last_in_sumsq = torch.empty(self.n * SUMSQ_SLOTS, dtype=torch.float64, device=self.x.device)
         f = _lib.MstFxFuse(in_scale.data_ptr() if in_scale is not None else None, sumsq.data_ptr() if want_sumsq else None,
                            in_sumsq.data_ptr() if in_sumsq is not None else None, 1 if in_sumsq is not None else 0,
                            float(post_gain) if post_gain is not None else 1.0,
-                           self.last_in_sumsq.data_ptr() if want_in_sumsq else None)
-        self._keep = (f, in_scale, sumsq, in_sumsq, self.last_in_sumsq)    # alive until the launches are queued
+                           self.last_in_sumsq.data_ptr() if want_in_sumsq else None,
+                           self.last_ms.data_ptr() if want_ms else None, in_ms.data_ptr() if in_ms is not None else None)
+        self._keep = (f, in_scale, sumsq, in_sumsq, self.last_in_sumsq, self.last_ms, in_ms)    # alive until the launches are queued
         return C.byref(f), sumsq
 
     def out(self, y):
@@ -252,7 +258,9 @@ class Compressor(Processor):
         y = torch.empty_like(d.x)
         nbytes = d.lib.mst_fx_compressor_scratch_bytes(d.n, d.L, d.C)
         sc = d.scratch((nbytes + 7) // 8)
-        fuse, sumsq = d.fuse(in_scale, want_sumsq)
+        # stereo, inside a chain: the apply pass also leaves the mid / side energies of its output behind (d.last_ms) - an imager that
+        # follows needs no energy pass of its own
+        fuse, sumsq = d.fuse(in_scale, want_sumsq, want_ms=bool(want_sumsq and d.C == 2))
         d.lib.check(d.lib.mst_fx_compressor(d.x.data_ptr(), y.data_ptr(), d.n, d.L, d.C, float(p.threshold.value),
                                             float(p.attack_time.value), float(p.release_time.value), float(p.ratio.value),
                                             float(self.sample_rate), sc.data_ptr(), nbytes, fuse, d.stream), "mst_fx_compressor")
@@ -279,12 +287,12 @@ class MidSideImager(Processor):
     def fusable(self, d):
         return d.C == 2
 
-    def _run(self, d, in_scale, want_sumsq, bal=None, in_sumsq=None, post_gain=None):
+    def _run(self, d, in_scale, want_sumsq, bal=None, in_sumsq=None, post_gain=None, in_ms=None):
         if d.C != 2:
             raise ValueError("MidSideImager needs stereo audio [L, 2]")
         y = torch.empty_like(d.x)
         sc = d.scratch(2 * SUMSQ_SLOTS * d.n)
-        fuse, sumsq = d.fuse(in_scale, want_sumsq, in_sumsq, post_gain)
+        fuse, sumsq = d.fuse(in_scale, want_sumsq, in_sumsq, post_gain, in_ms=in_ms)
         d.lib.check(d.lib.mst_fx_midside_imager(d.x.data_ptr(), y.data_ptr(), d.n, d.L,
                                                 float(self.parameters.bal.value if bal is None else bal),
                                                 sc.data_ptr(), fuse, d.stream), "mst_fx_midside_imager")
@@ -546,10 +554,11 @@ def _sumsq(d, t):
 class _Pending:
     """An array on its way through an AugmentationChain: device batch t [n, L, C], the per-item factor still to be applied to it
     (scale, float64 [n] or None) and sum(t^2) per item when its producer left it behind (sumsq, float64 [n] or None)."""
-    __slots__ = ("dev", "t", "scale", "sumsq", "deferred")
+    __slots__ = ("dev", "t", "scale", "sumsq", "deferred", "ms")
 
-    def __init__(self, dev, t, scale, sumsq, deferred=None):
+    def __init__(self, dev, t, scale, sumsq, deferred=None, ms=None):
         self.dev, self.t, self.scale, self.sumsq = dev, t, scale, sumsq
+        self.ms = ms            # mid / side energies of t left behind by its producer (the compressor), or None
         # deferred = (imager, bal): an rms-normalised MidSideImager step that has NOT run yet - if a Gain is next, the imager's pass
         # applies the rms factor and the gain itself (MstFxFuse tail folding); anything else runs it first (flush)
         self.deferred = deferred
@@ -562,9 +571,9 @@ class _Pending:
         d = self.dev.rebind(self.t)
         sumsq_x = self.sumsq if self.sumsq is not None else _sumsq(d, self.t)
         if gain is not None:
-            y, _ = imager._run(d, self.scale, False, bal=bal, in_sumsq=sumsq_x, post_gain=gain)
+            y, _ = imager._run(d, self.scale, False, bal=bal, in_sumsq=sumsq_x, post_gain=gain, in_ms=self.ms)
             return _Pending(d, y, None, None)
-        y, sumsq_y = imager._run(d, self.scale, True, bal=bal)
+        y, sumsq_y = imager._run(d, self.scale, True, bal=bal, in_ms=self.ms)
         scale = torch.empty(d.n, dtype=torch.float64, device=y.device)
         d.lib.check(d.lib.mst_fx_rms_pending(self.scale.data_ptr() if self.scale is not None else None, sumsq_x.data_ptr(),
                                              self.t.shape[1] * self.t.shape[2], sumsq_y.data_ptr(), y.shape[1] * y.shape[2],
@@ -619,7 +628,7 @@ class AugmentationChain:
             x = x.flush()
         d = x.dev
         if isinstance(processor, MidSideImager) and rms_normalize and processor.fusable(d.rebind(x.t)):
-            return _Pending(d, x.t, x.scale, x.sumsq, deferred=(processor, float(processor.parameters.bal.value)))
+            return _Pending(d, x.t, x.scale, x.sumsq, deferred=(processor, float(processor.parameters.bal.value)), ms=x.ms)
         if hasattr(processor, "fusable") and processor.fusable(d):
             # the pending rms factor of the previous step is folded into this processor's loads; its output leaves sum(y^2) behind
             d.rebind(x.t)
@@ -628,8 +637,9 @@ class AugmentationChain:
                 y, sumsq_y = processor._run(d, x.scale, True, want_in_sumsq=True)      # the equaliser leaves sum(x^2) of its input behind too
             else:
                 y, sumsq_y = processor._run(d, x.scale, rms_normalize)
+            ms = getattr(d, "last_ms", None)
             if not rms_normalize:
-                return _Pending(d, y, None, sumsq_y)
+                return _Pending(d, y, None, sumsq_y, ms=ms)
             sumsq_x = x.sumsq if x.sumsq is not None else (d.last_in_sumsq if d.last_in_sumsq is not None else _sumsq(d, x.t))
             if sumsq_y is None:
                 sumsq_y = _sumsq(d, y)
@@ -637,7 +647,7 @@ class AugmentationChain:
             d.lib.check(d.lib.mst_fx_rms_pending(x.scale.data_ptr() if x.scale is not None else None, sumsq_x.data_ptr(),
                                                  x.t.shape[1] * x.t.shape[2], sumsq_y.data_ptr(), y.shape[1] * y.shape[2],
                                                  scale.data_ptr(), d.n, d.stream), "mst_fx_rms_pending")
-            return _Pending(d, y, scale, sumsq_y)
+            return _Pending(d, y, scale, sumsq_y, ms=ms)
         xm = x.materialize()
         y = processor.process(xm)
         if rms_normalize:

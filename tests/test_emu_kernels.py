@@ -557,7 +557,7 @@ def test_time_parallel_fx_shapes_emulated(emu_default, L, n_items, C):
 
 @pytest.mark.parametrize("L,n_items,C", [(8 * 1024, 1, 2), (9 * 1024 + 517, 3, 2), (13 * 1024 + 31, 2, 1)])
 def test_compressor_time_slices_are_bit_identical_emulated(emu_default, L, n_items, C):
-    """The compressor's map / chain / apply kernels over FOUR time slices (mst_fx_set_tuning bits 0 | 1: the pipelined form the product uses
+    """The compressor's map / chain / apply kernels over THREE time slices (mst_fx_set_tuning bits 0 | 1: the pipelined form the product uses
     for large batches, here forced on a small one) against the single-slice run: the same bits - the smoother's value crosses a slice
     boundary as a float64 - and both against the oracle.  Slices of unequal batch counts, a ragged last batch, a short last chunk."""
     from music_mixing_style_transfer_amd.mixing_manipulator import Compressor
@@ -570,8 +570,8 @@ def test_compressor_time_slices_are_bit_identical_emulated(emu_default, L, n_ite
         emu_default.check(emu_default.mst_fx_set_tuning(0), "mst_fx_set_tuning")
         y1 = c.process(x.copy())
         emu_default.check(emu_default.mst_fx_set_tuning(3), "mst_fx_set_tuning")
-        y4 = c.process(x.copy())
-        emu_default.check(emu_default.mst_fx_set_tuning(3 | 2 << 2), "mst_fx_set_tuning")      # three slices: unequal batch counts
+        y4 = c.process(x.copy())                                                                  # three slices: unequal batch counts
+        emu_default.check(emu_default.mst_fx_set_tuning(3 | 2 << 2), "mst_fx_set_tuning")      # four
         y3 = c.process(x.copy())
         emu_default.check(emu_default.mst_fx_set_tuning(3 | 3 << 2), "mst_fx_set_tuning")      # eight
         y8 = c.process(x.copy())

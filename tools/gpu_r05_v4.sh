@@ -4,7 +4,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$(pwd); O=$R/gpurun_out/v4; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 timeout 900 python -m pytest tests -m gpu -q -k "fx or compressor or equaliser or chain or config4 or time_parallel or normaliz or stem_sized" > $O/pytest_fx_full.log 2>&1; tail -5 $O/pytest_fx_full.log
-for t in 1 9 1 9; do
+for t in 1 9 1 9; do   # 1 = the default (three slices), 9 = four
   timeout 300 python tools/bench_fx.py --fx-tuning $t > $O/bench_fx_t$t.json 2>> $O/bench_fx.err
   python -c "
 import json; d=json.load(open('$O/bench_fx_t$t.json')); print('fx tuning $t: chain ms', round(d['ms_per_chain'],4), 'dev', d['max_abs_dev_vs_oracle'], {k: round(v,3) for k,v in d['per_processor_ms'].items()})" | tee -a $O/fx_ab.txt
