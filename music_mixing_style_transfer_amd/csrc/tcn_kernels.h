@@ -721,11 +721,18 @@ __global__ __launch_bounds__(512, 1) void tcn_block_bf16_duo_kernel(TcnBlockArgs
     }
 
     int cur = 0, bprev = tb;
+    // (round 5, phase clocks of this wave - tools/probe_tcn_phases.py: the per-tile bookkeeping, i.e. the two 32-bit divisions of
+    //  tile_geometry, cost 1250 of the tile's 42 600 clocks.  A matrix wave needs the next tile's coordinates only for the fused output
+    //  head; otherwise only its batch item, and that only when every item has its own FiLM row: one division, or none)
+    const unsigned tiles_item = (unsigned)a.tiles_phase * (unsigned)a.tiles_step;
     for (;;) {
         const int b = tb, m0 = tm0, phi0 = tphi0;
         const unsigned tnext = tile + tstep;
         const bool has_next = tnext < tend;
-        if (has_next) tile_geometry(tnext, tb, tm0, tphi0);
+        if (has_next) {
+            if constexpr (FUSE_OUT) tile_geometry(tnext, tb, tm0, tphi0);
+            else if (a.film_rows > 1) tb = (int)(tnext / tiles_item);
+        }
         unsigned char *const sm = smem + cur * BUF;
         if (b != bprev) {              // a new batch item: its FiLM row (every matrix wave is past the previous tile's epilogue: barrier 2)
             stage_film(b);
