@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Phase clocks of the dominant kernel (tcn_block_bf16_duo_kernel<4>, the d = 64 block of the default TCN at 32 x 131072): a PROBE BUILD of the
-library (tools/_ab/probe.so: csrc/ with s_memtime stamps patched into matrix wave 0 of one workgroup, tools/_ab is untracked - the recipe is in
-EXPERIMENTS.md D.7) accumulates the shader clocks that wave spends per tile in: [0] loop bookkeeping, [1] accumulator init + ring preload +
+"""Phase clocks of the dominant kernel (tcn_block_bf16_duo_kernel<4>, the d = 64 block of the default TCN at 32 x 131072; --kernel x3: the
+split-bf16 tcn_block_bf16x3_kernel<2, 4>): a PROBE BUILD of the library (tools/_ab/probe.so, built by tools/build_probe.py: csrc/ with s_memtime
+stamps patched into one wave of one workgroup; tools/_ab is untracked) accumulates the shader clocks that wave spends per tile in: [0] loop bookkeeping, [1] accumulator init + ring preload +
 classes 0 .. 2, [2] the last class, [3] issuing the residual reads, [4] barrier 1, [5] epilogue arithmetic + LDS writes, [6] barrier 2; [7] tiles.
     python tools/probe_tcn_phases.py [--forwards 5]"""
 import argparse
@@ -18,6 +18,7 @@ sys.path.insert(0, REPO)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--forwards", type=int, default=5)
+    ap.add_argument("--kernel", default="duo", choices=["duo", "x3"])
     ap.add_argument("--lib", default=os.path.join(REPO, "tools", "_ab", "probe.so"))
     args = ap.parse_args()
     import yaml
@@ -33,7 +34,7 @@ def main():
                    kernel_size=cfg["kernel_size"], channel_width=cfg["channel_width"], stack_size=cfg["stack_size"],
                    cond_dim=cfg["condition_dimension"], causal=cfg["causal"]).to(dev)
     tcn.load_state_dict(synth.tcn_state_dict(seed=0))
-    tcn.precision = "bf16"
+    tcn.precision = "bf16" if args.kernel == "duo" else "bf16x3"
     x = synth.synth_audio((32, 2, 131072), seed=200).to(dev)
     cond = synth.synth_audio((1, cfg["condition_dimension"]), seed=3).to(dev)
     for _ in range(2):
@@ -48,8 +49,12 @@ def main():
     torch.cuda.synchronize()
     assert rd(out, 0) == 0
     v = [int(t) for t in out]
-    tiles = max(1, v[7])
     names = ["loop bookkeeping", "acc init + ring preload + classes 0..2", "last class", "residual reads issued", "barrier 1", "epilogue arithmetic + LDS writes", "barrier 2"]
+    if args.kernel == "x3":          # tcn_block_bf16x3_kernel<2, 4>: one 128-time tile per workgroup, two workgroups per CU
+        v = v[8:]
+        names = ["staging (loads, hi / lo split, LDS writes)", "barrier", "main loop (three MFMAs per product)", "barrier", "LeakyReLU / FiLM + transposed LDS writes", "barrier",
+                 "rows: residual from global + store"]
+    tiles = max(1, v[7])
     tot = sum(v[:7])
     print(f"tiles seen by the probed wave: {tiles} ({args.forwards} forwards); clocks per tile: {tot / tiles:.0f}")
     for n, t in zip(names, v[:7]):
