@@ -557,7 +557,12 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
             if constexpr (X3) acur_lo[ks] = anxt_lo[ks];
         }
         __syncthreads();
+        // (round 5, phase clocks of this loop on the 2048 -> 2048 layers - profiles/r05_enc_conv_phase_clocks.txt: issuing the next chunk's
+        //  eight loads and their address arithmetic took 1650 of a chunk's 5400 clocks - the co-resident workgroups' MFMA streams starve a
+        //  wave's VALU / VMEM issue; the issue runs at raised priority)
+        __builtin_amdgcn_s_setprio(3);
         if (kc + 1 < kc_hi) fetch(kc + 1);
+        __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll

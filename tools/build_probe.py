@@ -31,8 +31,9 @@ def main():
             open(os.path.join(DST, f), "w").write(open(os.path.join(SRC, f)).read())
     p = os.path.join(DST, "tcn_kernels.h")
     s = open(p).read()
-    s = patch(s, "struct TcnBlockArgs {", """__device__ long long mst_tcn_probe[16];
-#define MST_PROBE(k) do { if (probe_on) { const long long now_ = mst_clock(); mst_tcn_probe[k] += now_ - probe_t; probe_t = now_; } } while (0)
+    dev = os.path.join(DST, "mst_dev.h")
+    open(dev, "a").write("\n__device__ long long mst_tcn_probe[32];      // probe build only\n")
+    s = patch(s, "struct TcnBlockArgs {", """#define MST_PROBE(k) do { if (probe_on) { const long long now_ = mst_clock(); mst_tcn_probe[k] += now_ - probe_t; probe_t = now_; } } while (0)
 struct TcnBlockArgs {""")
     # ---- duo kernel, matrix wave 0
     s = patch(s, """    const unsigned tiles_item = (unsigned)a.tiles_phase * (unsigned)a.tiles_step;
@@ -127,13 +128,62 @@ struct TcnBlockArgs {""")
 }
 """, X3_BEGIN, X3_END)
     open(p, "w").write(s)
+    # ---- encoder conv kernel (enc_conv_nlc_kernel<4>): wave 0 of workgroup 100 of the launches with Cin = Cout = 2048; slots 16 .. 23
+    p = os.path.join(DST, "enc_kernels.h")
+    s = open(p).read()
+    s = patch(s, "struct EncNlcArgs {", """#define MST_EPROBE(k) do { if (eprobe_on) { const long long now_ = mst_clock(); mst_tcn_probe[k] += now_ - eprobe_t; eprobe_t = now_; } } while (0)
+struct EncNlcArgs {""")
+    NB, NE = "void enc_conv_nlc_kernel(EncNlcArgs a) {", "// The 128-channel x 128-column tile with its four waves 2 x 2"
+    s = patch(s, """    if (kc_lo < kc_hi) {
+        stab_entry(kc_lo);
+        fetch(kc_lo);
+    }
+    for (int kc = kc_lo; kc < kc_hi; ++kc) {
+        if (kc > kc_lo) __syncthreads();""", """    const bool eprobe_on = blockIdx.x == 100 && tid == 0 && a.Cin == 2048 && a.Cout == 2048 && MW == 4;
+    long long eprobe_t = mst_clock();
+    if (kc_lo < kc_hi) {
+        stab_entry(kc_lo);
+        fetch(kc_lo);
+    }
+    MST_EPROBE(16);              // prologue: descriptors, first fetch issued
+    for (int kc = kc_lo; kc < kc_hi; ++kc) {
+        if (kc > kc_lo) __syncthreads();
+        MST_EPROBE(17);          // barrier: every wave is done with the previous chunk's tile""", NB, NE)
+    s = patch(s, """        __syncthreads();
+        if (kc + 1 < kc_hi) fetch(kc + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = 128 * ni + 32 * q + ln;""", """        MST_EPROBE(18);          // wait for this chunk's loads + LDS writes of the B tile
+        __syncthreads();
+        MST_EPROBE(19);          // barrier: the tile is complete
+        if (kc + 1 < kc_hi) fetch(kc + 1);
+        MST_EPROBE(20);          // next chunk's loads issued
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = 128 * ni + 32 * q + ln;""", NB, NE)
+    s = patch(s, """                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[ks], bv, acc[q], 0, 0, 0);
+            }
+        }
+    }
+""", """                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[ks], bv, acc[q], 0, 0, 0);
+            }
+        }
+        MST_EPROBE(21);          // 16 MFMAs + 16 ds_read_b128
+        if (eprobe_on) mst_tcn_probe[23] += 1;
+    }
+""", NB, NE)
+    open(p, "w").write(s)
     p = os.path.join(DST, "mst_api.hip")
     s = open(p).read()
     s = s.replace('#include "../../include/mst_hip.h"', '#include "../../../include/mst_hip.h"')
     s += '''
 extern "C" int mst_probe_read(long long *out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mst_tcn_probe), 16 * sizeof(long long)) != hipSuccess) return -3;
-    if (reset) { long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(mst_tcn_probe), z, sizeof(z)) != hipSuccess) return -3; }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mst_tcn_probe), 32 * sizeof(long long)) != hipSuccess) return -3;
+    if (reset) { long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(mst_tcn_probe), z, sizeof(z)) != hipSuccess) return -3; }
     return 0;
 }
 '''

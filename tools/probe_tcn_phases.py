@@ -18,7 +18,7 @@ sys.path.insert(0, REPO)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--forwards", type=int, default=5)
-    ap.add_argument("--kernel", default="duo", choices=["duo", "x3"])
+    ap.add_argument("--kernel", default="duo", choices=["duo", "x3", "enc"])
     ap.add_argument("--lib", default=os.path.join(REPO, "tools", "_ab", "probe.so"))
     args = ap.parse_args()
     import yaml
@@ -34,18 +34,28 @@ def main():
                    kernel_size=cfg["kernel_size"], channel_width=cfg["channel_width"], stack_size=cfg["stack_size"],
                    cond_dim=cfg["condition_dimension"], causal=cfg["causal"]).to(dev)
     tcn.load_state_dict(synth.tcn_state_dict(seed=0))
-    tcn.precision = "bf16" if args.kernel == "duo" else "bf16x3"
+    tcn.precision = "bf16x3" if args.kernel == "x3" else "bf16"
+    if args.kernel == "enc":          # the FXencoder's channel-minor conv kernel on the 2048 -> 2048 layers (32 x 131072, bf16)
+        from music_mixing_style_transfer_amd.networks import FXencoder
+        with open(os.path.join(REPO, "music_mixing_style_transfer_amd", "networks", "configs.yaml")) as f:
+            ecfg = yaml.full_load(f)["Effects_Encoder"]["default"]
+        enc = FXencoder({k: (list(v) if isinstance(v, list) else v) for k, v in ecfg.items()}).to(dev)
+        enc.load_state_dict(synth.fxencoder_state_dict(ecfg, seed=0))
+        enc.precision = "bf16"
+        run = lambda: enc(x)
+    else:
+        run = lambda: tcn(x, cond)
     x = synth.synth_audio((32, 2, 131072), seed=200).to(dev)
     cond = synth.synth_audio((1, cfg["condition_dimension"]), seed=3).to(dev)
     for _ in range(2):
-        tcn(x, cond)
+        run()
     torch.cuda.synchronize()
-    out = (C.c_longlong * 16)()
+    out = (C.c_longlong * 32)()
     rd = b.cdll.mst_probe_read
     rd.argtypes = [C.POINTER(C.c_longlong), C.c_int]
     assert rd(out, 1) == 0
     for _ in range(args.forwards):
-        tcn(x, cond)
+        run()
     torch.cuda.synchronize()
     assert rd(out, 0) == 0
     v = [int(t) for t in out]
@@ -54,6 +64,11 @@ def main():
         v = v[8:]
         names = ["staging (loads, hi / lo split, LDS writes)", "barrier", "main loop (three MFMAs per product)", "barrier", "LeakyReLU / FiLM + transposed LDS writes", "barrier",
                  "rows: residual from global + store"]
+    if args.kernel == "enc":
+        v = [int(t) for t in out][16:24]
+        names = ["prologue (descriptors, first fetch)", "barrier (previous tile consumed)", "wait for the chunk's loads + LDS writes", "barrier (tile complete)",
+                 "next chunk's loads issued", "16 MFMAs + 16 ds_read_b128"]
+        v = v[:6] + [0, v[7]]
     tiles = max(1, v[7])
     tot = sum(v[:7])
     print(f"tiles seen by the probed wave: {tiles} ({args.forwards} forwards); clocks per tile: {tot / tiles:.0f}")
