@@ -194,7 +194,9 @@ int mst_enc_set_tuning(MstEnc *enc, long rows_min_tiles);
  * bit 2 (exact-fp32 mode, a test hook): gather through 64-bit addresses - the path that activations beyond the 32-bit offset range take
  * by themselves - instead of buffer loads.  Same bits either way.  (Round 5 built and measured an in-kernel split-K finalize - tickets, last
  * workgroup of a tile sums the partial tiles - as bit 3: correct, and 5 x SLOWER per layer (the device-scope release fence writes the
- * whole L2 back on this part; EXPERIMENTS.md D.3): not in the library.) */
+ * whole L2 back on this part; EXPERIMENTS.md D.3): not in the library.)
+ * bit 3 (default off, the reference form of a GPU / emulator test): the default encoder's stereo block (2 -> 2, k = 25 with skip; 2 -> 16, k = 25,
+ * stride 4) as two direct-kernel launches with the intermediate in HBM instead of the fused enc_stereo_block_kernel.  Same bits either way. */
 int mst_enc_set_schedule(MstEnc *enc, int flags);
 /* nn.AdaptiveAvgPool1d(1) on its own (architectures.py:63,67; FXencoder(conv_block='conv') runs its ConvBlocks one by one through
  * mst_enc_forward_conv and pools here): x_dev fp32 [rows, L] -> y_dev[rows] = mean over L. */

@@ -411,6 +411,206 @@ __global__ __launch_bounds__(256) void enc_direct_kernel(EncDirectArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The stereo block of the default encoder in ONE launch (round 5): Res_ConvBlock 0 = Conv1d_layer(2 -> 2, k = 25, stride 1) + skip, then
+// Conv1d_layer(2 -> 16, k = 25, stride 4) (network_utils.py:96-119 on configs.yaml's first entries).  Two enc_direct_kernel launches took
+// 71 + 60 us per 32 segments for 2.5 GFLOP and 4 x 33.5 MB: one thread per output step, one LDS read per multiply-add, the 33.5 MB
+// intermediate through HBM.  A first fused form on packed VALU multiply-adds with the weights through the scalar cache ran 94 us: every
+// tap waited for its scalar loads (SMEM returns out of order: s_waitcnt lgkmcnt(0) each time).  This form puts both convolutions on
+// v_mfma_f32_16x16x4_f32 - exact fp32, bit for bit a k-ordered fmaf chain, at the fp32 vector rate with the WEIGHTS RESIDENT IN REGISTERS as A
+// fragments (16 + 14 per lane, packed by the host) and one ds_read_b32 per MFMA for the B operand:
+//   * second conv: D[channel][time] = sum_k W[channel][k] T[k][time], k = ci * 28 + j (taps 25 .. 27: zero weights): 14 MFMAs per 16 output
+//     steps; lane (n, kq) reads intermediate sample 4 (t + n) + 4 a + kq.
+//   * first conv (2 output channels would fill an eighth of the rows): TOEPLITZ form - rows (co, r), r = 0 .. 7 the position inside a block of
+//     eight, columns = blocks: D[(co, r)][q] = sum_(ci, k') w[co][ci][k' - r] x[ci][8 q + k'], k' = 0 .. 31 (zero where k' - r is no tap):
+//     16 MFMAs per 128 positions x 2 channels, 1.6 x the useful multiply-adds instead of 8 x.
+// Zero weights are exact no-ops of an fmaf chain (finite data), the taps come in the direct kernels' order (ci outer, tap inner, from
+// zero, then shift / activation / skip): the same bits as the two direct kernels.  A workgroup owns TO = 240 outputs: 1056 staged input
+// samples per channel (reflection applied), 1024 intermediate slots per channel in LDS; both LDS images are skewed (10 floats per 8 input
+// samples, 6 per 4 intermediate samples) so that the 16 columns of a B fragment fall into different banks.  Intermediate positions outside
+// the segment (the second conv's reflection padding) are copies of their mirror positions inside the tile.
+// ------------------------------------------------------------------------------------------------
+struct EncStereoArgs {
+    const float *x;               // [B][2][L] fp32
+    void *y, *ylo;                // bf16 [B][Lout][16]; ylo non-null: split mode, the low parts' plane
+    const float *a0, *shift0;     // first conv: Toeplitz A fragments [16 k-steps][64 lanes] (enc_stereo_pack_a0), shift [2]
+    const float *a1, *shift1;     // second conv: A fragments [14 k-steps][64 lanes] (enc_stereo_pack_a1), shift [16]
+    int B, L, Lout, tiles;        // tiles = ceil(Lout / TO) per item
+    float slope0, slope1;
+};
+constexpr int ENC_STEREO_TO = 240, ENC_STEREO_K = 25, ENC_STEREO_KS0 = 16, ENC_STEREO_KS1 = 14;
+// host side: the fragment images of BN-folded weights w[Cout][2][25]
+inline void enc_stereo_pack_a0(const float *w, float *frag) {          // lane (row = (co, r), kq), k-step kk: ci = kk / 8, k' = 4 (kk % 8) + kq, tap k' - r
+    for (int kk = 0; kk < ENC_STEREO_KS0; ++kk)
+        for (int l = 0; l < 64; ++l) {
+            const int row = l & 15, kq = l >> 4, co = row >> 3, r = row & 7, ci = kk >> 3, j = 4 * (kk & 7) + kq - r;
+            frag[kk * 64 + l] = (j >= 0 && j < ENC_STEREO_K) ? w[(co * 2 + ci) * ENC_STEREO_K + j] : 0.0f;
+        }
+}
+inline void enc_stereo_pack_a1(const float *w, float *frag) {          // lane (row = channel, kq), k-step kk: ci = kk / 7, tap 4 (kk % 7) + kq
+    for (int kk = 0; kk < ENC_STEREO_KS1; ++kk)
+        for (int l = 0; l < 64; ++l) {
+            const int co = l & 15, kq = l >> 4, ci = kk / 7, j = 4 * (kk % 7) + kq;
+            frag[kk * 64 + l] = j < ENC_STEREO_K ? w[(co * 2 + ci) * ENC_STEREO_K + j] : 0.0f;
+        }
+}
+__device__ __forceinline__ int enc_reflect(int t, int L) {
+    if (t < 0) t = -t;
+    if (t >= L) t = 2 * (L - 1) - t;
+    return t;
+}
+__global__ __launch_bounds__(256) void enc_stereo_block_kernel(EncStereoArgs a) {
+    constexpr int KSZ = ENC_STEREO_K, S1 = 4, C1 = 16, TO = ENC_STEREO_TO, PAD = (KSZ - 1) / 2;
+    constexpr int NT = 1024, NX = NT + 32;               // intermediate slots (8 tiles of 16 blocks of 8); staged input samples (k' < 32)
+    constexpr int XP = NX / 8 * 10, TP = NT / 4 * 6;     // skewed images
+    constexpr int NT1 = TO / 16;                         // column tiles of the second conv
+    static_assert(TO % 16 == 0 && S1 * (TO - 1) + 4 * 7 <= NT && NT1 <= 16, "tile geometry");
+    __shared__ __attribute__((aligned(16))) float xs[2][XP];
+    __shared__ __attribute__((aligned(16))) float ts[2][TP];
+    auto xi = [](int p) { return p + 2 * (p >> 3); };                  // input sample p of the tile
+    auto ti = [](int s) { return 6 * (s >> 2) + (s & 3); };            // intermediate slot s
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.tiles, t0 = (blockIdx.x % a.tiles) * TO;
+    const int p_first = S1 * t0 - PAD;                     // position (in the intermediate signal) of slot 0
+    const float *xb = a.x + (size_t)b * 2 * a.L;
+    // A fragments: constant per launch, 30 registers
+    float A0[ENC_STEREO_KS0], A1[ENC_STEREO_KS1];
+#pragma unroll
+    for (int kk = 0; kk < ENC_STEREO_KS0; ++kk) A0[kk] = a.a0[kk * 64 + lane];
+#pragma unroll
+    for (int kk = 0; kk < ENC_STEREO_KS1; ++kk) A1[kk] = a.a1[kk * 64 + lane];
+    // ---- stage the input samples p_first - PAD + [0, NX).  An interior tile (p_first - PAD is a multiple of 4): all of a thread's
+    // 16-byte loads are in flight before the first LDS write; border tiles go element by element through the reflection
+    static_assert(NX % 8 == 0 && (2 * NX / 4 + 255) / 256 == 3, "three 16-byte pieces per thread");
+    if (p_first - PAD >= 0 && p_first - PAD + NX <= a.L && (a.L & 3) == 0) {          // uniform
+        f32x4 v[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = tid + 256 * r, ci = i >= NX / 4 ? 1 : 0, k = i - ci * (NX / 4);
+            if (i < 2 * NX / 4) v[r] = *(const f32x4 *)(xb + (size_t)ci * a.L + (p_first - PAD) + 4 * k);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int i = tid + 256 * r, ci = i >= NX / 4 ? 1 : 0, k = i - ci * (NX / 4);
+            if (i < 2 * NX / 4) {                           // four samples of one block of eight: contiguous in the skewed image, 8-byte aligned
+                float *q = &xs[ci][xi(4 * k)];
+                *(f32x2 *)q = f32x2{v[r][0], v[r][1]};
+                *(f32x2 *)(q + 2) = f32x2{v[r][2], v[r][3]};
+            }
+        }
+    } else {
+        for (int i = tid; i < 2 * NX; i += 256) {
+            const int ci = i >= NX ? 1 : 0, k = i - ci * NX;
+            const int t = enc_reflect(p_first - PAD + k, a.L);
+            xs[ci][xi(k)] = (t >= 0 && t < a.L) ? xb[(size_t)ci * a.L + t] : 0.0f;
+        }
+    }
+    __syncthreads();
+    // ---- first conv (Toeplitz) + shift + activation + skip: wave w owns column tiles 2 w, 2 w + 1 (128 slots each), interleaved (the
+    // dependent-accumulator latency of the instruction is 40 cycles against its 32-cycle issue)
+    {
+        f32x4 acc[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+        const float *bx = &xs[0][10 * (32 * w + n) + g];          // xi(8 q + 4 a + kq) = 10 q + 4 a + kq + 2 (a >> 1), q = 16 T + n
+#pragma unroll
+        for (int kk = 0; kk < ENC_STEREO_KS0; ++kk) {
+            const int ci = kk >> 3, av = kk & 7, off = ci * XP + 4 * av + 2 * (av >> 1);
+#pragma unroll
+            for (int T = 0; T < 2; ++T) acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[kk], bx[off + 160 * T], acc[T], 0, 0, 0);
+        }
+        // lane (n, g): channel co = g >> 1, slots s = 8 q + 4 (g & 1) + 0 .. 3
+        const int co = g >> 1;
+        const float sh = a.shift0[co];
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            const int s = 8 * (16 * (2 * w + T) + n) + 4 * (g & 1);
+            const float *xr = &xs[co][xi(s + PAD)];                 // the skip: input sample of the same position (one block of eight: contiguous)
+            const f32x2 x01 = *(const f32x2 *)xr, x23 = *(const f32x2 *)(xr + 2);
+            float *q = &ts[co][ti(s)];
+            *(f32x2 *)q = f32x2{enc_act(acc[T][0] + sh, a.slope0) + x01.x, enc_act(acc[T][1] + sh, a.slope0) + x01.y};
+            *(f32x2 *)(q + 2) = f32x2{enc_act(acc[T][2] + sh, a.slope0) + x23.x, enc_act(acc[T][3] + sh, a.slope0) + x23.y};
+        }
+    }
+    __syncthreads();
+    // ---- the second conv's reflection padding: a slot outside the segment takes the value of its mirror position
+    if (p_first < 0 || p_first + NT > a.L) {               // uniform: the first / last tiles of an item
+        float fix[2][4];
+        bool any = false;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int s = 4 * tid + p, pos = p_first + s;
+            fix[0][p] = ts[0][ti(s)];
+            fix[1][p] = ts[1][ti(s)];
+            if (pos < 0 || pos >= a.L) {
+                const int pr = enc_reflect(pos, a.L), sr = pr - p_first;
+                if (pr >= 0 && pr < a.L && sr >= 0 && sr < NT) {
+                    fix[0][p] = ts[0][ti(sr)];
+                    fix[1][p] = ts[1][ti(sr)];
+                } else {                                       // (a mirror position outside the tile: no default-geometry tile has one) computed from the input
+#pragma unroll 1
+                    for (int co = 0; co < 2; ++co) {
+                        float acc = 0.0f;
+                        if (pr >= 0 && pr < a.L) {
+#pragma unroll 1
+                            for (int ci = 0; ci < 2; ++ci)
+#pragma unroll 1
+                                for (int j = 0; j < KSZ; ++j) {
+                                    const int t = enc_reflect(pr - PAD + j, a.L);
+                                    // tap j of (co, ci) sits in row (co, r = 0) of the Toeplitz image at k' = j
+                                    const float wv = a.a0[(8 * ci + (j >> 2)) * 64 + 16 * (j & 3) + 8 * co];
+                                    acc = fmaf(wv, (t >= 0 && t < a.L) ? xb[(size_t)ci * a.L + t] : 0.0f, acc);
+                                }
+                            acc = enc_act(acc + a.shift0[co], a.slope0) + xb[(size_t)co * a.L + pr];
+                        }
+                        fix[co][p] = acc;
+                    }
+                }
+                any = true;
+            }
+        }
+        __syncthreads();                                       // every mirror source has been read
+        if (any) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                ts[0][ti(4 * tid + p)] = fix[0][p];
+                ts[1][ti(4 * tid + p)] = fix[1][p];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- second conv: wave w owns column tiles w, w + 4, w + 8, w + 12 (16 output steps each), two at a time
+    const f32x4 sh1 = *(const f32x4 *)(a.shift1 + 4 * g);
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        f32x4 acc[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
+        const int T0 = w + 8 * pr;                               // and T0 + 4 (wave 3's last pair has one tile: the other reads tile NT1 - 1 again)
+        const float *bt[2];                                      // ti(4 (16 T + n) + 4 a + kq) = 6 (16 T + n + a) + kq
+#pragma unroll
+        for (int T = 0; T < 2; ++T) bt[T] = &ts[0][6 * (16 * (T0 + 4 * T < NT1 ? T0 + 4 * T : NT1 - 1) + n) + g];
+#pragma unroll
+        for (int kk = 0; kk < ENC_STEREO_KS1; ++kk) {
+            const int ci = kk / 7, av = kk % 7, off = ci * TP + 6 * av;
+#pragma unroll
+            for (int T = 0; T < 2; ++T) acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[kk], bt[T][off], acc[T], 0, 0, 0);
+        }
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            const int o = 16 * (T0 + 4 * T) + n, to = t0 + o;        // lane (n, g): output step o of the tile, channels 4 g .. 4 g + 3
+            if (T0 + 4 * T < NT1 && to < a.Lout) {
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = enc_act(acc[T][e] + sh1[e], a.slope1);
+                    hi[e] = (__bf16)v;
+                    lo[e] = (__bf16)(v - (float)hi[e]);
+                }
+                const size_t at = ((size_t)b * a.Lout + to) * C1 + 4 * g;
+                *(bf16x4 *)((__bf16 *)a.y + at) = hi;
+                if (a.ylo) *(bf16x4 *)((__bf16 *)a.ylo + at) = lo;
+            }
+        }
+    }
+}
+
 struct EncNlcArgs {
     const __bf16 *x;     // [B][Lin][Cin]
     __bf16 *y;           // [B][Lout][Cout]

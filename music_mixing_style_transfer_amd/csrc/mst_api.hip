@@ -60,6 +60,7 @@ struct MstEncConv {
     __bf16 *wpk16 = nullptr;
     int *ktab = nullptr;
     float *w_direct = nullptr;   // [Cout][Cin][ksz] folded fp32 (layers with Cin < 8: direct kernel)
+    float *w_frag = nullptr;     // stereo block (Cin = 2, k = 25): the fused kernel's fp32 MFMA A fragments (enc_stereo_pack_a0 / _a1)
     __bf16 *wpk_nlc = nullptr;   // NLC pipeline A fragments, k = j*Cin + ci, K-chunk 64
     float slope = 0.0f;             // activation slope for negative values: 0 ReLU, 0.01 LeakyReLU, 1 none (MstEncDesc.act_slope)
     __bf16 *wpk_nlc_lo = nullptr;   // split mode: bf16(W' - bf16(W')) in the same fragment order
@@ -841,7 +842,7 @@ extern "C" int mst_tcn_forward_blocks(MstTcn *t, const float *x, float *act, int
 struct MstEnc {
     MstEncDesc d;
     std::vector<MstEncConv> conv;   // 2 per block
-    int schedule = 1;               // bit 1: 2 x 2 wave tiling of the 128-channel conv kernel (measured slower: off); bit 0: weight-major workgroup order for the weight-heavy layers (mst_enc_set_schedule)
+    int schedule = 1;               // bit 3: the stereo block as two direct-kernel launches instead of the fused kernel (the bit-identical reference form); bit 1: 2 x 2 wave tiling of the 128-channel conv kernel (measured slower: off); bit 0: weight-major workgroup order for the weight-heavy layers (mst_enc_set_schedule)
     void *zeros = nullptr;          // 256 bytes of zeros: what the channel-minor conv kernel fetches for rows / k-slots outside the problem
     long rows_min_tiles = 512;      // bf16 mode: layers with at least this many tiles keep their input rows resident in LDS (mst_enc_set_tuning)
 };
@@ -888,6 +889,7 @@ extern "C" int mst_enc_destroy(MstEnc *e) {
         (void)hipFree(c.wpk);
         (void)hipFree(c.wpk16);
         (void)hipFree(c.w_direct);
+        (void)hipFree(c.w_frag);
         (void)hipFree(c.wpk_nlc);
         (void)hipFree(c.wpk_nlc_lo);
         (void)hipFree(c.stab);
@@ -946,6 +948,15 @@ extern "C" int mst_enc_load_conv(MstEnc *e, int block, int which, const float *w
         for (int co = 0; co < c.cout; ++co)
             for (int k = 0; k < K; ++k) wd[(size_t)co * K + k] = w[(size_t)co * K + k] * scale[co];
         if ((rc = upload(&c.w_direct, wd))) return rc;
+        if (c.cin == 2 && c.ksz == ENC_STEREO_K && c.dil == 1 && c.cout == 2 && c.stride == 1) {
+            std::vector<float> fr((size_t)ENC_STEREO_KS0 * 64);
+            enc_stereo_pack_a0(wd.data(), fr.data());
+            if ((rc = upload(&c.w_frag, fr))) return rc;
+        } else if (c.cin == 2 && c.ksz == ENC_STEREO_K && c.dil == 1 && c.cout == 16 && c.stride == 4) {
+            std::vector<float> fr((size_t)ENC_STEREO_KS1 * 64);
+            enc_stereo_pack_a1(wd.data(), fr.data());
+            if ((rc = upload(&c.w_frag, fr))) return rc;
+        }
     } else if (c.cin % 8 == 0) {
         // NLC pipeline: contraction index k = j*Cin + ci; fragments [cot][kc64][ks 0..3][mi][lane][e]
         c.nchunks64 = (K + 63) / 64;
@@ -1000,7 +1011,7 @@ extern "C" int mst_enc_zero_stuff(const float *x, float *y, long rows, long L, i
 }
 
 extern "C" int mst_enc_set_schedule(MstEnc *e, int flags) {
-    if (!e || flags < 0 || flags > 7) return fail(MST_ERR_ARG, "mst_enc_set_schedule: flags 0..7");
+    if (!e || flags < 0 || flags > 15) return fail(MST_ERR_ARG, "mst_enc_set_schedule: flags 0..15");
     e->schedule = flags;
     return MST_OK;
 }
@@ -1196,6 +1207,32 @@ int enc_launch_direct(const MstEncConv &c, const float *x, void *y, bool out_nlc
     return MST_OK;
 }
 
+// the default encoder's stereo block (2 -> 2, k = 25 with skip; 2 -> 16, k = 25, stride 4) as one launch
+bool enc_stereo_block_fits(const MstEncConv &c0, const MstEncConv &c1, int L) {
+    auto same_pad = [](const MstEncConv &c) { return c.ksz == ENC_STEREO_K && c.dil == 1 && c.pad_l == 12 && c.pad_r == 12 && c.cin == 2 && c.w_frag; };
+    return same_pad(c0) && same_pad(c1) && c0.cout == 2 && c0.stride == 1 && c1.cout == 16 && c1.stride == 4 && L > 12 && L < (1 << 29);
+}
+int enc_launch_stereo_block(const MstEncConv &c0, const MstEncConv &c1, const float *x, void *y, void *ylo, int B, int L, int Lout, void *stream) {
+    EncStereoArgs a;
+    a.x = x;
+    a.y = y;
+    a.ylo = ylo;
+    a.a0 = c0.w_frag;
+    a.shift0 = c0.shift;
+    a.a1 = c1.w_frag;
+    a.shift1 = c1.shift;
+    a.B = B;
+    a.L = L;
+    a.Lout = Lout;
+    a.tiles = (Lout + ENC_STEREO_TO - 1) / ENC_STEREO_TO;
+    a.slope0 = c0.slope;
+    a.slope1 = c1.slope;
+    if ((long)B * a.tiles > 0x7fffffffL) return fail(MST_ERR_ARG, "enc_stereo_block_kernel: grid too large");
+    MST_LAUNCH(enc_stereo_block_kernel, dim3((unsigned)(B * a.tiles)), dim3(256), stream, a);
+    MST_CHECK_LAUNCH("enc_stereo_block_kernel");
+    return MST_OK;
+}
+
 // x3: split mode - x / y point at the high parts' planes, the low parts' planes follow at B * L * C elements
 int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scratch, int B, int Lin, int Lout, int residual,
                    long rows_min_tiles, void *stream, bool x3 = false, int schedule = 0, const void *zeros = nullptr) {
@@ -1313,9 +1350,13 @@ int enc_run_nlc(MstEnc *e, const float *x, float *emb, float *blk_out, int B, in
     for (int i = 0; i < n_run; ++i) {
         const int lout = (len - 1) / e->d.strides[i] + 1;
         if (i == 0) {
-            if ((rc = enc_launch_direct(e->conv[0], (const float *)cur, t1, false, B, len, len, 1, stream))) return rc;
             void *lo_plane = x3 ? (void *)((__bf16 *)o[pp] + (size_t)B * lout * e->conv[1].cout) : nullptr;
-            if ((rc = enc_launch_direct(e->conv[1], (const float *)t1, o[pp], true, B, len, lout, 0, stream, lo_plane))) return rc;
+            if (!(e->schedule & 8) && enc_stereo_block_fits(e->conv[0], e->conv[1], len) && lout == conv_out_length(e->conv[1], len)) {
+                if ((rc = enc_launch_stereo_block(e->conv[0], e->conv[1], (const float *)cur, o[pp], lo_plane, B, len, lout, stream))) return rc;
+            } else {
+                if ((rc = enc_launch_direct(e->conv[0], (const float *)cur, t1, false, B, len, len, 1, stream))) return rc;
+                if ((rc = enc_launch_direct(e->conv[1], (const float *)t1, o[pp], true, B, len, lout, 0, stream, lo_plane))) return rc;
+            }
         } else {
             if ((rc = enc_launch_nlc(e->conv[2 * i], (const __bf16 *)cur, (__bf16 *)t1, scratch, B, len, len, 1, e->rows_min_tiles, stream, x3, e->schedule, e->zeros))) return rc;
             if ((rc = enc_launch_nlc(e->conv[2 * i + 1], (const __bf16 *)t1, (__bf16 *)o[pp], scratch, B, len, lout, 0, e->rows_min_tiles, stream, x3, e->schedule, e->zeros))) return rc;

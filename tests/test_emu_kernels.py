@@ -644,7 +644,35 @@ def test_encoder_wave_tilings_and_workgroup_orders_match_emulated(emu_default):
     emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 1), "schedule")
     assert float((ref32 - emb).abs().max()) <= 2e-5 * float(emb.abs().max())
     with pytest.raises(ValueError):
-        emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 8), "schedule")
+        emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 16), "schedule")
+
+
+def test_encoder_fused_stereo_block_emulated(emu_default):
+    """The default encoder's stereo block (2 -> 2, k = 25, skip; 2 -> 16, k = 25, stride 4) as ONE kernel (intermediate in LDS, weights through the
+    scalar cache, two channels per packed multiply-add) against the two direct-kernel launches it replaces (mst_enc_set_schedule bit 3): same
+    operands in the same order - the same bits, in bf16 and in split mode (low plane) - over one-tile and many-tile lengths, lengths that are not
+    multiples of the stride, a last tile of one output, and the shortest legal input (reflection padding 12: 13 samples); and the oracle."""
+    from music_mixing_style_transfer_amd.networks import FXencoder
+    cfg = {"channels": [16], "kernels": [25], "strides": [4], "dilation": [1],
+           "bias": True, "norm": "batch", "conv_block": "res", "activation": "relu"}
+    sd = synth.fxencoder_state_dict(cfg, seed=21)
+    enc = FXencoder({k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()})
+    enc.load_state_dict(sd)
+    for shape in ((2, 2, 2037), (1, 2, 4001), (3, 2, 1000), (1, 2, 13), (2, 2, 14), (1, 2, 41), (1, 2, 999)):
+        x = synth.synth_audio(shape, seed=shape[2])
+        col = []
+        R.fxencoder_blocks(x, sd, cfg, collect=col)
+        for precision, tol in (("bf16", 2e-2), ("bf16x3", 5e-5)):
+            enc.precision = precision
+            run = enc._get_runner()
+            run._ensure(emu_default)
+            emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 1 | 8), "schedule")       # two launches, intermediate in HBM
+            ref = enc.forward_blocks(x, 1).clone()
+            emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 1), "schedule")           # the fused kernel (default)
+            got = enc.forward_blocks(x, 1)
+            assert got.shape == col[0].shape
+            assert torch.equal(got, ref), (shape, precision)
+            assert float((got - col[0]).abs().max()) <= tol * float(col[0].abs().max()), (shape, precision)
 
 
 def test_algorithmic_reverb_emulated(emu_default):

@@ -328,6 +328,32 @@ def test_encoder_batch_size_and_ragged_lengths_do_not_change_the_rows(nets):
         enc.precision = "fp32"
 
 
+def test_encoder_fused_stereo_block_is_bit_identical_to_the_direct_kernels(nets):
+    """The stereo block (2 -> 2, k = 25, skip; 2 -> 16, k = 25, stride 4) of the default encoder runs as ONE kernel on v_mfma_f32_16x16x4_f32 (first conv
+    in Toeplitz form, weights resident in registers, intermediate in LDS); `mst_enc_set_schedule` bit 3 selects the two direct VALU kernels it
+    replaced.  fp32 MFMA is a k-ordered fmaf chain and zero weights are exact no-ops: block 0's output must be the SAME BITS, in bf16 and in
+    split mode (both planes), at BASELINE's segment length, at a ragged length (border tiles at both ends, a last tile of a few outputs) and
+    for an input shorter than one tile."""
+    from music_mixing_style_transfer_amd import _lib
+    from music_mixing_style_transfer_amd.utils import synth
+    lib = _lib.lib()
+    enc = nets["enc"]
+    try:
+        for shape in ((3, 2, 131072), (2, 2, 30011), (1, 2, 777), (2, 2, 13)):
+            x = synth.synth_audio(shape, seed=shape[2]).cuda()
+            for precision in ("bf16", "bf16x3"):
+                enc.precision = precision
+                run = enc._get_runner()
+                run._ensure(lib)
+                lib.check(lib.mst_enc_set_schedule(run.handle, 1 | 8), "schedule")
+                ref = enc.forward_blocks(x, 1).clone()
+                lib.check(lib.mst_enc_set_schedule(run.handle, 1), "schedule")
+                got = enc.forward_blocks(x, 1)
+                assert torch.equal(got, ref), (shape, precision, float((got - ref).abs().max()))
+    finally:
+        enc.precision = "fp32"
+
+
 def test_encoder_bf16_vs_oracle(nets):
     from music_mixing_style_transfer_amd.utils import synth
     from oracle import networks_ref as R
