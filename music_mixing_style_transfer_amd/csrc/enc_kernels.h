@@ -819,6 +819,152 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Res_ConvBlock 1 of the default encoder in ONE launch, bf16 mode (round 5): Conv1d_layer(16 -> 16, k = 25, stride 1) + skip, then
+// Conv1d_layer(16 -> 32, k = 25, stride 4) (network_utils.py:96-119 on configs.yaml's second entries).  The two launches it replaces
+// (enc_conv_rows_kernel<1> + enc_conv_nlc_kernel<1>: 50 + 34 us per 32 segments) move 33.5 MB in, 2 x 33.5 MB of intermediate and 16.8 MB
+// out for 20 GFLOP: they are bound by memory and by launch-sized latencies, and their 32-row MFMA tiles are half empty at 16 channels.  Here a
+// workgroup owns TO = 240 outputs (the stereo kernel's geometry: 1056 staged input rows by LDS-DMA, 1024 intermediate rows in LDS, never in
+// HBM), both convs on v_mfma_f32_16x16x32_bf16 with the contraction k = j * 16 + ci (a k-step = two taps x 16 channels; the 26th tap has
+// zero weights) and the weights RESIDENT in registers as A fragments (13 per row tile).  B fragments are 16-byte reads of channel-minor rows:
+// consecutive rows for the first conv, every fourth row for the second - the intermediate image is skewed by 16 bytes per four rows so
+// that those reads spread over the banks.  Same operands as the two-launch form (bf16 weights, bf16 input, the intermediate rounded to bf16),
+// fp32 accumulation in another order (k-steps of 32 instead of 16): results agree to accumulation rounding, not bit for bit.
+// ------------------------------------------------------------------------------------------------
+struct EncBlock1Args {
+    const __bf16 *x;              // [B][L][16]
+    __bf16 *y;                    // [B][Lout][32]
+    const void *a0, *a1;          // A fragments: [13][64 lanes] x 16 bytes / [2 row tiles][13][64] x 16 bytes (enc_block1_pack)
+    const float *shift0, *shift1; // [16] / [32]
+    int B, L, Lout, tiles;
+    float slope0, slope1;
+    const void *zeros;            // 32 bytes of zeros (rows outside a reflected segment: shorter than the padding)
+};
+constexpr int ENC_B1_KS = 13;
+// host side: A fragments of one 16-row tile of BN-folded weights w[Cout][16][25]: lane (row, kg), k-step kk, element e: k = 32 kk + 8 kg + e
+inline void enc_block1_pack(const float *w, int row0, __bf16 *frag) {
+    for (int kk = 0; kk < ENC_B1_KS; ++kk)
+        for (int l = 0; l < 64; ++l)
+            for (int e = 0; e < 8; ++e) {
+                const int co = row0 + (l & 15), k = 32 * kk + 8 * (l >> 4) + e, j = k / 16, ci = k % 16;
+                frag[(kk * 64 + l) * 8 + e] = (__bf16)(j < 25 ? w[(co * 16 + ci) * 25 + j] : 0.0f);
+            }
+}
+__global__ __launch_bounds__(256, 2) void enc_block1_fused_kernel(EncBlock1Args a) {
+    constexpr int KSZ = 25, S1 = 4, TO = ENC_STEREO_TO, PAD = 12, NT = 1024, NX = NT + 32, KS = ENC_B1_KS, NT1 = TO / 16;
+    constexpr int XB = NX * 32, TB = NT * 32 + (NT / 4) * 16;
+    static_assert(S1 * (TO - 1) + 2 * KS <= NT && NT + 2 * KS <= NX && XB % 1024 == 0, "tile geometry");
+    __shared__ __attribute__((aligned(1024))) unsigned char xs[XB];      // input rows p_first - PAD + [0, NX): 32 bytes each
+    __shared__ __attribute__((aligned(16))) unsigned char ts[TB];        // intermediate slot s at 32 s + 16 (s >> 2)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.tiles, t0 = (blockIdx.x % a.tiles) * TO;
+    const int p_first = S1 * t0 - PAD;
+    const unsigned char *xb = (const unsigned char *)a.x + (size_t)b * a.L * 32;
+    // ---- stage the input rows: interior tiles by LDS-DMA (33 pieces of 1 KB: the image is contiguous in HBM), border tiles row by row
+    if (p_first - PAD >= 0 && p_first - PAD + NX <= a.L) {          // uniform
+        const unsigned char *src = xb + (size_t)(p_first - PAD) * 32 + lane * 16;
+        for (int k = w; k < XB / 1024; k += 4) mst_dma16(src + k * 1024, xs + k * 1024);
+    } else {
+        for (int i = tid; i < 2 * NX; i += 256) {
+            const int r = i >> 1, t = enc_reflect(p_first - PAD + r, a.L);
+            *(u32x4 *)(xs + 16 * i) = *(const u32x4 *)((t >= 0 && t < a.L) ? xb + (size_t)t * 32 + 16 * (i & 1) : (const unsigned char *)a.zeros);
+        }
+    }
+    bf16x8 A0[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) A0[kk] = ((const bf16x8 *)a.a0)[kk * 64 + lane];
+    mst_dma_wait_barrier<0>();
+    // ---- first conv + shift + activation + skip: wave w owns column tiles w, w + 4, ... (16 slots each), four at a time
+    {
+        const f32x4 sh = *(const f32x4 *)(a.shift0 + 4 * g);
+        const unsigned char *bx = xs + (n + (g >> 1)) * 32 + 16 * (g & 1);      // row s + j, j = 2 kk + (kg >> 1); channels 8 (kg & 1) ..
+#pragma unroll 1
+        for (int grp = 0; grp < NT / 16 / 16; ++grp) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const unsigned char *bg = bx + (w + 16 * grp) * 512;              // column tile T = w + 4 (4 grp + c)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0[kk], *(const bf16x8 *)(bg + c * 2048 + kk * 64), acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {          // lane (n, g): slot s, channels 4 g .. 4 g + 3
+                const int sl = 16 * (w + 4 * (4 * grp + c)) + n;
+                const bf16x4 r = *(const bf16x4 *)(xs + (sl + PAD) * 32 + 8 * g);
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)(enc_act(acc[c][e] + sh[e], a.slope0) + (float)r[e]);
+                *(bf16x4 *)(ts + 32 * sl + 16 * (sl >> 2) + 8 * g) = o;
+            }
+        }
+    }
+    bf16x8 A1[2][KS];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) A1[m][kk] = ((const bf16x8 *)a.a1)[(m * KS + kk) * 64 + lane];
+    __syncthreads();
+    // ---- the second conv's reflection padding: a slot outside the segment takes the row of its mirror position (inside the tile for every
+    // slot an output reads; slots beyond those keep what the first conv made of the zero / mirrored input - finite, multiplied by zero weights)
+    if (p_first < 0 || p_first + NT > a.L) {               // uniform: the first / last tiles of an item
+        u32x4 fix[8];
+        bool any[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int i = tid + 256 * p, sl = i >> 1, pos = p_first + sl, pr = enc_reflect(pos, a.L), sr = pr - p_first;
+            any[p] = (pos < 0 || pos >= a.L) && pr >= 0 && pr < a.L && sr >= 0 && sr < NT;
+            if (any[p]) fix[p] = *(const u32x4 *)(ts + 32 * sr + 16 * (sr >> 2) + 16 * (i & 1));
+        }
+        __syncthreads();                                       // every mirror source has been read
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int i = tid + 256 * p, sl = i >> 1;
+            if (any[p]) *(u32x4 *)(ts + 32 * sl + 16 * (sl >> 2) + 16 * (i & 1)) = fix[p];
+        }
+        __syncthreads();
+    }
+    // ---- second conv: wave w owns column tiles w, w + 4, w + 8, w + 12 (16 output steps each), two at a time, both row tiles
+    const f32x4 sh1[2] = {*(const f32x4 *)(a.shift1 + 4 * g), *(const f32x4 *)(a.shift1 + 16 + 4 * g)};
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) acc[c][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const int T0 = w + 8 * pr;                               // and T0 + 4 (wave 3's last pair has one tile: the other reads tile NT1 - 1 again)
+        const unsigned char *bt[2];                              // row 4 c + j at 32 (4 c + j) + 16 (c + (j >> 2)), c = 16 T + n
+#pragma unroll
+        for (int c = 0; c < 2; ++c) bt[c] = ts + 144 * (16 * (T0 + 4 * c < NT1 ? T0 + 4 * c : NT1 - 1) + n) + 16 * (g & 1);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int j = 2 * kk + (g >> 1);                     // lane-dependent: one shift-add per k-step
+            const int off = 32 * j + 16 * (j >> 2);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bf16x8 bv = *(const bf16x8 *)(bt[c] + off);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[c][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[m][kk], bv, acc[c][m], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int o = 16 * (T0 + 4 * c) + n, to = t0 + o;        // lane (n, g): output step o of the tile, channels 16 m + 4 g ..
+            if (T0 + 4 * c < NT1 && to < a.Lout) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    bf16x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = (__bf16)enc_act(acc[c][m][e] + sh1[m][e], a.slope1);
+                    *(bf16x4 *)(a.y + ((size_t)b * a.Lout + to) * 32 + 16 * m + 4 * g) = ov;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The 128-channel x 128-column tile with its four waves 2 x 2 ("nlc22", round 3).  In the kernel above a wave owns 32 channels x all
 // columns of the tile: one A fragment per k-step and one ds_read_b128 PER MFMA - four SIMDs issuing a 32x32x16 MFMA every 32 clocks read
 // 4 KB per 32 clocks = the CU's whole LDS bandwidth, and with every global load, barrier and ds_write taken out the loop still ran at

@@ -354,6 +354,41 @@ def test_encoder_fused_stereo_block_is_bit_identical_to_the_direct_kernels(nets)
         enc.precision = "fp32"
 
 
+def test_encoder_fused_block1_agrees_with_its_two_launches(nets):
+    """Block 1 of the default encoder (16 -> 16, k = 25, skip; 16 -> 32, k = 25, stride 4) in bf16 mode runs as ONE kernel (input rows by LDS-DMA,
+    intermediate in LDS, weights resident as A fragments of v_mfma_f32_16x16x32_bf16); `mst_enc_set_schedule` bit 4 selects the two conv launches
+    it replaced.  Same bf16 operands, another fp32 summation order: block 1's output agrees to accumulation rounding (isolated elements one
+    bf16 ulp apart, mean deviation far below), and with the oracle at the bf16 tolerance - at BASELINE's segment length, at a ragged length
+    and for an input of less than one tile."""
+    from music_mixing_style_transfer_amd import _lib
+    from music_mixing_style_transfer_amd.utils import synth
+    from oracle import networks_ref as R
+    lib = _lib.lib()
+    enc = nets["enc"]
+    enc.precision = "bf16"
+    try:
+        for shape in ((3, 2, 131072), (2, 2, 30011), (1, 2, 777)):
+            x = synth.synth_audio(shape, seed=shape[2])
+            run = enc._get_runner()
+            run._ensure(lib)
+            lib.check(lib.mst_enc_set_schedule(run.handle, 1 | 16), "schedule")
+            ref = enc.forward_blocks(x.cuda(), 2).cpu()
+            lib.check(lib.mst_enc_set_schedule(run.handle, 1), "schedule")
+            got = enc.forward_blocks(x.cuda(), 2).cpu()
+            scale = float(ref.abs().max())
+            d = (got - ref).abs()
+            print(f"FXencoder block 1 fused vs two launches at {shape}: max {float(d.max()):.3e}, mean {float(d.mean()):.3e}, "
+                  f"{int((d > 0).sum())} of {d.numel()} elements differ (scale {scale:.2f})")
+            assert float(d.max()) <= 1.6e-2 * scale and float(d.mean()) <= 2e-4 * scale, shape
+            if shape[2] == 30011:
+                col = []
+                R.fxencoder_blocks(x, nets["enc_sd"], nets["enc_cfg"], collect=col)
+                assert float((got - col[1]).abs().max()) <= 5e-2 * max(1.0, float(col[1].abs().max())), shape
+    finally:
+        lib.check(lib.mst_enc_set_schedule(enc._get_runner().handle, 1), "schedule")
+        enc.precision = "fp32"
+
+
 def test_encoder_bf16_vs_oracle(nets):
     from music_mixing_style_transfer_amd.utils import synth
     from oracle import networks_ref as R

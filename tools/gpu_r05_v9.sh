@@ -1,10 +1,10 @@
 #!/bin/bash
-# round 5, visit 9: the fused stereo-block kernel of the encoder (default) against the two direct-kernel launches (mst_enc_set_schedule bit 3):
+# round 5, visit 9: the fused encoder kernels (stereo block: mst_enc_set_schedule bit 3 selects the two direct launches; block 1: bit 4 the two conv launches):
 # whole-step A/B (alternating), per-launch encoder timeline of the default, GPU encoder tests
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$(pwd); O=$R/gpurun_out/v9; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-for sch in ${SCHEDS:-9 1 9 1}; do
+for sch in ${SCHEDS:-17 1 17 1}; do
   timeout 300 python bench.py --precision bf16 --workload configs1 --steps 10 --warmup 3 --no-cpu-baseline --enc-schedule $sch > $O/bench_sch$sch.json 2>> $O/bench.err
   python -c "
 import json; d=json.load(open('$O/bench_sch$sch.json')); print('enc schedule $sch: segments/s', round(d['value'],1), 'ms/step', round(d['ms_per_step'],3), 'feature_extraction', d.get('feature_extraction'))" | tee -a $O/enc_ab.txt
