@@ -3,7 +3,7 @@
 # FX chain; WITH_PMC=1 adds the FETCH_SIZE / WRITE_SIZE passes (TCN block kernel, FX chain) and the SQ counters.  Everything lands in
 # gpurun_out/round/ under the names it is committed with in profiles/ (prefix ${TAG:-r04_final}_).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-R=$(pwd); T=${TAG:-r04_final}; O=$R/gpurun_out/round; mkdir -p $O
+R=$(pwd); T=${TAG:-r05_final}; O=$R/gpurun_out/round; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 (rocm-smi --showproductname; lscpu | head -20; nproc) > $O/${T}_box.txt 2>&1
 if [ -z "$SKIP_TESTS" ]; then
@@ -30,8 +30,8 @@ python tools/rocprof_summary.py "$(find $O/prof_fx -name '*.db' | head -1)" "too
 if [ -n "$WITH_PMC" ]; then
 FD=$(dirname $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1)); WD=$(dirname $(find $O/pmc_write -name "*counter_collection.csv" | head -1))
 for d in $FD $WD; do f=$(ls $d/*counter_collection.csv | head -1); [ "$f" != "$d/pmc_counter_collection.csv" ] && cp $f $d/pmc_counter_collection.csv; done
-python tools/pmc_traffic.py $FD $WD tcn_block_bf16_duo_kernel $O/r04_tcn_block_bf16_traffic.json > $O/pmc_traffic.log 2>&1
-N=4 bash tools/gpu_fx_pmc.sh > $O/fx_pmc.log 2>&1; cp gpurun_out/fx_chain_traffic.json $O/r04_fx_chain_traffic.json
+python tools/pmc_traffic.py $FD $WD tcn_block_bf16_duo_kernel $O/r05_tcn_block_bf16_traffic.json > $O/pmc_traffic.log 2>&1
+N=4 bash tools/gpu_fx_pmc.sh > $O/fx_pmc.log 2>&1; cp gpurun_out/fx_chain_traffic.json $O/r05_fx_chain_traffic.json
 fi
 find $O -name "*.db" -delete; rm -rf $O/pmc_fetch $O/pmc_write $O/prof_bf16 $O/prof_x3 $O/prof_fx; ls $O
 tail -3 $O/${T}_pytest_gpu.log; cat $O/${T}_smoke.log | tail -4; cat $O/${T}_bench_driver_cmd.json
