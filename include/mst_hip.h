@@ -291,7 +291,11 @@ int mst_fx_biquad_cascade(const float *x_dev, float *y_dev, int n_items, long L,
  * low-priority side stream BESIDE the chain kernel of the neighbouring slice (the chain is one latency-bound walk per sequence on n_seq
  * workgroups; events order map_i -> chain_i -> apply_i, the caller's stream joins the side stream before the call returns to it).
  * Measured on configs[3] (64 x [131072, 2]): see DESIGN.md 3.3.  bit 1 (default 0; test / A-B hook): slices whatever the size (>= 8 batches);
- * bits 2-3 (A-B hook): number of slices, 0 -> 3 (default), 1 -> 2, 2 -> 4, 3 -> 8. */
+ * bits 2-3 (A-B hook): number of slices, 0 -> 3 (default), 1 -> 2, 2 -> 4, 3 -> 8.  bit 4 (default 0; the reference form of a test): the stereo
+ * equaliser's apply pass one lane per chunk straight from global memory (fx_biquad_chunk_kernel<true>) instead of 16-frame slabs through LDS
+ * (fx_biquad_stereo_apply_kernel); identical bits.  bit 5 (default 0; the reference form of a test): the stereo equaliser's state pass as float64
+ * VALU dot products with the impulse-state table in LDS (fx_biquad_stereo_ends_kernel) instead of v_mfma_f64_16x16x4_f64 with the table as A
+ * fragments (fx_biquad_stereo_ends_mfma_kernel); the same products added in the same (sample) order. */
 int mst_fx_set_tuning(int flags);
 
 /* Compressor.process / compressor_process (:529-587, :637-649), makeup gain 0.  With a scratch buffer of

@@ -14,6 +14,18 @@
 // depends on band k-1's output sequence).  One lane per (item, channel) sequence; samples are fetched 16 at
 // a time so the global loads are off the recursion's dependency chain.
 // ------------------------------------------------------------------------------------------------
+// One sample through one band (transposed direct form II, scipy.signal.lfilter's association: y = b0 x + z1; z1' = (z2 + b1 x) - a1 y;
+// z2' = b2 x - a2 y), as explicit fused multiply-adds: the two state updates hang on y by ONE operation each (the products with x do not
+// wait for y) - the recursion's dependent chain per band is fma -> fma instead of fma -> mul -> fma -> add, and 5 instructions instead of 6.
+// Every kernel that runs the recursion calls this: they produce the same bits.
+__host__ __device__ __forceinline__ double fx_biquad_band(double v, double &z1, double &z2, const double (&cf)[5]) {
+    const double p1 = fma(cf[1], v, z2), p2 = cf[2] * v;
+    const double yn = fma(cf[0], v, z1);
+    z1 = fma(-cf[3], yn, p1);
+    z2 = fma(-cf[4], yn, p2);
+    return yn;
+}
+
 struct BiquadArgs {
     const float *x;
     float *y;
@@ -42,12 +54,7 @@ __global__ __launch_bounds__(64) void fx_biquad_kernel(BiquadArgs a) {
             double v = (double)xin[i];
 #pragma unroll
             for (int k = 0; k < MST_MAX_BANDS; ++k) {
-                if (k < a.n_bands) {
-                    const double yn = a.coef[k][0] * v + z1[k];
-                    z1[k] = a.coef[k][1] * v - a.coef[k][3] * yn + z2[k];
-                    z2[k] = a.coef[k][2] * v - a.coef[k][4] * yn;
-                    v = yn;
-                }
+                if (k < a.n_bands) v = fx_biquad_band(v, z1[k], z2[k], a.coef[k]);
             }
             if (n0 + i < a.L) yp[(n0 + i) * a.C] = (float)v;
         }
@@ -116,12 +123,7 @@ __global__ __launch_bounds__(64) void fx_biquad_chunk_kernel(BiquadChunkArgs a) 
         if (APPLY) ssx += (double)(xi * xi);          // float32 square, float64 sum: the arithmetic of fx_sumsq_kernel
         double v = (double)(xi * sf);
 #pragma unroll
-        for (int b = 0; b < NBANDS; ++b) {
-            const double yn = a.coef[b][0] * v + z1[b];
-            z1[b] = a.coef[b][1] * v - a.coef[b][3] * yn + z2[b];
-            z2[b] = a.coef[b][2] * v - a.coef[b][4] * yn;
-            v = yn;
-        }
+        for (int b = 0; b < NBANDS; ++b) v = fx_biquad_band(v, z1[b], z2[b], a.coef[b]);
         const float out = (float)v;
         if (APPLY) ss += (double)out * (double)out;
         return out;
@@ -373,6 +375,195 @@ __global__ __launch_bounds__(256) void fx_biquad_stereo_ends_kernel(BiquadChunkA
 #pragma unroll
         for (int b = 0; b < NBANDS; ++b)
             *(double2 *)(a.ends + ((size_t)seq * a.nchunks + k) * (2 * MST_MAX_BANDS) + 2 * b) = full ? double2{acc[2 * b], acc[2 * b + 1]} : double2{0.0, 0.0};
+    }
+}
+
+// pass 1 for stereo audio on the float64 matrix cores (round 5).  fx_biquad_stereo_ends_kernel reads the impulse-state table from LDS - five
+// broadcast ds_read_b128 per sample and lane for ten multiply-adds: four waves keep the CU's LDS pipe busy ~2500 clocks per slab against 800
+// clocks of float64 arithmetic (40 us for 0.34 GFLOP).  The end states are a matrix product,  E[state][column] = sum_n H[state][n] X[n][column]
+// (columns = the (chunk, channel) sequences, n = the sample inside the chunk), and v_mfma_f64_16x16x4_f64 takes both operands from
+// registers: per 16-frame slab and 16 columns four MFMAs, the table as A fragments (one float64 per lane and MFMA, packed by the host in
+// fragment order and streamed from L2: 512 bytes per MFMA, the same for every wave), the samples as B fragments (one ds_read_b32 of the slab
+// per MFMA, converted on the way).  A wave owns 32 chunk pairs = 64 columns = four accumulator tiles for the whole chunk.  The instruction
+// runs at the float64 VECTOR rate - the gain is operand delivery, not arithmetic.  Same products, added in sample order like the table
+// kernel's fma chains; states beyond 2 * n_bands are rows of zeros.
+typedef double fx_f64x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void fx_biquad_stereo_ends_mfma_kernel(BiquadChunkArgs a, const double *__restrict__ afrag) {
+    constexpr int D = 4;                               // slabs in flight
+    __shared__ __attribute__((aligned(16))) unsigned char slab[4][32 * FXS_ROWB];
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (a.out_sumsq)          // the state pass clears the energy slots the apply pass adds to (no memset launch in front of the call)
+        for (long i = gid; i < (long)(a.n_seq / 2) * MST_SUMSQ_SLOTS; i += (long)gridDim.x * 256) a.out_sumsq[i] = 0.0;
+    if (a.out_in_sumsq)
+        for (long i = gid; i < (long)(a.n_seq / 2) * MST_SUMSQ_SLOTS; i += (long)gridDim.x * 256) a.out_in_sumsq[i] = 0.0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, kq = lane >> 4;
+    const long npairs = (long)(a.n_seq / 2) * a.nchunks, pair0 = (long)blockIdx.x * 128 + wave * 32;
+    if (pair0 >= npairs) return;                       // uniform per wave (no workgroup barrier below)
+    const FxStereoRows rows = fx_stereo_rows(a.x, pair0, npairs, a.nchunks, a.M, a.L, lane);
+    unsigned char *my = slab[wave];
+    // column n of tile q = channel n & 1 of pair pair0 + 8 q + (n >> 1): its item's pending scale factor, its record
+    float sfq[4];
+    long rec[4];          // index of the column's record in `ends`, or -1 (no such pair)
+    bool fullq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long g = pair0 + 8 * q + (n >> 1);
+        const bool live = g < npairs;
+        const long gg = live ? g : npairs - 1, item = gg / a.nchunks, k = gg - item * a.nchunks;
+        sfq[q] = a.in_scale ? (float)a.in_scale[item] : 1.0f;
+        rec[q] = live ? ((item * 2 + (n & 1)) * a.nchunks + k) * (2 * MST_MAX_BANDS) : -1;
+        fullq[q] = (k + 1) * a.M <= a.L;                 // a short last chunk has no successor: its end state is not needed
+    }
+    fx_f64x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = fx_f64x4{0.0, 0.0, 0.0, 0.0};
+    f32x4 ring[D][4];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d * FXS_TS < a.M) fx_stereo_fetch(rows, d * FXS_TS, lane, ring[d]);
+    const double *af = afrag + lane;
+    // the lane's sample inside a slab row: frame 4 kk + kq, channel n & 1; its row inside tile q: 8 q + (n >> 1)
+    const unsigned char *bx = my + (n >> 1) * FXS_ROWB + (2 * kq + (n & 1)) * 4;
+    // the A fragments of a slab are requested two slabs ahead, IN FRONT of that trip's sample fetch: the memory counter retires in order, so a
+    // wait for them never waits for the four slabs of samples requested behind them
+    const int nslab = a.M / FXS_TS;
+    double av[3][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) av[t][kk] = af[(size_t)((t < nslab ? t : nslab - 1) * 4 + kk) * 64];
+    for (int s0 = 0; s0 < a.M; s0 += 12 * FXS_TS) {         // 12 slabs per trip: the sample ring (4) and the fragment ring (3) both come round
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int s = s0 + u * FXS_TS, sb = s / FXS_TS;
+            if (s < a.M) {                                    // uniform
+                __builtin_amdgcn_wave_barrier();              // every lane is done with the previous slab
+                fx_stereo_to_lds(my, lane, ring[u % D]);
+                {
+                    const int sn = sb + 2 < nslab ? sb + 2 : nslab - 1;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) av[(u + 2) % 3][kk] = af[(size_t)(sn * 4 + kk) * 64];
+                }
+                if (s + D * FXS_TS < a.M) fx_stereo_fetch(rows, s + D * FXS_TS, lane, ring[u % D]);
+                mst_wave_lds_fence();
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float xv = *(const float *)(bx + 8 * q * FXS_ROWB + 32 * kk);
+                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u % 3][kk], (double)(xv * sfq[q]), acc[q], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    // D: column n, state kq + 4 r in register r
+    const int S = 2 * a.n_bands;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (rec[q] >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = kq + 4 * r;
+                if (j < S) a.ends[rec[q] + j] = fullq[q] ? acc[q][r] : 0.0;
+            }
+        }
+    }
+}
+
+// pass 2 for stereo audio on slabs (round 5, second attempt).  With one lane per (channel, chunk) reading and writing global memory directly
+// (fx_biquad_chunk_kernel<true>) the pass takes the same ~50 us from half a wave per SIMD to four (tools/micro/eq_apply_variants.hip): every
+// wave-load touches 32 lines of 128 bytes and comes back for each of them sixteen times - the lines do not survive in the vector cache, the
+// pass is bound by L2 -> L1 line traffic (16 x the bytes), not by float64.  Here the chunks move like in the state pass: 16-frame slabs, one
+// 128-byte run per chunk and slab fetched as eight 16-byte pieces, four slabs in flight, a lane reads its 16 samples from its LDS row; the 16
+// outputs go back through the same rows and leave as 16-byte pieces.  (The first attempt - EXPERIMENTS.md D.4 - unrolled four slabs and
+// spilled scalar registers; this one runs ONE slab per loop trip behind a scheduling fence.)  Same recursion, same arithmetic per sample as
+// fx_biquad_chunk_kernel<true>: the same bits; the energy sums are added per chunk in the same order.
+template <int NBANDS>
+__global__ __launch_bounds__(256) void fx_biquad_stereo_apply_kernel(BiquadChunkArgs a) {
+    constexpr int D = 4;                               // slabs in flight
+    __shared__ __attribute__((aligned(16))) unsigned char slab[4][32 * FXS_ROWB];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 1;
+    const long npairs = (long)(a.n_seq / 2) * a.nchunks, pair0 = (long)blockIdx.x * 128 + wave * 32;
+    if (pair0 >= npairs) return;                       // uniform per wave (no workgroup barrier below)
+    const FxStereoRows rows = fx_stereo_rows(a.x, pair0, npairs, a.nchunks, a.M, a.L, lane);
+    const long g = pair0 + (lane >> 1);
+    const bool live = g < npairs;
+    const long gg = live ? g : npairs - 1, item = gg / a.nchunks, k = gg - item * a.nchunks;
+    const long room = live ? a.L - k * a.M : 0;        // frames from this lane's chunk start to the end of its sequence
+    const int seq = (int)item * 2 + c;
+    const float sf = a.in_scale ? (float)a.in_scale[item] : 1.0f;
+    unsigned char *my = slab[wave];
+    double z1[NBANDS], z2[NBANDS];
+#pragma unroll
+    for (int b = 0; b < NBANDS; ++b) {
+        const double2 zz = *(const double2 *)(a.starts + ((size_t)seq * a.nchunks + k) * (2 * MST_MAX_BANDS) + 2 * b);
+        z1[b] = zz.x;
+        z2[b] = zz.y;
+    }
+    // the output rows: the pieces this lane stores (row = (lane >> 3) + 8 i, its 16-byte piece), like fx_stereo_rows' sources
+    float *dst[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i] = a.y + (rows.src[i] - a.x);
+    double ss = 0.0, ssx = 0.0;
+    f32x4 ring[D][4];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d * FXS_TS < a.M) fx_stereo_fetch(rows, d * FXS_TS, lane, ring[d]);
+    // one slab: EDGE (a wave that holds the last chunk of a sequence - it may be short) guards every sample and every piece; the other
+    // waves run the plain form.  The guards are selects, not branches: a branch per sample splits the unrolled recursion into basic blocks
+    auto one_slab = [&](auto EDGE, f32x4 (&rg)[4], int s) {
+        constexpr bool edge = decltype(EDGE)::value;
+        __builtin_amdgcn_wave_barrier();              // every lane is done with the previous slab (its output pieces have been read)
+        fx_stereo_to_lds(my, lane, rg);
+        if (s + D * FXS_TS < a.M) fx_stereo_fetch(rows, s + D * FXS_TS, lane, rg);
+        mst_wave_lds_fence();
+        float *mine = (float *)(my + (lane >> 1) * FXS_ROWB) + c;
+        float o[FXS_TS];
+#pragma unroll
+        for (int f = 0; f < FXS_TS; ++f) {
+            const float xi = mine[2 * f];
+            const bool in = !edge || s + f < room;
+            const double sq = (double)(xi * xi);      // float32 square, float64 sum: the arithmetic of fx_sumsq_kernel
+            ssx += in ? sq : 0.0;
+            double v = (double)(xi * sf);
+#pragma unroll
+            for (int b = 0; b < NBANDS; ++b) v = fx_biquad_band(v, z1[b], z2[b], a.coef[b]);
+            o[f] = (float)v;
+            const double oq = (double)o[f] * (double)o[f];
+            ss += in ? oq : 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();              // every lane has read its 16 inputs
+#pragma unroll
+        for (int f = 0; f < FXS_TS; ++f) mine[2 * f] = o[f];
+        mst_wave_lds_fence();
+        // the slab leaves as 16-byte pieces: lane (row, piece) like the fetch
+        const long f0 = s + 2 * (lane & 7);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = *(const f32x4 *)(my + ((lane >> 3) + 8 * i) * FXS_ROWB + (lane & 7) * 16);
+            float *p = dst[i] + (size_t)s * 2;
+            if (!edge || f0 + 1 < rows.room[i]) {
+                *(fx_f32x4u *)p = v;
+            } else if (f0 < rows.room[i]) {
+                p[0] = v[0];
+                p[1] = v[1];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int s0 = 0; s0 < a.M; s0 += D * FXS_TS) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int s = s0 + d * FXS_TS;
+            if (s < a.M) {                                    // uniform
+                if (rows.edge) one_slab(std::true_type{}, ring[d], s);
+                else one_slab(std::false_type{}, ring[d], s);
+            }
+        }
+    }
+    if (live) {
+        if (a.out_sumsq) atomicAdd(&a.out_sumsq[item * MST_SUMSQ_SLOTS + (k & (MST_SUMSQ_SLOTS - 1))], ss);     // spread over the slots: few atomics per address
+        if (a.out_in_sumsq) atomicAdd(&a.out_in_sumsq[item * MST_SUMSQ_SLOTS + (k & (MST_SUMSQ_SLOTS - 1))], ssx);
     }
 }
 

@@ -1518,6 +1518,8 @@ extern "C" int mst_embedding_mean(const float *emb, int n_rows, int dim, float *
 // FX processors
 // =================================================================================================
 namespace {
+int g_fx_eq_valu_ends = 0;      // mst_fx_set_tuning bit 5: stereo equaliser state pass on float64 VALU dot products with the table in LDS (the reference form of the MFMA kernel)
+int g_fx_eq_lane_apply = 0;     // mst_fx_set_tuning bit 4: stereo equaliser apply pass one lane per chunk straight from global memory (the reference form of the slab kernel)
 // Steps per chunk of the time-parallel biquad cascade: the number of 511-chunk scan blocks that minimises
 //     16 us per scan block + two chunk passes at 0.19 us per step of a chunk
 // (measured on an MI355X; a pass is one lane per chunk and its time falls with the chunk length until every SIMD holds a wave = 65536
@@ -1601,7 +1603,8 @@ const double *biquad_impulse_table(const double (*coef)[5], int n_bands, int M, 
     std::memset(t->coef, 0, sizeof(t->coef));
     std::memcpy(t->coef, coef, sizeof(double) * 5 * n_bands);
     t->stamp = ++clock_;
-    const size_t n_tab = (size_t)M * S, n_all = n_tab + (size_t)MST_BIQUAD_LEVELS * S * S;
+    // [M][S] table | [levels][S][S] powers | [M / 16][4][64] the table as A fragments of v_mfma_f64_16x16x4_f64 (state rows, 16 samples per slab)
+    const size_t n_tab = (size_t)M * S, n_pow = (size_t)MST_BIQUAD_LEVELS * S * S, n_frag = (size_t)((M + 15) / 16) * 4 * 64, n_all = n_tab + n_pow + n_frag;
     if (t->host.size() < n_all) {
         if (t->devp) (void)hipFree(t->devp);
         t->devp = nullptr;
@@ -1610,12 +1613,7 @@ const double *biquad_impulse_table(const double (*coef)[5], int n_bands, int M, 
     std::vector<double> z(S, 0.0);
     for (int m = 0; m < M; ++m) {
         double v = m == 0 ? 1.0 : 0.0;
-        for (int b = 0; b < n_bands; ++b) {
-            const double yn = coef[b][0] * v + z[2 * b];
-            z[2 * b] = coef[b][1] * v - coef[b][3] * yn + z[2 * b + 1];
-            z[2 * b + 1] = coef[b][2] * v - coef[b][4] * yn;
-            v = yn;
-        }
+        for (int b = 0; b < n_bands; ++b) v = fx_biquad_band(v, z[2 * b], z[2 * b + 1], coef[b]);
         for (int j = 0; j < S; ++j) t->host[(size_t)m * S + j] = z[j];
     }
     {   // A^M column by column (the cascade run M steps on zero input from each unit state), then squared up level by level
@@ -1625,12 +1623,7 @@ const double *biquad_impulse_table(const double (*coef)[5], int n_bands, int M, 
             u[col] = 1.0;
             for (int n = 0; n < M; ++n) {
                 double v = 0.0;
-                for (int b = 0; b < n_bands; ++b) {
-                    const double yn = coef[b][0] * v + u[2 * b];
-                    u[2 * b] = coef[b][1] * v - coef[b][3] * yn + u[2 * b + 1];
-                    u[2 * b + 1] = coef[b][2] * v - coef[b][4] * yn;
-                    v = yn;
-                }
+                for (int b = 0; b < n_bands; ++b) v = fx_biquad_band(v, u[2 * b], u[2 * b + 1], coef[b]);
             }
             for (int row = 0; row < S; ++row) pm[(size_t)row * S + col] = u[row];
         }
@@ -1643,6 +1636,13 @@ const double *biquad_impulse_table(const double (*coef)[5], int n_bands, int M, 
                     for (int j = 0; j < S; ++j) acc += cur[r * S + j] * cur[j * S + c];
                     nxt[r * S + c] = acc;
                 }
+        }
+    }
+    {   // fragment (slab sb, k-step kk), lane (state j = l & 15, kq = l >> 4): the weight of sample 16 sb + 4 kk + kq in the end state, h_(M - 1 - sample)[j]
+        double *fr = t->host.data() + n_tab + n_pow;
+        for (size_t i = 0; i < n_frag; ++i) {
+            const int l = (int)(i % 64), kk = (int)(i / 64 % 4), sb = (int)(i / 256), j = l & 15, smp = 16 * sb + 4 * kk + (l >> 4);
+            fr[i] = (j < S && smp < M) ? t->host[(size_t)(M - 1 - smp) * S + j] : 0.0;
         }
     }
     if (!t->devp && hipMalloc((void **)&t->devp, t->host.size() * sizeof(double)) != hipSuccess) {
@@ -1714,7 +1714,10 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         const double *htab = biquad_impulse_table(a.coef, n_bands, M, stream);
         if (!htab) return fail(MST_ERR_HIP, "mst_fx_biquad_cascade: impulse-state table");
         const long npairs = (long)n_items * nchunks;                       // stereo: (item, chunk) pairs - 32 per wave, slabs through LDS
-        if (C == 2) {
+        if (C == 2 && !g_fx_eq_valu_ends && M % 16 == 0) {          // stereo: the end states as a matrix product on the float64 matrix cores
+            const dim3 eg((unsigned)((npairs + 127) / 128));
+            MST_LAUNCH(fx_biquad_stereo_ends_mfma_kernel, eg, dim3(256), stream, a, htab + (size_t)M * S + (size_t)MST_BIQUAD_LEVELS * S * S);
+        } else if (C == 2) {
             const dim3 eg((unsigned)((npairs + 127) / 128));
             switch (n_bands) {
                 case 1: MST_LAUNCH(fx_biquad_stereo_ends_kernel<1>, eg, dim3(256), stream, a, htab); break;
@@ -1759,7 +1762,21 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         if (nchunks > 255) launch_scan(std::integral_constant<int, 512>{});
         else launch_scan(std::integral_constant<int, 256>{});
         MST_CHECK_LAUNCH("fx_biquad_scan_kernel");
-        launch_chunks(std::true_type{});
+        if (C == 2 && !g_fx_eq_lane_apply) {          // stereo: the chunks travel in 16-frame slabs through LDS, in and out
+            const dim3 ag((unsigned)((npairs + 127) / 128));
+            switch (n_bands) {
+                case 1: MST_LAUNCH(fx_biquad_stereo_apply_kernel<1>, ag, dim3(256), stream, a); break;
+                case 2: MST_LAUNCH(fx_biquad_stereo_apply_kernel<2>, ag, dim3(256), stream, a); break;
+                case 3: MST_LAUNCH(fx_biquad_stereo_apply_kernel<3>, ag, dim3(256), stream, a); break;
+                case 4: MST_LAUNCH(fx_biquad_stereo_apply_kernel<4>, ag, dim3(256), stream, a); break;
+                case 5: MST_LAUNCH(fx_biquad_stereo_apply_kernel<5>, ag, dim3(256), stream, a); break;
+                case 6: MST_LAUNCH(fx_biquad_stereo_apply_kernel<6>, ag, dim3(256), stream, a); break;
+                case 7: MST_LAUNCH(fx_biquad_stereo_apply_kernel<7>, ag, dim3(256), stream, a); break;
+                default: MST_LAUNCH(fx_biquad_stereo_apply_kernel<8>, ag, dim3(256), stream, a); break;
+            }
+        } else {
+            launch_chunks(std::true_type{});
+        }
         MST_CHECK_LAUNCH("fx_biquad_chunk_kernel<apply>");
         return MST_OK;
     }
@@ -1971,7 +1988,9 @@ int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size
 }  // namespace
 
 extern "C" int mst_fx_set_tuning(int flags) {
-    if (flags < 0 || flags > 15) return fail(MST_ERR_ARG, "mst_fx_set_tuning: unknown flag bits");
+    if (flags < 0 || flags > 63) return fail(MST_ERR_ARG, "mst_fx_set_tuning: unknown flag bits");
+    g_fx_eq_lane_apply = (flags >> 4) & 1;
+    g_fx_eq_valu_ends = (flags >> 5) & 1;
     g_fx_pipeline = flags & 1;
     g_fx_pipeline_any_size = (flags >> 1) & 1;
     static const int slices[4] = {3, 2, 4, 8};

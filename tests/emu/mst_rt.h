@@ -167,6 +167,25 @@ static inline emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c) {
     return c;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) emu_mfma_f32_16x16x4f32((a), (b), (c))
+// v_mfma_f64_16x16x4_f64: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15]; D: col = l&15, row = (l>>4) + 4*reg (NOT the f32 map); k-ordered fma chain
+typedef __attribute__((ext_vector_type(4))) double emu_f64x4;
+static inline emu_f64x4 emu_mfma_f64_16x16x4f64(double a, double b, emu_f64x4 c) {
+    struct AB { double a, b; } me = {a, b};
+    const unsigned char *base = emu::wave_publish(&me, sizeof(me));
+    const int l = emu::lane_id(), col = l & 15, hi = l >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = hi + 4 * r;
+        double acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            const AB *pa = (const AB *)(base + 64 * (row + 16 * k));
+            const AB *pb = (const AB *)(base + 64 * (col + 16 * k));
+            acc = fma(pa->a, pb->b, acc);
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) emu_mfma_f64_16x16x4f64((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) emu_mfma_f32_16x16x32_bf16((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu_mfma_f32_32x32x2f32((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu_mfma_f32_32x32x16_bf16((a), (b), (c))

@@ -582,6 +582,34 @@ def test_compressor_time_slices_are_bit_identical_emulated(emu_default, L, n_ite
     assert np.abs(y4[n_items - 1] - ref).max() <= 3e-7 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("L,n_items", [(1000, 2), (2049, 33), (4384, 3), (65, 1)])
+def test_equaliser_slab_apply_is_bit_identical_emulated(emu_default, L, n_items):
+    """The stereo equaliser's apply pass on 16-frame slabs through LDS (in and out as 16-byte pieces; mst_fx_set_tuning bit 4 off, the default)
+    against one lane per chunk straight from global memory (bit 4): the same recursion on the same samples from the same start states - the
+    same bits, with a short last chunk (guarded samples and pieces), whole chunks only, more chunk pairs than a workgroup and fewer than a
+    wave; one, two and five bands."""
+    from music_mixing_style_transfer_amd.mixing_manipulator import Equaliser
+    rng = np.random.default_rng(L)
+    x = (0.2 * rng.standard_normal((n_items, L, 2))).astype(np.float32)
+    try:
+        for bands in (("low_shelf",), ("first_band", "third_band"), ("low_shelf", "first_band", "second_band", "third_band", "high_shelf")):
+            eq = Equaliser(2, 44100, bands=bands)
+            for b in bands:
+                getattr(eq.parameters, b + "_gain").value = float(rng.uniform(-12, 12))
+            emu_default.check(emu_default.mst_fx_set_tuning(1 | 16), "mst_fx_set_tuning")
+            ref = eq.process(x.copy())
+            emu_default.check(emu_default.mst_fx_set_tuning(1), "mst_fx_set_tuning")
+            got = eq.process(x.copy())
+            assert np.array_equal(got, ref), (L, n_items, bands, float(np.abs(got - ref).max()))
+            # the state pass on the float64 matrix cores (default) against the VALU dot products with the table in LDS (bit 5): the same products in
+            # the same order - the same chunk start states, the same output bits
+            emu_default.check(emu_default.mst_fx_set_tuning(1 | 32), "mst_fx_set_tuning")
+            ref2 = eq.process(x.copy())
+            assert np.array_equal(got, ref2), (L, n_items, bands, float(np.abs(got - ref2).max()))
+    finally:
+        emu_default.check(emu_default.mst_fx_set_tuning(1), "mst_fx_set_tuning")
+
+
 def test_encoder_rows_kernel_matches_im2col_emulated(emu_default):
     """bf16 FXencoder: the LDS-resident-rows convolution kernel (long early layers) against the im2col kernel it replaces -
     same operands in the same k order, so bit-identical - over strides 1 / 2 / 4, even kernels, ragged last tiles."""
