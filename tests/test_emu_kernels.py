@@ -582,7 +582,7 @@ def test_compressor_time_slices_are_bit_identical_emulated(emu_default, L, n_ite
     assert np.abs(y4[n_items - 1] - ref).max() <= 3e-7 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("L,n_items", [(1000, 2), (2049, 33), (4384, 3), (65, 1)])
+@pytest.mark.parametrize("L,n_items", [(1000, 2), (2049, 33), (4384, 3), (65, 1), (70000, 1)])
 def test_equaliser_slab_apply_is_bit_identical_emulated(emu_default, L, n_items):
     """The stereo equaliser's apply pass on 16-frame slabs through LDS (in and out as 16-byte pieces; mst_fx_set_tuning bit 4 off, the default)
     against one lane per chunk straight from global memory (bit 4): the same recursion on the same samples from the same start states - the
