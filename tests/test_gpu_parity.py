@@ -618,6 +618,34 @@ def test_equaliser_and_compressor_on_a_stem_sized_signal(oracle_fx_lib):
     assert np.abs(y - ref).max() <= 2e-6 * np.abs(ref).max()
 
 
+def test_equaliser_kernel_forms_are_bit_identical_on_gpu():
+    """The stereo equaliser's time-parallel passes in their current forms - the state pass on v_mfma_f64_16x16x4_f64 (impulse-state table as A
+    fragments), the apply pass on 16-frame slabs through LDS - against their reference forms (`mst_fx_set_tuning` bit 5: VALU dot products with
+    the table in LDS; bit 4: one lane per chunk straight from global memory).  The matrix instruction adds its four products per output in
+    k order as fused multiply-adds, the slab kernel runs the same recursion on the same samples: the outputs must be the SAME BITS - at
+    BASELINE's 64 x [131072, 2] (whole chunks), at a ragged length (short last chunk: guarded samples and pieces), on a stem-sized signal
+    (several scan blocks) and with one band."""
+    from music_mixing_style_transfer_amd import _lib
+    from music_mixing_style_transfer_amd.mixing_manipulator import Equaliser
+    from oracle import fx_ref as F
+    lib = _lib.lib()
+    try:
+        for n, L, bands in ((64, 131072, None), (3, 50021, None), (1, 3_000_017, None), (2, 70001, ("low_shelf",))):
+            x = (0.15 * torch.randn(n, L, 2, generator=torch.Generator().manual_seed(L % 1000))).clamp_(-1, 1).cuda()
+            eq = Equaliser(2, 44100) if bands is None else Equaliser(2, 44100, bands=bands)
+            for band, (g, fc, q) in F.CONFIG4["eq"].items():
+                if hasattr(eq.parameters, band + "_gain"):
+                    getattr(eq.parameters, band + "_gain").value = g
+            outs = []
+            for flags in (1, 1 | 16, 1 | 32, 1 | 16 | 32):
+                lib.check(lib.mst_fx_set_tuning(flags), "mst_fx_set_tuning")
+                outs.append(eq.process(x).clone())
+            for o in outs[1:]:
+                assert torch.equal(o, outs[0]), (n, L, bands, float((o - outs[0]).abs().max()))
+    finally:
+        lib.check(lib.mst_fx_set_tuning(1), "mst_fx_set_tuning")
+
+
 def test_haas_panner_vs_golden_and_oracle():
     """a-D7 on the device: bit-exact vs the reference's outputs (golden) and vs the oracle at full segment size."""
     import os
