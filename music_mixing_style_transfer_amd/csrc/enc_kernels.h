@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void enc_stereo_block_kernel(EncStereoArgs a) 
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
         f32x4 acc[2] = {f32x4{0.0f, 0.0f, 0.0f, 0.0f}, f32x4{0.0f, 0.0f, 0.0f, 0.0f}};
-        const int T0 = w + 8 * pr;                               // and T0 + 4 (wave 3's last pair has one tile: the other reads tile NT1 - 1 again)
+        const int T0 = w + 8 * pr;                               // and T0 + 4
         const float *bt[2];                                      // ti(4 (16 T + n) + 4 a + kq) = 6 (16 T + n + a) + kq
 #pragma unroll
         for (int T = 0; T < 2; ++T) bt[T] = &ts[0][6 * (16 * (T0 + 4 * T < NT1 ? T0 + 4 * T : NT1 - 1) + n) + g];
@@ -839,7 +839,7 @@ struct EncBlock1Args {
     float slope0, slope1;
     const void *zeros;            // 32 bytes of zeros (rows outside a reflected segment: shorter than the padding)
 };
-constexpr int ENC_B1_KS = 13;
+constexpr int ENC_B1_KS = 13, ENC_B1_TO = 256;      // k-steps per conv; outputs per workgroup (32 x 8192 / 256 = 1024 workgroups = two full rounds at two per CU)
 // host side: A fragments of one 16-row tile of BN-folded weights w[Cout][16][25]: lane (row, kg), k-step kk, element e: k = 32 kk + 8 kg + e
 inline void enc_block1_pack(const float *w, int row0, __bf16 *frag) {
     for (int kk = 0; kk < ENC_B1_KS; ++kk)
@@ -850,9 +850,9 @@ inline void enc_block1_pack(const float *w, int row0, __bf16 *frag) {
             }
 }
 __global__ __launch_bounds__(256, 2) void enc_block1_fused_kernel(EncBlock1Args a) {
-    constexpr int KSZ = 25, S1 = 4, TO = ENC_STEREO_TO, PAD = 12, NT = 1024, NX = NT + 32, KS = ENC_B1_KS, NT1 = TO / 16;
+    constexpr int KSZ = 25, S1 = 4, TO = ENC_B1_TO, PAD = 12, NCT = 66, NT = 16 * NCT, NX = NT + 32, KS = ENC_B1_KS, NT1 = TO / 16;      // NCT column tiles of the first conv
     constexpr int XB = NX * 32, TB = NT * 32 + (NT / 4) * 16;
-    static_assert(S1 * (TO - 1) + 2 * KS <= NT && NT + 2 * KS <= NX && XB % 1024 == 0, "tile geometry");
+    static_assert(S1 * (TO - 1) + 2 * KS + 2 <= NT && NT + 2 * KS <= NX && XB % 1024 == 0 && NT1 == 16 && NCT == 66, "tile geometry (the last group of first-conv tiles holds one tile for waves 0, 1)");
     __shared__ __attribute__((aligned(1024))) unsigned char xs[XB];      // input rows p_first - PAD + [0, NX): 32 bytes each
     __shared__ __attribute__((aligned(16))) unsigned char ts[TB];        // intermediate slot s at 32 s + 16 (s >> 2)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
@@ -878,24 +878,33 @@ __global__ __launch_bounds__(256, 2) void enc_block1_fused_kernel(EncBlock1Args 
         const f32x4 sh = *(const f32x4 *)(a.shift0 + 4 * g);
         const unsigned char *bx = xs + (n + (g >> 1)) * 32 + 16 * (g & 1);      // row s + j, j = 2 kk + (kg >> 1); channels 8 (kg & 1) ..
 #pragma unroll 1
-        for (int grp = 0; grp < NT / 16 / 16; ++grp) {
+        for (int grp = 0; grp < (NCT + 15) / 16; ++grp) {      // column tile T = w + 4 (4 grp + c); the last group has tiles 64, 65 only (waves 0, 1)
+            const int nc = NCT - (w + 16 * grp) > 12 ? 4 : (NCT - (w + 16 * grp) + 3) / 4;      // uniform per wave
+            if (nc <= 0) break;
             f32x4 acc[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            const unsigned char *bg = bx + (w + 16 * grp) * 512;              // column tile T = w + 4 (4 grp + c)
+            const unsigned char *bg = bx + (w + 16 * grp) * 512;
+            if (nc == 4) {
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk)
+                for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0[kk], *(const bf16x8 *)(bg + c * 2048 + kk * 64), acc[c], 0, 0, 0);
+                    for (int c = 0; c < 4; ++c)
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0[kk], *(const bf16x8 *)(bg + c * 2048 + kk * 64), acc[c], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0[kk], *(const bf16x8 *)(bg + kk * 64), acc[0], 0, 0, 0);
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {          // lane (n, g): slot s, channels 4 g .. 4 g + 3
-                const int sl = 16 * (w + 4 * (4 * grp + c)) + n;
-                const bf16x4 r = *(const bf16x4 *)(xs + (sl + PAD) * 32 + 8 * g);
-                bf16x4 o;
+                if (c < nc) {
+                    const int sl = 16 * (w + 4 * (4 * grp + c)) + n;
+                    const bf16x4 r = *(const bf16x4 *)(xs + (sl + PAD) * 32 + 8 * g);
+                    bf16x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (__bf16)(enc_act(acc[c][e] + sh[e], a.slope0) + (float)r[e]);
-                *(bf16x4 *)(ts + 32 * sl + 16 * (sl >> 2) + 8 * g) = o;
+                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)(enc_act(acc[c][e] + sh[e], a.slope0) + (float)r[e]);
+                    *(bf16x4 *)(ts + 32 * sl + 16 * (sl >> 2) + 8 * g) = o;
+                }
             }
         }
     }
@@ -908,17 +917,18 @@ __global__ __launch_bounds__(256, 2) void enc_block1_fused_kernel(EncBlock1Args 
     // ---- the second conv's reflection padding: a slot outside the segment takes the row of its mirror position (inside the tile for every
     // slot an output reads; slots beyond those keep what the first conv made of the zero / mirrored input - finite, multiplied by zero weights)
     if (p_first < 0 || p_first + NT > a.L) {               // uniform: the first / last tiles of an item
-        u32x4 fix[8];
-        bool any[8];
+        constexpr int NF = (2 * NT + 255) / 256;
+        u32x4 fix[NF];
+        bool any[NF];
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
+        for (int p = 0; p < NF; ++p) {
             const int i = tid + 256 * p, sl = i >> 1, pos = p_first + sl, pr = enc_reflect(pos, a.L), sr = pr - p_first;
-            any[p] = (pos < 0 || pos >= a.L) && pr >= 0 && pr < a.L && sr >= 0 && sr < NT;
+            any[p] = i < 2 * NT && (pos < 0 || pos >= a.L) && pr >= 0 && pr < a.L && sr >= 0 && sr < NT;
             if (any[p]) fix[p] = *(const u32x4 *)(ts + 32 * sr + 16 * (sr >> 2) + 16 * (i & 1));
         }
         __syncthreads();                                       // every mirror source has been read
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
+        for (int p = 0; p < NF; ++p) {
             const int i = tid + 256 * p, sl = i >> 1;
             if (any[p]) *(u32x4 *)(ts + 32 * sl + 16 * (sl >> 2) + 16 * (i & 1)) = fix[p];
         }

@@ -1259,7 +1259,7 @@ int enc_launch_block1(const MstEncConv &c0, const MstEncConv &c1, const __bf16 *
     a.B = B;
     a.L = L;
     a.Lout = Lout;
-    a.tiles = (Lout + ENC_STEREO_TO - 1) / ENC_STEREO_TO;
+    a.tiles = (Lout + ENC_B1_TO - 1) / ENC_B1_TO;
     a.slope0 = c0.slope;
     a.slope1 = c1.slope;
     a.zeros = zeros;

@@ -25,7 +25,7 @@ int main() {
     (void)hipMemcpy(a1, f1.data(), f1.size() * 2, hipMemcpyHostToDevice); (void)hipMemcpy(sh, hs.data(), 128, hipMemcpyHostToDevice);
     EncBlock1Args a;
     a.x = (const __bf16 *)x; a.y = (__bf16 *)y; a.a0 = a0; a.a1 = a1; a.shift0 = sh; a.shift1 = sh; a.B = B; a.L = L; a.Lout = Lout;
-    a.tiles = (Lout + ENC_STEREO_TO - 1) / ENC_STEREO_TO; a.slope0 = a.slope1 = 0.0f; a.zeros = zr;
+    a.tiles = (Lout + ENC_B1_TO - 1) / ENC_B1_TO; a.slope0 = a.slope1 = 0.0f; a.zeros = zr;
     const int grid = B * a.tiles, reps = 20;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
