@@ -197,8 +197,8 @@ int mst_enc_set_tuning(MstEnc *enc, long rows_min_tiles);
  * whole L2 back on this part; EXPERIMENTS.md D.3): not in the library.)
  * bit 3 (default off, the reference form of a GPU / emulator test): the default encoder's stereo block (2 -> 2, k = 25 with skip; 2 -> 16, k = 25,
  * stride 4) as two direct-kernel launches with the intermediate in HBM instead of the fused enc_stereo_block_kernel.  Same bits either way.
- * bit 4 (default off, bf16 mode): block 1 of the default encoder (16 -> 16, k = 25 with skip; 16 -> 32, k = 25, stride 4) as its two conv launches
- * instead of the fused enc_block1_fused_kernel (intermediate in LDS, weights resident in registers); same operands, another fp32 summation
+ * bit 4 (default off, bf16 mode): blocks 1 and 2 of the default encoder (16 -> 16, k = 25 with skip; 16 -> 32, k = 25, stride 4 / 32 -> 32, k = 15;
+ * 32 -> 64, k = 15, stride 2) as their two conv launches each instead of the fused enc_block1_fused_kernel (intermediate in LDS, weights resident in registers); same operands, another fp32 summation
  * order: the two forms agree to accumulation rounding (one bf16 ulp on isolated elements). */
 int mst_enc_set_schedule(MstEnc *enc, int flags);
 /* nn.AdaptiveAvgPool1d(1) on its own (architectures.py:63,67; FXencoder(conv_block='conv') runs its ConvBlocks one by one through

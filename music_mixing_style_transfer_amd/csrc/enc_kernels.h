@@ -819,91 +819,122 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Res_ConvBlock 1 of the default encoder in ONE launch, bf16 mode (round 5): Conv1d_layer(16 -> 16, k = 25, stride 1) + skip, then
-// Conv1d_layer(16 -> 32, k = 25, stride 4) (network_utils.py:96-119 on configs.yaml's second entries).  The two launches it replaces
-// (enc_conv_rows_kernel<1> + enc_conv_nlc_kernel<1>: 50 + 34 us per 32 segments) move 33.5 MB in, 2 x 33.5 MB of intermediate and 16.8 MB
-// out for 20 GFLOP: they are bound by memory and by launch-sized latencies, and their 32-row MFMA tiles are half empty at 16 channels.  Here a
-// workgroup owns TO = 240 outputs (the stereo kernel's geometry: 1056 staged input rows by LDS-DMA, 1024 intermediate rows in LDS, never in
-// HBM), both convs on v_mfma_f32_16x16x32_bf16 with the contraction k = j * 16 + ci (a k-step = two taps x 16 channels; the 26th tap has
-// zero weights) and the weights RESIDENT in registers as A fragments (13 per row tile).  B fragments are 16-byte reads of channel-minor rows:
-// consecutive rows for the first conv, every fourth row for the second - the intermediate image is skewed by 16 bytes per four rows so
-// that those reads spread over the banks.  Same operands as the two-launch form (bf16 weights, bf16 input, the intermediate rounded to bf16),
-// fp32 accumulation in another order (k-steps of 32 instead of 16): results agree to accumulation rounding, not bit for bit.
+// Res_ConvBlocks 1 and 2 of the default encoder in ONE launch each, bf16 mode (round 5): Conv1d_layer(C -> C, k, stride 1) + skip, then
+// Conv1d_layer(C -> 2 C, k, stride S) (network_utils.py:96-119) for (C, k, S) = (16, 25, 4) and (32, 15, 2).  The two launches a block took
+// (enc_conv_rows_kernel + enc_conv_nlc_kernel / enc_conv_rows_kernel: 50 + 34 us and 23 + 24 us per 32 segments) move the intermediate
+// twice through HBM and are bound by memory and by launch-sized latencies; at 16 channels their 32-row MFMA tiles are half empty.  Here a
+// workgroup owns TO = 256 outputs: its input rows arrive by LDS-DMA (the image is contiguous in HBM), the intermediate rows live in LDS
+// only, both convs run on v_mfma_f32_16x16x32_bf16 with the contraction k = tap * C + ci (a k-step = 32 / C taps; taps beyond k have zero
+// weights) and the weights RESIDENT in registers as A fragments (KS per 16-row tile; the second conv in passes of two row tiles).  B
+// fragments are 16-byte reads of channel-minor rows: consecutive rows for the first conv, every S-th row for the second - the intermediate
+// image is skewed by 16 bytes per S rows so that those reads spread over the banks.  Same operands as the two-launch form (bf16 weights,
+// bf16 input, the intermediate rounded to bf16), fp32 accumulation in another order (k-steps of 32 instead of 16): results agree to
+// accumulation rounding, not bit for bit.  The first conv of block 1 (16 output channels: every 1 KB B fragment feeds ONE MFMA) runs at the
+// LDS read rate, twice its MFMA time (phase clocks: tools/micro/enc_block1_probe.hip).
 // ------------------------------------------------------------------------------------------------
 struct EncBlock1Args {
-    const __bf16 *x;              // [B][L][16]
-    __bf16 *y;                    // [B][Lout][32]
-    const void *a0, *a1;          // A fragments: [13][64 lanes] x 16 bytes / [2 row tiles][13][64] x 16 bytes (enc_block1_pack)
-    const float *shift0, *shift1; // [16] / [32]
+    const __bf16 *x;              // [B][L][C]
+    __bf16 *y;                    // [B][Lout][2 C]
+    const void *a0, *a1;          // A fragments: [C / 16 row tiles][KS][64 lanes] x 16 bytes / [2 C / 16][KS][64] x 16 bytes (enc_block1_pack)
+    const float *shift0, *shift1; // [C] / [2 C]
     int B, L, Lout, tiles;
     float slope0, slope1;
-    const void *zeros;            // 32 bytes of zeros (rows outside a reflected segment: shorter than the padding)
+    const void *zeros;            // 16 bytes of zeros (rows outside a reflected segment: shorter than the padding)
 };
-constexpr int ENC_B1_KS = 13, ENC_B1_TO = 256;      // k-steps per conv; outputs per workgroup (32 x 8192 / 256 = 1024 workgroups = two full rounds at two per CU)
-// host side: A fragments of one 16-row tile of BN-folded weights w[Cout][16][25]: lane (row, kg), k-step kk, element e: k = 32 kk + 8 kg + e
-inline void enc_block1_pack(const float *w, int row0, __bf16 *frag) {
-    for (int kk = 0; kk < ENC_B1_KS; ++kk)
+constexpr int ENC_B1_TO = 256;      // outputs per workgroup: 32 x 8192 / 256 = 1024 (block 1) and 32 x 4096 / 256 = 512 (block 2) workgroups = whole rounds at two per CU
+constexpr int enc_block1_ks(int cin, int ksz) { return (cin * ksz + 31) / 32; }
+// host side: A fragments of one 16-row tile of BN-folded weights w[Cout][cin][ksz]: lane (row, kg), k-step kk, element e: k = 32 kk + 8 kg + e = tap * cin + ci
+inline void enc_block1_pack(const float *w, int row0, int cin, int ksz, __bf16 *frag) {
+    for (int kk = 0; kk < enc_block1_ks(cin, ksz); ++kk)
         for (int l = 0; l < 64; ++l)
             for (int e = 0; e < 8; ++e) {
-                const int co = row0 + (l & 15), k = 32 * kk + 8 * (l >> 4) + e, j = k / 16, ci = k % 16;
-                frag[(kk * 64 + l) * 8 + e] = (__bf16)(j < 25 ? w[(co * 16 + ci) * 25 + j] : 0.0f);
+                const int co = row0 + (l & 15), k = 32 * kk + 8 * (l >> 4) + e, j = k / cin, ci = k % cin;
+                frag[(kk * 64 + l) * 8 + e] = (__bf16)(j < ksz ? w[(co * cin + ci) * ksz + j] : 0.0f);
             }
 }
+template <int CIN, int KSZ, int S1, int NCT>          // NCT: 16-slot column tiles of the first conv a workgroup computes
 __global__ __launch_bounds__(256, 2) void enc_block1_fused_kernel(EncBlock1Args a) {
-    constexpr int KSZ = 25, S1 = 4, TO = ENC_B1_TO, PAD = 12, NCT = 66, NT = 16 * NCT, NX = NT + 32, KS = ENC_B1_KS, NT1 = TO / 16;      // NCT column tiles of the first conv
-    constexpr int XB = NX * 32, TB = NT * 32 + (NT / 4) * 16;
-    static_assert(S1 * (TO - 1) + 2 * KS + 2 <= NT && NT + 2 * KS <= NX && XB % 1024 == 0 && NT1 == 16 && NCT == 66, "tile geometry (the last group of first-conv tiles holds one tile for waves 0, 1)");
-    __shared__ __attribute__((aligned(1024))) unsigned char xs[XB];      // input rows p_first - PAD + [0, NX): 32 bytes each
-    __shared__ __attribute__((aligned(16))) unsigned char ts[TB];        // intermediate slot s at 32 s + 16 (s >> 2)
+    constexpr int COUT = 2 * CIN, RB = 2 * CIN, TO = ENC_B1_TO, PAD = (KSZ - 1) / 2, KS = enc_block1_ks(CIN, KSZ);
+    constexpr int MA = CIN / 16, MB = COUT / 16, NT = 16 * NCT, NX = NT + 32, NT1 = TO / 16, JMAX = (32 * KS - 1) / CIN;      // JMAX: last tap a k-step touches
+    constexpr int XB = NX * RB, TB = NT * RB + (NT / S1) * 16;
+    static_assert(KSZ % 2 == 1 && (CIN == 16 || CIN == 32), "odd kernels; a k-step is a whole number of taps");
+    static_assert(S1 * (TO - 1) + JMAX < NT && NT + JMAX <= NX && XB % 1024 == 0 && NT1 == 16 && NCT % 16 <= 4 && NT % S1 == 0 && S1 * RB == 128,
+                  "tile geometry (the last group of first-conv tiles holds at most one tile per wave; lanes of a second-conv read are 144 bytes apart)");
+    static_assert(2 * (XB + TB) <= 160 * 1024, "two workgroups per CU");
+    __shared__ __attribute__((aligned(1024))) unsigned char xs[XB];      // input rows p_first - PAD + [0, NX): RB bytes each
+    __shared__ __attribute__((aligned(16))) unsigned char ts[TB];        // intermediate slot s at RB s + 16 (s / S1)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 15, g = lane >> 4;
     const int b = blockIdx.x / a.tiles, t0 = (blockIdx.x % a.tiles) * TO;
     const int p_first = S1 * t0 - PAD;
-    const unsigned char *xb = (const unsigned char *)a.x + (size_t)b * a.L * 32;
-    // ---- stage the input rows: interior tiles by LDS-DMA (33 pieces of 1 KB: the image is contiguous in HBM), border tiles row by row
+    const unsigned char *xb = (const unsigned char *)a.x + (size_t)b * a.L * RB;
+    // ---- stage the input rows: interior tiles by LDS-DMA (pieces of 1 KB: the image is contiguous in HBM), border tiles piece by piece
     if (p_first - PAD >= 0 && p_first - PAD + NX <= a.L) {          // uniform
-        const unsigned char *src = xb + (size_t)(p_first - PAD) * 32 + lane * 16;
+        const unsigned char *src = xb + (size_t)(p_first - PAD) * RB + lane * 16;
         for (int k = w; k < XB / 1024; k += 4) mst_dma16(src + k * 1024, xs + k * 1024);
     } else {
-        for (int i = tid; i < 2 * NX; i += 256) {
-            const int r = i >> 1, t = enc_reflect(p_first - PAD + r, a.L);
-            *(u32x4 *)(xs + 16 * i) = *(const u32x4 *)((t >= 0 && t < a.L) ? xb + (size_t)t * 32 + 16 * (i & 1) : (const unsigned char *)a.zeros);
+        constexpr int PR = RB / 16;                                  // 16-byte pieces per row
+        for (int i = tid; i < PR * NX; i += 256) {
+            const int r = i / PR, t = enc_reflect(p_first - PAD + r, a.L);
+            *(u32x4 *)(xs + 16 * i) = *(const u32x4 *)((t >= 0 && t < a.L) ? xb + (size_t)t * RB + 16 * (i % PR) : (const unsigned char *)a.zeros);
         }
     }
-    bf16x8 A0[KS];
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) A0[kk] = ((const bf16x8 *)a.a0)[kk * 64 + lane];
-    mst_dma_wait_barrier<0>();
-    // ---- first conv + shift + activation + skip: wave w owns column tiles w, w + 4, ... (16 slots each), four at a time
+    // lane (n, kg = g) of k-step kk reads 16 bytes of row (column + tap), tap = (32 kk + 8 g) / CIN, at channel (32 kk + 8 g) % CIN
+    auto tap_of = [](int kk, int kg) { return (32 * kk + 8 * kg) / CIN; };
+    auto chb_of = [](int kk, int kg) { return 2 * ((32 * kk + 8 * kg) % CIN); };
     {
-        const f32x4 sh = *(const f32x4 *)(a.shift0 + 4 * g);
-        const unsigned char *bx = xs + (n + (g >> 1)) * 32 + 16 * (g & 1);      // row s + j, j = 2 kk + (kg >> 1); channels 8 (kg & 1) ..
+        bf16x8 A0[MA][KS];
+#pragma unroll
+        for (int m = 0; m < MA; ++m)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) A0[m][kk] = ((const bf16x8 *)a.a0)[(m * KS + kk) * 64 + lane];
+        mst_dma_wait_barrier<0>();
+        // ---- first conv + shift + activation + skip: wave w owns column tiles w, w + 4, ... (16 slots each), four at a time, all row tiles
+        f32x4 sh[MA];
+#pragma unroll
+        for (int m = 0; m < MA; ++m) sh[m] = *(const f32x4 *)(a.shift0 + 16 * m + 4 * g);
+        // byte offset of the lane's piece in k-step 0 of column tile 0; a k-step adds 32 / CIN rows (CIN = 16: the odd k groups sit one row further)
+        const unsigned char *bx = xs + (n + tap_of(0, g)) * RB + chb_of(0, g);
+        constexpr int KSTEP = (32 / CIN) * RB;                       // bytes per k-step (CIN <= 32: a whole number of rows)
 #pragma unroll 1
-        for (int grp = 0; grp < (NCT + 15) / 16; ++grp) {      // column tile T = w + 4 (4 grp + c); the last group has tiles 64, 65 only (waves 0, 1)
+        for (int grp = 0; grp < (NCT + 15) / 16; ++grp) {           // column tile T = w + 4 (4 grp + c); the last group: one tile on the first waves
             const int nc = NCT - (w + 16 * grp) > 12 ? 4 : (NCT - (w + 16 * grp) + 3) / 4;      // uniform per wave
             if (nc <= 0) break;
-            f32x4 acc[4];
+            f32x4 acc[4][MA];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            const unsigned char *bg = bx + (w + 16 * grp) * 512;
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int m = 0; m < MA; ++m) acc[c][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const unsigned char *bg = bx + (w + 16 * grp) * 16 * RB;
             if (nc == 4) {
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0[kk], *(const bf16x8 *)(bg + c * 2048 + kk * 64), acc[c], 0, 0, 0);
+                    for (int c = 0; c < 4; ++c) {
+                        const bf16x8 bv = *(const bf16x8 *)(bg + c * 64 * RB + kk * KSTEP);
+#pragma unroll
+                        for (int m = 0; m < MA; ++m) acc[c][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0[m][kk], bv, acc[c][m], 0, 0, 0);
+                        if (c == 3 && kk % 2 == 1) __builtin_amdgcn_sched_barrier(0);      // (keeps the scheduler from hoisting all 4 KS fragment reads: it spilled 326 registers at C = 32)
+                    }
             } else {
 #pragma unroll
-                for (int kk = 0; kk < KS; ++kk) acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0[kk], *(const bf16x8 *)(bg + kk * 64), acc[0], 0, 0, 0);
+                for (int kk = 0; kk < KS; ++kk) {
+                    const bf16x8 bv = *(const bf16x8 *)(bg + kk * KSTEP);
+#pragma unroll
+                    for (int m = 0; m < MA; ++m) acc[0][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0[m][kk], bv, acc[0][m], 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {          // lane (n, g): slot s, channels 4 g .. 4 g + 3
+            for (int c = 0; c < 4; ++c) {          // lane (n, g): slot sl, channels 16 m + 4 g .. + 3
                 if (c < nc) {
                     const int sl = 16 * (w + 4 * (4 * grp + c)) + n;
-                    const bf16x4 r = *(const bf16x4 *)(xs + (sl + PAD) * 32 + 8 * g);
-                    bf16x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)(enc_act(acc[c][e] + sh[e], a.slope0) + (float)r[e]);
-                    *(bf16x4 *)(ts + 32 * sl + 16 * (sl >> 2) + 8 * g) = o;
+                    for (int m = 0; m < MA; ++m) {
+                        const bf16x4 r = *(const bf16x4 *)(xs + (sl + PAD) * RB + 32 * m + 8 * g);
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (__bf16)(enc_act(acc[c][m][e] + sh[m][e], a.slope0) + (float)r[e]);
+                        *(bf16x4 *)(ts + RB * sl + 16 * (sl / S1) + 32 * m + 8 * g) = o;
+                    }
                 }
             }
         }
@@ -917,57 +948,67 @@ __global__ __launch_bounds__(256, 2) void enc_block1_fused_kernel(EncBlock1Args 
     // ---- the second conv's reflection padding: a slot outside the segment takes the row of its mirror position (inside the tile for every
     // slot an output reads; slots beyond those keep what the first conv made of the zero / mirrored input - finite, multiplied by zero weights)
     if (p_first < 0 || p_first + NT > a.L) {               // uniform: the first / last tiles of an item
-        constexpr int NF = (2 * NT + 255) / 256;
+        constexpr int PR = RB / 16, NF = (PR * NT + 255) / 256;
         u32x4 fix[NF];
         bool any[NF];
 #pragma unroll
         for (int p = 0; p < NF; ++p) {
-            const int i = tid + 256 * p, sl = i >> 1, pos = p_first + sl, pr = enc_reflect(pos, a.L), sr = pr - p_first;
-            any[p] = i < 2 * NT && (pos < 0 || pos >= a.L) && pr >= 0 && pr < a.L && sr >= 0 && sr < NT;
-            if (any[p]) fix[p] = *(const u32x4 *)(ts + 32 * sr + 16 * (sr >> 2) + 16 * (i & 1));
+            const int i = tid + 256 * p, sl = i / PR, pos = p_first + sl, pr = enc_reflect(pos, a.L), sr = pr - p_first;
+            any[p] = i < PR * NT && (pos < 0 || pos >= a.L) && pr >= 0 && pr < a.L && sr >= 0 && sr < NT;
+            if (any[p]) fix[p] = *(const u32x4 *)(ts + RB * sr + 16 * (sr / S1) + 16 * (i % PR));
         }
         __syncthreads();                                       // every mirror source has been read
 #pragma unroll
         for (int p = 0; p < NF; ++p) {
-            const int i = tid + 256 * p, sl = i >> 1;
-            if (any[p]) *(u32x4 *)(ts + 32 * sl + 16 * (sl >> 2) + 16 * (i & 1)) = fix[p];
+            const int i = tid + 256 * p, sl = i / PR;
+            if (any[p]) *(u32x4 *)(ts + RB * sl + 16 * (sl / S1) + 16 * (i % PR)) = fix[p];
         }
         __syncthreads();
     }
-    // ---- second conv: wave w owns column tiles w, w + 4, w + 8, w + 12 (16 output steps each), two at a time, both row tiles
-    const f32x4 sh1[2] = {*(const f32x4 *)(a.shift1 + 4 * g), *(const f32x4 *)(a.shift1 + 16 + 4 * g)};
+    // ---- second conv: wave w owns column tiles w, w + 4, w + 8, w + 12 (16 output steps each), two at a time, two row tiles per pass
+#pragma unroll 1
+    for (int mp = 0; mp < MB / 2; ++mp) {
+        if (mp > 0) {
 #pragma unroll
-    for (int pr = 0; pr < 2; ++pr) {
-        f32x4 acc[2][2];
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+                for (int kk = 0; kk < KS; ++kk) A1[m][kk] = ((const bf16x8 *)a.a1)[((2 * mp + m) * KS + kk) * 64 + lane];
+        }
+        const f32x4 sh1[2] = {*(const f32x4 *)(a.shift1 + 32 * mp + 4 * g), *(const f32x4 *)(a.shift1 + 32 * mp + 16 + 4 * g)};
 #pragma unroll
-            for (int m = 0; m < 2; ++m) acc[c][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        const int T0 = w + 8 * pr;                               // and T0 + 4 (wave 3's last pair has one tile: the other reads tile NT1 - 1 again)
-        const unsigned char *bt[2];                              // row 4 c + j at 32 (4 c + j) + 16 (c + (j >> 2)), c = 16 T + n
+        for (int pr = 0; pr < 2; ++pr) {
+            f32x4 acc[2][2];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) bt[c] = ts + 144 * (16 * (T0 + 4 * c < NT1 ? T0 + 4 * c : NT1 - 1) + n) + 16 * (g & 1);
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            const int j = 2 * kk + (g >> 1);                     // lane-dependent: one shift-add per k-step
-            const int off = 32 * j + 16 * (j >> 2);
+                for (int m = 0; m < 2; ++m) acc[c][m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            const int T0 = w + 8 * pr;                               // and T0 + 4
+            const unsigned char *bt[2];                              // row S c + j at RB (S c + j) + 16 (c + j / S) = 144 c + ..., c = 16 T + n
+#pragma unroll
+            for (int c = 0; c < 2; ++c) bt[c] = ts + (S1 * RB + 16) * (16 * (T0 + 4 * c) + n);
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int j = tap_of(kk, g);                         // lane-dependent when a k-step spans two taps
+                const int off = RB * j + 16 * (j / S1) + chb_of(kk, g);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const bf16x8 bv = *(const bf16x8 *)(bt[c] + off);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) acc[c][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[m][kk], bv, acc[c][m], 0, 0, 0);
+                }
+                if (kk % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const bf16x8 bv = *(const bf16x8 *)(bt[c] + off);
+                const int o = 16 * (T0 + 4 * c) + n, to = t0 + o;        // lane (n, g): output step o of the tile, channels 32 mp + 16 m + 4 g ..
+                if (to < a.Lout) {
 #pragma unroll
-                for (int m = 0; m < 2; ++m) acc[c][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[m][kk], bv, acc[c][m], 0, 0, 0);
-            }
-        }
+                    for (int m = 0; m < 2; ++m) {
+                        bf16x4 ov;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int o = 16 * (T0 + 4 * c) + n, to = t0 + o;        // lane (n, g): output step o of the tile, channels 16 m + 4 g ..
-            if (T0 + 4 * c < NT1 && to < a.Lout) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    bf16x4 ov;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ov[e] = (__bf16)enc_act(acc[c][m][e] + sh1[m][e], a.slope1);
-                    *(bf16x4 *)(a.y + ((size_t)b * a.Lout + to) * 32 + 16 * m + 4 * g) = ov;
+                        for (int e = 0; e < 4; ++e) ov[e] = (__bf16)enc_act(acc[c][m][e] + sh1[m][e], a.slope1);
+                        *(bf16x4 *)(a.y + ((size_t)b * a.Lout + to) * COUT + 32 * mp + 16 * m + 4 * g) = ov;
+                    }
                 }
             }
         }

@@ -60,7 +60,7 @@ struct MstEncConv {
     __bf16 *wpk16 = nullptr;
     int *ktab = nullptr;
     float *w_direct = nullptr;   // [Cout][Cin][ksz] folded fp32 (layers with Cin < 8: direct kernel)
-    __bf16 *w_frag16 = nullptr;  // block 1 of the default encoder (Cin = 16, k = 25): the fused kernel's bf16 A fragments, one 16-row tile after the other (enc_block1_pack)
+    __bf16 *w_frag16 = nullptr;  // blocks 1 / 2 of the default encoder (Cin = 16, k = 25 / Cin = 32, k = 15): the fused kernel's bf16 A fragments, one 16-row tile after the other (enc_block1_pack)
     float *w_frag = nullptr;     // stereo block (Cin = 2, k = 25): the fused kernel's fp32 MFMA A fragments (enc_stereo_pack_a0 / _a1)
     __bf16 *wpk_nlc = nullptr;   // NLC pipeline A fragments, k = j*Cin + ci, K-chunk 64
     float slope = 0.0f;             // activation slope for negative values: 0 ReLU, 0.01 LeakyReLU, 1 none (MstEncDesc.act_slope)
@@ -843,7 +843,7 @@ extern "C" int mst_tcn_forward_blocks(MstTcn *t, const float *x, float *act, int
 struct MstEnc {
     MstEncDesc d;
     std::vector<MstEncConv> conv;   // 2 per block
-    int schedule = 1;               // bit 4: block 1 (bf16 mode) as two launches instead of the fused kernel; bit 3: the stereo block as two direct-kernel launches instead of the fused kernel (the bit-identical reference form); bit 1: 2 x 2 wave tiling of the 128-channel conv kernel (measured slower: off); bit 0: weight-major workgroup order for the weight-heavy layers (mst_enc_set_schedule)
+    int schedule = 1;               // bit 4: blocks 1 / 2 (bf16 mode) as two launches each instead of the fused kernel; bit 3: the stereo block as two direct-kernel launches instead of the fused kernel (the bit-identical reference form); bit 1: 2 x 2 wave tiling of the 128-channel conv kernel (measured slower: off); bit 0: weight-major workgroup order for the weight-heavy layers (mst_enc_set_schedule)
     void *zeros = nullptr;          // 256 bytes of zeros: what the channel-minor conv kernel fetches for rows / k-slots outside the problem
     long rows_min_tiles = 512;      // bf16 mode: layers with at least this many tiles keep their input rows resident in LDS (mst_enc_set_tuning)
 };
@@ -985,12 +985,14 @@ extern "C" int mst_enc_load_conv(MstEnc *e, int block, int which, const float *w
         }
         if ((rc = upload(&c.wpk_nlc, wn))) return rc;
         if ((rc = upload(&c.wpk_nlc_lo, wl))) return rc;
-        if (c.cin == 16 && c.ksz == 25 && c.dil == 1 && (c.cout == 16 || c.cout == 32)) {      // block 1 of the default encoder: fused-kernel fragments
+        if (c.dil == 1 && ((c.cin == 16 && c.ksz == 25) || (c.cin == 32 && c.ksz == 15)) && (c.cout == c.cin || c.cout == 2 * c.cin)) {
+            // blocks 1 / 2 of the default encoder: the fused kernel's fragments, one 16-row tile after the other
             std::vector<float> wf((size_t)c.cout * K);
             for (int co = 0; co < c.cout; ++co)
                 for (int k = 0; k < K; ++k) wf[(size_t)co * K + k] = w[(size_t)co * K + k] * scale[co];
-            std::vector<__bf16> fr((size_t)(c.cout / 16) * ENC_B1_KS * 64 * 8);
-            for (int m = 0; m < c.cout / 16; ++m) enc_block1_pack(wf.data(), 16 * m, fr.data() + (size_t)m * ENC_B1_KS * 64 * 8);
+            const size_t per_tile = (size_t)enc_block1_ks(c.cin, c.ksz) * 64 * 8;
+            std::vector<__bf16> fr((size_t)(c.cout / 16) * per_tile);
+            for (int m = 0; m < c.cout / 16; ++m) enc_block1_pack(wf.data(), 16 * m, c.cin, c.ksz, fr.data() + (size_t)m * per_tile);
             if ((rc = upload(&c.w_frag16, fr))) return rc;
         }
         if ((rc = upload(&c.stab, st))) return rc;
@@ -1243,12 +1245,17 @@ int enc_launch_stereo_block(const MstEncConv &c0, const MstEncConv &c1, const fl
     return MST_OK;
 }
 
-// block 1 of the default encoder (16 -> 16, k = 25 with skip; 16 -> 32, k = 25, stride 4), bf16 mode, as one launch
-bool enc_block1_fits(const MstEncConv &c0, const MstEncConv &c1, int L) {
-    auto same_pad = [](const MstEncConv &c) { return c.ksz == 25 && c.dil == 1 && c.pad_l == 12 && c.pad_r == 12 && c.cin == 16 && c.w_frag16; };
-    return same_pad(c0) && same_pad(c1) && c0.cout == 16 && c0.stride == 1 && c1.cout == 32 && c1.stride == 4 && L > 12 && L < (1 << 26);
+// blocks 1 / 2 of the default encoder (C -> C, k with skip; C -> 2 C, k, stride S for (C, k, S) = (16, 25, 4), (32, 15, 2)), bf16 mode, as one launch each
+int enc_block1_form(const MstEncConv &c0, const MstEncConv &c1, int L) {          // 1 / 2: which instantiation fits, 0: none
+    auto same = [&](const MstEncConv &c, int cin, int ksz) {
+        return c.cin == cin && c.ksz == ksz && c.dil == 1 && c.pad_l == (ksz - 1) / 2 && c.pad_r == (ksz - 1) / 2 && c.w_frag16;
+    };
+    if (L <= c0.pad_l || L >= (1 << 25)) return 0;
+    if (same(c0, 16, 25) && same(c1, 16, 25) && c0.cout == 16 && c0.stride == 1 && c1.cout == 32 && c1.stride == 4) return 1;
+    if (same(c0, 32, 15) && same(c1, 32, 15) && c0.cout == 32 && c0.stride == 1 && c1.cout == 64 && c1.stride == 2) return 2;
+    return 0;
 }
-int enc_launch_block1(const MstEncConv &c0, const MstEncConv &c1, const __bf16 *x, __bf16 *y, int B, int L, int Lout, const void *zeros, void *stream) {
+int enc_launch_block1(int form, const MstEncConv &c0, const MstEncConv &c1, const __bf16 *x, __bf16 *y, int B, int L, int Lout, const void *zeros, void *stream) {
     EncBlock1Args a;
     a.x = x;
     a.y = y;
@@ -1264,7 +1271,8 @@ int enc_launch_block1(const MstEncConv &c0, const MstEncConv &c1, const __bf16 *
     a.slope1 = c1.slope;
     a.zeros = zeros;
     if ((long)B * a.tiles > 0x7fffffffL) return fail(MST_ERR_ARG, "enc_block1_fused_kernel: grid too large");
-    MST_LAUNCH(enc_block1_fused_kernel, dim3((unsigned)(B * a.tiles)), dim3(256), stream, a);
+    if (form == 1) MST_LAUNCH((enc_block1_fused_kernel<16, 25, 4, 66>), dim3((unsigned)(B * a.tiles)), dim3(256), stream, a);
+    else MST_LAUNCH((enc_block1_fused_kernel<32, 15, 2, 33>), dim3((unsigned)(B * a.tiles)), dim3(256), stream, a);
     MST_CHECK_LAUNCH("enc_block1_fused_kernel");
     return MST_OK;
 }
@@ -1393,8 +1401,9 @@ int enc_run_nlc(MstEnc *e, const float *x, float *emb, float *blk_out, int B, in
                 if ((rc = enc_launch_direct(e->conv[0], (const float *)cur, t1, false, B, len, len, 1, stream))) return rc;
                 if ((rc = enc_launch_direct(e->conv[1], (const float *)t1, o[pp], true, B, len, lout, 0, stream, lo_plane))) return rc;
             }
-        } else if (i == 1 && !x3 && !(e->schedule & 16) && enc_block1_fits(e->conv[2], e->conv[3], len) && lout == conv_out_length(e->conv[3], len)) {
-            if ((rc = enc_launch_block1(e->conv[2], e->conv[3], (const __bf16 *)cur, (__bf16 *)o[pp], B, len, lout, e->zeros, stream))) return rc;
+        } else if (!x3 && !(e->schedule & 16) && enc_block1_form(e->conv[2 * i], e->conv[2 * i + 1], len) && lout == conv_out_length(e->conv[2 * i + 1], len)) {
+            if ((rc = enc_launch_block1(enc_block1_form(e->conv[2 * i], e->conv[2 * i + 1], len), e->conv[2 * i], e->conv[2 * i + 1], (const __bf16 *)cur,
+                                        (__bf16 *)o[pp], B, len, lout, e->zeros, stream))) return rc;
         } else {
             if ((rc = enc_launch_nlc(e->conv[2 * i], (const __bf16 *)cur, (__bf16 *)t1, scratch, B, len, len, 1, e->rows_min_tiles, stream, x3, e->schedule, e->zeros))) return rc;
             if ((rc = enc_launch_nlc(e->conv[2 * i + 1], (const __bf16 *)t1, (__bf16 *)o[pp], scratch, B, len, lout, 0, e->rows_min_tiles, stream, x3, e->schedule, e->zeros))) return rc;

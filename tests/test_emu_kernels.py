@@ -704,33 +704,35 @@ def test_encoder_fused_stereo_block_emulated(emu_default):
 
 
 def test_encoder_fused_block1_emulated(emu_default):
-    """Block 1 of the default encoder (16 -> 16, k = 25, skip; 16 -> 32, k = 25, stride 4) in bf16 mode as ONE kernel (input rows by LDS-DMA, the
-    intermediate in LDS, weights resident as A fragments of v_mfma_f32_16x16x32_bf16) against its two conv launches (mst_enc_set_schedule bit 4):
+    """Blocks 1 and 2 of the default encoder (16 -> 16, k = 25, skip; 16 -> 32, k = 25, stride 4 / 32 -> 32, k = 15, skip; 32 -> 64, k = 15, stride 2) in
+    bf16 mode as ONE kernel each (input rows by LDS-DMA, the intermediate in LDS, weights resident as A fragments of v_mfma_f32_16x16x32_bf16;
+    the second conv of block 2 in two passes of two row tiles) against their two conv launches each (mst_enc_set_schedule bit 4):
     same bf16 operands, fp32 accumulation in k-steps of 32 instead of 16 - agreement to accumulation rounding (a rounding flip of the bf16
     intermediate / output moves an element by one bf16 ulp), and the oracle at the bf16 tolerance.  One-tile and many-tile lengths, lengths
     that are not multiples of the strides, border tiles at both ends, the shortest input the reflection padding allows."""
     from music_mixing_style_transfer_amd.networks import FXencoder
-    cfg = {"channels": [16, 32], "kernels": [25, 25], "strides": [4, 4], "dilation": [1, 1],
-           "bias": True, "norm": "batch", "conv_block": "res", "activation": "relu"}
+    cfg = {"channels": [16, 32, 64], "kernels": [25, 25, 15], "strides": [4, 4, 2], "dilation": [1, 1, 1],
+           "bias": True, "norm": "batch", "conv_block": "res", "activation": "relu"}          # blocks 1 and 2 are the default encoder's (16 / 32 channels, k = 25 / 15)
     sd = synth.fxencoder_state_dict(cfg, seed=22)
     enc = FXencoder({k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()})
     enc.load_state_dict(sd)
     enc.precision = "bf16"
-    for shape in ((2, 2, 8150), (1, 2, 16003), (3, 2, 4000), (1, 2, 52), (2, 2, 3997)):
+    for shape in ((2, 2, 8150), (1, 2, 16003), (3, 2, 4000), (1, 2, 200), (2, 2, 3997), (1, 2, 33000)):
         x = synth.synth_audio(shape, seed=shape[2])
         col = []
         R.fxencoder_blocks(x, sd, cfg, collect=col)
         run = enc._get_runner()
         run._ensure(emu_default)
-        emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 1 | 16), "schedule")      # two launches
-        ref = enc.forward_blocks(x, 2).clone()
-        emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 1), "schedule")           # the fused kernel (default)
-        got = enc.forward_blocks(x, 2)
-        scale = float(col[1].abs().max())
-        assert got.shape == col[1].shape
-        assert float((got - ref).abs().max()) <= 1.6e-2 * scale, (shape, float((got - ref).abs().max()), scale)
-        assert float((got - ref).abs().mean()) <= 2e-4 * scale, shape                           # isolated rounding flips, not a shifted result
-        assert float((got - col[1]).abs().max()) <= 2e-2 * scale, shape
+        for nb in (2, 3):
+            emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 1 | 16), "schedule")      # two launches per block
+            ref = enc.forward_blocks(x, nb).clone()
+            emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 1), "schedule")           # the fused kernels (default)
+            got = enc.forward_blocks(x, nb)
+            scale = float(col[nb - 1].abs().max())
+            assert got.shape == col[nb - 1].shape
+            assert float((got - ref).abs().max()) <= 1.6e-2 * scale, (shape, nb, float((got - ref).abs().max()), scale)
+            assert float((got - ref).abs().mean()) <= 2e-4 * scale, (shape, nb)                      # isolated rounding flips, not a shifted result
+            assert float((got - col[nb - 1]).abs().max()) <= 2e-2 * scale, (shape, nb)
 
 
 def test_algorithmic_reverb_emulated(emu_default):

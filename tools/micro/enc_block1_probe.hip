@@ -14,9 +14,9 @@ int main() {
     for (auto &v : hx) v = (__bf16)rnd();
     for (auto &v : w0) v = 0.1f * rnd();
     for (auto &v : w1) v = 0.1f * rnd();
-    enc_block1_pack(w0.data(), 0, f0.data());
-    enc_block1_pack(w1.data(), 0, f1.data());
-    enc_block1_pack(w1.data(), 16, f1.data() + 13 * 64 * 8);
+    enc_block1_pack(w0.data(), 0, 16, 25, f0.data());
+    enc_block1_pack(w1.data(), 0, 16, 25, f1.data());
+    enc_block1_pack(w1.data(), 16, 16, 25, f1.data() + 13 * 64 * 8);
     void *x, *y, *a0, *a1, *zr;
     float *sh;
     (void)hipMalloc(&x, hx.size() * 2); (void)hipMalloc(&y, (size_t)B * Lout * 32 * 2); (void)hipMalloc(&a0, f0.size() * 2); (void)hipMalloc(&a1, f1.size() * 2);
@@ -29,11 +29,11 @@ int main() {
     const int grid = B * a.tiles, reps = 20;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(enc_block1_fused_kernel, dim3(grid), dim3(256), 0, 0, a);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((enc_block1_fused_kernel<16, 25, 4, 66>), dim3(grid), dim3(256), 0, 0, a);
     unsigned long long zero[8] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(block1_probe), zero, sizeof(zero));
     (void)hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(enc_block1_fused_kernel, dim3(grid), dim3(256), 0, 0, a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((enc_block1_fused_kernel<16, 25, 4, 66>), dim3(grid), dim3(256), 0, 0, a);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms = 0;
