@@ -199,7 +199,10 @@ int mst_enc_set_tuning(MstEnc *enc, long rows_min_tiles);
  * stride 4) as two direct-kernel launches with the intermediate in HBM instead of the fused enc_stereo_block_kernel.  Same bits either way.
  * bit 4 (default off, bf16 mode): blocks 1 and 2 of the default encoder (16 -> 16, k = 25 with skip; 16 -> 32, k = 25, stride 4 / 32 -> 32, k = 15;
  * 32 -> 64, k = 15, stride 2) as their two conv launches each instead of the fused enc_block1_fused_kernel (intermediate in LDS, weights resident in registers); same operands, another fp32 summation
- * order: the two forms agree to accumulation rounding (one bf16 ulp on isolated elements). */
+ * order: the two forms agree to accumulation rounding (one bf16 ulp on isolated elements).
+ * bit 5 (default off, bf16 mode): the 128-channel layers (kernel 5 / 10, stride 1 / 2, input channels a multiple of 64, output length a multiple
+ * of 32) on the four-wave im2col kernel (enc_conv_nlc_kernel<4>) instead of enc_conv_taps_kernel (raw input rows staged once per 64-channel
+ * block by LDS-DMA, loader + matrix waves, 256-column tiles, split-K over channel blocks); same operands, another fp32 summation order. */
 int mst_enc_set_schedule(MstEnc *enc, int flags);
 /* nn.AdaptiveAvgPool1d(1) on its own (architectures.py:63,67; FXencoder(conv_block='conv') runs its ConvBlocks one by one through
  * mst_enc_forward_conv and pools here): x_dev fp32 [rows, L] -> y_dev[rows] = mean over L. */

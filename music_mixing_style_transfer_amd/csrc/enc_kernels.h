@@ -819,6 +819,175 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The 128-channel conv kernel on RAW INPUT ROWS with loader waves (round 5, bf16 mode): blocks 4 ... 11 of the default encoder.
+// enc_conv_nlc_kernel<4> stages an im2col B tile (128 columns x 64 k = 16 KB) per k-chunk and uses it for 16 MFMAs per wave: on the late
+// layers the B tiles (332 MB per launch) and the weight fragments (each crosses L2 -> CU once per 128-column tile: 336 MB) together run the
+// L2 at ~13 TB/s - that, not the matrix pipe (0.28 busy), bounds the launch (EXPERIMENTS.md D.12: loader waves on the same tiles and wider
+// tiles alone change nothing).  This kernel is built like the TCN's: a workgroup = 8 waves = 128 channels x 256 columns; per 64-CHANNEL BLOCK
+// the loader waves (4-7) fetch the input rows of the tile's columns ONCE by LDS-DMA (a 32-column sub-tile is 32 consecutive output steps of
+// one item: 31 s + k input rows of 128 bytes, mirrored at the item's ends) into one of two buffers, and the matrix waves (0-3: 32 channels x
+// 256 columns = 8 accumulator tiles of 32 x 32 each) walk ALL k taps over them - tap j of column n is row n s + j - so a staged byte feeds k
+// times the MFMAs (5-10 x less staging), a weight fragment twice the MFMAs, and there is ONE barrier per channel block (k chunks = 160-320
+// MFMAs per wave).  The k-chunks are the four-wave kernel's (chunk = tap j x 64-channel block cb: its A fragments are fetched as they lie),
+// visited block-major instead of tap-major; split-K runs over channel blocks.  Same products, another fp32 summation order.
+// ------------------------------------------------------------------------------------------------
+struct EncTapsArgs {
+    const __bf16 *x;     // [B][Lin][Cin]
+    __bf16 *y;           // [B][Lout][Cout]
+    float *part;         // split-K partial sums [S][Ntot][Cout] fp32 (null when S == 1)
+    const void *wpk;     // bf16 A fragments [co_tiles][nchunks][4][4][64][8], k = j * Cin + ci (enc_conv_nlc_kernel's image)
+    const float *shift;  // [co_tiles * 128]
+    int B, Cin, Lin, Cout, Lout, stride, ksz, pad_l, nchunks, residual, S;
+    long Ntot;
+    float slope;
+    const void *zeros;   // 16 bytes of zeros
+};
+template <int KSZ, int STRIDE>
+__global__ __launch_bounds__(512, 1) void enc_conv_taps_kernel(EncTapsArgs a) {
+    constexpr int MW = 4, MT = 128, NQ = 8, NT = 32 * NQ, RQ = 31 * STRIDE + KSZ;      // rows of a 32-column sub-tile
+    constexpr int NR = (NQ * RQ + 7) / 8 * 8, BUF = NR * 128, NP = NR / 8, NPW = (NP + 3) / 4;      // image rows (whole DMA pieces of 8), pieces, pieces per loader wave
+    static_assert(2 * BUF <= 160 * 1024 - 512, "two images fit the CU's LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char Bs[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool loader = wv >= 4;
+    const int w = wv & 3;
+    const long n0 = (long)blockIdx.x * NT;
+    const int cot = blockIdx.y, z = blockIdx.z;
+    const int nblk = a.Cin / 64;                                        // channel blocks; chunk (tap j, block cb) = j * nblk + cb
+    const int cb_lo = (int)((long)z * nblk / a.S), cb_hi = (int)((long)(z + 1) * nblk / a.S), nb = cb_hi - cb_lo;
+
+    if (loader) {
+        // ================================================================= loader waves: piece pi = w + 4 i = image rows 8 pi .. 8 pi + 7; lane = (row lane >> 3, position lane & 7)
+        const unsigned char *rowp[NPW];                                 // the lane's row in HBM at channel block 0, at its 16-byte piece; zeros: no such row
+        bool live[NPW];
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int R = 8 * (w + 4 * i) + (lane >> 3), q = R / RQ, r = R - q * RQ;
+            const long n = n0 + 32 * q;                                  // first column of the sub-tile: (item, first output step)
+            live[i] = w + 4 * i < NP && q < NQ && n < a.Ntot;
+            const long nn = live[i] ? n : 0;
+            const int b = (int)(nn / a.Lout), to = (int)(nn % a.Lout);
+            int ti = to * STRIDE - a.pad_l + r;
+            if (ti < 0) ti = -ti;
+            if (ti >= a.Lin) ti = 2 * (a.Lin - 1) - ti;
+            live[i] = live[i] && ti >= 0 && ti < a.Lin;
+            // position p of row R holds the 16-byte slot p ^ (R & 7)
+            rowp[i] = (const unsigned char *)(a.x + ((size_t)b * a.Lin + (live[i] ? ti : 0)) * a.Cin) + 16 * ((lane & 7) ^ (R & 7));
+        }
+        auto stage = [&](int cb, int buf) {
+#pragma unroll
+            for (int i = 0; i < NPW; ++i) {
+                if (w + 4 * i < NP) {                                     // uniform per wave
+                    const unsigned char *src = live[i] ? rowp[i] + (size_t)cb * 128 : (const unsigned char *)a.zeros;
+                    mst_dma16(src, Bs + buf * BUF + (w + 4 * i) * 1024);
+                }
+            }
+        };
+        if (nb > 0) stage(cb_lo, 0);
+        mst_dma_wait_barrier<0>();                                       // (P) block cb_lo has landed
+        for (int i = 0; i < nb; ++i) {
+            if (i + 1 < nb) stage(cb_lo + i + 1, (i + 1) & 1);           // the other buffer: everybody left it at barrier i - 1
+            mst_dma_wait_barrier<0>();                                   // (i) block i + 1 has landed; the matrix waves are done with block i
+        }
+        return;
+    }
+
+    // ===================================================================== matrix waves, 2 x 2: wave w = channels 64 (w & 1) .. + 63, columns 128 (w >> 1) .. + 127 of the tile:
+    // a B fragment (one ds_read_b128) feeds TWO MFMAs - with one read per MFMA four SIMDs ask for the CU's whole LDS bandwidth (128 B / clock) -
+    // an A fragment four; every weight fragment is fetched by the two waves of its channel half
+    __builtin_amdgcn_s_setprio(2);
+    const int ln = lane & 31, h = lane >> 5, mi2 = w & 1, ni2 = w >> 1;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ma][q][i] = 0.0f;
+    const unsigned wbytes = (unsigned)a.nchunks * 4u * MW * 64u * 16u;                      // one channel tile's fragments (host: < 2^31)
+    const MstStream16 ws = mst_stream16((const unsigned char *)a.wpk + (size_t)cot * wbytes, wbytes);
+    const unsigned wlane = (unsigned)((2 * mi2) * 64 + lane) * 16u;
+    bf16x8 A0[4][2], A1[4][2];
+    auto fetch_a = [&](bf16x8 (&A)[4][2], int t) {       // tap t of the sequence of all blocks' taps (clamped)
+        const int tt = t < nb * KSZ ? t : nb * KSZ - 1, ib = tt / KSZ, jt = tt - ib * KSZ, kc = jt * nblk + cb_lo + ib;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int ma = 0; ma < 2; ++ma)
+                A[ks][ma] = __builtin_bit_cast(bf16x8, mst_stream_load16(ws, wlane + ma * 1024u, (unsigned)(kc * 4 + ks) * (MW * 64u * 16u)));
+    };
+    if (nb > 0) fetch_a(A0, 0);
+    mst_dma_wait_barrier<63>();                                          // (P)
+    int t = 0, j = 0, blk = 0;                                           // tap of the sequence = (block blk, tap j)
+    // B fragments one k-step ahead (a ring of two sets of four): issued right in front of its MFMAs a read's LDS latency is exposed four times per tap
+    bf16x8 Bf[2][4];
+    auto read_b = [&](bf16x8 (&B)[4], int blkr, int jr, int ks) {
+        const unsigned char *bt = Bs + (blkr & 1) * BUF + (4 * ni2 * RQ + jr) * 128;
+        int lr = ln * STRIDE, hh = h;                    // (opaque per read set: hipcc otherwise keeps the swizzled addresses of all (tap, sub-tile) pairs live and spills)
+        asm volatile("" : "+v"(lr), "+v"(hh));
+        const int jj = jr + 4 * ni2 * RQ;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int R = q * RQ + lr, sw = (R + jj) & 7;
+            B[q] = *(const bf16x8 *)(bt + R * 128 + (((2 * ks + hh) ^ sw) << 4));
+        }
+    };
+    auto tap = [&](bf16x8 (&A)[4][2], bf16x8 (&Anext)[4][2]) {
+        if (blk >= nb) return;                                           // uniform
+        fetch_a(Anext, t + 1);
+        if (j == 0) read_b(Bf[0], blk, 0, 0);                            // a block's first fragments: its image has just landed (barrier)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) read_b(Bf[(ks + 1) & 1], blk, j, ks + 1);
+            else if (j + 1 < KSZ) read_b(Bf[0], blk, j + 1, 0);          // uniform
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int ma = 0; ma < 2; ++ma) acc[ma][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks][ma], Bf[ks & 1][q], acc[ma][q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                          // (keeps the reads of one k-step ahead, not of a whole tap)
+        }
+        ++t;
+        if (++j == KSZ) {
+            j = 0;
+            ++blk;
+            mst_dma_wait_barrier<63>();                                  // (blk - 1): done with this block's image; the next one has landed
+        }
+    };
+    while (blk < nb) {
+        tap(A0, A1);
+        tap(A1, A0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long n = n0 + 128 * ni2 + 32 * q + ln;
+        if (n < a.Ntot) {
+            const int b = (int)(n / a.Lout), to = (int)(n % a.Lout);
+#pragma unroll
+            for (int ma = 0; ma < 2; ++ma)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co0 = cot * MT + 64 * mi2 + 32 * ma + 8 * g + 4 * h;
+                    if (co0 < a.Cout) {
+                        if (a.part) {
+                            f32x4 o;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) o[i] = acc[ma][q][4 * g + i];
+                            *(f32x4 *)(a.part + ((size_t)z * a.Ntot + n) * a.Cout + co0) = o;
+                        } else {
+                            const f32x4 sh = *(const f32x4 *)(a.shift + co0);
+                            bf16x4 o, r = {0, 0, 0, 0};
+                            if (a.residual) r = *(const bf16x4 *)(a.x + ((size_t)b * a.Lin + to) * a.Cin + co0);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) o[i] = (__bf16)(enc_act(acc[ma][q][4 * g + i] + sh[i], a.slope) + (float)r[i]);
+                            *(bf16x4 *)(a.y + ((size_t)b * a.Lout + to) * a.Cout + co0) = o;
+                        }
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Res_ConvBlocks 1 and 2 of the default encoder in ONE launch each, bf16 mode (round 5): Conv1d_layer(C -> C, k, stride 1) + skip, then
 // Conv1d_layer(C -> 2 C, k, stride S) (network_utils.py:96-119) for (C, k, S) = (16, 25, 4) and (32, 15, 2).  The two launches a block took
 // (enc_conv_rows_kernel + enc_conv_nlc_kernel / enc_conv_rows_kernel: 50 + 34 us and 23 + 24 us per 32 segments) move the intermediate

@@ -843,7 +843,7 @@ extern "C" int mst_tcn_forward_blocks(MstTcn *t, const float *x, float *act, int
 struct MstEnc {
     MstEncDesc d;
     std::vector<MstEncConv> conv;   // 2 per block
-    int schedule = 1;               // bit 4: blocks 1 / 2 (bf16 mode) as two launches each instead of the fused kernel; bit 3: the stereo block as two direct-kernel launches instead of the fused kernel (the bit-identical reference form); bit 1: 2 x 2 wave tiling of the 128-channel conv kernel (measured slower: off); bit 0: weight-major workgroup order for the weight-heavy layers (mst_enc_set_schedule)
+    int schedule = 1;               // bit 5: the 128-channel layers on the four-wave im2col kernel instead of the raw-rows kernel with loader waves; bit 4: blocks 1 / 2 (bf16 mode) as two launches each instead of the fused kernel; bit 3: the stereo block as two direct-kernel launches instead of the fused kernel (the bit-identical reference form); bit 1: 2 x 2 wave tiling of the 128-channel conv kernel (measured slower: off); bit 0: weight-major workgroup order for the weight-heavy layers (mst_enc_set_schedule)
     void *zeros = nullptr;          // 256 bytes of zeros: what the channel-minor conv kernel fetches for rows / k-slots outside the problem
     long rows_min_tiles = 512;      // bf16 mode: layers with at least this many tiles keep their input rows resident in LDS (mst_enc_set_tuning)
 };
@@ -1023,7 +1023,7 @@ extern "C" int mst_enc_zero_stuff(const float *x, float *y, long rows, long L, i
 }
 
 extern "C" int mst_enc_set_schedule(MstEnc *e, int flags) {
-    if (!e || flags < 0 || flags > 31) return fail(MST_ERR_ARG, "mst_enc_set_schedule: flags 0..31");
+    if (!e || flags < 0 || flags > 63) return fail(MST_ERR_ARG, "mst_enc_set_schedule: flags 0..63");
     e->schedule = flags;
     return MST_OK;
 }
@@ -1147,6 +1147,18 @@ bool enc_nlc_eligible(const MstEnc *e) {
     return true;
 }
 
+// the raw-rows kernel (enc_conv_taps_kernel: 256-column tiles, one workgroup per CU): which layers it serves and its k-slices (over 64-channel
+// blocks): aim at one workgroup per CU of the chip - a second round of a few workgroups doubles the launch
+bool enc_taps_fits(const MstEncConv &c, int Lout) {
+    return c.mw == 4 && c.dil == 1 && c.cin % 64 == 0 && Lout % 32 == 0 && (c.ksz == 5 || c.ksz == 10) && (c.stride == 1 || c.stride == 2);
+}
+int enc_splitk_taps(long tiles256, int nblk) {
+    const long cus = mst_num_cus();
+    int S = (int)((cus + tiles256 / 2) / std::max(1L, tiles256));
+    if (S > 8) S = 8;
+    if (S > nblk) S = nblk;
+    return S < 1 ? 1 : S;
+}
 int enc_splitk(long tiles, int nchunks) {
     if (tiles >= 512) return 1;
     int S = (int)((768 + tiles - 1) / tiles);
@@ -1168,6 +1180,10 @@ size_t enc_scratch_floats(const MstEnc *e, int B, int L) {
             const int nch = (c.cin * c.ksz + 63) / 64;
             const int S = enc_splitk(tiles, nch);
             if (S > 1) mx = std::max(mx, (size_t)S * ntot * c.cout);
+            if (enc_taps_fits(c, which ? lout : len)) {
+                const int St = enc_splitk_taps(((ntot + 255) / 256) * ((c.cout + MT - 1) / MT), c.cin / 64);
+                if (St > 1) mx = std::max(mx, (size_t)St * ntot * c.cout);
+            }
             const int Sf = enc_splitk_f32(tiles, c.nchunks);          // exact-fp32 mode slices
             if (Sf > 1) mx = std::max(mx, (size_t)Sf * ntot * c.cout);
         }
@@ -1344,6 +1360,43 @@ int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scrat
             MST_CHECK_LAUNCH("enc_conv_rows_kernel");
             return MST_OK;
         }
+    }
+    if (!x3 && !(schedule & 2) && !(schedule & 32) && enc_taps_fits(c, Lout)) {          // the 128-channel layers on raw input rows with loader waves
+        EncTapsArgs t;
+        t.x = x;
+        t.y = y;
+        t.wpk = c.wpk_nlc;
+        t.shift = c.shift;
+        t.B = B;
+        t.Cin = c.cin;
+        t.Lin = Lin;
+        t.Cout = c.cout;
+        t.Lout = Lout;
+        t.stride = c.stride;
+        t.ksz = c.ksz;
+        t.pad_l = c.pad_l;
+        t.nchunks = c.nchunks64;
+        t.residual = residual;
+        t.Ntot = a.Ntot;
+        t.slope = c.slope;
+        t.zeros = zeros;
+        const long nt2 = (a.Ntot + 255) / 256;
+        t.S = enc_splitk_taps(nt2 * cotiles, c.cin / 64);
+        t.part = t.S > 1 ? scratch : nullptr;
+        const dim3 g2((unsigned)nt2, (unsigned)cotiles, (unsigned)t.S);
+        if (c.ksz == 5 && c.stride == 1) MST_LAUNCH((enc_conv_taps_kernel<5, 1>), g2, dim3(512), stream, t);
+        else if (c.ksz == 5) MST_LAUNCH((enc_conv_taps_kernel<5, 2>), g2, dim3(512), stream, t);
+        else if (c.stride == 1) MST_LAUNCH((enc_conv_taps_kernel<10, 1>), g2, dim3(512), stream, t);
+        else MST_LAUNCH((enc_conv_taps_kernel<10, 2>), g2, dim3(512), stream, t);
+        MST_CHECK_LAUNCH("enc_conv_taps_kernel");
+        if (t.S > 1) {
+            const long total = a.Ntot * (c.cout / 4);
+            MST_LAUNCH(enc_splitk_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), stream, (const float *)scratch,
+                       t.S, a.Ntot, c.cout, (const float *)c.shift, residual ? x : (const __bf16 *)nullptr, y,
+                       (const __bf16 *)nullptr, (__bf16 *)nullptr, c.slope);
+            MST_CHECK_LAUNCH("enc_splitk_finalize_kernel");
+        }
+        return MST_OK;
     }
     a.S = enc_splitk(ntiles * cotiles, c.nchunks64);
     a.part = a.S > 1 ? scratch : nullptr;

@@ -672,7 +672,43 @@ def test_encoder_wave_tilings_and_workgroup_orders_match_emulated(emu_default):
     emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 1), "schedule")
     assert float((ref32 - emb).abs().max()) <= 2e-5 * float(emb.abs().max())
     with pytest.raises(ValueError):
-        emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 32), "schedule")
+        emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 64), "schedule")
+
+
+def test_encoder_raw_rows_conv_kernel_emulated(emu_default):
+    """The 128-channel layers (blocks 4 ... 11 of the default encoder) on enc_conv_taps_kernel - 256-column tiles, the input rows of a 64-channel block
+    staged once by LDS-DMA and every tap read from them, loader + matrix waves, split-K over channel blocks - against the four-wave im2col kernel
+    (mst_enc_set_schedule bit 5): same bf16 operands, another fp32 summation order (block-major instead of tap-major chunks, other k-slices):
+    agreement to accumulation rounding, and the oracle at the bf16 tolerance.  All four instantiations (k = 5 / 10, stride 1 / 2), tiles that end
+    inside the batch (columns beyond N), mirrored rows at both ends of every item, one and several channel blocks, layers that keep the old kernel
+    (output lengths that are not multiples of 32)."""
+    from music_mixing_style_transfer_amd.networks import FXencoder
+    for cfg, shapes in (({"channels": [16, 64, 128, 256], "kernels": [25, 10, 10, 5], "strides": [4, 2, 2, 1]}, ((3, 2, 4096), (1, 2, 2048))),
+                        ({"channels": [16, 64, 128, 128, 256], "kernels": [25, 10, 10, 5, 5], "strides": [4, 2, 1, 2, 1]}, ((2, 2, 4096), (5, 2, 1024), (1, 2, 3000)))):
+        cfg = dict(cfg, dilation=[1] * len(cfg["kernels"]), bias=True, norm="batch", conv_block="res", activation="relu")
+        sd = synth.fxencoder_state_dict(cfg, seed=31)
+        enc = FXencoder({k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()})
+        enc.load_state_dict(sd)
+        enc.precision = "bf16"
+        nb = len(cfg["kernels"])
+        for shape in shapes:
+            x = synth.synth_audio(shape, seed=shape[2] + shape[0])
+            col = []
+            R.fxencoder_blocks(x, sd, cfg, collect=col)
+            run = enc._get_runner()
+            run._ensure(emu_default)
+            for n in range(3, nb + 1):
+                emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 1 | 32), "schedule")      # four-wave im2col kernel
+                ref = enc.forward_blocks(x, n).clone()
+                emu_default.check(emu_default.mst_enc_set_schedule(run.handle, 1), "schedule")           # raw rows + loader waves (default)
+                got = enc.forward_blocks(x, n)
+                scale = float(col[n - 1].abs().max())
+                assert got.shape == col[n - 1].shape
+                assert float((got - ref).abs().max()) <= 1.6e-2 * scale, (shape, n, float((got - ref).abs().max()), scale)
+                assert float((got - ref).abs().mean()) <= 3e-4 * scale, (shape, n)
+                assert float((got - col[n - 1]).abs().max()) <= 3e-2 * scale, (shape, n)
+            emb = R.fxencoder_forward(sd, cfg, x)
+            assert float((enc(x) - emb).abs().max()) <= 3e-2 * float(emb.abs().max())
 
 
 def test_encoder_fused_stereo_block_emulated(emu_default):

@@ -391,6 +391,42 @@ def test_encoder_fused_block1_agrees_with_its_two_launches(nets):
         enc.precision = "fp32"
 
 
+def test_encoder_raw_rows_conv_kernel_agrees_with_the_im2col_kernel(nets):
+    """Blocks 4 ... 11 of the default encoder (bf16 mode) run on enc_conv_taps_kernel - 128 channels x 256 columns per workgroup, the input rows of a
+    64-channel block staged once by LDS-DMA and every tap read from them, loader + matrix waves, split-K over channel blocks;
+    `mst_enc_set_schedule` bit 5 selects the four-wave im2col kernel it replaced.  Same bf16 operands, another fp32 summation order: every block's
+    output agrees to accumulation rounding (isolated elements a bf16 ulp apart), the embedding to 1e-2 of its scale - at BASELINE's batch of 32
+    segments, for a batch whose last tile ends inside the batch, and at a ragged length where only some layers qualify (output lengths that are
+    multiples of 32)."""
+    from music_mixing_style_transfer_amd import _lib
+    from music_mixing_style_transfer_amd.utils import synth
+    lib = _lib.lib()
+    enc = nets["enc"]
+    enc.precision = "bf16"
+    try:
+        for shape in ((32, 2, 131072), (5, 2, 131072), (3, 2, 65536), (2, 2, 30011)):
+            x = synth.synth_audio(shape, seed=shape[0] + shape[2]).cuda()
+            run = enc._get_runner()
+            run._ensure(lib)
+            for nb in (5, 8, 12):
+                lib.check(lib.mst_enc_set_schedule(run.handle, 1 | 32), "schedule")
+                ref = enc.forward_blocks(x, nb).cpu()
+                lib.check(lib.mst_enc_set_schedule(run.handle, 1), "schedule")
+                got = enc.forward_blocks(x, nb).cpu()
+                scale = float(ref.abs().max())
+                d = (got - ref).abs()
+                print(f"FXencoder blocks 1..{nb} raw-rows vs im2col kernel at {shape}: max {float(d.max()):.3e}, mean {float(d.mean()):.3e} (scale {scale:.2f})")
+                assert float(d.max()) <= 3e-2 * scale and float(d.mean()) <= 1e-3 * scale, (shape, nb)
+            lib.check(lib.mst_enc_set_schedule(run.handle, 1 | 32), "schedule")
+            e0 = enc(x).cpu()
+            lib.check(lib.mst_enc_set_schedule(run.handle, 1), "schedule")
+            e1 = enc(x).cpu()
+            assert float((e1 - e0).abs().max()) <= 1e-2 * float(e0.abs().max()), shape
+    finally:
+        lib.check(lib.mst_enc_set_schedule(enc._get_runner().handle, 1), "schedule")
+        enc.precision = "fp32"
+
+
 def test_encoder_bf16_vs_oracle(nets):
     from music_mixing_style_transfer_amd.utils import synth
     from oracle import networks_ref as R
