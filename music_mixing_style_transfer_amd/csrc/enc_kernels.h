@@ -835,7 +835,7 @@ struct EncTapsArgs {
     const __bf16 *x;     // [B][Lin][Cin]
     __bf16 *y;           // [B][Lout][Cout]
     float *part;         // split-K partial sums [S][Ntot][Cout] fp32 (null when S == 1)
-    const void *wpk;     // bf16 A fragments [co_tiles][nchunks][4][4][64][8], k = j * Cin + ci (enc_conv_nlc_kernel's image)
+    const void *wpk;     // bf16 A fragments of v_mfma_f32_16x16x32_bf16 [co_tiles][nchunks][2][8][64][8] (enc_taps_pack)
     const float *shift;  // [co_tiles * 128]
     int B, Cin, Lin, Cout, Lout, stride, ksz, pad_l, nchunks, residual, S;
     long Ntot;
@@ -844,7 +844,7 @@ struct EncTapsArgs {
 };
 template <int KSZ, int STRIDE>
 __global__ __launch_bounds__(512, 1) void enc_conv_taps_kernel(EncTapsArgs a) {
-    constexpr int MW = 4, MT = 128, NQ = 8, NT = 32 * NQ, RQ = 31 * STRIDE + KSZ;      // rows of a 32-column sub-tile
+    constexpr int MT = 128, NQ = 8, NT = 32 * NQ, RQ = 31 * STRIDE + KSZ;      // rows of a 32-column sub-tile
     constexpr int NR = (NQ * RQ + 7) / 8 * 8, BUF = NR * 128, NP = NR / 8, NPW = (NP + 3) / 4;      // image rows (whole DMA pieces of 8), pieces, pieces per loader wave
     static_assert(2 * BUF <= 160 * 1024 - 512, "two images fit the CU's LDS");
     __shared__ __attribute__((aligned(1024))) unsigned char Bs[2 * BUF];
@@ -892,59 +892,62 @@ __global__ __launch_bounds__(512, 1) void enc_conv_taps_kernel(EncTapsArgs a) {
         return;
     }
 
-    // ===================================================================== matrix waves, 2 x 2: wave w = channels 64 (w & 1) .. + 63, columns 128 (w >> 1) .. + 127 of the tile:
-    // a B fragment (one ds_read_b128) feeds TWO MFMAs - with one read per MFMA four SIMDs ask for the CU's whole LDS bandwidth (128 B / clock) -
-    // an A fragment four; every weight fragment is fetched by the two waves of its channel half
+    // ===================================================================== matrix waves, 2 x 2: wave w = channels 64 (w & 1) .. + 63, columns 128 (w >> 1) .. + 127 of the tile,
+    // on v_mfma_f32_16x16x32_bf16 (four row tiles x eight column tiles of 16 x 16 = 128 accumulator registers): a B fragment (one ds_read_b128) feeds
+    // FOUR MFMAs, an A fragment eight.  (A first form on v_mfma_f32_32x32x16_bf16 - the four-wave kernel's instruction and weight image - ran 45 us
+    // on the 2048 -> 2048 layers whatever its operand traffic: knock-out builds without the weight stream and without the LDS reads took the same
+    // time, i.e. that instruction stream itself issued at ~76 nominal clocks per MFMA; the TCN's 16 x 16 x 32 stream sustains twice that.)
     __builtin_amdgcn_s_setprio(2);
-    const int ln = lane & 31, h = lane >> 5, mi2 = w & 1, ni2 = w >> 1;
-    f32x16 acc[2][4];
+    const int n16 = lane & 15, kg = lane >> 4, mi2 = w & 1, ni2 = w >> 1;
+    f32x4 acc[4][8];
 #pragma unroll
-    for (int ma = 0; ma < 2; ++ma)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[ma][q][i] = 0.0f;
-    const unsigned wbytes = (unsigned)a.nchunks * 4u * MW * 64u * 16u;                      // one channel tile's fragments (host: < 2^31)
+        for (int c = 0; c < 8; ++c) acc[m][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // A fragments: w16[channel tile][chunk = tap * nblk + block][k-step 0..1][row tile 0..7][lane] x 16 bytes (enc_taps_pack)
+    const unsigned wbytes = (unsigned)a.nchunks * 2u * 8u * 64u * 16u;                      // one channel tile's fragments (host: < 2^31)
     const MstStream16 ws = mst_stream16((const unsigned char *)a.wpk + (size_t)cot * wbytes, wbytes);
-    const unsigned wlane = (unsigned)((2 * mi2) * 64 + lane) * 16u;
-    bf16x8 A0[4][2], A1[4][2];
-    auto fetch_a = [&](bf16x8 (&A)[4][2], int t) {       // tap t of the sequence of all blocks' taps (clamped)
+    const unsigned wlane = (unsigned)((4 * mi2) * 64 + lane) * 16u;
+    bf16x8 A0[2][4], A1[2][4];
+    auto fetch_a = [&](bf16x8 (&A)[2][4], int t) {       // tap t of the sequence of all blocks' taps (clamped)
         const int tt = t < nb * KSZ ? t : nb * KSZ - 1, ib = tt / KSZ, jt = tt - ib * KSZ, kc = jt * nblk + cb_lo + ib;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-            for (int ma = 0; ma < 2; ++ma)
-                A[ks][ma] = __builtin_bit_cast(bf16x8, mst_stream_load16(ws, wlane + ma * 1024u, (unsigned)(kc * 4 + ks) * (MW * 64u * 16u)));
+            for (int m = 0; m < 4; ++m)
+                A[kh][m] = __builtin_bit_cast(bf16x8, mst_stream_load16(ws, wlane + m * 1024u, (unsigned)(kc * 2 + kh) * (8u * 64u * 16u)));
     };
     if (nb > 0) fetch_a(A0, 0);
     mst_dma_wait_barrier<63>();                                          // (P)
     int t = 0, j = 0, blk = 0;                                           // tap of the sequence = (block blk, tap j)
-    // B fragments one k-step ahead (a ring of two sets of four): issued right in front of its MFMAs a read's LDS latency is exposed four times per tap
+    // B fragments half a k-step ahead (a ring of two sets of four column tiles)
     bf16x8 Bf[2][4];
-    auto read_b = [&](bf16x8 (&B)[4], int blkr, int jr, int ks) {
-        const unsigned char *bt = Bs + (blkr & 1) * BUF + (4 * ni2 * RQ + jr) * 128;
-        int lr = ln * STRIDE, hh = h;                    // (opaque per read set: hipcc otherwise keeps the swizzled addresses of all (tap, sub-tile) pairs live and spills)
-        asm volatile("" : "+v"(lr), "+v"(hh));
-        const int jj = jr + 4 * ni2 * RQ;
+    auto read_b = [&](bf16x8 (&B)[4], int blkr, int jr, int grp) {     // group grp = 2 kh + hq: k-step kh, column tiles 4 hq .. 4 hq + 3 of the wave
+        const int kh = grp >> 1, hq = grp & 1;
+        const unsigned char *bt = Bs + (blkr & 1) * BUF + ((4 * ni2 + 2 * hq) * RQ + jr) * 128;
+        int lr = n16 * STRIDE, kk = kg;                  // (opaque per read set: hipcc otherwise keeps the swizzled addresses of all (tap, column tile) pairs live and spills)
+        asm volatile("" : "+v"(lr), "+v"(kk));
+        const int jj = jr + (4 * ni2 + 2 * hq) * RQ;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int R = q * RQ + lr, sw = (R + jj) & 7;
-            B[q] = *(const bf16x8 *)(bt + R * 128 + (((2 * ks + hh) ^ sw) << 4));
+        for (int c = 0; c < 4; ++c) {                                    // column tile 4 hq + c: 32-column sub-tile 2 hq + (c >> 1) of the wave's four, its half c & 1
+            const int R = (c >> 1) * RQ + (c & 1) * 16 * STRIDE + lr, sw = (R + jj) & 7;
+            B[c] = *(const bf16x8 *)(bt + R * 128 + (((4 * kh + kk) ^ sw) << 4));
         }
     };
-    auto tap = [&](bf16x8 (&A)[4][2], bf16x8 (&Anext)[4][2]) {
+    auto tap = [&](bf16x8 (&A)[2][4], bf16x8 (&Anext)[2][4]) {
         if (blk >= nb) return;                                           // uniform
         fetch_a(Anext, t + 1);
         if (j == 0) read_b(Bf[0], blk, 0, 0);                            // a block's first fragments: its image has just landed (barrier)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks < 3) read_b(Bf[(ks + 1) & 1], blk, j, ks + 1);
+        for (int grp = 0; grp < 4; ++grp) {
+            if (grp < 3) read_b(Bf[(grp + 1) & 1], blk, j, grp + 1);
             else if (j + 1 < KSZ) read_b(Bf[0], blk, j + 1, 0);          // uniform
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int ma = 0; ma < 2; ++ma) acc[ma][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks][ma], Bf[ks & 1][q], acc[ma][q], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);                          // (keeps the reads of one k-step ahead, not of a whole tap)
+                for (int m = 0; m < 4; ++m)
+                    acc[m][4 * (grp & 1) + c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[grp >> 1][m], Bf[grp & 1][c], acc[m][4 * (grp & 1) + c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                          // (keeps the reads of one group ahead, not of a whole tap)
         }
         ++t;
         if (++j == KSZ) {
@@ -957,34 +960,44 @@ __global__ __launch_bounds__(512, 1) void enc_conv_taps_kernel(EncTapsArgs a) {
         tap(A0, A1);
         tap(A1, A0);
     }
+    // D: lane (n16, kg) holds rows 4 kg .. 4 kg + 3 of a row tile = four consecutive channels of one column
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const long n = n0 + 128 * ni2 + 32 * q + ln;
+    for (int c = 0; c < 8; ++c) {
+        const long n = n0 + 128 * ni2 + 16 * c + n16;
         if (n < a.Ntot) {
             const int b = (int)(n / a.Lout), to = (int)(n % a.Lout);
 #pragma unroll
-            for (int ma = 0; ma < 2; ++ma)
+            for (int m = 0; m < 4; ++m) {
+                const int co0 = cot * MT + 64 * mi2 + 16 * m + 4 * kg;
+                if (co0 < a.Cout) {
+                    if (a.part) {
+                        *(f32x4 *)(a.part + ((size_t)z * a.Ntot + n) * a.Cout + co0) = acc[m][c];
+                    } else {
+                        const f32x4 sh = *(const f32x4 *)(a.shift + co0);
+                        bf16x4 o, r = {0, 0, 0, 0};
+                        if (a.residual) r = *(const bf16x4 *)(a.x + ((size_t)b * a.Lin + to) * a.Cin + co0);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int co0 = cot * MT + 64 * mi2 + 32 * ma + 8 * g + 4 * h;
-                    if (co0 < a.Cout) {
-                        if (a.part) {
-                            f32x4 o;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) o[i] = acc[ma][q][4 * g + i];
-                            *(f32x4 *)(a.part + ((size_t)z * a.Ntot + n) * a.Cout + co0) = o;
-                        } else {
-                            const f32x4 sh = *(const f32x4 *)(a.shift + co0);
-                            bf16x4 o, r = {0, 0, 0, 0};
-                            if (a.residual) r = *(const bf16x4 *)(a.x + ((size_t)b * a.Lin + to) * a.Cin + co0);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) o[i] = (__bf16)(enc_act(acc[ma][q][4 * g + i] + sh[i], a.slope) + (float)r[i]);
-                            *(bf16x4 *)(a.y + ((size_t)b * a.Lout + to) * a.Cout + co0) = o;
-                        }
+                        for (int i = 0; i < 4; ++i) o[i] = (__bf16)(enc_act(acc[m][c][i] + sh[i], a.slope) + (float)r[i]);
+                        *(bf16x4 *)(a.y + ((size_t)b * a.Lout + to) * a.Cout + co0) = o;
                     }
                 }
+            }
         }
     }
+}
+// host side: the A fragments of enc_conv_taps_kernel for BN-folded weights w[Cout][Cin][ksz] (Cin a multiple of 64): image
+// [channel tile of 128][chunk = tap * (Cin / 64) + block][k-step 0..1][row tile 0..7][lane (row = l & 15, kg = l >> 4)][8]: k = 32 kh + 8 kg + e inside the block
+inline void enc_taps_pack(const float *w, int cout, int cin, int ksz, __bf16 *img) {
+    const int nblk = cin / 64, cot = (cout + 127) / 128;
+    for (int ct = 0; ct < cot; ++ct)
+        for (int kc = 0; kc < ksz * nblk; ++kc)
+            for (int kh = 0; kh < 2; ++kh)
+                for (int rt = 0; rt < 8; ++rt)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 8; ++e) {
+                            const int co = ct * 128 + 16 * rt + (l & 15), j = kc / nblk, ci = 64 * (kc % nblk) + 32 * kh + 8 * (l >> 4) + e;
+                            img[(((((size_t)ct * ksz * nblk + kc) * 2 + kh) * 8 + rt) * 64 + l) * 8 + e] = (__bf16)(co < cout ? w[((size_t)co * cin + ci) * ksz + j] : 0.0f);
+                        }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -60,6 +60,7 @@ struct MstEncConv {
     __bf16 *wpk16 = nullptr;
     int *ktab = nullptr;
     float *w_direct = nullptr;   // [Cout][Cin][ksz] folded fp32 (layers with Cin < 8: direct kernel)
+    __bf16 *w_taps = nullptr;    // 128-channel layers (Cin a multiple of 64, k = 5 / 10): enc_conv_taps_kernel's A fragments (enc_taps_pack)
     __bf16 *w_frag16 = nullptr;  // blocks 1 / 2 of the default encoder (Cin = 16, k = 25 / Cin = 32, k = 15): the fused kernel's bf16 A fragments, one 16-row tile after the other (enc_block1_pack)
     float *w_frag = nullptr;     // stereo block (Cin = 2, k = 25): the fused kernel's fp32 MFMA A fragments (enc_stereo_pack_a0 / _a1)
     __bf16 *wpk_nlc = nullptr;   // NLC pipeline A fragments, k = j*Cin + ci, K-chunk 64
@@ -892,6 +893,7 @@ extern "C" int mst_enc_destroy(MstEnc *e) {
         (void)hipFree(c.w_direct);
         (void)hipFree(c.w_frag);
         (void)hipFree(c.w_frag16);
+        (void)hipFree(c.w_taps);
         (void)hipFree(c.wpk_nlc);
         (void)hipFree(c.wpk_nlc_lo);
         (void)hipFree(c.stab);
@@ -985,6 +987,14 @@ extern "C" int mst_enc_load_conv(MstEnc *e, int block, int which, const float *w
         }
         if ((rc = upload(&c.wpk_nlc, wn))) return rc;
         if ((rc = upload(&c.wpk_nlc_lo, wl))) return rc;
+        if (c.mw == 4 && c.dil == 1 && c.cin % 64 == 0 && (c.ksz == 5 || c.ksz == 10)) {          // the raw-rows kernel's fragment image
+            std::vector<float> wf((size_t)c.cout * K);
+            for (int co = 0; co < c.cout; ++co)
+                for (int k = 0; k < K; ++k) wf[(size_t)co * K + k] = w[(size_t)co * K + k] * scale[co];
+            std::vector<__bf16> img((size_t)((c.cout + 127) / 128) * c.ksz * (c.cin / 64) * 2 * 8 * 64 * 8);
+            enc_taps_pack(wf.data(), c.cout, c.cin, c.ksz, img.data());
+            if ((rc = upload(&c.w_taps, img))) return rc;
+        }
         if (c.dil == 1 && ((c.cin == 16 && c.ksz == 25) || (c.cin == 32 && c.ksz == 15)) && (c.cout == c.cin || c.cout == 2 * c.cin)) {
             // blocks 1 / 2 of the default encoder: the fused kernel's fragments, one 16-row tile after the other
             std::vector<float> wf((size_t)c.cout * K);
@@ -1150,7 +1160,7 @@ bool enc_nlc_eligible(const MstEnc *e) {
 // the raw-rows kernel (enc_conv_taps_kernel: 256-column tiles, one workgroup per CU): which layers it serves and its k-slices (over 64-channel
 // blocks): aim at one workgroup per CU of the chip - a second round of a few workgroups doubles the launch
 bool enc_taps_fits(const MstEncConv &c, int Lout) {
-    return c.mw == 4 && c.dil == 1 && c.cin % 64 == 0 && Lout % 32 == 0 && (c.ksz == 5 || c.ksz == 10) && (c.stride == 1 || c.stride == 2);
+    return c.mw == 4 && c.dil == 1 && c.cin % 64 == 0 && Lout % 32 == 0 && (c.ksz == 5 || c.ksz == 10) && (c.stride == 1 || c.stride == 2) && c.w_taps;
 }
 int enc_splitk_taps(long tiles256, int nblk) {
     const long cus = mst_num_cus();
@@ -1365,7 +1375,7 @@ int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scrat
         EncTapsArgs t;
         t.x = x;
         t.y = y;
-        t.wpk = c.wpk_nlc;
+        t.wpk = c.w_taps;
         t.shift = c.shift;
         t.B = B;
         t.Cin = c.cin;
