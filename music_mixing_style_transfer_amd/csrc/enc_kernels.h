@@ -985,19 +985,19 @@ __global__ __launch_bounds__(512, 1) void enc_conv_taps_kernel(EncTapsArgs a) {
         }
     }
 }
-// host side: the A fragments of enc_conv_taps_kernel for BN-folded weights w[Cout][Cin][ksz] (Cin a multiple of 64): image
-// [channel tile of 128][chunk = tap * (Cin / 64) + block][k-step 0..1][row tile 0..7][lane (row = l & 15, kg = l >> 4)][8]: k = 32 kh + 8 kg + e inside the block
-inline void enc_taps_pack(const float *w, int cout, int cin, int ksz, __bf16 *img) {
-    const int nblk = cin / 64, cot = (cout + 127) / 128;
-    for (int ct = 0; ct < cot; ++ct)
-        for (int kc = 0; kc < ksz * nblk; ++kc)
+// host side: the A fragments of enc_conv_taps_kernel for weights w[Cout][Cin][ksz] times the BN scale of their channel (Cin a multiple of 64), channel tile ct
+// of the image [channel tile of 128][chunk = tap * (Cin / 64) + block][k-step 0..1][row tile 0..7][lane (row = l & 15, kg = l >> 4)][8]: k = 32 kh + 8 kg + e inside the block
+inline void enc_taps_pack(const float *w, const float *scale, int cout, int cin, int ksz, int ct, __bf16 *img) {
+    const int nblk = cin / 64;
+    for (int j = 0; j < ksz; ++j)
+        for (int cb = 0; cb < nblk; ++cb)
             for (int kh = 0; kh < 2; ++kh)
                 for (int rt = 0; rt < 8; ++rt)
-                    for (int l = 0; l < 64; ++l)
-                        for (int e = 0; e < 8; ++e) {
-                            const int co = ct * 128 + 16 * rt + (l & 15), j = kc / nblk, ci = 64 * (kc % nblk) + 32 * kh + 8 * (l >> 4) + e;
-                            img[(((((size_t)ct * ksz * nblk + kc) * 2 + kh) * 8 + rt) * 64 + l) * 8 + e] = (__bf16)(co < cout ? w[((size_t)co * cin + ci) * ksz + j] : 0.0f);
-                        }
+                    for (int l = 0; l < 64; ++l) {
+                        const int co = ct * 128 + 16 * rt + (l & 15), ci0 = 64 * cb + 32 * kh + 8 * (l >> 4);
+                        __bf16 *q = img + (((((size_t)ct * ksz * nblk + (j * nblk + cb)) * 2 + kh) * 8 + rt) * 64 + l) * 8;
+                        for (int e = 0; e < 8; ++e) q[e] = (__bf16)(co < cout ? w[((size_t)co * cin + ci0 + e) * ksz + j] * scale[co] : 0.0f);
+                    }
 }
 
 // ------------------------------------------------------------------------------------------------

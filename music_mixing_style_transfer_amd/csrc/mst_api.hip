@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "enc_kernels.h"
@@ -42,6 +43,21 @@ template <typename T> int upload(T **dev, const std::vector<T> &host) {
 }
 
 // eval-mode BatchNorm as y = x*scale + shift
+// host-side weight packing of the large encoder layers (81 M parameters, five images): the independent tiles of an image on a few threads
+template <typename F> void host_parallel_for(int n, F fn) {
+    const int nt = std::max(1, std::min({n, 16, (int)std::thread::hardware_concurrency()}));
+    if (nt == 1) {
+        for (int i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([=]() {
+            for (int i = t; i < n; i += nt) fn(i);
+        });
+    for (auto &t : th) t.join();
+}
+
 void bn_fold(const float *w, const float *b, const float *mean, const float *var, float eps, int c,
              std::vector<float> &scale, std::vector<float> &shift) {
     scale.resize(c);
@@ -79,7 +95,7 @@ int pack_conv_f32(MstEncConv &c, const float *w, const std::vector<float> &scale
     const int MT = 32 * c.mw, K = c.cin * c.ksz;
     const int co_tiles = (c.cout + MT - 1) / MT;
     std::vector<float> wp((size_t)co_tiles * c.nchunks * 16 * MT, 0.0f);
-    for (int cot = 0; cot < co_tiles; ++cot)
+    host_parallel_for(co_tiles, [&](int cot) {
         for (int kc = 0; kc < c.nchunks; ++kc)
             for (int kr = 0; kr < 16; ++kr) {
                 const int k = kc * 16 + kr;
@@ -89,6 +105,7 @@ int pack_conv_f32(MstEncConv &c, const float *w, const std::vector<float> &scale
                     if (co < c.cout) wp[(((size_t)cot * c.nchunks + kc) * 16 + kr) * MT + m] = w[(size_t)co * K + k] * scale[co];
                 }
             }
+    });
     std::vector<int> kt((size_t)c.nchunks32 * 32 * 2);
     for (int k = 0; k < c.nchunks32 * 32; ++k) {
         kt[2 * k] = k < K ? k / c.ksz : -1;
@@ -930,7 +947,7 @@ extern "C" int mst_enc_load_conv(MstEnc *e, int block, int which, const float *w
     for (int co = 0; co < c.cout; ++co) sh[co] = shift[co] + (bias ? bias[co] * scale[co] : 0.0f);
     // bf16 A fragments of v_mfma_f32_32x32x16_bf16: [cot][kc32][ks][mi][lane][e]
     std::vector<__bf16> wp16((size_t)co_tiles * c.nchunks32 * 2 * c.mw * 64 * 8);
-    for (int cot = 0; cot < co_tiles; ++cot)
+    host_parallel_for(co_tiles, [&](int cot) {
         for (int kc = 0; kc < c.nchunks32; ++kc)
             for (int ks = 0; ks < 2; ++ks)
                 for (int mi = 0; mi < c.mw; ++mi)
@@ -941,6 +958,7 @@ extern "C" int mst_enc_load_conv(MstEnc *e, int block, int which, const float *w
                             const float v = (co < c.cout && k < K) ? w[(size_t)co * K + k] * scale[co] : 0.0f;
                             wp16[((((((size_t)cot * c.nchunks32 + kc) * 2 + ks) * c.mw + mi) * 64 + l) * 8) + e] = (__bf16)v;
                         }
+    });
     std::vector<int> kt((size_t)c.nchunks32 * 32 * 2);
     for (int k = 0; k < c.nchunks32 * 32; ++k) {
         kt[2 * k] = k < K ? k / c.ksz : -1;
@@ -965,7 +983,7 @@ extern "C" int mst_enc_load_conv(MstEnc *e, int block, int which, const float *w
         // NLC pipeline: contraction index k = j*Cin + ci; fragments [cot][kc64][ks 0..3][mi][lane][e]
         c.nchunks64 = (K + 63) / 64;
         std::vector<__bf16> wn((size_t)co_tiles * c.nchunks64 * 4 * c.mw * 64 * 8), wl(wn.size());
-        for (int cot = 0; cot < co_tiles; ++cot)
+        host_parallel_for(co_tiles, [&](int cot) {
             for (int kc = 0; kc < c.nchunks64; ++kc)
                 for (int ks = 0; ks < 4; ++ks)
                     for (int mi = 0; mi < c.mw; ++mi)
@@ -979,6 +997,7 @@ extern "C" int mst_enc_load_conv(MstEnc *e, int block, int which, const float *w
                                 wn[at] = (__bf16)v;
                                 wl[at] = (__bf16)(v - (float)wn[at]);
                             }
+        });
         std::vector<int> st((size_t)c.nchunks64 * 8 * 2);
         for (int sidx = 0; sidx < c.nchunks64 * 8; ++sidx) {
             const int k0 = sidx * 8;
@@ -988,11 +1007,8 @@ extern "C" int mst_enc_load_conv(MstEnc *e, int block, int which, const float *w
         if ((rc = upload(&c.wpk_nlc, wn))) return rc;
         if ((rc = upload(&c.wpk_nlc_lo, wl))) return rc;
         if (c.mw == 4 && c.dil == 1 && c.cin % 64 == 0 && (c.ksz == 5 || c.ksz == 10)) {          // the raw-rows kernel's fragment image
-            std::vector<float> wf((size_t)c.cout * K);
-            for (int co = 0; co < c.cout; ++co)
-                for (int k = 0; k < K; ++k) wf[(size_t)co * K + k] = w[(size_t)co * K + k] * scale[co];
             std::vector<__bf16> img((size_t)((c.cout + 127) / 128) * c.ksz * (c.cin / 64) * 2 * 8 * 64 * 8);
-            enc_taps_pack(wf.data(), c.cout, c.cin, c.ksz, img.data());
+            host_parallel_for((c.cout + 127) / 128, [&](int ct) { enc_taps_pack(w, scale.data(), c.cout, c.cin, c.ksz, ct, img.data()); });
             if ((rc = upload(&c.w_taps, img))) return rc;
         }
         if (c.dil == 1 && ((c.cin == 16 && c.ksz == 25) || (c.cin == 32 && c.ksz == 15)) && (c.cout == c.cin || c.cout == 2 * c.cin)) {
