@@ -680,11 +680,11 @@ def test_encoder_raw_rows_conv_kernel_emulated(emu_default):
     staged once by LDS-DMA and every tap read from them, loader + matrix waves, split-K over channel blocks - against the four-wave im2col kernel
     (mst_enc_set_schedule bit 5): same bf16 operands, another fp32 summation order (block-major instead of tap-major chunks, other k-slices):
     agreement to accumulation rounding, and the oracle at the bf16 tolerance.  All four instantiations (k = 5 / 10, stride 1 / 2), tiles that end
-    inside the batch (columns beyond N), mirrored rows at both ends of every item, one and several channel blocks, layers that keep the old kernel
-    (output lengths that are not multiples of 32)."""
+    inside the batch (columns beyond N), mirrored rows at both ends of every item, one and several channel blocks, items of 32 columns (the shortest the kernel takes: eight items per tile), layers that keep
+    the old kernel (output lengths that are not multiples of 32)."""
     from music_mixing_style_transfer_amd.networks import FXencoder
     for cfg, shapes in (({"channels": [16, 64, 128, 256], "kernels": [25, 10, 10, 5], "strides": [4, 2, 2, 1]}, ((3, 2, 4096), (1, 2, 2048))),
-                        ({"channels": [16, 64, 128, 128, 256], "kernels": [25, 10, 10, 5, 5], "strides": [4, 2, 1, 2, 1]}, ((2, 2, 4096), (5, 2, 1024), (1, 2, 3000)))):
+                        ({"channels": [16, 64, 128, 128, 256], "kernels": [25, 10, 10, 5, 5], "strides": [4, 2, 1, 2, 1]}, ((2, 2, 4096), (5, 2, 1024), (1, 2, 3000), (3, 2, 512)))):
         cfg = dict(cfg, dilation=[1] * len(cfg["kernels"]), bias=True, norm="batch", conv_block="res", activation="relu")
         sd = synth.fxencoder_state_dict(cfg, seed=31)
         enc = FXencoder({k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()})
