@@ -797,7 +797,7 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
                     } else {
                         const f32x4 sh = *(const f32x4 *)(a.shift + co0);
                         bf16x4 o, r = {0, 0, 0, 0};
-                        if (a.residual) r = *(const bf16x4 *)(a.x + ((size_t)b * a.Lin + to) * a.Cin + co0);
+                        if (a.residual) r = *(const bf16x4 *)(a.x + (size_t)n * a.Cin + co0);
                         if constexpr (X3) {
                             bf16x4 rl = {0, 0, 0, 0}, ol;
                             if (a.residual) rl = *(const bf16x4 *)(a.xlo + ((size_t)b * a.Lin + to) * a.Cin + co0);
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(256) void enc_conv_nlc_kernel(EncNlcArgs a) {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) o[i] = (__bf16)(enc_act(acc[q][4 * g + i] + sh[i], a.slope) + (float)r[i]);
                         }
-                        *(bf16x4 *)(a.y + ((size_t)b * a.Lout + to) * a.Cout + co0) = o;
+                        *(bf16x4 *)(a.y + (size_t)n * a.Cout + co0) = o;
                     }
                 }
             }
@@ -865,14 +865,16 @@ __global__ __launch_bounds__(512, 1) void enc_conv_taps_kernel(EncTapsArgs a) {
             const int R = 8 * (w + 4 * i) + (lane >> 3), q = R / RQ, r = R - q * RQ;
             const long n = n0 + 32 * q;                                  // first column of the sub-tile: (item, first output step)
             live[i] = w + 4 * i < NP && q < NQ && n < a.Ntot;
-            const long nn = live[i] ? n : 0;
-            const int b = (int)(nn / a.Lout), to = (int)(nn % a.Lout);
+            const unsigned nn = live[i] ? (unsigned)n : 0u;                // (host: Ntot < 2^31 - one 32-bit division per piece on the way to the first DMA)
+            const int b = (int)(nn / (unsigned)a.Lout), to = (int)(nn - (unsigned)b * (unsigned)a.Lout);
             int ti = to * STRIDE - a.pad_l + r;
             if (ti < 0) ti = -ti;
             if (ti >= a.Lin) ti = 2 * (a.Lin - 1) - ti;
             live[i] = live[i] && ti >= 0 && ti < a.Lin;
             // position p of row R holds the 16-byte slot p ^ (R & 7)
             rowp[i] = (const unsigned char *)(a.x + ((size_t)b * a.Lin + (live[i] ? ti : 0)) * a.Cin) + 16 * ((lane & 7) ^ (R & 7));
+            // the first block's piece leaves as soon as its pointer exists (the HBM latency of piece i under the address arithmetic of piece i + 1)
+            if (nb > 0 && w + 4 * i < NP) mst_dma16(live[i] ? rowp[i] + (size_t)cb_lo * 128 : (const unsigned char *)a.zeros, Bs + (w + 4 * i) * 1024);
         }
         auto stage = [&](int cb, int buf) {
 #pragma unroll
@@ -883,7 +885,6 @@ __global__ __launch_bounds__(512, 1) void enc_conv_taps_kernel(EncTapsArgs a) {
                 }
             }
         };
-        if (nb > 0) stage(cb_lo, 0);
         mst_dma_wait_barrier<0>();                                       // (P) block cb_lo has landed
         for (int i = 0; i < nb; ++i) {
             if (i + 1 < nb) stage(cb_lo + i + 1, (i + 1) & 1);           // the other buffer: everybody left it at barrier i - 1
@@ -964,8 +965,7 @@ __global__ __launch_bounds__(512, 1) void enc_conv_taps_kernel(EncTapsArgs a) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const long n = n0 + 128 * ni2 + 16 * c + n16;
-        if (n < a.Ntot) {
-            const int b = (int)(n / a.Lout), to = (int)(n % a.Lout);
+        if (n < a.Ntot) {                                                // (column n = (item, step) of y, and - a residual layer keeps the shape - of x)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const int co0 = cot * MT + 64 * mi2 + 16 * m + 4 * kg;
@@ -975,10 +975,10 @@ __global__ __launch_bounds__(512, 1) void enc_conv_taps_kernel(EncTapsArgs a) {
                     } else {
                         const f32x4 sh = *(const f32x4 *)(a.shift + co0);
                         bf16x4 o, r = {0, 0, 0, 0};
-                        if (a.residual) r = *(const bf16x4 *)(a.x + ((size_t)b * a.Lin + to) * a.Cin + co0);
+                        if (a.residual) r = *(const bf16x4 *)(a.x + (size_t)n * a.Cin + co0);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) o[i] = (__bf16)(enc_act(acc[m][c][i] + sh[i], a.slope) + (float)r[i]);
-                        *(bf16x4 *)(a.y + ((size_t)b * a.Lout + to) * a.Cout + co0) = o;
+                        *(bf16x4 *)(a.y + (size_t)n * a.Cout + co0) = o;
                     }
                 }
             }
@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(256) void enc_conv_nlc22_kernel(EncNlcArgs a) {
                         } else {
                             const f32x4 sh = *(const f32x4 *)(a.shift + co0);
                             bf16x4 o, r = {0, 0, 0, 0};
-                            if (a.residual) r = *(const bf16x4 *)(a.x + ((size_t)b * a.Lin + to) * a.Cin + co0);
+                            if (a.residual) r = *(const bf16x4 *)(a.x + (size_t)n * a.Cin + co0);
                             if constexpr (X3) {
                                 bf16x4 rl = {0, 0, 0, 0}, ol;
                                 if (a.residual) rl = *(const bf16x4 *)(a.xlo + ((size_t)b * a.Lin + to) * a.Cin + co0);
@@ -1362,7 +1362,7 @@ __global__ __launch_bounds__(256) void enc_conv_nlc22_kernel(EncNlcArgs a) {
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) o[i] = (__bf16)(enc_act(acc[ma][q][4 * g + i] + sh[i], a.slope) + (float)r[i]);
                             }
-                            *(bf16x4 *)(a.y + ((size_t)b * a.Lout + to) * a.Cout + co0) = o;
+                            *(bf16x4 *)(a.y + (size_t)n * a.Cout + co0) = o;
                         }
                     }
                 }

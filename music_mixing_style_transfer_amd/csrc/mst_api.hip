@@ -1387,7 +1387,7 @@ int enc_launch_nlc(const MstEncConv &c, const __bf16 *x, __bf16 *y, float *scrat
             return MST_OK;
         }
     }
-    if (!x3 && !(schedule & 2) && !(schedule & 32) && enc_taps_fits(c, Lout)) {          // the 128-channel layers on raw input rows with loader waves
+    if (!x3 && !(schedule & 2) && !(schedule & 32) && enc_taps_fits(c, Lout) && a.Ntot < 0x7fffff00L && (!residual || (Lin == Lout && c.cin == c.cout))) {          // the 128-channel layers on raw input rows with loader waves
         EncTapsArgs t;
         t.x = x;
         t.y = y;
