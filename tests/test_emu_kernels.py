@@ -684,7 +684,9 @@ def test_encoder_raw_rows_conv_kernel_emulated(emu_default):
     the old kernel (output lengths that are not multiples of 32)."""
     from music_mixing_style_transfer_amd.networks import FXencoder
     for cfg, shapes in (({"channels": [16, 64, 128, 256], "kernels": [25, 10, 10, 5], "strides": [4, 2, 2, 1]}, ((3, 2, 4096), (1, 2, 2048))),
-                        ({"channels": [16, 64, 128, 128, 256], "kernels": [25, 10, 10, 5, 5], "strides": [4, 2, 1, 2, 1]}, ((2, 2, 4096), (5, 2, 1024), (1, 2, 3000), (3, 2, 512)))):
+                        ({"channels": [16, 64, 128, 128, 256], "kernels": [25, 10, 10, 5, 5], "strides": [4, 2, 1, 2, 1]}, ((2, 2, 4096), (5, 2, 1024), (1, 2, 3000), (3, 2, 512))),
+                        # channel counts that are no multiples of 128 (a last channel tile of 64 valid rows) and three channel blocks (uneven k-slices)
+                        ({"channels": [16, 64, 192, 320], "kernels": [25, 10, 5, 10], "strides": [4, 2, 2, 1]}, ((2, 2, 2048), (3, 2, 1024)))):
         cfg = dict(cfg, dilation=[1] * len(cfg["kernels"]), bias=True, norm="batch", conv_block="res", activation="relu")
         sd = synth.fxencoder_state_dict(cfg, seed=31)
         enc = FXencoder({k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()})

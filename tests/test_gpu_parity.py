@@ -427,6 +427,40 @@ def test_encoder_raw_rows_conv_kernel_agrees_with_the_im2col_kernel(nets):
         enc.precision = "fp32"
 
 
+def test_encoder_raw_rows_kernel_odd_channel_counts_on_gpu():
+    """enc_conv_taps_kernel away from the default encoder's shapes: channel counts that are no multiples of 128 (a last channel tile with 64 valid rows),
+    three channel blocks (uneven k-slices of the split-K), items of 32 columns, a batch whose tiles end inside it - against the four-wave im2col kernel
+    (accumulation rounding) and the oracle (bf16 tolerance)."""
+    from music_mixing_style_transfer_amd import _lib
+    from music_mixing_style_transfer_amd.networks import FXencoder
+    from music_mixing_style_transfer_amd.utils import synth
+    from oracle import networks_ref as R
+    lib = _lib.lib()
+    cfg = {"channels": [16, 64, 192, 320], "kernels": [25, 10, 5, 10], "strides": [4, 2, 2, 1], "dilation": [1] * 4,
+           "bias": True, "norm": "batch", "conv_block": "res", "activation": "relu"}
+    sd = synth.fxencoder_state_dict(cfg, seed=31)
+    enc = FXencoder({k: (list(v) if isinstance(v, list) else v) for k, v in cfg.items()})
+    enc.load_state_dict(sd)
+    enc.precision = "bf16"
+    for shape in ((2, 2, 2048), (3, 2, 512), (7, 2, 4096)):
+        x = synth.synth_audio(shape, seed=shape[0] + shape[2])
+        col = []
+        R.fxencoder_blocks(x, sd, cfg, collect=col)
+        xd = x.cuda()
+        run = enc._get_runner()
+        run._ensure(lib)
+        lib.check(lib.mst_enc_set_schedule(run.handle, 1 | 32), "schedule")
+        ref = enc.forward_blocks(xd, 4).cpu()
+        lib.check(lib.mst_enc_set_schedule(run.handle, 1), "schedule")
+        got = enc.forward_blocks(xd, 4).cpu()
+        scale = float(col[3].abs().max())
+        d = (got - ref).abs()
+        print(f"FXencoder 192 -> 320 channels, raw-rows vs im2col kernel at {shape}: max {float(d.max()):.3e} mean {float(d.mean()):.3e} (scale {scale:.2f})")
+        assert got.shape == col[3].shape
+        assert float(d.max()) <= 1.6e-2 * scale and float(d.mean()) <= 3e-4 * scale, shape
+        assert float((got - col[3]).abs().max()) <= 3e-2 * scale, shape
+
+
 def test_encoder_bf16_vs_oracle(nets):
     from music_mixing_style_transfer_amd.utils import synth
     from oracle import networks_ref as R
