@@ -179,7 +179,8 @@ typedef struct {
 int mst_enc_create(const MstEncDesc *desc, MstEnc **out);
 int mst_enc_destroy(MstEnc *enc);
 /* which = 0: encoder.{block}.conv1 (cin->cin, stride 1), 1: encoder.{block}.conv2 (cin->cout, stride s).
- * w [cout, cin, k]; bias [cout] or NULL; BN arrays [cout]. */
+ * w [cout, cin, k]; bias [cout] or NULL; BN arrays [cout].  Host side: BN folding and the MFMA-fragment images of the layer (fp32, bf16, bf16 hi / lo, raw-rows),
+ * packed on up to 16 short-lived host threads (one per 128-channel tile) before the synchronous upload; the default encoder's 81 M weights load in a few hundred ms. */
 int mst_enc_load_conv(MstEnc *enc, int block, int which, const float *w, const float *bias,
                       const float *bn_weight, const float *bn_bias, const float *bn_mean, const float *bn_var,
                       float bn_eps, void *stream);
