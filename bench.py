@@ -133,11 +133,15 @@ def cpu_baseline(enc_cfg, enc_sd, tcn_sd):
     from music_mixing_style_transfer_amd.utils import synth
     cfg = dict(enc_cfg)
 
+    keep = {}
+
     def one(x):
         t0 = time.perf_counter()
         emb = R.fxencoder_forward(enc_sd, cfg, x)
-        R.tcn_forward(tcn_sd, x, emb.mean(0, keepdim=True))
-        return time.perf_counter() - t0
+        y = R.tcn_forward(tcn_sd, x, emb.mean(0, keepdim=True))
+        dt = time.perf_counter() - t0
+        keep[x.shape[-1]] = y
+        return dt
 
     all_cores = torch.get_num_threads()
     x = synth.synth_audio((1, 2, SEG_LEN), seed=1)
@@ -156,7 +160,8 @@ def cpu_baseline(enc_cfg, enc_sd, tcn_sd):
         t1 = statistics.median([one(xs) for _ in range(2)]) * 8.0
     finally:
         torch.set_num_threads(all_cores)
-    return {"value": 1.0 / statistics.median(ts), "unit": "segments/s", "cores": cores, "kind": "port",
+    return {"y_ref": keep[SEG_LEN], "x": x,
+            "value": 1.0 / statistics.median(ts), "unit": "segments/s", "cores": cores, "kind": "port",
             "samples_s": [round(t, 3) for t in ts], "thread_sweep_s": {str(k): round(v, 3) for k, v in sweep.items()},
             "value_all_cores": 1.0 / sweep[all_cores], "host_cores": all_cores, "value_1thread": 1.0 / t1,
             "sample": f"FXencoder+TCN fp32 forward of 1 segment of 2x{SEG_LEN} (oracle/networks_ref.py, torch-CPU): one warm-up, one sample "
@@ -310,7 +315,7 @@ def bench_track60(enc, tcn, world, rank, dist, dev, steps, warmup, with_host=Tru
     out = {"workload": f"configs[4]: one 60-min stereo stem = {n_seg} segments of 2x{SEG_LEN} (reference and input role), "
                        f"contiguous segment shards over {world} GPU(s), all-gather of [{n_seg}, 2048] embeddings, "
                        f"passes of <= {eng.pass_samples // SEG_LEN} segments",
-           "scaling": "strong", "segments": n_seg, "segments_rank0": hi - lo, "n_gpus": world,
+           "scaling": "strong", "segments": n_seg, "segments_rank0": hi - lo, "segments_rank_local": hi - lo, "n_gpus": world,
            "value": n_seg / t_res, "unit": "segments/s", "t_ms": t_res * 1e3}
     if with_host:
         h_in, h_ref = x_in.cpu().pin_memory(), x_ref.cpu().pin_memory()
@@ -392,8 +397,18 @@ def bench_fx_chain(dev, steps=5):
         out = chain([x])[0]
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    ref = F.fx_chain(x[17].cpu().numpy(), compressor_fn=_oracle_c_compressor())
+    x17, c_comp = x[17].cpu().numpy(), _oracle_c_compressor()
+    ref = F.fx_chain(x17, compressor_fn=c_comp)
     dev_max = float(np.abs(out[17].cpu().numpy() - ref).max())
+    # the oracle chain (numpy / scipy float64 + the C compressor of oracle/fx_ref.c) on this host, ONE thread, a bounded sample: median of 5 segments
+    ts = []
+    for k in range(5):
+        xk = x[20 + k].cpu().numpy()
+        tc = time.perf_counter()
+        F.fx_chain(xk, compressor_fn=c_comp)
+        ts.append(time.perf_counter() - tc)
+    cpu = {"value": 1.0 / statistics.median(ts), "unit": "segments/s", "cores": 1, "kind": "port",
+           "sample": "oracle/fx_ref.py chain (scipy lfilter EQ, oracle/fx_ref.c compressor, numpy imager / gain / rms) on 5 segments of [131072, 2], median, 1 thread"}
     # row f-3 beside it: the convolution reverb (1.5 s stereo impulse response) on the same batch - the library's own FFT kernels
     from music_mixing_style_transfer_amd.mixing_manipulator import ConvolutionalReverb
     from music_mixing_style_transfer_amd.utils import synth
@@ -426,7 +441,7 @@ def bench_fx_chain(dev, steps=5):
                          "frac_on_traffic": round(traffic / dt / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None,
                          "equivalent_unfused_GBps": alg / dt / 1e9, "unfused_bytes_survey_8d": alg},
             "max_abs_vs_oracle": dev_max, "probe": "item 17 vs oracle/fx_ref.py chain (EQ parity unpinned, see DESIGN.md)",
-            "tolerance": "2e-6 * max|ref|",
+            "tolerance": "2e-6 * max|ref|", "cpu_baseline": cpu,
             "conv_reverb": {"value": n / rv_dt, "unit": "segments/s", "ms_per_batch": rv_dt * 1e3, "ir_samples": Lh,
                             "rel_dev_vs_oracle": rv_dev, "what": "ConvolutionalReverb.process on the same 64 segments, 1.5 s stereo response"}}
 
@@ -500,8 +515,14 @@ def main():
         dist.all_reduce(seen)
         ranks_seen = int(seen.item())
         assert ranks_seen == args.gpus, (ranks_seen, args.gpus)
+        comm = {"backend": backend}
+        if backend == "nccl":
+            try:
+                comm["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:          # the build of torch decides whether the query exists; the run does not depend on it
+                comm["rccl_version"] = f"unknown ({type(e).__name__})"
     else:
-        ranks_seen = 1
+        ranks_seen, comm = 1, None
 
     from music_mixing_style_transfer_amd import _lib
     from music_mixing_style_transfer_amd.inference import StyleTransferEngine, build_models
@@ -531,9 +552,21 @@ def main():
     dtype = {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3"}[args.precision]
     base = {"n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
             "dtype": dtype, "data": "synthetic"}
+    if comm is not None:
+        base["comm"] = comm
+
+    def per_rank(n):
+        """[n of rank 0, n of rank 1, ...]: what every rank says it owns, gathered with the job's own backend (proof that N ranks worked)"""
+        if world == 1:
+            return [int(n)]
+        t = torch.tensor([int(n)], dtype=torch.int64, device=dev if comm["backend"] == "nccl" else "cpu")
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        return [int(g.item()) for g in got]
 
     if args.workload == "track60":
         tr = bench_track60(enc, tcn, world, rank, dist, dev, args.steps, args.warmup)
+        tr["segments_rank"] = per_rank(tr["segments_rank_local"])
         if rank == 0:
             out = dict(base, metric="stereo 44.1 kHz segments/sec (FXencoder+MixFXcloner fwd)", value=tr["value"],
                        unit="segments/s", ms_per_step=tr["t_ms"], scaling="strong",
@@ -552,6 +585,8 @@ def main():
     track = None
     if args.workload == "all" and args.precision == "bf16":
         track = bench_track60(enc, tcn, world, rank, dist, dev, 2, 1)
+        track["segments_rank"] = per_rank(track["segments_rank_local"])
+    seg_rank = per_rank(B)
 
     if rank == 0:
         # HBM bytes per launch of the dominant kernel: PMC counters need their own rocprofv3 passes (tools/pmc_traffic.py), so the figure is a
@@ -575,7 +610,7 @@ def main():
                     f"synthetic weights, {args.precision} MFMA (fp32 accumulate)")
         out = dict(base, metric="stereo 44.1 kHz segments/sec (FXencoder+MixFXcloner fwd)",
                    value=world * B * args.steps / dt, unit="segments/s", ms_per_step=dt / args.steps * 1e3, scaling="weak",
-                   config={"workload": workload, "segments_per_gpu": B, "segment_length": SEG_LEN,
+                   config={"workload": workload, "segments_per_gpu": B, "segment_length": SEG_LEN, "segments_rank": seg_rank,
                            "parallelism": f"segment-sharded x{world}, all-gather of embeddings"},
                    step_ms={k: round(v, 3) for k, v in (stats.get("step_ms") or {}).items()},
                    roofline=slim_roofline(rl))
@@ -596,7 +631,8 @@ def main():
                                                  frac_of_bf16_peak=457.6e9 * B / 32 / (fe_ms * 1e-3) / 1e12 / PEAK["bf16"] * MFMA_PER_FLOP[args.precision])
         if track is not None:
             details["track60"] = track
-            out["track60"] = {"value": round(track["value"], 1), "ms": round(track["t_ms"], 1), "segments": track["segments"], "scaling": "strong"}
+            out["track60"] = {"value": round(track["value"], 1), "ms": round(track["t_ms"], 1), "segments": track["segments"], "scaling": "strong",
+                              "segments_rank": track["segments_rank"]}
             if "pcie_inclusive" in track:
                 out["track60"]["pcie_value"] = round(track["pcie_inclusive"]["value"], 1)
             for k in ("t1_ms_same_job", "efficiency_t1_over_n_tn"):
@@ -622,6 +658,7 @@ def main():
                                "max_abs_vs_oracle": fx["max_abs_vs_oracle"], "traffic": fx["roofline"]["traffic"],
                                "traffic_over_algorithmic": fx["roofline"]["traffic_over_algorithmic"],
                                "frac_on_traffic": fx["roofline"]["frac_on_traffic"],
+                               "cpu_baseline": {"value": round(fx["cpu_baseline"]["value"], 2), "unit": "segments/s", "cores": 1, "kind": "port"},
                                "conv_reverb": {"value": round(fx["conv_reverb"]["value"]), "ms": round(fx["conv_reverb"]["ms_per_batch"], 3),
                                                "rel_dev_vs_oracle": fx["conv_reverb"]["rel_dev_vs_oracle"]}}
             nz = bench_input_normalizer()
@@ -630,6 +667,14 @@ def main():
             out["file_to_file"] = {"value": round(f2f["value"], 4), "unit": f2f.get("unit", "s/song")}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(enc_cfg, enc_sd, tcn_sd)
+            xs, y_ref = cb.pop("x"), cb.pop("y_ref")
+            # the headline precision against the oracle AT the headline's segment length: the segment the CPU baseline just converted
+            # (reference role = input role, like its sample), one item through the same engine
+            y_dev, _ = engine.step(xs.to(dev), xs.to(dev))
+            out["max_abs_vs_oracle"] = float((y_dev.cpu() - y_ref).abs().max())
+            out["tolerance"] = {"bf16": 1e-2, "fp32": 1e-4, "bf16x3": 1e-4}[args.precision]
+            details["headline"]["max_abs_vs_oracle"] = {"value": out["max_abs_vs_oracle"], "tolerance": out["tolerance"],
+                                                        "probe": f"1 reference + 1 input segment of 2x{SEG_LEN} (the CPU baseline's sample) vs oracle/networks_ref.py"}
             details["cpu_baseline"] = cb
             out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
                                    "sample": f"oracle/networks_ref.py (torch-CPU fp32), 1 segment of 2x{SEG_LEN}, warm median of 3 at {cb['cores']} threads"}

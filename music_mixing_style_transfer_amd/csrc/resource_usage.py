@@ -1,6 +1,6 @@
 """Print VGPR/AGPR/LDS/occupancy per kernel from hipcc -Rpass-analysis=kernel-resource-usage."""
-import re, subprocess, sys
-out = subprocess.run(["make", "-s", "resource-usage"], capture_output=True, text=True).stderr
+import os, re, subprocess, sys
+out = subprocess.run(["make", "-s", "resource-usage"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stderr
 cur = {}
 rows = []
 for line in out.splitlines():

@@ -151,8 +151,12 @@ __device__ __forceinline__ void tcn_class_major_whole_tile(f32x4 (&acc)[2][NC], 
 // A/B at 32 x 131072): the d = 4096 / 8192 blocks skip 10 % / 20 % of their MFMAs but run 1.58 -> 1.85 / 1.57 -> 1.74 ms - the wave-uniform
 // branches around the MFMA pairs break the (mfma, mfma, ds_read) software pipeline; the split-bf16 kernel (6 MFMAs per branch) gains 3-5 %
 constexpr int TCN_LIVE_MIN_P = 16;
-template <int P, bool FUSE_OUT, int NQ>
+// WHOLE (round 6): every tile of the launch spans its whole phase sequence (tiles_step == 1 and ceil(L / d) == MT: the host checks) - the
+// kernel holds ONLY the unrolled class-major loop.  With both loops in one kernel (chosen per workgroup) the register allocation was the
+// maximum over the two and <4, false, 4> spilled 10 VGPRs at three workgroups per CU (44 bytes of scratch per lane); split, neither form spills.
+template <int P, bool FUSE_OUT, int NQ, bool WHOLE = false>
 __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1))) void tcn_block_bf16_kernel(TcnBlockArgs a) {
+    static_assert(!WHOLE || ((P == 8 || P == 4) && NQ == 4), "whole-sequence tiles: 128 times of four / eight phases");
     constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NC = 2 * NQ;
     __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
     __shared__ __attribute__((aligned(16))) float par[4 * 128];     // shift | FiLM r | FiLM b | res of this block / batch item
@@ -291,20 +295,20 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
                 }
             }
         };
-        if constexpr ((P == 8 || P == 4) && NQ == 4) {
-            // only the tile that spans its WHOLE phase sequence takes the unrolled class-major form (the one-sided forms for a sequence of two
-            // tiles - 10 % fewer MFMAs each - were measured slower in the tap-major order: two unrolled 12 KB loops alternating on a CU)
-            if (m0 == 0 && MT == nsteps) tcn_class_major_whole_tile<P, NC>(acc, smem, wst, aoff, l16, g);          // workgroup-uniform
-            else tap_major();
-        } else {
-            tap_major();
-        }
+        // only a tile that spans its WHOLE phase sequence takes the unrolled class-major form (the one-sided forms for a sequence of two
+        // tiles - 10 % fewer MFMAs each - were measured slower in the tap-major order: two unrolled 12 KB loops alternating on a CU)
+        if constexpr (WHOLE) tcn_class_major_whole_tile<P, NC>(acc, smem, wst, aoff, l16, g);
+        else tap_major();
     }
 
     // ---- fused epilogue
     // residual inputs (centre tap rows) -> registers, then the input tile is dead and LDS is reused to transpose
     // the output tile so that global stores are whole 256-byte rows, 16 B per lane.  A lane's four accumulator rows of a tile are four
     // consecutive channels co0 .. co0 + 3 of output time 16 q + l16.
+    // The row pass behind the epilogue starts from an OPAQUE copy of the thread index: its lane coordinates (slot, row, time, pointers) equal
+    // the staging pass's, and hipcc otherwise keeps them alive across the main loop - at three workgroups per CU that was the spill.
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
     bf16x4 xin[2][NC];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2 * T / 256; ++i) {
-            const int idx = tid + 256 * i, c = idx / T, o = idx % T;
+            const int idx = tid_e + 256 * i, c = idx / T, o = idx % T;
             const long t = (long)(m0 + o / P) * a.d + phi0 + (o % P);
             if (c < a.nout && t < a.L) {
                 const float v = part[(0 * 2 + c) * T + o] + part[(1 * 2 + c) * T + o] + part[(2 * 2 + c) * T + o] +
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
         }
     } else {
         __syncthreads();
-        const int slot = tid & 15, prow = tid >> 4;
+        const int slot = tid_e & 15, prow = tid_e >> 4;
         const long dt = (long)(16 / P) * a.d;
         long t = (long)(m0 + prow / P) * a.d + phi0 + (prow % P);
         __bf16 *dstp = yb + t * 128 + slot * 8;

@@ -14,7 +14,7 @@ def _ensure_hip_library():
     never builds implicitly - it fails loudly without the library."""
     csrc = os.path.join(REPO, "music_mixing_style_transfer_amd", "csrc")
     if os.path.exists("/opt/rocm/bin/hipcc"):
-        subprocess.run(["make", "-C", csrc], check=False, capture_output=True)
+        subprocess.run(["make", "-j4", "-C", csrc], check=False, capture_output=True)
 
 
 def pytest_configure(config):

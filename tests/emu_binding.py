@@ -28,5 +28,5 @@ class EmuBinding(_lib.Binding):
 
 def bind_emulator(build=True):
     if build:
-        subprocess.run(["make", "-C", EMU_DIR], check=True, capture_output=True)
+        subprocess.run(["make", "-j4", "-C", EMU_DIR], check=True, capture_output=True)
     return EmuBinding(EMU_LIB)

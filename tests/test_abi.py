@@ -11,7 +11,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def hip_lib():
-    subprocess.run(["make", "-C", os.path.join(REPO, "music_mixing_style_transfer_amd", "csrc")], check=True, capture_output=True)
+    subprocess.run(["make", "-j4", "-C", os.path.join(REPO, "music_mixing_style_transfer_amd", "csrc")], check=True, capture_output=True)
     from music_mixing_style_transfer_amd import _lib
     return _lib.bind(_lib.LIB_PATH)
 

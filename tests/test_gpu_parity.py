@@ -1472,7 +1472,7 @@ def test_bench_two_ranks_gloo_prints_the_strong_scaling_efficiency():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["scaling"] == "strong" and out["track60"]["segments"] == 1212
-    assert out["track60"]["segments_rank0"] == 606
+    assert out["track60"]["segments_rank0"] == 606 and out["track60"]["segments_rank"] == [606, 606] and out["comm"]["backend"] == "gloo"
     eff = out["track60"]["efficiency_t1_over_n_tn"]
     assert 0.2 < eff <= 0.6, eff
     assert abs(eff - out["track60"]["t1_ms_same_job"] / (2 * out["track60"]["t_ms"])) < 1e-9

@@ -177,9 +177,10 @@ struct EncNlcArgs {""")
     }
 """, NB, NE)
     open(p, "w").write(s)
-    p = os.path.join(DST, "mst_api.hip")
+    hp = os.path.join(DST, "mst_host.h")
+    open(hp, "w").write(open(hp).read().replace('#include "../../include/mst_hip.h"', '#include "../../../include/mst_hip.h"'))
+    p = os.path.join(DST, "mst_tcn.hip")          # the translation unit that holds the TCN kernels (and so the probe array)
     s = open(p).read()
-    s = s.replace('#include "../../include/mst_hip.h"', '#include "../../../include/mst_hip.h"')
     s += '''
 extern "C" int mst_probe_read(long long *out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mst_tcn_probe), 32 * sizeof(long long)) != hipSuccess) return -3;
@@ -191,7 +192,7 @@ extern "C" int mst_probe_read(long long *out, int reset) {
     mk = os.path.join(DST, "Makefile")
     text = open(mk).read().replace("../../include/mst_hip.h", "../../../include/mst_hip.h")
     open(mk, "w").write(text)
-    subprocess.run(["make", "-C", DST], check=True)
+    subprocess.run(["make", "-j4", "-C", DST], check=True)
     subprocess.run(["cp", os.path.join(DST, "libmst_hip.so"), os.path.join(R, "tools", "_ab", "probe.so")], check=True)
     print("built tools/_ab/probe.so")
 
