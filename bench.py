@@ -430,7 +430,7 @@ def bench_fx_chain(dev, steps=5):
     # what the chain REALLY moves: FETCH_SIZE / WRITE_SIZE counter passes over its kernels (tools/gpu_fx_pmc.sh -> profiles/*fx_chain_traffic.json;
     # offline: counters need their own rocprofv3 passes).  `achieved` / `frac` stay on the ALGORITHMIC basis (one read + one write of the audio,
     # 16 L per segment - what a perfectly fused chain would move); `frac_on_traffic` is the measured bytes over the same time.
-    traffic, tsrc = stored_traffic("r05_fx_chain_traffic.json", "fx")
+    traffic, tsrc = stored_traffic("r06_fx_chain_traffic.json", "fx")
     return {"workload": "configs[3]: EQ -> rms -> compressor -> rms -> imager -> rms -> gain on 64 segments of [131072, 2]",
             "value": n / dt, "unit": "segments/s", "ms_per_chain": dt * 1e3,
             "roofline": {"bound": "hbm", "achieved": 16 * L * n / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -593,7 +593,7 @@ def main():
         # stored one - printed only when it was measured on this build of the kernels and with the default tuning flags, else null + the reason
         traffic, tsrc = (None, "counter file covers the bf16 headline workload with the default tuning flags only")
         if args.precision == "bf16" and B == BATCH and args.tcn_tuning in (None, _lib.TCN_TUNING_DEFAULT):
-            traffic, tsrc = stored_traffic("r05_tcn_block_bf16_traffic.json", "tcn")
+            traffic, tsrc = stored_traffic("r06_tcn_block_bf16_traffic.json", "tcn")
         rl = roofline(block_ms, nb, B, args.precision, traffic, fused0=stats.get("fused0", False))
         rl["timed_forwards"] = nf
         rl["traffic_source"] = tsrc

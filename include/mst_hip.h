@@ -112,6 +112,29 @@ int mst_tcn_forward(MstTcn *tcn, const float *x_dev, float *y_dev, int B, int L,
 int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int B, int L, int precision, int n_run,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- Kernel-form switches at a glance (round 6) ------------------------------------------------------------------------------------------
+ * None of them changes WHAT is computed; "=" bit-identical to the default, "~" equal up to fp32 summation order.  The library keeps no
+ * process-wide switch: every one lives in a handle or in the arguments of one call.  Defaults are the measured-fastest forms.
+ *
+ *   where                          bit / field            default  selects                                                  result  why it is still here
+ *   mst_tcn_set_tuning (handle)    bit 0                  1        bf16x3: 128-time tiles of <= 2 phases, 2 workgroups / CU   ~       256-time form needed where < 64 steps per phase
+ *                                  bits 1-2 = 2           2        bf16: persistent duo kernel (matrix + loader waves)       ~/=     form 0 runs the blocks the duo form cannot (d >= 4096 at 131072, fused head, odd d)
+ *                                  bit 3, form 1          -        (removed kernels: rejected with MST_ERR_ARG)
+ *                                  bit 4                  1        bf16 duo: class-major main loop                           ~       tap-major loop = the P = 1 path and the GPU test's other side
+ *                                  bit 5                  1        bf16: block 0 inside the d = 2 block's launch             =       separate block-0 kernel = probes, other precisions, short segments
+ *                                  bit 6                  1        bf16x3: class-major loop in the eight-phase half kernel    ~       other side of a GPU test
+ *   mst_enc_set_tuning (handle)    rows_min_tiles         512      bf16: rows-resident conv kernel from this many tiles on    =       small layers run the im2col kernel
+ *   mst_enc_set_schedule (handle)  bit 0                  1        weight-major workgroup order of weight-heavy layers        =
+ *                                  bit 1                  0        2 x 2 wave tiling of the 128-channel kernel (slower)       ~       A/B record only
+ *                                  bit 2                  0        fp32: 64-bit gather addresses                              =       the path > 4 GiB activations take anyway (test hook)
+ *                                  bit 3                  0        stereo block as two direct launches                        =       reference form of the fused kernel's bit-identity test
+ *                                  bit 4                  0        blocks 1 / 2 as two launches each                          ~       reference form of the fused kernel's test
+ *                                  bit 5                  0        128-channel layers on the four-wave im2col kernel          ~       reference form of the raw-rows kernel's test; layers the raw-rows kernel cannot take
+ *   MstFxFuse.forms (per call)     EQ_LANE_APPLY          0        stereo equaliser apply pass, one lane per chunk            =       reference form of a GPU / emulator test; non-stereo path
+ *                                  EQ_VALU_ENDS           0        stereo equaliser state pass on VALU dot products           =       reference form; chunk lengths that are no multiple of 16
+ *                                  COMP_SLICE_SMALL       0        compressor: three time slices whatever the size            =       lets small emulated problems take the pipelined path
+ * (mst_fx_set_tuning - a process-wide switch - left the ABI in round 6.)
+ * ------------------------------------------------------------------------------------------------------------------------------------------ */
 /* tuning flags (choose between forms of the block kernels; flags = x3_small_tiles | bf16_form << 1 | bf16_reuse << 4 | bf16_fuse0 << 5 |
  * x3_half_cm << 6, default 117; bit 3 and form 1 named kernels that were measured slower and left the library in round 5 - they are rejected):
  * bit 0 (bf16x3 mode; default 1, measured 5.13 instead of 5.45 ms per launch at 32 x 131072): the split-bf16 block kernel on 128-time
@@ -255,7 +278,24 @@ int mst_embedding_mean(const float *emb_dev, int n_rows, int dim, float *out_dev
  * one tiny mst_fx_rms_pending launch instead of two energy passes and a scale pass over the audio.  fuse = NULL or both
  * members NULL: the plain processor.  mst_fx_scale_items applies a pending factor when a chain ends with one. */
 #define MST_SUMSQ_SLOTS 64     /* an energy sum is kept as 64 partial sums per item (producers spread their atomics over them) */
+#define MST_FX_FORM_EQ_LANE_APPLY 1   /* MstFxFuse.forms */
+#define MST_FX_FORM_EQ_VALU_ENDS 2
+#define MST_FX_FORM_COMP_SLICE_SMALL 4
 typedef struct {
+    /* = sizeof(MstFxFuse) of the header the CALLER was built against: an entry point given another value returns MST_ERR_ARG instead of
+     * reading a struct of another layout (the struct has grown twice) */
+    unsigned struct_size;
+    /* kernel forms of this call - per call, not per process (round 6: the library keeps no mutable global state); results do not depend on
+     * them.  mst_fx_biquad_cascade, stereo: MST_FX_FORM_EQ_LANE_APPLY = the apply pass one lane per chunk straight from global memory
+     * (fx_biquad_chunk_kernel<true>) instead of 16-frame slabs through LDS (fx_biquad_stereo_apply_kernel), identical bits;
+     * MST_FX_FORM_EQ_VALU_ENDS = the state pass as float64 VALU dot products with the impulse-state table in LDS
+     * (fx_biquad_stereo_ends_kernel) instead of v_mfma_f64_16x16x4_f64 with the table as A fragments (fx_biquad_stereo_ends_mfma_kernel),
+     * the same products added in the same (sample) order.  Both are the reference forms of a GPU test.  mst_fx_compressor:
+     * MST_FX_FORM_COMP_SLICE_SMALL = cut the time-parallel compressor into its three time slices (map / apply kernels of neighbouring slices
+     * on an internal low-priority side stream beside the chain kernel, events order map_i -> chain_i -> apply_i, the caller's stream joins
+     * the side stream before the call returns) whatever the size of the batch (>= 8 chain batches) - large batches (>= 32 chain batches of
+     * 1024 samples and >= 4e6 samples in all) always are; the hook lets small emulated problems take that path.  0: the defaults. */
+    int forms;
     const double *in_scale_dev;   /* [n_items] or NULL */
     double *out_sumsq_dev;        /* [n_items][MST_SUMSQ_SLOTS] or NULL; overwritten */
     /* tail folding (mst_fx_midside_imager only; the other entry points refuse post_rms != 0): the rms-normalise that FOLLOWS the
@@ -268,11 +308,11 @@ typedef struct {
     /* mst_fx_biquad_cascade only (the others refuse it): also leave sum(x_raw^2) of the call's raw input here
      * ([n_items][MST_SUMSQ_SLOTS], the arithmetic of mst_fx_sumsq) - the first rms-normalise of a chain then needs no energy pass over x */
     double *out_in_sumsq_dev;
-    /* mid / side energies handed from mst_fx_compressor (stereo, time-parallel path; the others refuse it) to mst_fx_midside_imager (round 5):
-     * the compressor's apply pass leaves sum((l + r)^2), sum((l - r)^2) of its raw output - float32 sums and squares per frame, float64
-     * accumulation, the arithmetic of the imager's own energy pass - as MST_SUMSQ_SLOTS pairs per item in out_ms_dev
-     * ([n_items][MST_SUMSQ_SLOTS][2]; cleared by the call), and an imager given the same array as in_ms_dev skips its energy pass over the
-     * audio (one launch and one read of the batch less per chain).  NULL: off. */
+    /* mid / side energies handed from mst_fx_compressor (stereo; the others refuse it) to mst_fx_midside_imager: the compressor leaves
+     * sum((l + r)^2), sum((l - r)^2) of its raw output - float32 sums and squares per frame, float64 accumulation, the arithmetic of the
+     * imager's own energy pass - as MST_SUMSQ_SLOTS pairs per item in out_ms_dev ([n_items][MST_SUMSQ_SLOTS][2]: slot s covers a 64th of the
+     * frames, summed in a fixed order - deterministic since round 6), and an imager given the same array as in_ms_dev skips its energy pass
+     * over the audio.  NULL: off. */
     double *out_ms_dev;
     const double *in_ms_dev;
 } MstFxFuse;
@@ -290,17 +330,6 @@ int mst_fx_scale_items(const float *x_dev, float *y_dev, int n_items, long per_i
 size_t mst_fx_biquad_scratch_bytes(int n_items, long L, int C, int n_bands);
 int mst_fx_biquad_cascade(const float *x_dev, float *y_dev, int n_items, long L, int C, const double *coef_host,
                           int n_bands, double *scratch_dev, size_t scratch_bytes, const MstFxFuse *fuse, void *stream);
-/* process-wide tuning of the FX kernels (results do not depend on it).  bit 0 (default 1): the time-parallel compressor of a large batch
- * (>= 32 chain batches of 1024 samples and >= 4e6 samples in all) is cut into three time slices whose map / apply kernels run on an internal
- * low-priority side stream BESIDE the chain kernel of the neighbouring slice (the chain is one latency-bound walk per sequence on n_seq
- * workgroups; events order map_i -> chain_i -> apply_i, the caller's stream joins the side stream before the call returns to it).
- * Measured on configs[3] (64 x [131072, 2]): see DESIGN.md 3.3.  bit 1 (default 0; test / A-B hook): slices whatever the size (>= 8 batches);
- * bits 2-3 (A-B hook): number of slices, 0 -> 3 (default), 1 -> 2, 2 -> 4, 3 -> 8.  bit 4 (default 0; the reference form of a test): the stereo
- * equaliser's apply pass one lane per chunk straight from global memory (fx_biquad_chunk_kernel<true>) instead of 16-frame slabs through LDS
- * (fx_biquad_stereo_apply_kernel); identical bits.  bit 5 (default 0; the reference form of a test): the stereo equaliser's state pass as float64
- * VALU dot products with the impulse-state table in LDS (fx_biquad_stereo_ends_kernel) instead of v_mfma_f64_16x16x4_f64 with the table as A
- * fragments (fx_biquad_stereo_ends_mfma_kernel); the same products added in the same (sample) order. */
-int mst_fx_set_tuning(int flags);
 
 /* Compressor.process / compressor_process (:529-587, :637-649), makeup gain 0.  With a scratch buffer of
  * mst_fx_compressor_scratch_bytes() (about 9 bytes per sample) the gain computer and the gain application run over all samples

@@ -18,7 +18,7 @@ MST_PREC_F32 = 0
 MST_PREC_BF16 = 1
 MST_PREC_BF16X3 = 2
 MST_MAX_BLOCKS = 32
-TCN_TUNING_DEFAULT = 117    # mst_tcn_set_tuning flags a fresh handle starts with (csrc/mst_api.hip: x3_small_tiles = 1, bf16_form = 2, x3_duo = 0, bf16_reuse = 1, bf16_fuse0 = 1, x3_half_cm = 1)
+TCN_TUNING_DEFAULT = 117    # mst_tcn_set_tuning flags a fresh handle starts with (csrc/mst_tcn.hip: bit 0 x3_small_tiles, bits 1-2 bf16_form = 2, bit 4 bf16_reuse, bit 5 bf16_fuse0, bit 6 x3_half_cm; bit 3 is refused)
 PRECISIONS = {"fp32": MST_PREC_F32, "f32": MST_PREC_F32, "bf16": MST_PREC_BF16, "bf16x3": MST_PREC_BF16X3}
 
 STATUS_NAMES = {0: "MST_OK", -1: "MST_ERR_ARG", -2: "MST_ERR_UNSUPPORTED", -3: "MST_ERR_HIP", -4: "MST_ERR_STATE",
@@ -30,9 +30,19 @@ class MstTcnDesc(C.Structure):
                 ("kernel_size", C.c_int), ("cond_dim", C.c_int), ("dilations", C.c_int * MST_MAX_BLOCKS), ("causal", C.c_int)]
 
 
+FX_FORM_EQ_LANE_APPLY, FX_FORM_EQ_VALU_ENDS, FX_FORM_COMP_SLICE_SMALL = 1, 2, 4          # MstFxFuse.forms (include/mst_hip.h)
+
+
 class MstFxFuse(C.Structure):
-    _fields_ = [("in_scale_dev", C.c_void_p), ("out_sumsq_dev", C.c_void_p), ("in_sumsq_dev", C.c_void_p), ("post_rms", C.c_int),
-                ("post_gain", C.c_float), ("out_in_sumsq_dev", C.c_void_p), ("out_ms_dev", C.c_void_p), ("in_ms_dev", C.c_void_p)]
+    """include/mst_hip.h MstFxFuse; struct_size is filled in here (the library refuses a struct of another layout)."""
+    _fields_ = [("struct_size", C.c_uint), ("forms", C.c_int), ("in_scale_dev", C.c_void_p), ("out_sumsq_dev", C.c_void_p),
+                ("in_sumsq_dev", C.c_void_p), ("post_rms", C.c_int), ("post_gain", C.c_float), ("out_in_sumsq_dev", C.c_void_p),
+                ("out_ms_dev", C.c_void_p), ("in_ms_dev", C.c_void_p)]
+
+    def __init__(self, in_scale_dev=None, out_sumsq_dev=None, in_sumsq_dev=None, post_rms=0, post_gain=0.0, out_in_sumsq_dev=None,
+                 out_ms_dev=None, in_ms_dev=None, forms=0):
+        super().__init__(C.sizeof(MstFxFuse), forms, in_scale_dev, out_sumsq_dev, in_sumsq_dev, post_rms, post_gain, out_in_sumsq_dev,
+                         out_ms_dev, in_ms_dev)
 
 
 class MstEncDesc(C.Structure):
@@ -80,7 +90,6 @@ SIGNATURES = {
     "mst_fx_sumsq": (C.c_int, [_F, C.c_int, C.c_long, _P, _P]),
     "mst_fx_rms_pending": (C.c_int, [_P, _P, C.c_long, _P, C.c_long, _P, C.c_int, _P]),
     "mst_fx_scale_items": (C.c_int, [_F, _F, C.c_int, C.c_long, _P, _P]),
-    "mst_fx_set_tuning": (C.c_int, [C.c_int]),
     "mst_fx_compressor_scratch_bytes": (C.c_size_t, [C.c_int, C.c_long, C.c_int]),
     "mst_fx_compressor": (C.c_int, [_F, _F, C.c_int, C.c_long, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                     C.c_double, _P, C.c_size_t, _P, _P]),

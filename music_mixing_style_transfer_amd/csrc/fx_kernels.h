@@ -902,7 +902,7 @@ struct CompMapArgs {
     // time slices (the host pipelines map -> chain -> apply over slices of whole batches, mst_api.hip compressor_run): the map launch covers
     // chunks chunk0 .. chunk0 + gridDim.x - 1, the chain launch batches batch0 .. batch1 - 1 (of MST_CHAIN_CB chunks); a chain launch with
     // batch0 > 0 starts from ycarry[seq] (what the launch before it left there) instead of yL_prev = 0, and every launch leaves its last value
-    int chunk0 = 0, batch0 = 0, batch1 = 0, clear_sumsq = 1;
+    int chunk0 = 0, batch0 = 0, batch1 = 0;
     double *ycarry = nullptr;      // [n_seq]
 };
 #define MST_CHAIN_CB 32                    // chunks per batch of the chain kernel
@@ -922,12 +922,6 @@ __global__ __launch_bounds__(64) MST_WAVES_PER_SIMD(4) MST_HEAVY_UNROLL void fx_
     // the level differences x_l are computed here from the audio (a lane walks its own sequence: 32 frames = 256 contiguous bytes that
     // it shares with the lane of the other channel), not read from a float64 scratch that a separate pass would have to write
     for (int i = threadIdx.x; i < 256; i += 64) tab[i] = a.log_tab[i];
-    if (ca.out_sumsq && a.clear_sumsq) {      // the first launch of a compressor call clears the energy slots its apply passes add to
-        const long nthr = (long)gridDim.x * gridDim.y * 64, me = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 64 + threadIdx.x;
-        for (long i = me; i < (long)(ca.n_seq / ca.C) * MST_SUMSQ_SLOTS; i += nthr) ca.out_sumsq[i] = 0.0;
-        if (ca.out_ms)
-            for (long i = me; i < (long)(ca.n_seq / ca.C) * MST_SUMSQ_SLOTS * 2; i += nthr) ca.out_ms[i] = 0.0;
-    }
     const int item = (int)(sq / ca.C);
     const FxCompCurve cv = fx_comp_curve(ca, item);
     const float *xp = ca.x + ((size_t)(ca.shared_x ? 0 : item) * ca.L) * ca.C + sq % ca.C;
@@ -1115,8 +1109,11 @@ __global__ __launch_bounds__(MST_CHAIN_THREADS) void fx_comp_chain_kernel(CompMa
 // grid (ceil(L / 64), ceil(n_seq / 64)), 256 threads.  FILL: the whole tail of the compressor on a 64 x 64 (time x sequence) tile - level
 // differences from the audio (yl = the log10 table), the smoother inside each chunk from its true start value (two chunks per tile, one
 // (chunk, sequence) per thread of the first two waves), the gain application: neither x_l nor y_l ever travels to HBM.
+// Energy sums for the chain fusion leave as per-tile partials (tile_sums[time tile][item][3]: sum y^2 and, for stereo with an imager
+// downstream, sum (l + r)^2, sum (l - r)^2; otherwise [time tile][sequence]), reduced in a fixed order by fx_tile_sums_kernel: the same bits on
+// every run (round 5 added them with float64 atomics from concurrently running launches).
 template <bool FILL>
-__global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const double *yl, const double *ystart, int nchunks, int tile0) {
+__global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const double *yl, const double *ystart, int nchunks, int tile0, double *tile_sums) {
     __shared__ double t[64][65];
     const long tx = (long)blockIdx.x + tile0;                       // time tile (a launch covers the tiles of one time slice)
     const long n0 = tx * 64;
@@ -1194,7 +1191,7 @@ __global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const do
         // stereo chain, an imager downstream: the tile holds the OUTPUT samples (exact float32 values); thread (pair p = tid & 31, frames
         // nl = 8 (tid >> 5) .. + 7) forms l^2 + r^2 and the imager's mid / side terms - m = l + r, s = l - r and their squares in float32,
         // sums in float64, like fx_energy_parts_kernel - then lanes p and p + 32 meet by a shuffle, the four waves through LDS, and pair p
-        // leaves three atomics per tile (C == 2: the tile's sequences 2 p, 2 p + 1 are the channels of one item)
+        // writes the tile's three partial sums of its item (C == 2: the tile's sequences 2 p, 2 p + 1 are the channels of one item)
         __shared__ double red[4][32][3];
         __syncthreads();
         const int p = threadIdx.x & 31, g8 = threadIdx.x >> 5;
@@ -1217,19 +1214,54 @@ __global__ __launch_bounds__(256) void fx_comp_apply_kernel(CompArgs a, const do
         }
         __syncthreads();
         if (threadIdx.x < 32 && s0 + 2 * p < a.n_seq) {
-            const int item = (s0 + 2 * p) / 2, slot = (int)(tx & (MST_SUMSQ_SLOTS - 1));
-            atomicAdd(&a.out_sumsq[item * MST_SUMSQ_SLOTS + slot], red[0][p][0] + red[1][p][0] + red[2][p][0] + red[3][p][0]);
-            atomicAdd(&a.out_ms[(item * MST_SUMSQ_SLOTS + slot) * 2 + 0], red[0][p][1] + red[1][p][1] + red[2][p][1] + red[3][p][1]);
-            atomicAdd(&a.out_ms[(item * MST_SUMSQ_SLOTS + slot) * 2 + 1], red[0][p][2] + red[1][p][2] + red[2][p][2] + red[3][p][2]);
+            double *q = tile_sums + ((size_t)tx * (a.n_seq / 2) + (s0 + 2 * p) / 2) * 3;
+            q[0] = (red[0][p][0] + red[1][p][0]) + (red[2][p][0] + red[3][p][0]);
+            q[1] = (red[0][p][1] + red[1][p][1]) + (red[2][p][1] + red[3][p][1]);
+            q[2] = (red[0][p][2] + red[1][p][2]) + (red[2][p][2] + red[3][p][2]);
         }
-    } else if (a.out_sumsq) {             // column sums of the tile: one atomic per (tile, sequence)
+    } else if (a.out_sumsq) {             // column sums of the tile: one partial per (tile, sequence); the reduction adds the channels of an item
         __syncthreads();
         if (threadIdx.x < 64 && s0 + (int)threadIdx.x < a.n_seq) {
             double cs = 0.0;
 #pragma unroll 8
             for (int nl = 0; nl < 64; ++nl) cs += t[nl][threadIdx.x];
-            atomicAdd(&a.out_sumsq[((s0 + threadIdx.x) / a.C) * MST_SUMSQ_SLOTS + (tx & (MST_SUMSQ_SLOTS - 1))], cs);
+            tile_sums[(size_t)tx * a.n_seq + s0 + threadIdx.x] = cs;
         }
+    }
+}
+
+// the per-tile partials of fx_comp_apply_kernel -> the MST_SUMSQ_SLOTS slots per item the chain fusion hands on: slot s of an item = its tiles
+// s, s + SLOTS, s + 2 SLOTS, ... - sixteen interleaved sub-sequences of them (one thread each: at 131072 samples two loads per thread, all in
+// flight at once - the kernel sits between the last apply launch and the next processor), joined in a fixed order; the channels of an item in
+// channel order: the same bits on every run.  grid n_items, 16 * MST_SUMSQ_SLOTS threads.  stereo_ms: partials are [tile][item][3] and out_ms
+// is written too, else [tile][sequence].
+#define MST_TILE_SUBS 16
+__global__ __launch_bounds__(MST_TILE_SUBS * MST_SUMSQ_SLOTS) void fx_tile_sums_kernel(const double *tile_sums, long ntiles, int n_items, int C, int stereo_ms,
+                                                                                       double *out_sumsq, double *out_ms) {
+    __shared__ double part[MST_TILE_SUBS][MST_SUMSQ_SLOTS][3];
+    const int item = blockIdx.x, slot = threadIdx.x & (MST_SUMSQ_SLOTS - 1), sub = threadIdx.x / MST_SUMSQ_SLOTS;
+    double e2 = 0.0, em = 0.0, es = 0.0;
+#pragma unroll 4
+    for (long tx = slot + (long)sub * MST_SUMSQ_SLOTS; tx < ntiles; tx += MST_TILE_SUBS * MST_SUMSQ_SLOTS) {
+        if (stereo_ms) {
+            const double *q = tile_sums + ((size_t)tx * n_items + item) * 3;
+            e2 += q[0];
+            em += q[1];
+            es += q[2];
+        } else {
+            for (int c = 0; c < C; ++c) e2 += tile_sums[(size_t)tx * n_items * C + (size_t)item * C + c];
+        }
+    }
+    part[sub][slot][0] = e2;
+    part[sub][slot][1] = em;
+    part[sub][slot][2] = es;
+    __syncthreads();
+    if (sub < 3 && (sub == 0 || stereo_ms)) {          // thread (sub = which of the three sums, slot): sixteen parts in ascending order
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < MST_TILE_SUBS; ++j) v += part[j][slot][sub];
+        if (sub == 0) out_sumsq[item * MST_SUMSQ_SLOTS + slot] = v;
+        else out_ms[(item * MST_SUMSQ_SLOTS + slot) * 2 + (sub - 1)] = v;
     }
 }
 

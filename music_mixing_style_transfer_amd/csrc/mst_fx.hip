@@ -8,8 +8,12 @@
 // FX processors
 // =================================================================================================
 namespace {
-int g_fx_eq_valu_ends = 0;      // mst_fx_set_tuning bit 5: stereo equaliser state pass on float64 VALU dot products with the table in LDS (the reference form of the MFMA kernel)
-int g_fx_eq_lane_apply = 0;     // mst_fx_set_tuning bit 4: stereo equaliser apply pass one lane per chunk straight from global memory (the reference form of the slab kernel)
+// an MstFxFuse built against another layout of the struct would be read as garbage: its first member is its own size
+int fuse_check(const MstFxFuse *fuse, const char *who) {
+    if (fuse && fuse->struct_size != sizeof(MstFxFuse)) return fail(MST_ERR_ARG, std::string(who) + ": MstFxFuse.struct_size does not match this library's layout");
+    if (fuse && (fuse->forms & ~(MST_FX_FORM_EQ_LANE_APPLY | MST_FX_FORM_EQ_VALU_ENDS | MST_FX_FORM_COMP_SLICE_SMALL))) return fail(MST_ERR_ARG, std::string(who) + ": unknown MstFxFuse.forms bits");
+    return MST_OK;
+}
 // Steps per chunk of the time-parallel biquad cascade: the number of 511-chunk scan blocks that minimises
 //     16 us per scan block + two chunk passes at 0.19 us per step of a chunk
 // (measured on an MI355X; a pass is one lane per chunk and its time falls with the chunk length until every SIMD holds a wave = 65536
@@ -51,7 +55,8 @@ namespace {
 // Impulse-state table of a biquad cascade for fx_biquad_ends_kernel: h_m = the cascade's state m steps after a unit impulse, m = 0 .. M - 1,
 // [M][2 * n_bands] float64.  Built on the host (the kernels' own recursion) and kept on the device per (device, coefficients, M): a chain calls
 // its equaliser with the same settings again and again.  An entry owns its host copy (the asynchronous upload reads it) and its device
-// buffer; the 16 most recent entries per device are kept, evicting one waits for the device (rare: randomised parameter sweeps).
+// buffer; the 16 most recent entries per device are kept.  A miss (rare: a new equaliser setting) uploads and WAITS for the upload; evicting
+// an entry also waits for the device (randomised parameter sweeps) - neither can happen inside a stream capture.
 struct BiquadTab {
     int dev = -1, n_bands = 0, M = 0;
     double coef[MST_MAX_BANDS][5];
@@ -140,7 +145,10 @@ const double *biquad_impulse_table(const double (*coef)[5], int n_bands, int M, 
         t->devp = nullptr;
         return nullptr;
     }
-    if (hipMemcpyAsync(t->devp, t->host.data(), n_all * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+    // a cache HIT hands devp to whatever stream (or thread) asks next, with no ordering against this upload: the table is complete before
+    // this function - and with it the mutex - lets anybody see the entry (a miss is rare: once per equaliser setting)
+    if (hipMemcpyAsync(t->devp, t->host.data(), n_all * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
         t->dev = -1;
         return nullptr;
     }
@@ -159,6 +167,9 @@ extern "C" size_t mst_fx_biquad_scratch_bytes(int n_items, long L, int C, int n_
 extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long L, int C, const double *coef, int n_bands,
                                      double *scratch, size_t scratch_bytes, const MstFxFuse *fuse, void *stream) {
     if (!x || !y || !coef || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_biquad_cascade: bad argument");
+    if (int rc = fuse_check(fuse, "mst_fx_biquad_cascade")) return rc;
+    // kernel forms of THIS call (MstFxFuse.forms; results do not depend on them): the reference forms of the stereo passes
+    const bool eq_lane_apply = fuse && (fuse->forms & MST_FX_FORM_EQ_LANE_APPLY), eq_valu_ends = fuse && (fuse->forms & MST_FX_FORM_EQ_VALU_ENDS);
     if (fuse && fuse->post_rms) return fail(MST_ERR_UNSUPPORTED, "mst_fx_biquad_cascade: tail folding (post_rms) is the imager's");
     if (fuse && (fuse->out_ms_dev || fuse->in_ms_dev)) return fail(MST_ERR_UNSUPPORTED, "mst_fx_biquad_cascade: the mid / side energies travel from the compressor to the imager");
     if (n_bands < 0 || n_bands > MST_MAX_BANDS) return fail(MST_ERR_UNSUPPORTED, "mst_fx_biquad_cascade: at most 8 bands");
@@ -204,7 +215,7 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         const double *htab = biquad_impulse_table(a.coef, n_bands, M, stream);
         if (!htab) return fail(MST_ERR_HIP, "mst_fx_biquad_cascade: impulse-state table");
         const long npairs = (long)n_items * nchunks;                       // stereo: (item, chunk) pairs - 32 per wave, slabs through LDS
-        if (C == 2 && !g_fx_eq_valu_ends && M % 16 == 0) {          // stereo: the end states as a matrix product on the float64 matrix cores
+        if (C == 2 && !eq_valu_ends && M % 16 == 0) {          // stereo: the end states as a matrix product on the float64 matrix cores
             const dim3 eg((unsigned)((npairs + 127) / 128));
             MST_LAUNCH(fx_biquad_stereo_ends_mfma_kernel, eg, dim3(256), stream, a, htab + (size_t)M * S + (size_t)MST_BIQUAD_LEVELS * S * S);
         } else if (C == 2) {
@@ -252,7 +263,7 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
         if (nchunks > 255) launch_scan(std::integral_constant<int, 512>{});
         else launch_scan(std::integral_constant<int, 256>{});
         MST_CHECK_LAUNCH("fx_biquad_scan_kernel");
-        if (C == 2 && !g_fx_eq_lane_apply) {          // stereo: the chunks travel in 16-frame slabs through LDS, in and out
+        if (C == 2 && !eq_lane_apply) {          // stereo: the chunks travel in 16-frame slabs through LDS, in and out
             const dim3 ag((unsigned)((npairs + 127) / 128));
             switch (n_bands) {
                 case 1: MST_LAUNCH(fx_biquad_stereo_apply_kernel<1>, ag, dim3(256), stream, a); break;
@@ -287,8 +298,8 @@ extern "C" int mst_fx_biquad_cascade(const float *x, float *y, int n_items, long
 
 namespace {
 // scratch = level differences [L][n_seq] (serial fallback only) | chunk maps [n_seq][nchunks][NP + 1] | chunk start values
-// [nchunks][n_seq] | log10 table [256]
-struct CompScratch { size_t xl, maps, ystart, tab, carry, total; long nchunks; };
+// [nchunks][n_seq] | log10 table [256] | carry [n_seq] | energy partials of the apply pass [ceil(L / 64)][max(n_seq, 3 n_items)]
+struct CompScratch { size_t xl, maps, ystart, tab, carry, tsums, total; long nchunks, ntiles; };
 CompScratch comp_scratch(int n_items, long L, int C) {
     CompScratch c;
     const size_t n_seq = (size_t)n_items * C;
@@ -298,7 +309,9 @@ CompScratch comp_scratch(int n_items, long L, int C) {
     c.ystart = n_seq * (size_t)c.nchunks * sizeof(double);
     c.tab = 256 * sizeof(double);
     c.carry = n_seq * sizeof(double);                                      // the smoother's value between two time slices of the chain
-    c.total = c.xl + c.maps + c.ystart + c.tab + c.carry;
+    c.ntiles = (L + 63) / 64;
+    c.tsums = (size_t)c.ntiles * std::max(n_seq, (size_t)3 * n_items) * sizeof(double);      // the apply pass's energy partials per 64-sample tile
+    c.total = c.xl + c.maps + c.ystart + c.tab + c.carry + c.tsums;
     return c;
 }
 }  // namespace
@@ -336,9 +349,7 @@ struct FxSide {
     hipEvent_t fork = nullptr, join = nullptr, map_done[8] = {}, chain_done[8] = {};
     std::mutex mu;
 };
-int g_fx_pipeline = 1;          // mst_fx_set_tuning bit 0
-int g_fx_pipeline_any_size = 0; // mst_fx_set_tuning bit 1 (test / A-B hook: slices whatever the size of the batch)
-int g_fx_slices = 3;            // mst_fx_set_tuning bits 2-3: 0 -> 3 slices (default: measured 0.523-0.539 ms per chain against 0.540-0.550 with 4), 1 -> 2, 2 -> 4, 3 -> 8
+constexpr int FX_SLICES = 3;    // time slices of a large compressor call (measured: 0.523-0.539 ms per chain with 3, 0.540-0.550 with 4, 0.556-0.580 with 2, 0.67 with 8; profiles/r05_fx_slices_ab.txt)
 FxSide *fx_side() {
     static std::mutex mu;
     static FxSide *sides[64] = {};
@@ -364,135 +375,145 @@ FxSide *fx_side() {
     return sides[dev];
 }
 
-int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size_t scratch_bytes, void *stream) {
-    if (scratch) {
-        if (scratch_bytes < mst_fx_compressor_scratch_bytes(n_items, L, C))
-            return fail(MST_ERR_WORKSPACE, "mst_fx_compressor: scratch too small");
-        const dim3 tiles((unsigned)((L + 63) / 64), (unsigned)((a.n_seq + 63) / 64));      // 64 x 64 (time x sequence) tiles
-        const CompScratch cs = comp_scratch(n_items, L, C);
-        if (cs.nchunks < 4) {
-            if (a.out_sumsq) MST_HIP_TRY(hipMemsetAsync(a.out_sumsq, 0, (size_t)n_items * MST_SUMSQ_SLOTS * sizeof(double), (hipStream_t)stream));
-            if (a.out_ms) MST_HIP_TRY(hipMemsetAsync(a.out_ms, 0, (size_t)n_items * MST_SUMSQ_SLOTS * 2 * sizeof(double), (hipStream_t)stream));
-            MST_LAUNCH(fx_comp_gain_kernel, tiles, dim3(256), stream, a, scratch);
-            MST_CHECK_LAUNCH("fx_comp_gain_kernel");
-            MST_LAUNCH(fx_comp_smooth_kernel, dim3((a.n_seq + 63) / 64), dim3(64), stream, a, scratch);
-            MST_CHECK_LAUNCH("fx_comp_smooth_kernel");
-        } else {       // the smoother parallel in time: chunk maps (convex piecewise-linear), a chain over chunks, the rest in one pass
-            CompMapArgs m;
-            const double *tab = log10_table(stream);          // a constant of the device: built on first use
-            if (!tab) return fail(MST_ERR_HIP, "mst_fx_compressor: log10 table");
-            m.log_tab = tab;
-            m.maps = (double *)((unsigned char *)scratch + cs.xl);
-            m.ystart = (double *)((unsigned char *)scratch + cs.xl + cs.maps);
-            m.n_seq = a.n_seq;
-            m.nchunks = (int)cs.nchunks;
-            m.L = L;
-            m.aA = a.alpha_att;
-            m.aR = a.alpha_rel;
-            m.use_min = a.alpha_att > a.alpha_rel ? 1 : 0;
-            // the piece at sorted position p of a chunk of n steps has been through n - p attack and p release steps
-            const int n_last = (int)(L - (cs.nchunks - 1) * MST_COMP_T);
-            for (int which = 0; which < 2; ++which) {
-                const int n = which ? n_last : MST_COMP_T;
-                for (int p = 0; p < MST_COMP_NP; ++p) {
-                    m.slope[which][p] = p <= n ? std::pow(m.aA, n - p) * std::pow(m.aR, p) : 0.0;
-                    m.inv_slope[which][p] = p <= n ? 1.0 / m.slope[which][p] : 0.0;
-                }
-            }
-            m.ycarry = (double *)((unsigned char *)scratch + cs.xl + cs.maps + cs.ystart + cs.tab);
-            // Time slices.  The chain is ONE dependent walk per sequence (n_seq workgroups, latency-bound: most of the chip idles beside it) while
-            // the map and apply kernels are throughput work.  The signal is cut into NS (three) slices of whole chain batches; the caller's stream runs
-            // the chain of slice 0, 1, ... back to back, a side stream (lower priority) the maps of slice 1, 2, ... and the applies of slice
-            // 0 .. NS - 2 beside it (events order map_i -> chain_i -> apply_i); the last apply follows the last chain on the caller's stream, which
-            // then waits for the side stream.  Same arithmetic, same results (the smoother's value crosses a slice boundary as a float64 in
-            // ycarry); without concurrency (a profiler serialising the queues) the launches simply run one after the other.
-            const int nbatch = (int)((cs.nchunks + MST_CHAIN_CB - 1) / MST_CHAIN_CB);
-            const int gy = (a.n_seq + 63) / 64;
-            int ns = 1;
-            if (g_fx_pipeline && ((nbatch >= 32 && (double)a.n_seq * (double)L >= 4.0e6) || (g_fx_pipeline_any_size && nbatch >= 8))) ns = g_fx_slices;
-            FxSide *side = ns > 1 ? fx_side() : nullptr;
-            if (!side) ns = 1;
-            auto launch_map = [&](int b0, int b1, void *st) -> int {
-                CompMapArgs mm = m;
-                mm.chunk0 = b0 * MST_CHAIN_CB;
-                mm.clear_sumsq = b0 == 0 ? 1 : 0;
-                const long c1 = std::min<long>((long)b1 * MST_CHAIN_CB, cs.nchunks);
-                const dim3 cg((unsigned)(c1 - mm.chunk0), (unsigned)gy);
-                if (m.use_min) MST_LAUNCH(fx_comp_map_kernel<true>, cg, dim3(64), st, mm, a);
-                else MST_LAUNCH(fx_comp_map_kernel<false>, cg, dim3(64), st, mm, a);
-                MST_CHECK_LAUNCH("fx_comp_map_kernel");
-                return MST_OK;
-            };
-            auto launch_chain = [&](int b0, int b1, void *st) -> int {
-                CompMapArgs mm = m;
-                mm.batch0 = b0;
-                mm.batch1 = b1;
-                MST_LAUNCH(fx_comp_chain_kernel, dim3(a.n_seq), dim3(MST_CHAIN_THREADS), st, mm);
-                MST_CHECK_LAUNCH("fx_comp_chain_kernel");
-                return MST_OK;
-            };
-            auto launch_apply = [&](int b0, int b1, void *st) -> int {      // a batch is 32 chunks = 16 time tiles of 64 samples
-                const long t0 = (long)b0 * (MST_CHAIN_CB / 2), t1 = std::min<long>((long)b1 * (MST_CHAIN_CB / 2), (long)tiles.x);
-                MST_LAUNCH((fx_comp_apply_kernel<true>), dim3((unsigned)(t1 - t0), tiles.y), dim3(256), st, a, tab, (const double *)m.ystart, m.nchunks, (int)t0);
-                MST_CHECK_LAUNCH("fx_comp_apply_kernel");
-                return MST_OK;
-            };
-            static_assert(MST_COMP_T == 32 && MST_CHAIN_CB % 2 == 0, "two chunks per 64-sample apply tile");
-            int rc;
-            if (ns == 1) {
-                if ((rc = launch_map(0, nbatch, stream)) || (rc = launch_chain(0, nbatch, stream)) || (rc = launch_apply(0, nbatch, stream))) return rc;
-                return MST_OK;
-            }
-            std::lock_guard<std::mutex> lock(side->mu);          // one fork / join at a time per device: the events are reused
-            hipStream_t main_s = (hipStream_t)stream, side_s = side->stream;
-            auto bound = [&](int i) { return (int)((long)nbatch * i / ns); };
-            if ((rc = launch_map(0, bound(1), stream))) return rc;          // slice 0's map: nothing to overlap it with
-            MST_HIP_TRY(hipEventRecord(side->fork, main_s));               // the side stream sees the input (and slice 0's cleared energy slots)
-            MST_HIP_TRY(hipStreamWaitEvent(side_s, side->fork, 0));
-            for (int i = 1; i < ns; ++i) {
-                if ((rc = launch_map(bound(i), bound(i + 1), side_s))) return rc;
-                MST_HIP_TRY(hipEventRecord(side->map_done[i], side_s));
-            }
-            for (int i = 0; i < ns; ++i) {
-                if (i > 0) MST_HIP_TRY(hipStreamWaitEvent(main_s, side->map_done[i], 0));
-                if ((rc = launch_chain(bound(i), bound(i + 1), stream))) return rc;
-                if (i + 1 < ns) {
-                    MST_HIP_TRY(hipEventRecord(side->chain_done[i], main_s));
-                    MST_HIP_TRY(hipStreamWaitEvent(side_s, side->chain_done[i], 0));
-                    if ((rc = launch_apply(bound(i), bound(i + 1), side_s))) return rc;
-                }
-            }
-            if ((rc = launch_apply(bound(ns - 1), nbatch, stream))) return rc;
-            MST_HIP_TRY(hipEventRecord(side->join, side_s));
-            MST_HIP_TRY(hipStreamWaitEvent(main_s, side->join, 0));
-            return MST_OK;
-        }
-        MST_LAUNCH((fx_comp_apply_kernel<false>), tiles, dim3(256), stream, a, (const double *)scratch, (const double *)nullptr, 0, 0);
-        MST_CHECK_LAUNCH("fx_comp_apply_kernel");
+int compressor_run(CompArgs a, int n_items, long L, int C, double *scratch, size_t scratch_bytes, void *stream, bool slice_small = false) {
+    if (!scratch) {
+        MST_LAUNCH(fx_compressor_kernel, dim3((a.n_seq + 3) / 4), dim3(256), stream, a);
+        MST_CHECK_LAUNCH("fx_compressor_kernel");
         return MST_OK;
     }
-    MST_LAUNCH(fx_compressor_kernel, dim3((a.n_seq + 3) / 4), dim3(256), stream, a);
-    MST_CHECK_LAUNCH("fx_compressor_kernel");
-    return MST_OK;
+    if (scratch_bytes < mst_fx_compressor_scratch_bytes(n_items, L, C))
+        return fail(MST_ERR_WORKSPACE, "mst_fx_compressor: scratch too small");
+    if (a.out_ms && C != 2) return fail(MST_ERR_ARG, "mst_fx_compressor: mid / side energies need stereo items");
+    const CompScratch cs = comp_scratch(n_items, L, C);
+    const dim3 tiles((unsigned)cs.ntiles, (unsigned)((a.n_seq + 63) / 64));      // 64 x 64 (time x sequence) tiles
+    double *tsums = (double *)((unsigned char *)scratch + cs.xl + cs.maps + cs.ystart + cs.tab + cs.carry);
+    // the energy sums of the output (chain fusion): per-tile partials from the apply pass, reduced in a fixed order
+    auto finish = [&]() -> int {
+        if (!a.out_sumsq) return MST_OK;
+        MST_LAUNCH(fx_tile_sums_kernel, dim3((unsigned)n_items), dim3(MST_TILE_SUBS * MST_SUMSQ_SLOTS), stream, (const double *)tsums, cs.ntiles, n_items, C,
+                   a.out_ms ? 1 : 0, a.out_sumsq, a.out_ms);
+        MST_CHECK_LAUNCH("fx_tile_sums_kernel");
+        return MST_OK;
+    };
+    if (cs.nchunks < 4) {                               // very short signals: level differences, serial smoother, gain application
+        MST_LAUNCH(fx_comp_gain_kernel, tiles, dim3(256), stream, a, scratch);
+        MST_CHECK_LAUNCH("fx_comp_gain_kernel");
+        MST_LAUNCH(fx_comp_smooth_kernel, dim3((a.n_seq + 63) / 64), dim3(64), stream, a, scratch);
+        MST_CHECK_LAUNCH("fx_comp_smooth_kernel");
+        MST_LAUNCH((fx_comp_apply_kernel<false>), tiles, dim3(256), stream, a, (const double *)scratch, (const double *)nullptr, 0, 0, tsums);
+        MST_CHECK_LAUNCH("fx_comp_apply_kernel");
+        return finish();
+    }
+    // the smoother parallel in time: chunk maps (convex piecewise-linear), a chain over chunks, the rest in one pass
+    CompMapArgs m;
+    const double *tab = log10_table(stream);          // a constant of the device: built on first use
+    if (!tab) return fail(MST_ERR_HIP, "mst_fx_compressor: log10 table");
+    m.log_tab = tab;
+    m.maps = (double *)((unsigned char *)scratch + cs.xl);
+    m.ystart = (double *)((unsigned char *)scratch + cs.xl + cs.maps);
+    m.n_seq = a.n_seq;
+    m.nchunks = (int)cs.nchunks;
+    m.L = L;
+    m.aA = a.alpha_att;
+    m.aR = a.alpha_rel;
+    m.use_min = a.alpha_att > a.alpha_rel ? 1 : 0;
+    // the piece at sorted position p of a chunk of n steps has been through n - p attack and p release steps
+    const int n_last = (int)(L - (cs.nchunks - 1) * MST_COMP_T);
+    for (int which = 0; which < 2; ++which) {
+        const int n = which ? n_last : MST_COMP_T;
+        for (int p = 0; p < MST_COMP_NP; ++p) {
+            m.slope[which][p] = p <= n ? std::pow(m.aA, n - p) * std::pow(m.aR, p) : 0.0;
+            m.inv_slope[which][p] = p <= n ? 1.0 / m.slope[which][p] : 0.0;
+        }
+    }
+    m.ycarry = (double *)((unsigned char *)scratch + cs.xl + cs.maps + cs.ystart + cs.tab);
+    // Time slices.  The chain is ONE dependent walk per sequence (n_seq workgroups, latency-bound: most of the chip idles beside it) while
+    // the map and apply kernels are throughput work.  The signal is cut into FX_SLICES (three) slices of whole chain batches; the caller's
+    // stream runs the chain of slice 0, 1, ... back to back, a side stream (lower priority) the maps of slice 1, 2, ... and the applies of slice
+    // 0 .. NS - 2 beside it (events order map_i -> chain_i -> apply_i); the last apply follows the last chain on the caller's stream, which
+    // then waits for the side stream.  Same arithmetic, same results (the smoother's value crosses a slice boundary as a float64 in
+    // ycarry); without concurrency (a profiler serialising the queues) the launches simply run one after the other.
+    // (Round 6 measured two other ways of overlapping the three kernels - the tail inside the chain kernel, and ONE chain launch that polls
+    //  the map kernel's progress counters with the apply kernel polling the chain's: 0.74 and 0.51 ms per chain against 0.49 with the slices;
+    //  EXPERIMENTS.md section E.3, tools/proto/r06_fx_*.)
+    const int nbatch = (int)((cs.nchunks + MST_CHAIN_CB - 1) / MST_CHAIN_CB);
+    const int gy = (a.n_seq + 63) / 64;
+    int ns = ((nbatch >= 32 && (double)a.n_seq * (double)L >= 4.0e6) || (slice_small && nbatch >= 8)) ? FX_SLICES : 1;
+    FxSide *side = ns > 1 ? fx_side() : nullptr;
+    if (!side) ns = 1;
+    auto launch_map = [&](int b0, int b1, void *st) -> int {
+        CompMapArgs mm = m;
+        mm.chunk0 = b0 * MST_CHAIN_CB;
+        const long c1 = std::min<long>((long)b1 * MST_CHAIN_CB, cs.nchunks);
+        const dim3 cg((unsigned)(c1 - mm.chunk0), (unsigned)gy);
+        if (m.use_min) MST_LAUNCH(fx_comp_map_kernel<true>, cg, dim3(64), st, mm, a);
+        else MST_LAUNCH(fx_comp_map_kernel<false>, cg, dim3(64), st, mm, a);
+        MST_CHECK_LAUNCH("fx_comp_map_kernel");
+        return MST_OK;
+    };
+    auto launch_chain = [&](int b0, int b1, void *st) -> int {
+        CompMapArgs mm = m;
+        mm.batch0 = b0;
+        mm.batch1 = b1;
+        MST_LAUNCH(fx_comp_chain_kernel, dim3(a.n_seq), dim3(MST_CHAIN_THREADS), st, mm);
+        MST_CHECK_LAUNCH("fx_comp_chain_kernel");
+        return MST_OK;
+    };
+    auto launch_apply = [&](int b0, int b1, void *st) -> int {      // a batch is 32 chunks = 16 time tiles of 64 samples
+        const long t0 = (long)b0 * (MST_CHAIN_CB / 2), t1 = std::min<long>((long)b1 * (MST_CHAIN_CB / 2), (long)tiles.x);
+        MST_LAUNCH((fx_comp_apply_kernel<true>), dim3((unsigned)(t1 - t0), tiles.y), dim3(256), st, a, tab, (const double *)m.ystart, m.nchunks, (int)t0, tsums);
+        MST_CHECK_LAUNCH("fx_comp_apply_kernel");
+        return MST_OK;
+    };
+    static_assert(MST_COMP_T == 32 && MST_CHAIN_CB % 2 == 0, "two chunks per 64-sample apply tile");
+    int rc;
+    if (ns == 1) {
+        if ((rc = launch_map(0, nbatch, stream)) || (rc = launch_chain(0, nbatch, stream)) || (rc = launch_apply(0, nbatch, stream))) return rc;
+        return finish();
+    }
+    std::lock_guard<std::mutex> lock(side->mu);          // one fork / join at a time per device: the events are reused
+    hipStream_t main_s = (hipStream_t)stream, side_s = side->stream;
+    auto bound = [&](int i) { return (int)((long)nbatch * i / ns); };
+    if ((rc = launch_map(0, bound(1), stream))) return rc;          // slice 0's map: nothing to overlap it with
+    MST_HIP_TRY(hipEventRecord(side->fork, main_s));               // the side stream sees the input
+    MST_HIP_TRY(hipStreamWaitEvent(side_s, side->fork, 0));
+    // From here on the side stream may hold work on the caller's buffers.  Whatever goes wrong below, the caller's stream is made to wait
+    // for it before this call returns (torch's allocator hands the buffers to the next user of the CALLER's stream).
+    auto forked = [&]() -> int {
+        int r;
+        hipError_t e;
+        for (int i = 1; i < ns; ++i) {
+            if ((r = launch_map(bound(i), bound(i + 1), side_s))) return r;
+            if ((e = hipEventRecord(side->map_done[i], side_s)) != hipSuccess) return fail(MST_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e));
+        }
+        for (int i = 0; i < ns; ++i) {
+            if (i > 0 && (e = hipStreamWaitEvent(main_s, side->map_done[i], 0)) != hipSuccess) return fail(MST_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
+            if ((r = launch_chain(bound(i), bound(i + 1), stream))) return r;
+            if (i + 1 < ns) {
+                if ((e = hipEventRecord(side->chain_done[i], main_s)) != hipSuccess || (e = hipStreamWaitEvent(side_s, side->chain_done[i], 0)) != hipSuccess)
+                    return fail(MST_ERR_HIP, std::string("chain -> apply event: ") + hipGetErrorString(e));
+                if ((r = launch_apply(bound(i), bound(i + 1), side_s))) return r;
+            }
+        }
+        return launch_apply(bound(ns - 1), nbatch, stream);
+    };
+    rc = forked();
+    hipError_t e = hipEventRecord(side->join, side_s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(main_s, side->join, 0);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(side_s);            // the join could not be expressed as an event: wait for the side stream here
+        if (rc == MST_OK) rc = fail(MST_ERR_HIP, std::string("mst_fx_compressor: side stream join: ") + hipGetErrorString(e));
+    }
+    return rc ? rc : finish();
 }
 }  // namespace
-
-extern "C" int mst_fx_set_tuning(int flags) {
-    if (flags < 0 || flags > 63) return fail(MST_ERR_ARG, "mst_fx_set_tuning: unknown flag bits");
-    g_fx_eq_lane_apply = (flags >> 4) & 1;
-    g_fx_eq_valu_ends = (flags >> 5) & 1;
-    g_fx_pipeline = flags & 1;
-    g_fx_pipeline_any_size = (flags >> 1) & 1;
-    static const int slices[4] = {3, 2, 4, 8};
-    g_fx_slices = slices[(flags >> 2) & 3];
-    return MST_OK;
-}
 
 extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, int C, double threshold_db,
                                  double attack_ms, double release_ms, double ratio, double sample_rate, double *scratch,
                                  size_t scratch_bytes, const MstFxFuse *fuse, void *stream) {
     if (!x || !y || n_items < 1 || L < 1 || C < 1 || attack_ms <= 0 || release_ms <= 0 || ratio <= 0 || sample_rate <= 0)
         return fail(MST_ERR_ARG, "mst_fx_compressor: bad argument");
+    if (int rc = fuse_check(fuse, "mst_fx_compressor")) return rc;
     const bool fused = fuse && (fuse->in_scale_dev || fuse->out_sumsq_dev);
     if (fuse && (fuse->post_rms || fuse->out_in_sumsq_dev))
         return fail(MST_ERR_UNSUPPORTED, "mst_fx_compressor: tail folding (post_rms) is the imager's, out_in_sumsq_dev the equaliser's");
@@ -520,7 +541,7 @@ extern "C" int mst_fx_compressor(const float *x, float *y, int n_items, long L, 
         if (C != 2 || !fuse->out_sumsq_dev) return fail(MST_ERR_UNSUPPORTED, "mst_fx_compressor: out_ms_dev needs stereo audio and out_sumsq_dev");
         a.out_ms = fuse->out_ms_dev;
     }
-    return compressor_run(a, n_items, L, C, scratch, scratch_bytes, stream);
+    return compressor_run(a, n_items, L, C, scratch, scratch_bytes, stream, fuse && (fuse->forms & MST_FX_FORM_COMP_SLICE_SMALL));
 }
 
 extern "C" int mst_fx_compressor_grid(const float *x, float *y, int n_items, long L, int C, const double *threshold_db_dev,
@@ -597,6 +618,7 @@ int energy(const float *x, double *acc, int n_items, long per_item, int mode, vo
 extern "C" int mst_fx_midside_imager(const float *x, float *y, int n_items, long L, double bal, double *scratch, const MstFxFuse *fuse,
                                      void *stream) {
     if (!x || !y || !scratch || n_items < 1 || L < 1) return fail(MST_ERR_ARG, "mst_fx_midside_imager: bad argument");
+    if (int rc = fuse_check(fuse, "mst_fx_midside_imager")) return rc;
     const bool fold = fuse && fuse->post_rms;
     if (fuse && fuse->out_in_sumsq_dev) return fail(MST_ERR_UNSUPPORTED, "mst_fx_midside_imager: out_in_sumsq_dev is the equaliser's");
     if (fold && !fuse->in_sumsq_dev) return fail(MST_ERR_ARG, "mst_fx_midside_imager: post_rms needs in_sumsq_dev");
@@ -623,6 +645,7 @@ extern "C" int mst_fx_midside_imager(const float *x, float *y, int n_items, long
 extern "C" int mst_fx_gain(const float *x, float *y, int n_items, long L, int C, double gain_db, int invert, const MstFxFuse *fuse,
                            void *stream) {
     if (!x || !y || n_items < 1 || L < 1 || C < 1) return fail(MST_ERR_ARG, "mst_fx_gain: bad argument");
+    if (int rc = fuse_check(fuse, "mst_fx_gain")) return rc;
     if (fuse && (fuse->post_rms || fuse->out_in_sumsq_dev || fuse->out_ms_dev || fuse->in_ms_dev))
         return fail(MST_ERR_UNSUPPORTED, "mst_fx_gain: tail folding (post_rms) is the imager's, out_in_sumsq_dev the equaliser's, the mid / side energies the compressor's / imager's");
     double g = std::pow(10.0, gain_db / 20.0);

@@ -104,14 +104,14 @@ class _Dev:
     def scratch(self, n_doubles):
         return torch.empty(n_doubles, dtype=torch.float64, device=self.x.device)
 
-    def fuse(self, in_scale, want_sumsq, in_sumsq=None, post_gain=None, want_in_sumsq=False, want_ms=False, in_ms=None):
+    def fuse(self, in_scale, want_sumsq, in_sumsq=None, post_gain=None, want_in_sumsq=False, want_ms=False, in_ms=None, forms=0):
         """(MstFxFuse pointer or None, sumsq tensor or None) for a processor call inside a fused chain.
         in_sumsq + post_gain: tail folding (the rms-normalise behind the processor and a gain behind that in the processor's last pass).
         want_ms (compressor): the mid / side energies of the raw output are left in self.last_ms; in_ms (imager): such an array, instead of
         the imager's own energy pass over the audio."""
         self.last_in_sumsq = None
         self.last_ms = None
-        if in_scale is None and not want_sumsq and in_sumsq is None and not want_in_sumsq and in_ms is None:
+        if in_scale is None and not want_sumsq and in_sumsq is None and not want_in_sumsq and in_ms is None and not forms:
             return None, None
         if want_ms:             # [n][SUMSQ_SLOTS][2], cleared by the producer
             self.last_ms = torch.empty(self.n * SUMSQ_SLOTS * 2, dtype=torch.float64, device=self.x.device)
@@ -122,7 +122,7 @@ class _Dev:
                            in_sumsq.data_ptr() if in_sumsq is not None else None, 1 if in_sumsq is not None else 0,
                            float(post_gain) if post_gain is not None else 1.0,
                            self.last_in_sumsq.data_ptr() if want_in_sumsq else None,
-                           self.last_ms.data_ptr() if want_ms else None, in_ms.data_ptr() if in_ms is not None else None)
+                           self.last_ms.data_ptr() if want_ms else None, in_ms.data_ptr() if in_ms is not None else None, forms=forms)
         self._keep = (f, in_scale, sumsq, in_sumsq, self.last_in_sumsq, self.last_ms, in_ms)    # alive until the launches are queued
         return C.byref(f), sumsq
 
@@ -218,7 +218,7 @@ class Equaliser(Processor):
         y = torch.empty_like(d.x)
         nbytes = d.lib.mst_fx_biquad_scratch_bytes(d.n, d.L, d.C, coef.shape[0])      # time-parallel (chunked scan) path
         sc = d.scratch((nbytes + 7) // 8)
-        fuse, sumsq = d.fuse(in_scale, want_sumsq, want_in_sumsq=want_in_sumsq)
+        fuse, sumsq = d.fuse(in_scale, want_sumsq, want_in_sumsq=want_in_sumsq, forms=getattr(self, "kernel_forms", 0))      # kernel_forms: _lib.FX_FORM_* (tests)
         d.lib.check(d.lib.mst_fx_biquad_cascade(d.x.data_ptr(), y.data_ptr(), d.n, d.L, d.C,
                                                 coef.ctypes.data_as(C.POINTER(C.c_double)), coef.shape[0],
                                                 sc.data_ptr(), nbytes, fuse, d.stream), "mst_fx_biquad_cascade")
@@ -260,7 +260,7 @@ class Compressor(Processor):
         sc = d.scratch((nbytes + 7) // 8)
         # stereo, inside a chain: the apply pass also leaves the mid / side energies of its output behind (d.last_ms) - an imager that
         # follows needs no energy pass of its own
-        fuse, sumsq = d.fuse(in_scale, want_sumsq, want_ms=bool(want_sumsq and d.C == 2))
+        fuse, sumsq = d.fuse(in_scale, want_sumsq, want_ms=bool(want_sumsq and d.C == 2), forms=getattr(self, "kernel_forms", 0))      # kernel_forms: _lib.FX_FORM_* (tests)
         d.lib.check(d.lib.mst_fx_compressor(d.x.data_ptr(), y.data_ptr(), d.n, d.L, d.C, float(p.threshold.value),
                                             float(p.attack_time.value), float(p.release_time.value), float(p.ratio.value),
                                             float(self.sample_rate), sc.data_ptr(), nbytes, fuse, d.stream), "mst_fx_compressor")
@@ -633,6 +633,7 @@ class AugmentationChain:
             # the pending rms factor of the previous step is folded into this processor's loads; its output leaves sum(y^2) behind
             d.rebind(x.t)
             d.last_in_sumsq = None
+            d.last_ms = None          # only what THIS processor's run leaves behind may travel on (a run that never reaches d.fuse() leaves nothing)
             if rms_normalize and x.sumsq is None and isinstance(processor, Equaliser):
                 y, sumsq_y = processor._run(d, x.scale, True, want_in_sumsq=True)      # the equaliser leaves sum(x^2) of its input behind too
             else:

@@ -46,7 +46,8 @@ def test_argument_errors_without_gpu(hip_lib):
         hip_lib.check(-2, "x")
     assert hip_lib.mst_fx_gain(None, None, 1, 10, 2, 0.0, 0, None, None) == -1
     # b_0, lb_1 .. lb_32 and a pad per 32-sample chunk + one start value per chunk + the 256-entry log10 table + one carry value per sequence
-    assert hip_lib.mst_fx_compressor_scratch_bytes(64, 131072, 2) == 128 * (4096 * 34 * 8 + 4096 * 8) + 2048 + 128 * 8
+    # + three energy partials per item and 64-sample tile
+    assert hip_lib.mst_fx_compressor_scratch_bytes(64, 131072, 2) == 128 * (4096 * 34 * 8 + 4096 * 8) + 2048 + 128 * 8 + 2048 * 192 * 8
     assert hip_lib.mst_tcn_workspace_bytes(None, 32, 131072, 1) == 2 * 32 * 131072 * 128 * 2
 
 

@@ -557,57 +557,63 @@ def test_time_parallel_fx_shapes_emulated(emu_default, L, n_items, C):
 
 @pytest.mark.parametrize("L,n_items,C", [(8 * 1024, 1, 2), (9 * 1024 + 517, 3, 2), (13 * 1024 + 31, 2, 1)])
 def test_compressor_time_slices_are_bit_identical_emulated(emu_default, L, n_items, C):
-    """The compressor's map / chain / apply kernels over THREE time slices (mst_fx_set_tuning bits 0 | 1: the pipelined form the product uses
-    for large batches, here forced on a small one) against the single-slice run: the same bits - the smoother's value crosses a slice
-    boundary as a float64 - and both against the oracle.  Slices of unequal batch counts, a ragged last batch, a short last chunk."""
+    """The compressor's map / chain / apply kernels over THREE time slices (the pipelined form the product uses for large batches, here forced
+    on a small one by the per-call hook MstFxFuse.forms = FX_FORM_COMP_SLICE_SMALL) against the single-slice run: the same bits - the
+    smoother's value crosses a slice boundary as a float64 - and both against the oracle.  Slices of unequal batch counts, a ragged last
+    batch, a short last chunk; the energy sums handed to the chain fusion (per-tile partials reduced in a fixed order) agree with a direct sum."""
+    from music_mixing_style_transfer_amd import _lib
     from music_mixing_style_transfer_amd.mixing_manipulator import Compressor
     rng = np.random.default_rng(L)
     x = (0.25 * rng.standard_normal((n_items, L, C))).astype(np.float32)
     c = Compressor(44100)
     c.parameters.threshold.value, c.parameters.attack_time.value = -28.0, 3.0
     c.parameters.release_time.value, c.parameters.ratio.value = 120.0, 6.0
-    try:
-        emu_default.check(emu_default.mst_fx_set_tuning(0), "mst_fx_set_tuning")
-        y1 = c.process(x.copy())
-        emu_default.check(emu_default.mst_fx_set_tuning(3), "mst_fx_set_tuning")
-        y4 = c.process(x.copy())                                                                  # three slices: unequal batch counts
-        emu_default.check(emu_default.mst_fx_set_tuning(3 | 2 << 2), "mst_fx_set_tuning")      # four
-        y3 = c.process(x.copy())
-        emu_default.check(emu_default.mst_fx_set_tuning(3 | 3 << 2), "mst_fx_set_tuning")      # eight
-        y8 = c.process(x.copy())
-    finally:
-        emu_default.check(emu_default.mst_fx_set_tuning(1), "mst_fx_set_tuning")
-    assert np.array_equal(y1, y4) and np.array_equal(y1, y3) and np.array_equal(y1, y8)
+    y1 = c.process(x.copy())
+    c.kernel_forms = _lib.FX_FORM_COMP_SLICE_SMALL
+    y3 = c.process(x.copy())                                                                  # three slices: unequal batch counts
+    assert np.array_equal(y1, y3)
     ref = F.compressor(x[n_items - 1].copy(), -28.0, 3.0, 120.0, 6.0)
-    assert np.abs(y4[n_items - 1] - ref).max() <= 3e-7 * max(1.0, np.abs(ref).max())
+    assert np.abs(y3[n_items - 1] - ref).max() <= 3e-7 * max(1.0, np.abs(ref).max())
+    # the fused form: sum(y^2) per item (and for stereo the mid / side energies) left behind for the next rms-normalise / imager
+    import torch
+    from music_mixing_style_transfer_amd.mixing_manipulator.common_audioeffects import _Dev, SUMSQ_SLOTS
+    for forms in (0, _lib.FX_FORM_COMP_SLICE_SMALL):
+        c.kernel_forms = forms
+        d = _Dev(torch.from_numpy(x.copy()))
+        yt, sumsq = c._run(d, None, True)
+        yy = yt.numpy().astype(np.float64)
+        got = sumsq.numpy().reshape(n_items, SUMSQ_SLOTS).sum(1)
+        assert np.allclose(got, (yy ** 2).sum((1, 2)), rtol=1e-12), forms
+        if C == 2:
+            ms = d.last_ms.numpy().reshape(n_items, SUMSQ_SLOTS, 2).sum(1)
+            m32, s32 = (yt.numpy()[..., 0] + yt.numpy()[..., 1]), (yt.numpy()[..., 0] - yt.numpy()[..., 1])
+            assert np.allclose(ms[:, 0], (m32 * m32).astype(np.float64).sum(1), rtol=1e-12) and np.allclose(ms[:, 1], (s32 * s32).astype(np.float64).sum(1), rtol=1e-12)
 
 
 @pytest.mark.parametrize("L,n_items", [(1000, 2), (2049, 33), (4384, 3), (65, 1), (70000, 1)])
 def test_equaliser_slab_apply_is_bit_identical_emulated(emu_default, L, n_items):
-    """The stereo equaliser's apply pass on 16-frame slabs through LDS (in and out as 16-byte pieces; mst_fx_set_tuning bit 4 off, the default)
-    against one lane per chunk straight from global memory (bit 4): the same recursion on the same samples from the same start states - the
+    """The stereo equaliser's apply pass on 16-frame slabs through LDS (in and out as 16-byte pieces; the default)
+    against one lane per chunk straight from global memory (MstFxFuse.forms, per call): the same recursion on the same samples from the same start states - the
     same bits, with a short last chunk (guarded samples and pieces), whole chunks only, more chunk pairs than a workgroup and fewer than a
     wave; one, two and five bands."""
     from music_mixing_style_transfer_amd.mixing_manipulator import Equaliser
     rng = np.random.default_rng(L)
     x = (0.2 * rng.standard_normal((n_items, L, 2))).astype(np.float32)
-    try:
-        for bands in (("low_shelf",), ("first_band", "third_band"), ("low_shelf", "first_band", "second_band", "third_band", "high_shelf")):
-            eq = Equaliser(2, 44100, bands=bands)
-            for b in bands:
-                getattr(eq.parameters, b + "_gain").value = float(rng.uniform(-12, 12))
-            emu_default.check(emu_default.mst_fx_set_tuning(1 | 16), "mst_fx_set_tuning")
-            ref = eq.process(x.copy())
-            emu_default.check(emu_default.mst_fx_set_tuning(1), "mst_fx_set_tuning")
-            got = eq.process(x.copy())
-            assert np.array_equal(got, ref), (L, n_items, bands, float(np.abs(got - ref).max()))
-            # the state pass on the float64 matrix cores (default) against the VALU dot products with the table in LDS (bit 5): the same products in
-            # the same order - the same chunk start states, the same output bits
-            emu_default.check(emu_default.mst_fx_set_tuning(1 | 32), "mst_fx_set_tuning")
-            ref2 = eq.process(x.copy())
-            assert np.array_equal(got, ref2), (L, n_items, bands, float(np.abs(got - ref2).max()))
-    finally:
-        emu_default.check(emu_default.mst_fx_set_tuning(1), "mst_fx_set_tuning")
+    from music_mixing_style_transfer_amd import _lib
+    for bands in (("low_shelf",), ("first_band", "third_band"), ("low_shelf", "first_band", "second_band", "third_band", "high_shelf")):
+        eq = Equaliser(2, 44100, bands=bands)
+        for b in bands:
+            getattr(eq.parameters, b + "_gain").value = float(rng.uniform(-12, 12))
+        eq.kernel_forms = _lib.FX_FORM_EQ_LANE_APPLY
+        ref = eq.process(x.copy())
+        eq.kernel_forms = 0
+        got = eq.process(x.copy())
+        assert np.array_equal(got, ref), (L, n_items, bands, float(np.abs(got - ref).max()))
+        # the state pass on the float64 matrix cores (default) against the VALU dot products with the table in LDS: the same products in
+        # the same order - the same chunk start states, the same output bits
+        eq.kernel_forms = _lib.FX_FORM_EQ_VALU_ENDS
+        ref2 = eq.process(x.copy())
+        assert np.array_equal(got, ref2), (L, n_items, bands, float(np.abs(got - ref2).max()))
 
 
 def test_encoder_rows_kernel_matches_im2col_emulated(emu_default):

@@ -692,30 +692,26 @@ def test_equaliser_and_compressor_on_a_stem_sized_signal(oracle_fx_lib):
 
 def test_equaliser_kernel_forms_are_bit_identical_on_gpu():
     """The stereo equaliser's time-parallel passes in their current forms - the state pass on v_mfma_f64_16x16x4_f64 (impulse-state table as A
-    fragments), the apply pass on 16-frame slabs through LDS - against their reference forms (`mst_fx_set_tuning` bit 5: VALU dot products with
-    the table in LDS; bit 4: one lane per chunk straight from global memory).  The matrix instruction adds its four products per output in
+    fragments), the apply pass on 16-frame slabs through LDS - against their reference forms (per call, `MstFxFuse.forms`: VALU dot products with
+    the table in LDS; one lane per chunk straight from global memory).  The matrix instruction adds its four products per output in
     k order as fused multiply-adds, the slab kernel runs the same recursion on the same samples: the outputs must be the SAME BITS - at
     BASELINE's 64 x [131072, 2] (whole chunks), at a ragged length (short last chunk: guarded samples and pieces), on a stem-sized signal
     (several scan blocks) and with one band."""
     from music_mixing_style_transfer_amd import _lib
     from music_mixing_style_transfer_amd.mixing_manipulator import Equaliser
     from oracle import fx_ref as F
-    lib = _lib.lib()
-    try:
-        for n, L, bands in ((64, 131072, None), (3, 50021, None), (1, 3_000_017, None), (2, 70001, ("low_shelf",))):
-            x = (0.15 * torch.randn(n, L, 2, generator=torch.Generator().manual_seed(L % 1000))).clamp_(-1, 1).cuda()
-            eq = Equaliser(2, 44100) if bands is None else Equaliser(2, 44100, bands=bands)
-            for band, (g, fc, q) in F.CONFIG4["eq"].items():
-                if hasattr(eq.parameters, band + "_gain"):
-                    getattr(eq.parameters, band + "_gain").value = g
-            outs = []
-            for flags in (1, 1 | 16, 1 | 32, 1 | 16 | 32):
-                lib.check(lib.mst_fx_set_tuning(flags), "mst_fx_set_tuning")
-                outs.append(eq.process(x).clone())
-            for o in outs[1:]:
-                assert torch.equal(o, outs[0]), (n, L, bands, float((o - outs[0]).abs().max()))
-    finally:
-        lib.check(lib.mst_fx_set_tuning(1), "mst_fx_set_tuning")
+    for n, L, bands in ((64, 131072, None), (3, 50021, None), (1, 3_000_017, None), (2, 70001, ("low_shelf",))):
+        x = (0.15 * torch.randn(n, L, 2, generator=torch.Generator().manual_seed(L % 1000))).clamp_(-1, 1).cuda()
+        eq = Equaliser(2, 44100) if bands is None else Equaliser(2, 44100, bands=bands)
+        for band, (g, fc, q) in F.CONFIG4["eq"].items():
+            if hasattr(eq.parameters, band + "_gain"):
+                getattr(eq.parameters, band + "_gain").value = g
+        outs = []
+        for forms in (0, _lib.FX_FORM_EQ_LANE_APPLY, _lib.FX_FORM_EQ_VALU_ENDS, _lib.FX_FORM_EQ_LANE_APPLY | _lib.FX_FORM_EQ_VALU_ENDS):
+            eq.kernel_forms = forms
+            outs.append(eq.process(x).clone())
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), (n, L, bands, float((o - outs[0]).abs().max()))
 
 
 def test_haas_panner_vs_golden_and_oracle():
@@ -1480,3 +1476,70 @@ def test_bench_two_ranks_gloo_prints_the_strong_scaling_efficiency():
     bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--workload", "track60"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                          capture_output=True, text=True, timeout=300, cwd=REPO)
     assert bad.returncode != 0 and "must agree" in bad.stderr
+
+
+def test_two_host_threads_two_handles_two_streams_are_bit_identical(nets):
+    """SURVEY 8(b) threading contract: a handle is driven by one stream at a time, the library keeps no mutable state outside handles (round 6:
+    the FX kernel forms are per call, the FiLM table never reallocates on the data path).  Two host threads, each with its OWN FXencoder /
+    TCNModel handles and its own stream, convert different batches at the same time - networks in bf16 and fp32 and the FX chain (whose
+    compressor shares ONE internal side stream per device) - and must reproduce, bit for bit, what each produces alone."""
+    import threading
+    from music_mixing_style_transfer_amd.inference import StyleTransferEngine, build_models
+    from music_mixing_style_transfer_amd.mixing_manipulator import AugmentationChain, Compressor, Equaliser, Gain, MidSideImager
+    from music_mixing_style_transfer_amd.utils import synth
+    from oracle import fx_ref as F
+    dev = torch.device("cuda:0")
+    enc_cfg, tcn_cfg = nets["enc_cfg"], nets["tcn_cfg"]
+
+    def worker_state(seed):
+        enc, tcn = build_models({k: (list(v) if isinstance(v, list) else v) for k, v in enc_cfg.items()}, tcn_cfg, dev, "bf16")
+        enc.load_state_dict(nets["enc_sd"])
+        tcn.load_state_dict(nets["tcn_sd"])
+        ref = synth.synth_audio((3, 2, 40000 + 1000 * seed), seed=300 + seed).to(dev)
+        inp = synth.synth_audio((3, 2, 40000 + 1000 * seed), seed=400 + seed).to(dev)
+        fx_x = (0.1 * torch.randn(8, 131072, 2, generator=torch.Generator().manual_seed(seed))).clamp_(-1, 1).to(dev)      # the sliced compressor path (>= 4e6 samples)
+        eq = Equaliser(2, 44100)
+        for band, (gg, _, _) in F.CONFIG4["eq"].items():
+            getattr(eq.parameters, band + "_gain").value = gg + 0.5 * seed
+        comp, im, gn = Compressor(44100), MidSideImager(), Gain()
+        for k, v in F.CONFIG4["comp"].items():
+            getattr(comp.parameters, k).value = v
+        im.parameters.bal.value, gn.parameters.gain.value = F.CONFIG4["imager_bal"], F.CONFIG4["gain_db"]
+        chain = AugmentationChain(fxs=[(eq, 1.0, True), (comp, 1.0, True), (im, 1.0, True), (gn, 1.0, False)], randomize_param_value=False)
+        return dict(enc=enc, tcn=tcn, eng=StyleTransferEngine(enc, tcn), ref=ref, inp=inp, fx_x=fx_x, chain=chain)
+
+    def run(st, rounds):
+        outs = []
+        for r in range(rounds):
+            for prec in ("bf16", "fp32"):
+                st["enc"].precision = st["tcn"].precision = prec
+                y, emb = st["eng"].step(st["ref"], st["inp"])
+                outs.append((prec, y.clone(), emb.clone()))
+            outs.append(("fx", st["chain"]([st["fx_x"]])[0].clone(), None))
+        return outs
+
+    states = [worker_state(0), worker_state(1)]
+    alone = [run(s, 1) for s in states]
+    torch.cuda.synchronize()
+    got, errs = [None, None], []
+
+    def thread_main(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                got[i] = run(states[i], 3)
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:          # surfaced in the main thread
+            errs.append((i, repr(e)))
+
+    ths = [threading.Thread(target=thread_main, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        for k, (name, y, emb) in enumerate(got[i]):
+            name0, y0, emb0 = alone[i][k % len(alone[i])]
+            assert name == name0 and torch.equal(y, y0), (i, k, name, float((y - y0).abs().max()))
+            if emb is not None:
+                assert torch.equal(emb, emb0), (i, k, name)
