@@ -18,7 +18,7 @@ MST_PREC_F32 = 0
 MST_PREC_BF16 = 1
 MST_PREC_BF16X3 = 2
 MST_MAX_BLOCKS = 32
-TCN_TUNING_DEFAULT = 117    # mst_tcn_set_tuning flags a fresh handle starts with (csrc/mst_tcn.hip: bit 0 x3_small_tiles, bits 1-2 bf16_form = 2, bit 4 bf16_reuse, bit 5 bf16_fuse0, bit 6 x3_half_cm; bit 3 is refused)
+TCN_TUNING_DEFAULT = 245    # mst_tcn_set_tuning flags a fresh handle starts with (csrc/mst_tcn.hip: bit 0 x3_small_tiles, bits 1-2 bf16_form = 2, bit 4 bf16_reuse, bit 5 bf16_fuse0, bit 6 x3_half_cm, bit 7 bf16_cm128; bit 3 is refused)
 PRECISIONS = {"fp32": MST_PREC_F32, "f32": MST_PREC_F32, "bf16": MST_PREC_BF16, "bf16x3": MST_PREC_BF16X3}
 
 STATUS_NAMES = {0: "MST_OK", -1: "MST_ERR_ARG", -2: "MST_ERR_UNSUPPORTED", -3: "MST_ERR_HIP", -4: "MST_ERR_STATE",

@@ -37,6 +37,8 @@ struct MstTcn {
     int last_fused0 = 0;          // whether the last forward of this handle really ran block 0 inside block 1's launch (mst_tcn_get_tuning)
     int bf16_reuse = 1;           // bf16 mode, duo kernel: the class-major main loop (mst_tcn_set_tuning bit 4; measured 1.40 vs 1.46 ms per launch)
     int bf16_form = 2;            // bf16 mode, form of the block kernel (mst_tcn_set_tuning bits 1-2): 0 one tile per workgroup, 2 duo (default)
+    int bf16_onetile = 1;         // bf16 mode: the four-phase class-major blocks on the ONE-TILE kernel's 256-time tiles, two workgroups per CU, instead of the duo
+                                  // kernel (mst_tcn_set_tuning bit 7, round 6: 1.31 against 1.40 ms per launch, bit-identical)
     std::vector<hipEvent_t> ev;   // timing hook: (nblocks + 2) events per recorded forward
     int ev_max = 0, ev_used = 0;
 };
@@ -317,7 +319,7 @@ template <int P, int NQ> int launch_block_duo(TcnBlockArgs a, void *stream, int 
 }
 
 template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream, int x3_small = 0, int bf16_form = 0,
-                                  int bf16_small4 = 0, int bf16_reuse = 0, int x3_half_cm = 0) {
+                                  int bf16_small4 = 0, int bf16_reuse = 0, int x3_half_cm = 0, int bf16_onetile = 0) {
     TcnBlockArgs a = a0;
     if constexpr (P == 4) {
         // (the same 128-time form for EVERY block - three workgroups per CU instead of the duo kernel - measured 1.53-1.58 ms per launch
@@ -329,11 +331,11 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
             if (g2 % 8 == 0) a.xcd_tiles = (int)(g2 / 8);
             const bool whole = a.tiles_step == 1 && nsteps == 128 / P;          // every tile spans its whole phase sequence: unrolled class-major loop
             if (a.y_out && whole)
-                MST_LAUNCH((tcn_block_bf16_kernel<P, true, 4, true>), dim3((unsigned)g2), dim3(256), stream, a);
+                MST_LAUNCH((tcn_block_bf16_kernel<P, true, 4, 1>), dim3((unsigned)g2), dim3(256), stream, a);
             else if (a.y_out)
                 MST_LAUNCH((tcn_block_bf16_kernel<P, true, 4>), dim3((unsigned)g2), dim3(256), stream, a);
             else if (whole)
-                MST_LAUNCH((tcn_block_bf16_kernel<P, false, 4, true>), dim3((unsigned)g2), dim3(256), stream, a);
+                MST_LAUNCH((tcn_block_bf16_kernel<P, false, 4, 1>), dim3((unsigned)g2), dim3(256), stream, a);
             else
                 MST_LAUNCH((tcn_block_bf16_kernel<P, false, 4>), dim3((unsigned)g2), dim3(256), stream, a);
             MST_CHECK_LAUNCH("tcn_block_bf16_kernel");
@@ -344,6 +346,15 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
         // 256-time tiles only: at P = 8 (128-time tiles: half the work per tile for the same two barriers) the duo form measured
         // 1.62-1.82 ms against 1.50 ms, those blocks run the one-tile-per-workgroup kernel
         // (the last block - fused output head, 32 more live registers - spills in the duo form and runs the one-tile kernel too)
+        if constexpr (P == 4) {
+            // bit 7 (round 6): the class-major four-phase blocks on the one-tile kernel, 256-time tiles, two workgroups per CU
+            if (!a.y_out && bf16_onetile && bf16_reuse) {
+                if (grid % 8 == 0) a.xcd_tiles = grid / 8;
+                MST_LAUNCH((tcn_block_bf16_kernel<P, false, 8, 2>), dim3(grid), dim3(256), stream, a);
+                MST_CHECK_LAUNCH("tcn_block_bf16_kernel");
+                return MST_OK;
+            }
+        }
         if constexpr (P <= 4) {
             if (!a.y_out) return launch_block_duo<P, 8>(a, stream, bf16_reuse);
         }
@@ -391,11 +402,11 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
             if (xcd_on && g2 % 8 == 0) a.xcd_tiles = (int)(g2 / 8);
             const bool whole = a.tiles_step == 1 && nsteps == 128 / P;
             if (a.y_out && whole)
-                MST_LAUNCH((tcn_block_bf16_kernel<P, true, 4, true>), dim3((unsigned)g2), dim3(256), stream, a);
+                MST_LAUNCH((tcn_block_bf16_kernel<P, true, 4, 1>), dim3((unsigned)g2), dim3(256), stream, a);
             else if (a.y_out)
                 MST_LAUNCH((tcn_block_bf16_kernel<P, true, 4>), dim3((unsigned)g2), dim3(256), stream, a);
             else if (whole)
-                MST_LAUNCH((tcn_block_bf16_kernel<P, false, 4, true>), dim3((unsigned)g2), dim3(256), stream, a);
+                MST_LAUNCH((tcn_block_bf16_kernel<P, false, 4, 1>), dim3((unsigned)g2), dim3(256), stream, a);
             else
                 MST_LAUNCH((tcn_block_bf16_kernel<P, false, 4>), dim3((unsigned)g2), dim3(256), stream, a);
         } else {
@@ -540,10 +551,10 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         if (grid > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_tcn_forward: grid too large");
         int rc;
         switch (P) {
-            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm); break;
-            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm); break;
-            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm); break;
-            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm); break;
+            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm, t->bf16_onetile); break;
+            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm, t->bf16_onetile); break;
+            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm, t->bf16_onetile); break;
+            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm, t->bf16_onetile); break;
             default: rc = launch_block<16>(precision, a, (int)grid, stream, 0, t->bf16_form); break;
         }
         if (rc) return rc;
@@ -589,20 +600,21 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
 
 extern "C" int mst_tcn_set_tuning(MstTcn *t, int flags) {
     if (!t) return fail(MST_ERR_ARG, "mst_tcn_set_tuning: null handle");
-    if (flags < 0 || flags > 127 || (((flags >> 1) & 3) != 0 && ((flags >> 1) & 3) != 2) || ((flags >> 3) & 1))
+    if (flags < 0 || flags > 255 || (((flags >> 1) & 3) != 0 && ((flags >> 1) & 3) != 2) || ((flags >> 3) & 1))
         return fail(MST_ERR_ARG, "mst_tcn_set_tuning: unknown flag bits (form 1 - the stream kernel - and bit 3 - the split-bf16 duo kernel - left the library in round 5)");
     t->x3_small_tiles = flags & 1;
     t->bf16_form = (flags >> 1) & 3;
     t->bf16_reuse = (flags >> 4) & 1;
     t->bf16_fuse0 = (flags >> 5) & 1;
     t->x3_half_cm = (flags >> 6) & 1;
+    t->bf16_onetile = (flags >> 7) & 1;
     return MST_OK;
 }
 
 extern "C" int mst_tcn_get_tuning(const MstTcn *t, int *flags, int *last_forward_fused_block0) {
     if (!t) return fail(MST_ERR_ARG, "mst_tcn_get_tuning: null handle");
     if (flags)
-        *flags = t->x3_small_tiles | t->bf16_form << 1 | t->bf16_reuse << 4 | t->bf16_fuse0 << 5 | t->x3_half_cm << 6;
+        *flags = t->x3_small_tiles | t->bf16_form << 1 | t->bf16_reuse << 4 | t->bf16_fuse0 << 5 | t->x3_half_cm << 6 | t->bf16_onetile << 7;
     if (last_forward_fused_block0) *last_forward_fused_block0 = t->last_fused0;
     return MST_OK;
 }

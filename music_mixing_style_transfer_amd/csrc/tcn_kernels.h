@@ -154,9 +154,21 @@ constexpr int TCN_LIVE_MIN_P = 16;
 // WHOLE (round 6): every tile of the launch spans its whole phase sequence (tiles_step == 1 and ceil(L / d) == MT: the host checks) - the
 // kernel holds ONLY the unrolled class-major loop.  With both loops in one kernel (chosen per workgroup) the register allocation was the
 // maximum over the two and <4, false, 4> spilled 10 VGPRs at three workgroups per CU (44 bytes of scratch per lane); split, neither form spills.
-template <int P, bool FUSE_OUT, int NQ, bool WHOLE = false>
+// WHOLE: 0 tap-major loop; 1 every tile spans its whole phase sequence (128-time tiles, dead pairs left out);
+// 2 (round 6, mst_tcn_set_tuning bit 7): 256-time tiles of two / four phases with the duo kernel's class-major loop (tcn_reuse_class: the duo
+// kernel's products in the duo kernel's order - bit-identical to it), two workgroups per CU = two matrix waves per SIMD whose staging and
+// epilogue hide behind each other's main loops.  Same-box alternating A/B at 32 x 131072, d = 4 ... 2048 (profiles/r06_tcn_forms_onetile_ab.txt):
+// duo kernel 1.404-1.409 ms per launch, 128-time class-major tiles at three workgroups per CU 1.336-1.338, this form 1.312-1.318.  The
+// three-workgroup form keeps the matrix pipe busy 0.94 of the kernel's cycles (profiles/r06_pmc_sq_tcn_block_bf16_cm128.txt) but pulls the
+// shader clock to ~1.55-1.7 GHz under the chip's power limit: what a tile costs in ENERGY decides, and 256-time tiles stream every weight
+// fragment from L2 half as often (8 GB per launch instead of 16) and stage 1.22 instead of 1.44 rows per output row.
+template <int P, int NU, bool LAST, int NUMAX, bool WRAP = true>
+__device__ __forceinline__ void tcn_reuse_class(f32x4 (&acc)[2][16], bf16x8 (&A0)[NUMAX][2], bf16x8 (&A1)[NUMAX][2], bf16x8 (&ring)[4],
+                                                const unsigned char *sm, const MstStream16 &wst, unsigned aoff, int c, int cn, int l16, int g);
+template <int P, bool FUSE_OUT, int NQ, int WHOLE = 0>
 __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1))) void tcn_block_bf16_kernel(TcnBlockArgs a) {
-    static_assert(!WHOLE || ((P == 8 || P == 4) && NQ == 4), "whole-sequence tiles: 128 times of four / eight phases");
+    static_assert(WHOLE != 1 || ((P == 8 || P == 4) && NQ == 4), "whole-sequence tiles: 128 times of four / eight phases");
+    static_assert(WHOLE != 2 || ((P == 4 || P == 2) && NQ == 8), "class-major 256-time tiles of two / four phases");
     constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NC = 2 * NQ;
     __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
     __shared__ __attribute__((aligned(16))) float par[4 * 128];     // shift | FiLM r | FiLM b | res of this block / batch item
@@ -297,8 +309,24 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
         };
         // only a tile that spans its WHOLE phase sequence takes the unrolled class-major form (the one-sided forms for a sequence of two
         // tiles - 10 % fewer MFMAs each - were measured slower in the tap-major order: two unrolled 12 KB loops alternating on a CU)
-        if constexpr (WHOLE) tcn_class_major_whole_tile<P, NC>(acc, smem, wst, aoff, l16, g);
-        else tap_major();
+        if constexpr (WHOLE == 1) tcn_class_major_whole_tile<P, NC>(acc, smem, wst, aoff, l16, g);
+        else if constexpr (WHOLE == 2) {
+            constexpr int NCLS = 16 / P, NUMAX = (15 + NCLS - 1) / NCLS;
+            bf16x8 A0[NUMAX][2], A1[NUMAX][2], ring[4];
+#pragma unroll
+            for (int u = 0; u < NUMAX; ++u) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) A0[u][m] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + m * 4096, (unsigned)(4 * NCLS * u) * 8192u));
+            }
+            {
+                const unsigned char *rp0 = smem + l16 * 256 + ((g ^ l16) << 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ring[i] = *(const bf16x8 *)(rp0 + i * 4096);
+            }
+#pragma unroll 1
+            for (int c = 0; c < NCLS - 1; ++c) tcn_reuse_class<P, NUMAX, false, NUMAX>(acc, A0, A1, ring, smem, wst, aoff, c, c + 1, l16, g);
+            tcn_reuse_class<P, 15 / NCLS, true, NUMAX, false>(acc, A0, A1, ring, smem, wst, aoff, NCLS - 1, 0, l16, g);
+        } else tap_major();
     }
 
     // ---- fused epilogue
@@ -406,7 +434,9 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
 // On entry ring[0..3] = windows 0..3 of (c, kk = 0) and A0 = the fragments of (c, kk = 0); on exit the same for class cn (LAST: the
 // next tile's image may not have landed yet - no window of it is read here; A0 is the next tile's first phase: the same weights).
 // ------------------------------------------------------------------------------------------------
-template <int P, int NU, bool LAST, int NUMAX>
+// WRAP = false (one tile per workgroup): behind the last class there is no next tile - its first weight fragments (32 KB per workgroup, 6.5 % of
+// the tile's weight stream) are not requested.
+template <int P, int NU, bool LAST, int NUMAX, bool WRAP>
 __device__ __forceinline__ void tcn_reuse_class(f32x4 (&acc)[2][16], bf16x8 (&A0)[NUMAX][2], bf16x8 (&A1)[NUMAX][2], bf16x8 (&ring)[4],
                                                 const unsigned char *sm, const MstStream16 &wst, unsigned aoff, int c, int cn, int l16, int g) {
     constexpr int NW = 15 + NU, NCLS = 16 / P;
@@ -420,6 +450,7 @@ __device__ __forceinline__ void tcn_reuse_class(f32x4 (&acc)[2][16], bf16x8 (&A0
 #pragma unroll
         for (int u = 0; u < NUMAX; ++u) {
             if (kk < 3 && u >= NU) continue;
+            if (LAST && !WRAP && kk == 3) continue;
             int j = (kk < 3 ? c : cn) + NCLS * u;
             j = j < 15 ? j : 14;                                   // the last class has one tap less: that slot holds a fragment nobody uses
             const unsigned so = (unsigned)(j * 4 + (kk < 3 ? kk + 1 : 0)) * 8192u;

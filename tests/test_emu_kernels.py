@@ -1,6 +1,8 @@
 """The gfx950 kernel sources + C-ABI host code, compiled for the host against the SIMT emulator (tests/emu),
 checked against the oracle.  Catches index math / MFMA fragment layout / LDS swizzle / packing bugs without a
 GPU.  Same sources as libmst_hip.so, same C ABI, driven through the same module API."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -139,6 +141,30 @@ def test_tcn_bf16_duo_reuse_main_loop_emulated(emu_default):
         assert float((y1 - y0).abs().max()) <= 5e-3 and float((a1 - a0).abs().max()) <= 5e-2
         differs += int(not torch.equal(a1, a0))
     assert differs > 0          # the other summation order did run (bit-identical activations everywhere would mean the flag was ignored)
+
+
+def test_tcn_bf16_one_tile_class_major_256_time_tiles_emulated(emu_default):
+    """mst_tcn_set_tuning bit 7 (round 6, default): the four-phase class-major blocks on the ONE-TILE kernel's 256-time tiles (two workgroups
+    per CU) instead of the duo kernel - the duo kernel's products in the duo kernel's order: bit-identical, several tiles per phase sequence,
+    ragged last tiles, per-item FiLM rows; and against the oracle at the bf16 tolerance."""
+    cases = [(4, (2, 2, 1500), synth.synth_audio((2, 64), seed=11)),        # d = 4, 8: 6 / 3 tiles per sequence, the last ragged
+             (5, (1, 2, 2100), synth.synth_audio((1, 64), seed=2))]         # d = 4, 8, 16 (d = 16: 132 steps = 3 tiles, the last ragged)
+    for nb, shape, cnd in cases:
+        m, sd = _tcn(nb)
+        m.precision = "bf16"
+        x = synth.synth_audio(shape, seed=1)
+        y_ref = R.tcn_forward(sd, x, cnd, nblocks=nb)
+        m._ensure(emu_default)
+        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 21), "tuning")           # duo, class-major
+        y0, a0 = m(x, cnd), m.forward_blocks(x, cnd, nb - 1)
+        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 21 | 128), "tuning")     # + bit 7
+        fl = C.c_int(0)
+        emu_default.check(emu_default.mst_tcn_get_tuning(m._handle, C.byref(fl), None), "get")
+        assert fl.value == 21 | 128
+        y1, a1 = m(x, cnd), m.forward_blocks(x, cnd, nb - 1)
+        assert torch.equal(y0, y1) and torch.equal(a0, a1)
+        assert float((y1 - y_ref).abs().max()) <= 4e-2
+    assert emu_default.mst_tcn_set_tuning(m._handle, 256) != 0          # no flag bits beyond bit 7
 
 
 def test_tcn_bf16_block0_fused_into_block1_emulated(emu_default):

@@ -110,13 +110,15 @@ def test_tcn_bf16_vs_oracle(nets):
         tcn.precision = "fp32"
 
 
-@pytest.mark.parametrize("form", [1, 5, 21, 53])
+@pytest.mark.parametrize("form", [1, 5, 21, 53, 181])
 def test_tcn_bf16_block_kernel_forms_vs_oracle(nets, form):
     """The forms of the bf16 block kernel (mst_tcn_set_tuning bits 1-2: 0 = one tile per workgroup, 2 = "duo", persistent, input rows by
     LDS-DMA; the "stream" form 1 left the library in round 5) against the oracle - per block and on the waveform, ragged length (tiles that end outside the segment), per-item
     FiLM rows, a batch larger than the persistent grid's first wave of tiles.  21 = the duo form with the class-major main loop (bit 4):
     the same products in another fp32 summation order - agrees with 5 to accumulation rounding.  53 = 21 + block 0 computed inside
-    the d = 2 block's launch (bit 5, the default since round 5): bit-identical to 21, and `mst_tcn_get_tuning` reports that the fusion ran."""
+    the d = 2 block's launch (bit 5, the default since round 5): bit-identical to 21, and `mst_tcn_get_tuning` reports that the fusion ran.
+    181 = 53 + the four-phase blocks on the ONE-TILE kernel's 256-time tiles with the duo kernel's class-major loop, two workgroups per CU
+    (bit 7, the default since round 6 together with the bf16x3-only bit 6 = 245): the duo kernel's summation order - bit-identical to 53."""
     from music_mixing_style_transfer_amd import _lib
     from music_mixing_style_transfer_amd.utils import synth
     from oracle import networks_ref as R
@@ -158,12 +160,19 @@ def test_tcn_bf16_block_kernel_forms_vs_oracle(nets, form):
             assert d2 <= 2.0 ** -7, d2
         if form == 53:         # block 0 inside block 1's launch: the same arithmetic, bit for bit - and it must really have run fused
             fl, fused = tcn_tuning_state(lib, tcn)
-            assert fl == 53 and fused == 1          # (53 = the default 117 without the bf16x3-only bit 6)
+            assert fl == 53 and fused == 1          # (53 = round 5's default 117 without the bf16x3-only bit 6)
             a53 = tcn.forward_blocks(x.cuda(), cond.cuda(), 2).cpu()
             lib.check(lib.mst_tcn_set_tuning(tcn._handle, 21), "mst_tcn_set_tuning")
             assert torch.equal(tcn(x.cuda(), cond.cuda()).cpu(), y)
             assert tcn_tuning_state(lib, tcn) == (21, 0)
             assert torch.equal(tcn.forward_blocks(x.cuda(), cond.cuda(), 2).cpu(), a53)
+        if form == 181:        # the one-tile kernel at d = 4 ... 4096 here: the duo kernel's order, bit for bit
+            assert tcn_tuning_state(lib, tcn) == (181, 1)
+            acts = [tcn.forward_blocks(x.cuda(), cond.cuda(), n).cpu() for n in (3, 7, 10, 14)]
+            lib.check(lib.mst_tcn_set_tuning(tcn._handle, 53), "mst_tcn_set_tuning")
+            assert torch.equal(tcn(x.cuda(), cond.cuda()).cpu(), y)
+            for n, a in zip((3, 7, 10, 14), acts):
+                assert torch.equal(tcn.forward_blocks(x.cuda(), cond.cuda(), n).cpu(), a), n
     finally:
         lib.check(lib.mst_tcn_set_tuning(tcn._handle, _lib.TCN_TUNING_DEFAULT), "mst_tcn_set_tuning")
         tcn.precision = "fp32"
