@@ -123,6 +123,8 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
  *                                  bit 4                  1        bf16 duo: class-major main loop                           ~       tap-major loop = the P = 1 path and the GPU test's other side
  *                                  bit 5                  1        bf16: block 0 inside the d = 2 block's launch             =       separate block-0 kernel = probes, other precisions, short segments
  *                                  bit 6                  1        bf16x3: class-major loop in the eight-phase half kernel    ~       other side of a GPU test
+ *                                  bit 7                  1        bf16: four-phase class-major blocks, one 256-time tile     =       the duo kernel stays for the d = 2 block (+ block 0) and as the other side of
+ *                                                                  per workgroup, two workgroups per CU (round 6)                     the bit-identity tests (emulator + GPU form 181 / 53)
  *   mst_enc_set_tuning (handle)    rows_min_tiles         512      bf16: rows-resident conv kernel from this many tiles on    =       small layers run the im2col kernel
  *   mst_enc_set_schedule (handle)  bit 0                  1        weight-major workgroup order of weight-heavy layers        =
  *                                  bit 1                  0        2 x 2 wave tiling of the 128-channel kernel (slower)       ~       A/B record only
@@ -136,7 +138,7 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
  * (mst_fx_set_tuning - a process-wide switch - left the ABI in round 6.)
  * ------------------------------------------------------------------------------------------------------------------------------------------ */
 /* tuning flags (choose between forms of the block kernels; flags = x3_small_tiles | bf16_form << 1 | bf16_reuse << 4 | bf16_fuse0 << 5 |
- * x3_half_cm << 6, default 117; bit 3 and form 1 named kernels that were measured slower and left the library in round 5 - they are rejected):
+ * x3_half_cm << 6 | bf16_onetile << 7, default 245; bit 3 and form 1 named kernels that were measured slower and left the library in round 5 - they are rejected):
  * bit 0 (bf16x3 mode; default 1, measured 5.13 instead of 5.45 ms per launch at 32 x 131072): the split-bf16 block kernel on 128-time
  *   tiles of <= 2 phases (two workgroups per CU) wherever the segment has at least 64 steps per phase, 0 = 256-time tiles (one
  *   workgroup per CU); the two-phase 128-time tiles run the class-major loop (B fragment pairs reused by the two taps of a class: 4.62 ->
@@ -160,7 +162,13 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
  * bit 6 (bf16x3 mode; default 1 since round 5): the eight-phase half-tile kernel (d >= 4096 at L = 131072: 2 of that mode's 13 launches) runs a
  *   class-major loop too (pseudo-classes of two taps of one parity); results agree with bit 6 off to accumulation rounding (GPU test:
  *   <= 1e-5 on the waveform, both within 1e-4 of the oracle).  Measured, same box, alternating: 571.7 / 572.1 against 566.2 segments/s for the
- *   whole bf16x3 step at 32 x 131072 (profiles/r05_x3_ab_bit6_53_117.jsonl). */
+ *   whole bf16x3 step at 32 x 131072 (profiles/r05_x3_ab_bit6_53_117.jsonl).
+ * bit 7 (bf16 mode, with form 2 and bit 4; default 1 since round 6): the four-phase blocks (d = 4 ... 2048 at L = 131072: 10 of the 13 dense launches)
+ *   run tcn_block_bf16_kernel<4, false, 8, 2> - ONE 256-time tile per workgroup of four waves, TWO workgroups per CU, the duo kernel's
+ *   class-major loop (same products, same order: bit-identical to bit 7 off) - instead of the persistent duo kernel: two matrix waves per SIMD
+ *   cover each other's staging and epilogue.  Same box, alternating (profiles/r06_tcn_forms_onetile_ab.txt): 1.312-1.318 ms per launch against
+ *   1.404-1.409 for the duo kernel (a 128-time form at three workgroups per CU: 1.336-1.338 - it streams every weight fragment twice as often,
+ *   and under the chip's power limit a tile's energy is what counts; EXPERIMENTS.md E.6). */
 int mst_tcn_set_tuning(MstTcn *tcn, int flags);
 /* the flags in force and whether the handle's LAST forward ran block 0 inside block 1's launch (bit 5 is a request: see its conditions above);
  * either pointer may be null. */
