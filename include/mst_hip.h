@@ -123,8 +123,8 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
  *                                  bit 4                  1        bf16 duo: class-major main loop                           ~       tap-major loop = the P = 1 path and the GPU test's other side
  *                                  bit 5                  1        bf16: block 0 inside the d = 2 block's launch             =       separate block-0 kernel = probes, other precisions, short segments
  *                                  bit 6                  1        bf16x3: class-major loop in the eight-phase half kernel    ~       other side of a GPU test
- *                                  bit 7                  1        bf16: four-phase class-major blocks, one 256-time tile     =       the duo kernel stays for the d = 2 block (+ block 0) and as the other side of
- *                                                                  per workgroup, two workgroups per CU (round 6)                     the bit-identity tests (emulator + GPU form 181 / 53)
+ *                                  bit 7                  1        bf16: two- / four-phase class-major blocks, one 256-time   =       the duo kernel is the other side of the bit-identity tests (emulator + GPU
+ *                                                                  tile per workgroup, two workgroups per CU (round 6)                forms 181 / 53) and what bit 7 off selects
  *   mst_enc_set_tuning (handle)    rows_min_tiles         512      bf16: rows-resident conv kernel from this many tiles on    =       small layers run the im2col kernel
  *   mst_enc_set_schedule (handle)  bit 0                  1        weight-major workgroup order of weight-heavy layers        =
  *                                  bit 1                  0        2 x 2 wave tiling of the 128-channel kernel (slower)       ~       A/B record only
@@ -163,12 +163,14 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
  *   class-major loop too (pseudo-classes of two taps of one parity); results agree with bit 6 off to accumulation rounding (GPU test:
  *   <= 1e-5 on the waveform, both within 1e-4 of the oracle).  Measured, same box, alternating: 571.7 / 572.1 against 566.2 segments/s for the
  *   whole bf16x3 step at 32 x 131072 (profiles/r05_x3_ab_bit6_53_117.jsonl).
- * bit 7 (bf16 mode, with form 2 and bit 4; default 1 since round 6): the four-phase blocks (d = 4 ... 2048 at L = 131072: 10 of the 13 dense launches)
- *   run tcn_block_bf16_kernel<4, false, 8, 2> - ONE 256-time tile per workgroup of four waves, TWO workgroups per CU, the duo kernel's
+ * bit 7 (bf16 mode, with form 2 and bit 4; default 1 since round 6): the two- and four-phase blocks (d = 2 ... 2048 at L = 131072: 11 of the 13 dense launches)
+ *   run tcn_block_bf16_kernel<P, false, 8, 2> - ONE 256-time tile per workgroup of four waves, TWO workgroups per CU, the duo kernel's
  *   class-major loop (same products, same order: bit-identical to bit 7 off) - instead of the persistent duo kernel: two matrix waves per SIMD
- *   cover each other's staging and epilogue.  Same box, alternating (profiles/r06_tcn_forms_onetile_ab.txt): 1.312-1.318 ms per launch against
- *   1.404-1.409 for the duo kernel (a 128-time form at three workgroups per CU: 1.336-1.338 - it streams every weight fragment twice as often,
- *   and under the chip's power limit a tile's energy is what counts; EXPERIMENTS.md E.6). */
+ *   cover each other's staging and epilogue.  With bit 5 the d = 2 block's workgroups compute block 0 in their staging phase (<2, false, 8, 2, true>:
+ *   the duo loader's arithmetic, bit for bit).  Same box, alternating (profiles/r06_tcn_forms_onetile_ab.txt, r06_tcn_forms_onetile_fuse0_ab.txt):
+ *   1.312-1.318 ms per launch against 1.404-1.409 for the duo kernel, the d = 2 launch with block 0 inside 1.47 against 1.56 (a 128-time form at
+ *   three workgroups per CU: 1.336-1.338 - it streams every weight fragment twice as often, and under the chip's power limit a tile's energy is
+ *   what counts; EXPERIMENTS.md E.6). */
 int mst_tcn_set_tuning(MstTcn *tcn, int flags);
 /* the flags in force and whether the handle's LAST forward ran block 0 inside block 1's launch (bit 5 is a request: see its conditions above);
  * either pointer may be null. */

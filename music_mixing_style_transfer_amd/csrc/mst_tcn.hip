@@ -37,8 +37,8 @@ struct MstTcn {
     int last_fused0 = 0;          // whether the last forward of this handle really ran block 0 inside block 1's launch (mst_tcn_get_tuning)
     int bf16_reuse = 1;           // bf16 mode, duo kernel: the class-major main loop (mst_tcn_set_tuning bit 4; measured 1.40 vs 1.46 ms per launch)
     int bf16_form = 2;            // bf16 mode, form of the block kernel (mst_tcn_set_tuning bits 1-2): 0 one tile per workgroup, 2 duo (default)
-    int bf16_onetile = 1;         // bf16 mode: the four-phase class-major blocks on the ONE-TILE kernel's 256-time tiles, two workgroups per CU, instead of the duo
-                                  // kernel (mst_tcn_set_tuning bit 7, round 6: 1.31 against 1.40 ms per launch, bit-identical)
+    int bf16_onetile = 1;         // bf16 mode: the two- / four-phase class-major blocks on the ONE-TILE kernel's 256-time tiles, two workgroups per CU, instead of the duo
+                                  // kernel (mst_tcn_set_tuning bit 7, round 6: 1.31 against 1.40 ms per launch, the d = 2 block with block 0 inside 1.47 against 1.56; bit-identical)
     std::vector<hipEvent_t> ev;   // timing hook: (nblocks + 2) events per recorded forward
     int ev_max = 0, ev_used = 0;
 };
@@ -355,6 +355,16 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
                 return MST_OK;
             }
         }
+        if constexpr (P == 2) {
+            // ... and the two-phase blocks (the d = 2 block; with bit 5 block 0 is computed in its staging)
+            if (!a.y_out && bf16_onetile && bf16_reuse) {
+                if (grid % 8 == 0) a.xcd_tiles = grid / 8;
+                if (a.x0) MST_LAUNCH((tcn_block_bf16_kernel<P, false, 8, 2, true>), dim3(grid), dim3(256), stream, a);
+                else MST_LAUNCH((tcn_block_bf16_kernel<P, false, 8, 2>), dim3(grid), dim3(256), stream, a);
+                MST_CHECK_LAUNCH("tcn_block_bf16_kernel");
+                return MST_OK;
+            }
+        }
         if constexpr (P <= 4) {
             if (!a.y_out) return launch_block_duo<P, 8>(a, stream, bf16_reuse);
         }
@@ -468,8 +478,8 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         MST_HIP_TRY(hipEventRecord(ev[0], (hipStream_t)stream));
     }
 
-    // block 0 inside block 1's launch (bf16, tuning bit 5): block 1 must be the d = 2 block on the duo kernel's two-phase class-major tiles
-    // and not the last block; the probes of block 0 itself (n_run == 1) always run the separate kernel
+    // block 0 inside block 1's launch (bf16, tuning bit 5): block 1 must be the d = 2 block on two-phase class-major tiles (the one-tile kernel
+    // with bit 7, else the duo kernel) and not the last block; the probes of block 0 itself (n_run == 1) always run the separate kernel
     const bool fuse0 = precision == MST_PREC_BF16 && t->bf16_fuse0 && t->bf16_reuse && t->bf16_form == 2 && t->blk[0].w_bf16 && n_run >= 2 &&
                        t->d.nblocks > 2 && t->d.dilations[0] == 1 && t->d.dilations[1] == 2 && choose_phases(2, L, precision) == 2;
     t->last_fused0 = fuse0 ? 1 : 0;

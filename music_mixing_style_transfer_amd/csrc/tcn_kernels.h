@@ -165,13 +165,20 @@ constexpr int TCN_LIVE_MIN_P = 16;
 template <int P, int NU, bool LAST, int NUMAX, bool WRAP = true>
 __device__ __forceinline__ void tcn_reuse_class(f32x4 (&acc)[2][16], bf16x8 (&A0)[NUMAX][2], bf16x8 (&A1)[NUMAX][2], bf16x8 (&ring)[4],
                                                 const unsigned char *sm, const MstStream16 &wst, unsigned aoff, int c, int cn, int l16, int g);
-template <int P, bool FUSE_OUT, int NQ, int WHOLE = 0>
+// FUSE0 (round 6; two-phase class-major tiles, d = 2: a tile's rows are consecutive samples): block 0 is not launched - the workgroup computes
+// its tile's input rows from the waveform with tcn_block0_mfma_kernel's arithmetic (the duo kernel's FUSE0 loader, same fragments, same MFMA
+// order, same epilogue function: the same bits) instead of fetching them; the other workgroup of the CU runs its main loop meanwhile.
+template <int P, bool FUSE_OUT, int NQ, int WHOLE = 0, bool FUSE0 = false>
 __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1))) void tcn_block_bf16_kernel(TcnBlockArgs a) {
     static_assert(WHOLE != 1 || ((P == 8 || P == 4) && NQ == 4), "whole-sequence tiles: 128 times of four / eight phases");
     static_assert(WHOLE != 2 || ((P == 4 || P == 2) && NQ == 8), "class-major 256-time tiles of two / four phases");
+    static_assert(!FUSE0 || (P == 2 && NQ == 8 && WHOLE == 2 && !FUSE_OUT), "block 0 is fused into the d = 2 block's two-phase class-major tiles");
     constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NC = 2 * NQ;
     __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
     __shared__ __attribute__((aligned(16))) float par[4 * 128];     // shift | FiLM r | FiLM b | res of this block / batch item
+    constexpr int XWP = 304;                                         // FUSE0: waveform samples per channel a tile needs (R + 14 = 298), padded
+    __shared__ float xs0[FUSE0 ? 2 * XWP : 1];                       // FUSE0: the tile's waveform window
+    __shared__ __attribute__((aligned(16))) float par0[FUSE0 ? 4 * 128 : 4];          // FUSE0: block 0's shift | FiLM r | FiLM b | res
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int l16 = lane & 15, g = lane >> 4;
 
@@ -185,7 +192,72 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
     __bf16 *yb = (__bf16 *)a.y + (size_t)b * a.Lp * 128;
     // ---- stage the (256 + 14P) input rows: 16 lanes x 16 B per row, XOR-swizzled 16-B slots so that the
     //      32 consecutive rows of one B-fragment read hit 16 distinct slots per ds_read_b128 lane group
-    {
+    if constexpr (FUSE0) {
+        // the rows of tile (b, m0) are block 0's outputs at the consecutive times t_first + r; rows outside the segment are zero rows (this
+        // block's padding).  Wave w computes the 32-row groups w and w + 4 (all four channel quarters) and its quarter of the halo group 8.
+        const int ln = lane & 31, h = lane >> 5;
+        float *xw0 = xs0, *xw1 = xs0 + XWP;
+        const long t_first = (long)(m0 - 7) * a.d + phi0;           // time of row 0
+        for (int i = tid; i < 2 * XWP; i += 256) {
+            const int ci = i >= XWP ? 1 : 0, k = i - ci * XWP;
+            const long t = t_first - 7 + k;
+            (ci ? xw1 : xw0)[k] = (t >= 0 && t < a.L) ? a.x0[((size_t)b * 2 + ci) * a.L + t] : 0.0f;
+        }
+        if (tid < 128) {
+            const float *frow0 = a.film + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+            const float *frow00 = a.film0 + (a.film_rows > 1 ? (size_t)b * 256 : 0);
+            par[tid] = a.shift[tid];
+            par[128 + tid] = frow0[tid];
+            par[256 + tid] = frow0[128 + tid];
+            par[384 + tid] = a.res[tid];
+            par0[tid] = a.shift0[tid];
+            par0[128 + tid] = frow00[tid];
+            par0[256 + tid] = frow00[128 + tid];
+            par0[384 + tid] = a.res0[tid];
+        }
+        __syncthreads();
+        const bf16x8 *const w0p = (const bf16x8 *)a.w0pk + lane;
+        static_assert(!FUSE0 || (R + 31) / 32 == 9, "eight row groups + one halo group");
+#pragma unroll 1
+        for (int q = w; q < 12; q += 4) {
+            const bool halo = q >= 8;                                  // third trip: group 8, one quarter
+            if (halo) q = 8;
+            bf16x8 bh[2], bl[2];
+#pragma unroll
+            for (int sI = 0; sI < 2; ++sI) tcn_block0_bfrag(xw0, xw1, 32 * q + ln, sI, h, bh[sI], bl[sI]);
+            const int o = 32 * q + ln;
+            const long t = t_first + o;
+            const bool inside = t >= 0 && t < a.L;
+#pragma unroll 1
+            for (int cw = halo ? w : 0; cw < (halo ? w + 1 : 4); ++cw) {      // channel quarters (what the four waves of the block-0 kernel do)
+                f32x16 acc0;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x4 sh = *(const f32x4 *)(par0 + 32 * cw + 8 * gq + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc0[4 * gq + i] = sh[i];
+                }
+#pragma unroll
+                for (int sI = 0; sI < 2; ++sI) {
+                    const bf16x8 af = w0p[(sI ? 256 : 0) + 64 * cw];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bh[sI], acc0, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bl[sI], acc0, 0, 0, 0);
+                }
+                const float xres = ((cw >> 1) ? xw1 : xw0)[o + 7];      // grouped residual: channels 0..63 read input 0, 64..127 input 1
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int co0 = 32 * cw + 8 * gq + 4 * h;
+                    const f32x4 fr = *(const f32x4 *)(par0 + 128 + co0);
+                    const f32x4 fb = *(const f32x4 *)(par0 + 256 + co0);
+                    const f32x4 rs = *(const f32x4 *)(par0 + 384 + co0);
+                    bf16x4 out;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) out[i] = inside ? tcn_block0_out(acc0[4 * gq + i], fr[i], fb[i], rs[i], xres) : (__bf16)0.0f;
+                    if (o < R) *(bf16x4 *)(smem + o * 256 + (((co0 >> 3) ^ (o & 15)) << 4) + 8 * h) = out;
+                }
+            }
+        }
+    } else {
         // all (R+15)/16 row loads of a thread are issued back to back (one exposed memory latency per tile;
         // the accumulators are not live yet, so the registers are free), then written to LDS
         // consecutive passes of a thread are 16 / P dilation steps apart in time and 4096 bytes apart in LDS (the XOR

@@ -168,10 +168,11 @@ def test_tcn_bf16_one_tile_class_major_256_time_tiles_emulated(emu_default):
 
 
 def test_tcn_bf16_block0_fused_into_block1_emulated(emu_default):
-    """mst_tcn_set_tuning bit 5 (experimental, off by default): block 0 is not launched, the loader waves of the d = 2 block's duo kernel
-    compute its outputs into the LDS image with tcn_block0_mfma_kernel's arithmetic - the same bits as the separate kernel on every
-    activation and on the waveform.  Several tiles per workgroup (the buffers are refilled), ragged lengths (zero rows on both sides, a last
-    tile mostly outside the segment), segments shorter than a tile, per-item FiLM rows; probes of block 0 alone stay on the separate kernel."""
+    """mst_tcn_set_tuning bit 5 (default): block 0 is not launched - the d = 2 block computes its input rows from the waveform with
+    tcn_block0_mfma_kernel's arithmetic, in the loader waves of the duo kernel (bit 7 off) or in the staging of the one-tile kernel (bit 7, the
+    default since round 6): the same bits as the separate kernel on every activation and on the waveform, in both forms.  Several tiles per
+    workgroup (the duo kernel's buffers are refilled), ragged lengths (zero rows on both sides, a last tile mostly outside the segment), segments
+    shorter than a tile, per-item FiLM rows; probes of block 0 alone stay on the separate kernel."""
     cases = [(4, (2, 2, 777), synth.synth_audio((1, 64), seed=2)),
              (3, (3, 2, 1500), synth.synth_audio((3, 64), seed=11)),
              (3, (2, 2, 41), synth.synth_audio((2, 64), seed=4))]          # (more shapes: tools/emu_sweep_tcn.py --fuse0)
@@ -183,12 +184,16 @@ def test_tcn_bf16_block0_fused_into_block1_emulated(emu_default):
         emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 21), "tuning")
         y0 = m(x, cnd)
         a0 = [m.forward_blocks(x, cnd, n) for n in (1, 2, nb)]
-        emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, 21 | 32), "tuning")
-        y1 = m(x, cnd)
-        a1 = [m.forward_blocks(x, cnd, n) for n in (1, 2, nb)]
-        assert torch.equal(y1, y0), shape
-        for u, v in zip(a0, a1):
-            assert torch.equal(u, v), shape
+        for flags in (21 | 32, 21 | 32 | 128, 21 | 128):          # fused in the duo kernel / in the one-tile kernel; the one-tile kernel unfused
+            emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, flags), "tuning")
+            y1 = m(x, cnd)
+            fl, fused = C.c_int(0), C.c_int(0)
+            emu_default.check(emu_default.mst_tcn_get_tuning(m._handle, C.byref(fl), C.byref(fused)), "get")
+            assert fl.value == flags and fused.value == (1 if flags & 32 else 0)
+            a1 = [m.forward_blocks(x, cnd, n) for n in (1, 2, nb)]
+            assert torch.equal(y1, y0), (shape, flags)
+            for u, v in zip(a0, a1):
+                assert torch.equal(u, v), (shape, flags)
         y_ref = R.tcn_forward(sd, x, cnd, nblocks=nb)
         assert float((y1 - y_ref).abs().max()) <= 4e-2
     # without the class-major duo form there is nothing to fuse into: the flag is ignored, block 0 runs on its own
