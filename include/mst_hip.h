@@ -123,7 +123,7 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
  *                                  bit 4                  1        bf16 duo: class-major main loop                           ~       tap-major loop = the P = 1 path and the GPU test's other side
  *                                  bit 5                  1        bf16: block 0 inside the d = 2 block's launch             =       separate block-0 kernel = probes, other precisions, short segments
  *                                  bit 6                  1        bf16x3: class-major loop in the eight-phase half kernel    ~       other side of a GPU test
- *                                  bit 7                  1        bf16: two- / four-phase class-major blocks, one 256-time   =       the duo kernel is the other side of the bit-identity tests (emulator + GPU
+ *                                  bit 7                  1        bf16: two- / four-phase class-major blocks, one 256-time   =/~     the duo kernel is the other side of the bit-identity tests (emulator + GPU
  *                                                                  tile per workgroup, two workgroups per CU (round 6)                forms 181 / 53) and what bit 7 off selects
  *   mst_enc_set_tuning (handle)    rows_min_tiles         512      bf16: rows-resident conv kernel from this many tiles on    =       small layers run the im2col kernel
  *   mst_enc_set_schedule (handle)  bit 0                  1        weight-major workgroup order of weight-heavy layers        =
@@ -170,7 +170,10 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
  *   the duo loader's arithmetic, bit for bit).  Same box, alternating (profiles/r06_tcn_forms_onetile_ab.txt, r06_tcn_forms_onetile_fuse0_ab.txt):
  *   1.312-1.318 ms per launch against 1.404-1.409 for the duo kernel, the d = 2 launch with block 0 inside 1.47 against 1.56 (a 128-time form at
  *   three workgroups per CU: 1.336-1.338 - it streams every weight fragment twice as often, and under the chip's power limit a tile's energy is
- *   what counts; EXPERIMENTS.md E.6). */
+ *   what counts; EXPERIMENTS.md E.6).  One case is NOT bit-identical to bit 7 off: a LAST block with two / four phases (segments of >= 2^19 samples: d = 8192
+ *   has 64 steps per phase) carries the fused output head and ran the one-tile kernel's tap-major loop; with bit 7 it runs the class-major loop
+ *   (<4, true, 8, 2>: 1.32 against 1.36 ms) - its activation differs by fp32 summation order, the waveform by <= 2e-3 after the bf16 re-rounding
+ *   (profiles/r06_tcn_forms_2p19_segments.txt; both within the bf16 tolerance of the oracle and of the reference's real-audio goldens). */
 int mst_tcn_set_tuning(MstTcn *tcn, int flags);
 /* the flags in force and whether the handle's LAST forward ran block 0 inside block 1's launch (bit 5 is a request: see its conditions above);
  * either pointer may be null. */

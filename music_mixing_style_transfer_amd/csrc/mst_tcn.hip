@@ -348,9 +348,10 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
         // (the last block - fused output head, 32 more live registers - spills in the duo form and runs the one-tile kernel too)
         if constexpr (P == 4) {
             // bit 7 (round 6): the class-major four-phase blocks on the one-tile kernel, 256-time tiles, two workgroups per CU
-            if (!a.y_out && bf16_onetile && bf16_reuse) {
+            if (bf16_onetile && bf16_reuse) {
                 if (grid % 8 == 0) a.xcd_tiles = grid / 8;
-                MST_LAUNCH((tcn_block_bf16_kernel<P, false, 8, 2>), dim3(grid), dim3(256), stream, a);
+                if (a.y_out) MST_LAUNCH((tcn_block_bf16_kernel<P, true, 8, 2>), dim3(grid), dim3(256), stream, a);          // the last block of a long segment: fused head
+                else MST_LAUNCH((tcn_block_bf16_kernel<P, false, 8, 2>), dim3(grid), dim3(256), stream, a);
                 MST_CHECK_LAUNCH("tcn_block_bf16_kernel");
                 return MST_OK;
             }

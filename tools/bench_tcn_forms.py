@@ -41,8 +41,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--forms", default="1,5,21,53")
+    ap.add_argument("--segment", type=int, default=131072, help="segment length (the reference's default is 2^19: --segment 524288 --batch 8)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
+    global SEG
+    SEG = args.segment
     import yaml
     from music_mixing_style_transfer_amd import _lib
     from music_mixing_style_transfer_amd.networks import TCNModel
