@@ -254,7 +254,7 @@ def roofline(block_ms, nb, B, precision, traffic=None, fused0=False):
     flop = TCN_FLOP_PER_SAMPLE_BLOCK * B * SEG_LEN
     achieved = flop / (avg_ms * 1e-3) / 1e12
     out = {"kernel": "%s (dilated 128x128x15 conv + fused BN/LeakyReLU/FiLM/residual)" %
-                     {"bf16": "tcn_block_bf16_kernel<4, false, 8, 2> (10 of the 13 launches, d = 4 ... 2048: four-phase 256-time tiles, class-major main loop, one tile per workgroup, two workgroups per CU; d = 4096 and the last block, d = 8192, the whole-sequence 128-time forms of the same kernel - the last with the fused head; d = 2 + block 0 in one launch of its two-phase form <2, false, 8, 2, true>)",
+                     {"bf16": "tcn_block_bf16_kernel<4, false, 8, 2> (9 of the 13 launches, d = 4 ... 1024: four-phase 256-time tiles, class-major main loop, one tile per workgroup, two workgroups per CU; d = 2048 / 4096 / 8192 - one 256-time tile = a whole phase sequence of 4 x 64 / 8 x 32 / 16 x 16 steps - the unrolled forms <4 | 8 | 16, ., 8, 1> of the same kernel without all-padding tap tiles, the last with the fused head; d = 2 + block 0 in one launch of its two-phase form <2, false, 8, 2, true>)",
                       "fp32": "tcn_block_f32_kernel", "bf16x3": "tcn_block_bf16x3_kernel / _half_kernel"}[precision],
            "bound": "mfma", "achieved": achieved, "peak": PEAK[precision], "unit": "TFLOP/s",
            "frac": achieved / PEAK[precision], "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": len(dense),

@@ -324,7 +324,7 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
     if constexpr (P == 4) {
         // (the same 128-time form for EVERY block - three workgroups per CU instead of the duo kernel - measured 1.53-1.58 ms per launch
         //  against 1.48-1.53: it only wins where the eight-phase tiles' halo is the alternative)
-        if (precision == MST_PREC_BF16 && bf16_small4) {          // 128-time tiles of 4 phases (one-tile kernel, three workgroups per CU)
+        if (precision == MST_PREC_BF16 && bf16_small4 == 1) {          // 128-time tiles of 4 phases (one-tile kernel, three workgroups per CU)
             const long nsteps = ((long)a.L + a.d - 1) / a.d;
             a.tiles_step = (int)((nsteps + 128 / P - 1) / (128 / P));
             const long g2 = (long)a.B * a.tiles_phase * a.tiles_step;
@@ -338,6 +338,22 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
                 MST_LAUNCH((tcn_block_bf16_kernel<P, false, 4, 1>), dim3((unsigned)g2), dim3(256), stream, a);
             else
                 MST_LAUNCH((tcn_block_bf16_kernel<P, false, 4>), dim3((unsigned)g2), dim3(256), stream, a);
+            MST_CHECK_LAUNCH("tcn_block_bf16_kernel");
+            return MST_OK;
+        }
+    }
+    if constexpr (P == 16 || P == 8 || P == 4) {
+        if (precision == MST_PREC_BF16 && bf16_small4 == 3) {          // one 256-time tile = the whole phase sequence (tcn_run checked the shape)
+            a.tiles_step = 1;
+            grid = (int)((long)a.B * a.tiles_phase);
+            if (grid % 8 == 0) a.xcd_tiles = grid / 8;
+            if constexpr (P == 16) {
+                if (a.y_out) MST_LAUNCH((tcn_block_bf16_kernel<P, true, 8, 1>), dim3(grid), dim3(256), stream, a);
+                else MST_LAUNCH((tcn_block_bf16_kernel<P, false, 8, 1>), dim3(grid), dim3(256), stream, a);
+            } else {
+                if (a.y_out) return fail(MST_ERR_STATE, "tcn_block_bf16_kernel: the fused head exists for the sixteen-phase whole-sequence tile only");
+                MST_LAUNCH((tcn_block_bf16_kernel<P, false, 8, 1>), dim3(grid), dim3(256), stream, a);
+            }
             MST_CHECK_LAUNCH("tcn_block_bf16_kernel");
             return MST_OK;
         }
@@ -525,6 +541,19 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
                 bf16_small4 = 1;
             }
         }
+        // bf16 (tuning bit 7), a block whose phase sequences are EXACTLY one 256-time tile - sixteen phases x 16 steps (d = 8192 at L = 131072, the last
+        // block), eight x 32 (d = 4096), four x 64 (d = 2048): the unrolled class-major loop without the all-padding (column tile, tap) pairs, an LDS image
+        // without the halo steps no live row window reaches (256 / 272 / 280 rows), two workgroups per CU
+        if (precision == MST_PREC_BF16 && t->bf16_onetile && t->bf16_reuse && t->bf16_form == 2) {
+            const long ns = ((long)L + d - 1) / d;
+            const int Pw = ns == 16 ? 16 : (ns == 32 ? 8 : (ns == 64 ? 4 : 0));
+            // (with the fused output head - the last block - only the sixteen-phase form fits 256 registers: 248; the other two would spill)
+            const bool head = !act_out && n == t->d.nblocks - 1;
+            if (Pw && d % Pw == 0 && (long)L == ns * d && (!head || Pw == 16)) {
+                P = Pw;
+                bf16_small4 = 3;
+            }
+        }
         TcnBlockArgs a;
         a.x = buf[cur];
         a.y = buf[cur ^ 1];
@@ -566,7 +595,7 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
             case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm, t->bf16_onetile); break;
             case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm, t->bf16_onetile); break;
             case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm, t->bf16_onetile); break;
-            default: rc = launch_block<16>(precision, a, (int)grid, stream, 0, t->bf16_form); break;
+            default: rc = launch_block<16>(precision, a, (int)grid, stream, 0, t->bf16_form, bf16_small4); break;
         }
         if (rc) return rc;
         if (ev) MST_HIP_TRY(hipEventRecord(ev[n + 1], (hipStream_t)stream));

@@ -80,28 +80,67 @@ __device__ __forceinline__ __bf16 tcn_block0_out(float v, float fr, float fb, fl
 // q - 1 = the rows of tap j, column tile q); a class is walked in groups of <= 4 taps ("pseudo-classes": 4 + 4 + 4 + 3 taps at both P)
 // so that a group's A fragments are 32 registers, double-buffered over the 16 phases (pseudo-class x k-step).
 // ------------------------------------------------------------------------------------------------
-template <int P, int NC>
+// H = halo steps kept in the LDS image on either side: 7 (the general image) for the 128-time tiles.  Round 6: 256-time tiles that span their whole
+// phase sequence - sixteen phases x 16 steps (the last block, d = 8192 at L = 131072), eight x 32 (d = 4096), four x 64 (d = 2048) - keep only the
+// 16 / P - 1 halo steps a row window (16 rows = 16 / P steps) can straddle into: windows that are all zero padding are neither staged nor read, the
+// image is 256 / 272 / 280 rows instead of 480 / 368 / 312, and the windows of a pseudo-class are walked over their live range only.
+template <int P, int NC, int H>
+struct tcn_whole_tab {
+    static constexpr int S = 16 / P, MT = 16 * NC / P;
+    static constexpr int j0_of(int pc) { return pc % S + 4 * S * (pc / S); }          // first tap of pseudo-class pc
+    static constexpr int nu_of(int pc) { return pc < 3 ? 4 : 3; }
+    static constexpr int nw_of(int pc) { return NC - 1 + nu_of(pc); }
+    // live window range of a pseudo-class: everything with the full halo; else the windows that reach into the tile's own steps (window i of the
+    // pseudo-class with first tap j0 covers steps j0 + S i - 7 ... + S - 1)
+    static constexpr int cdiv(int a, int b) { return a <= 0 ? 0 : (a + b - 1) / b; }
+    static constexpr int lo_of(int pc) { return H == 7 ? 0 : cdiv(8 - S - j0_of(pc), S); }
+    static constexpr int hi_of(int pc) { return H == 7 ? nw_of(pc) : (cdiv(MT + 7 - j0_of(pc), S) < nw_of(pc) ? cdiv(MT + 7 - j0_of(pc), S) : nw_of(pc)); }
+    static constexpr int cnt_of(int pc) { return hi_of(pc) - lo_of(pc); }
+    // the window sequence as TABLES (built at compile time): with the loop counters of the unrolled main loop as indices the optimiser folds a table
+    // lookup reliably; a search loop per window it did not always fold (a first build of the eight- and four-phase forms ran 25 x slower: 35 ms)
+    struct Seq {
+        int n0[17];                         // windows in front of phase ph = (pseudo-class ph >> 2, k-step ph & 3); n0[16] = all of them
+        int ph[16 * (NC + 3)], i[16 * (NC + 3)];
+    };
+    static constexpr Seq make() {
+        Seq q{};
+        int n = 0;
+        for (int ph = 0; ph < 16; ++ph) {
+            q.n0[ph] = n;
+            for (int i = lo_of(ph >> 2); i < hi_of(ph >> 2); ++i) {
+                q.ph[n] = ph;
+                q.i[n] = i;
+                ++n;
+            }
+        }
+        q.n0[16] = n;
+        return q;
+    }
+    static constexpr Seq seq = make();
+    static constexpr int NWIN = seq.n0[16];
+};
+template <int P, int NC, int H = 7>
 __device__ __forceinline__ void tcn_class_major_whole_tile(f32x4 (&acc)[2][NC], const unsigned char *smem, const MstStream16 &wst, unsigned aoff,
                                                            int l16, int g) {
-    static_assert((P == 4 || P == 8) && NC == 8, "128-time tiles of four / eight phases");
-    constexpr int S = 16 / P, MT = 16 * NC / P, NW4 = NC + 3, NW3 = NC + 2, NWIN = 12 * NW4 + 4 * NW3;
-    auto j0_of = [](int pc) { return pc % S + 4 * S * (pc / S); };          // first tap of pseudo-class pc
-    auto nu_of = [](int pc) { return pc < 3 ? 4 : 3; };
+    static_assert(((P == 4 || P == 8) && NC == 8 && H == 7) || ((P == 16 || P == 8 || P == 4) && NC == 16 && H == 16 / P - 1),
+                  "128-time tiles of four / eight phases with the full halo; 256-time tiles of four / eight / sixteen phases with the straddled halo steps only");
+    using TB = tcn_whole_tab<P, NC, H>;
+    constexpr int S = TB::S, MT = TB::MT, NWIN = TB::NWIN;
     auto dead = [](int q, int j) {          // rows of steps < 0 / >= MT are padding (the tile starts at the first step and ends at the last)
         const int s_lo = (16 * q) / P + j - 7, s_hi = (16 * q + 15) / P + j - 7;
         return s_hi < 0 || s_lo >= MT;
     };
     auto window = [&](int n) -> const unsigned char * {                      // LDS address of this lane's 16 bytes of window n
-        const int ph = n < 12 * NW4 ? n / NW4 : 12 + (n - 12 * NW4) / NW3, i = n < 12 * NW4 ? n % NW4 : (n - 12 * NW4) % NW3;
-        const int row0 = P * j0_of(ph >> 2), kk = ph & 3;
+        const int ph = TB::seq.ph[n], i = TB::seq.i[n];
+        const int row0 = P * TB::j0_of(ph >> 2) - (7 - H) * P, kk = ph & 3;          // ((7 - H) P is a multiple of 16: the swizzle term is that of the full image)
         return smem + (row0 + 16 * i + l16) * 256 + (((4 * kk + g) ^ ((row0 + l16) & 15)) << 4);
     };
     auto load_a = [&](bf16x8 (&A)[4][2], int ph) {
         const int pc = ph >> 2, kk = ph & 3;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (u >= nu_of(pc)) continue;
-            const unsigned so = (unsigned)((j0_of(pc) + S * u) * 4 + kk) * 8192u;
+            if (u >= TB::nu_of(pc)) continue;
+            const unsigned so = (unsigned)((TB::j0_of(pc) + S * u) * 4 + kk) * 8192u;
             A[u][0] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff, so));
             A[u][1] = __builtin_bit_cast(bf16x8, mst_stream_load16(wst, aoff + 4096u, so));
         }
@@ -115,15 +154,15 @@ __device__ __forceinline__ void tcn_class_major_whole_tile(f32x4 (&acc)[2][NC], 
         bf16x8 (&cur)[4][2] = (ph & 1) ? A1 : A0;
         bf16x8 (&nxt)[4][2] = (ph & 1) ? A0 : A1;
         if (ph < 15) load_a(nxt, ph + 1);
-        const int pc = ph >> 2, nw = pc < 3 ? NW4 : NW3, n0 = pc < 3 ? ph * NW4 : 12 * NW4 + (ph - 12) * NW3;
+        const int pc = ph >> 2, n0 = TB::seq.n0[ph], lo = TB::lo_of(pc), hi = TB::hi_of(pc);
 #pragma unroll
-        for (int i = 0; i < nw; ++i) {
-            const int n = n0 + i;
+        for (int i = lo; i < hi; ++i) {
+            const int n = n0 + i - lo;
             const bf16x8 b = ring[n & 3];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int q = i - u, j = j0_of(pc) + S * u;
-                if (u < nu_of(pc) && q >= 0 && q < NC && !dead(q, j)) {
+                const int q = i - u, j = TB::j0_of(pc) + S * u;
+                if (u < TB::nu_of(pc) && q >= 0 && q < NC && !dead(q, j)) {
                     acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u][0], b, acc[0][q], 0, 0, 0);
                     acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[u][1], b, acc[1][q], 0, 0, 0);
                 }
@@ -169,11 +208,13 @@ __device__ __forceinline__ void tcn_reuse_class(f32x4 (&acc)[2][16], bf16x8 (&A0
 // its tile's input rows from the waveform with tcn_block0_mfma_kernel's arithmetic (the duo kernel's FUSE0 loader, same fragments, same MFMA
 // order, same epilogue function: the same bits) instead of fetching them; the other workgroup of the CU runs its main loop meanwhile.
 template <int P, bool FUSE_OUT, int NQ, int WHOLE = 0, bool FUSE0 = false>
-__global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1))) void tcn_block_bf16_kernel(TcnBlockArgs a) {
-    static_assert(WHOLE != 1 || ((P == 8 || P == 4) && NQ == 4), "whole-sequence tiles: 128 times of four / eight phases");
+__global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 || WHOLE == 1 ? 2 : 1))) void tcn_block_bf16_kernel(TcnBlockArgs a) {
+    static_assert(WHOLE != 1 || ((P == 8 || P == 4) && NQ == 4) || ((P == 16 || P == 8 || P == 4) && NQ == 8),
+                  "whole-sequence tiles: 128 times of four / eight phases, 256 times of four / eight / sixteen");
     static_assert(WHOLE != 2 || ((P == 4 || P == 2) && NQ == 8), "class-major 256-time tiles of two / four phases");
     static_assert(!FUSE0 || (P == 2 && NQ == 8 && WHOLE == 2 && !FUSE_OUT), "block 0 is fused into the d = 2 block's two-phase class-major tiles");
-    constexpr int T = 32 * NQ, R = T + 14 * P, MT = T / P, NC = 2 * NQ;
+    constexpr int H = (WHOLE == 1 && NQ == 8) ? 16 / P - 1 : 7;    // halo steps in the LDS image (256-time whole-sequence tiles: only what a row window straddles, tcn_class_major_whole_tile)
+    constexpr int T = 32 * NQ, R = T + 2 * H * P, MT = T / P, NC = 2 * NQ;
     __shared__ __attribute__((aligned(16))) unsigned char smem[R * 256];
     __shared__ __attribute__((aligned(16))) float par[4 * 128];     // shift | FiLM r | FiLM b | res of this block / batch item
     constexpr int XWP = 304;                                         // FUSE0: waveform samples per channel a tile needs (R + 14 = 298), padded
@@ -268,7 +309,7 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
         const int slot = tid & 15, prow = tid >> 4;
         constexpr int NPASS = (R + 15) / 16;
         const long dt = (long)(16 / P) * a.d;
-        long t = (long)(m0 + prow / P - 7) * a.d + phi0 + (prow % P);
+        long t = (long)(m0 + prow / P - H) * a.d + phi0 + (prow % P);
         const __bf16 *src = xb + t * 128 + slot * 8;
         const __bf16 *zsrc = (const __bf16 *)a.zeros + slot * 8;
         bf16x8 v[NPASS];
@@ -381,7 +422,7 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
         };
         // only a tile that spans its WHOLE phase sequence takes the unrolled class-major form (the one-sided forms for a sequence of two
         // tiles - 10 % fewer MFMAs each - were measured slower in the tap-major order: two unrolled 12 KB loops alternating on a CU)
-        if constexpr (WHOLE == 1) tcn_class_major_whole_tile<P, NC>(acc, smem, wst, aoff, l16, g);
+        if constexpr (WHOLE == 1) tcn_class_major_whole_tile<P, NC, H>(acc, smem, wst, aoff, l16, g);
         else if constexpr (WHOLE == 2) {
             constexpr int NCLS = 16 / P, NUMAX = (15 + NCLS - 1) / NCLS;
             bf16x8 A0[NUMAX][2], A1[NUMAX][2], ring[4];
@@ -415,7 +456,7 @@ __global__ __launch_bounds__(256, (NQ == 4 ? (P <= 4 ? 3 : 2) : (P <= 4 ? 2 : 1)
         const int co0 = 32 * w + 16 * m + 4 * g;
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
-            const int row = 16 * q + l16 + 7 * P;
+            const int row = 16 * q + l16 + H * P;
             xin[m][q] = *(const bf16x4 *)(smem + row * 256 + (((co0 >> 3) ^ (row & 15)) << 4) + 2 * (co0 & 7));
         }
     }

@@ -173,6 +173,37 @@ def test_tcn_bf16_one_tile_class_major_256_time_tiles_emulated(emu_default):
     assert emu_default.mst_tcn_set_tuning(m._handle, 256) != 0          # no flag bits beyond bit 7
 
 
+def test_tcn_bf16_whole_sequence_256_time_tiles_emulated(emu_default):
+    """Round 6 (with mst_tcn_set_tuning bit 7): a block whose phase sequences are EXACTLY one 256-time tile - 64 steps (four phases), 32 (eight) or 16
+    (sixteen: d = 2048 / 4096 / 8192 at L = 131072) - runs the unrolled class-major loop on an LDS image that keeps only the halo steps a row window
+    can straddle into (3 / 1 / 0): all-padding windows are neither staged nor read; the sixteen-phase form also with the fused output head (the last
+    block).  At L = 512: d = 8, 16, 32.  The four-phase form sums in the duo kernel's order (bit-identical to bit 7 off); the other two agree with
+    round 5's 128-time forms to accumulation rounding (one bf16 ulp on the activation); all within the bf16 tolerance of the oracle."""
+    for nb, shape, cnd in [(6, (3, 2, 512), synth.synth_audio((3, 64), seed=11)),        # d = 32 is the last block: fused head
+                           (5, (16, 2, 512), synth.synth_audio((1, 64), seed=2))]:      # d = 16 (eight phases) is the last block: its head runs round 5's form
+        m, sd = _tcn(nb)
+        m.precision = "bf16"
+        x = synth.synth_audio(shape, seed=1)
+        col = []
+        y_ref = R.tcn_forward(sd, x, cnd, nblocks=nb, collect=col)
+        m._ensure(emu_default)
+        out = {}
+        for flags in (53, 53 | 128):
+            emu_default.check(emu_default.mst_tcn_set_tuning(m._handle, flags), "tuning")
+            out[flags] = [m(x, cnd)] + [m.forward_blocks(x, cnd, n) for n in range(3, nb + 1)]
+        assert float((out[181][0] - y_ref).abs().max()) <= 4e-2 and float((out[181][0] - out[53][0]).abs().max()) <= 5e-3
+        differs = 0
+        for k, n in enumerate(range(3, nb + 1)):
+            a1, a0, r = out[181][1 + k], out[53][1 + k], col[n - 1]
+            assert float((a1 - r).abs().max()) <= 4e-2 * float(r.abs().max()), n
+            if n <= 4:          # d = 4 (several tiles per sequence), d = 8 (the whole-sequence four-phase tile): the duo kernel's order
+                assert torch.equal(a1, a0), n
+            else:
+                assert float((a1 - a0).abs().max()) <= 2.0 ** -6 * float(a0.abs().max()), n
+                differs += int(not torch.equal(a1, a0))
+        assert differs > 0          # (the other summation order really ran)
+
+
 def test_tcn_bf16_block0_fused_into_block1_emulated(emu_default):
     """mst_tcn_set_tuning bit 5 (default): block 0 is not launched - the d = 2 block computes its input rows from the waveform with
     tcn_block0_mfma_kernel's arithmetic, in the loader waves of the duo kernel (bit 7 off) or in the staging of the one-tile kernel (bit 7, the
