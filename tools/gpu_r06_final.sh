@@ -20,7 +20,7 @@ python tools/rocprof_summary.py "$(find $O/prof_driver -name '*.db' | head -1)" 
 python tools/rocprof_summary.py "$(find $O/prof_bf16 -name '*.db' | head -1)" "bench.py --workload configs1 --precision bf16 --steps 10 --warmup 1: the 10 TIMED steps only (first 1/11 of every kernel's dispatches dropped)" --drop-first 0.0909 > $O/r06_bench_bf16_kernel_stats_timed_steps.txt 2>&1
 FD=$(dirname $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1)); WD=$(dirname $(find $O/pmc_write -name "*counter_collection.csv" | head -1))
 for d in $FD $WD; do f=$(ls $d/*counter_collection.csv | head -1); [ "$f" != "$d/pmc_counter_collection.csv" ] && cp $f $d/pmc_counter_collection.csv; done
-python tools/pmc_traffic.py $FD $WD "tcn_block_bf16_kernel<4, false, 8, 2>" $O/r06_tcn_block_bf16_traffic.json > $O/pmc_traffic.log 2>&1
+python tools/pmc_traffic.py $FD $WD "tcn_block_bf16_kernel<4, false, 8, 2," $O/r06_tcn_block_bf16_traffic.json > $O/pmc_traffic.log 2>&1
 N=4 bash tools/gpu_fx_pmc.sh > $O/fx_pmc.log 2>&1; cp gpurun_out/fx_chain_traffic.json $O/r06_fx_chain_traffic.json
 timeout 200 python tools/bench_fx.py > $O/r06_bench_fx.json 2> $O/bench_fx.err
 cd /tmp; timeout 300 rocprofv3 --kernel-trace --output-format rocpd -d $O/trace_fx -- python $R/tools/bench_fx.py --chain-only 3 > /dev/null 2>&1; cd $R
