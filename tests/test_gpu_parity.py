@@ -178,6 +178,45 @@ def test_tcn_bf16_block_kernel_forms_vs_oracle(nets, form):
         tcn.precision = "fp32"
 
 
+def test_tcn_bf16_whole_sequence_256_time_tiles_vs_oracle(nets):
+    """Round 6 (tuning bit 7): at L = 65536 the blocks d = 1024 / 2048 / 4096 have exactly 64 / 32 / 16 steps per phase - one 256-time tile per phase
+    sequence: the unrolled class-major forms <4 | 8 | 16, false, 8, 1> on their trimmed LDS images (at L = 131072 - the bench - it is d = 2048 / 4096 and
+    the last block with the fused head; tests/test_real_audio.py and test_full_size_against_reference_golden run that).  Against the oracle per block
+    and on the waveform, and against round 5's forms (bit 7 off): the four-phase form and everything in front of it bit for bit, the other two to
+    accumulation rounding; batch items stay independent."""
+    from music_mixing_style_transfer_amd import _lib
+    from music_mixing_style_transfer_amd.utils import synth
+    from oracle import networks_ref as R
+    tcn = nets["tcn"]
+    lib = _lib.lib()
+    x = synth.synth_audio((2, 2, 65536), seed=31)
+    cond = synth.synth_audio((2, 2048), seed=9, amp=0.5).abs()
+    col = []
+    y_ref = R.tcn_forward(nets["tcn_sd"], x, cond, collect=col)
+    tcn.precision = "bf16"
+    try:
+        tcn._ensure(lib)
+        out = {}
+        for form in (53, 181):
+            lib.check(lib.mst_tcn_set_tuning(tcn._handle, form), "mst_tcn_set_tuning")
+            out[form] = [tcn(x.cuda(), cond.cuda()).cpu()] + [tcn.forward_blocks(x.cuda(), cond.cuda(), n).cpu() for n in (10, 11, 12, 13)]
+        y = out[181][0]
+        err = float((y - y_ref).abs().max())
+        print(f"whole-sequence tiles at 2 x 65536: waveform max-abs vs oracle {err:.2e}; vs bit 7 off {float((y - out[53][0]).abs().max()):.2e}")
+        assert err <= 1e-2 and float((y - out[53][0]).abs().max()) <= 5e-3
+        for k, n in enumerate((10, 11, 12, 13)):          # outputs of the blocks d = 512, 1024, 2048, 4096
+            a1, a0, r = out[181][1 + k], out[53][1 + k], col[n - 1]
+            assert float((a1 - r).abs().max()) <= 3e-2 * float(r.abs().max()), n
+            if n <= 11:
+                assert torch.equal(a1, a0), n          # d = 512: generic tiles; d = 1024: the four-phase whole-sequence form - the duo kernel's order
+            else:
+                assert float((a1 - a0).abs().max()) <= 2.0 ** -6 * float(a0.abs().max()), n
+        assert torch.equal(tcn(x[1:2].cuda(), cond[1:2].cuda()).cpu()[0], y[1])
+    finally:
+        lib.check(lib.mst_tcn_set_tuning(tcn._handle, _lib.TCN_TUNING_DEFAULT), "mst_tcn_set_tuning")
+        tcn.precision = "fp32"
+
+
 @pytest.mark.parametrize("B,L", [(2, 16384), (1, 20001)])
 def test_encoder_vs_oracle(nets, B, L):
     from music_mixing_style_transfer_amd.utils import synth
