@@ -173,7 +173,12 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
  *   what counts; EXPERIMENTS.md E.6).  One case is NOT bit-identical to bit 7 off: a LAST block with two / four phases (segments of >= 2^19 samples: d = 8192
  *   has 64 steps per phase) carries the fused output head and ran the one-tile kernel's tap-major loop; with bit 7 it runs the class-major loop
  *   (<4, true, 8, 2>: 1.32 against 1.36 ms) - its activation differs by fp32 summation order, the waveform by <= 2e-3 after the bf16 re-rounding
- *   (profiles/r06_tcn_forms_2p19_segments.txt; both within the bf16 tolerance of the oracle and of the reference's real-audio goldens). */
+ *   (profiles/r06_tcn_forms_2p19_segments.txt; both within the bf16 tolerance of the oracle and of the reference's real-audio goldens).
+ *   Bit 7 also selects, for a block whose phase sequences are EXACTLY one 256-time tile (L = 64 d, 32 d or 16 d: d = 2048 / 4096 / 8192 at L = 131072), the
+ *   unrolled forms <4 | 8 | 16, ., 8, 1>: no all-padding (column tile, tap) pair exists, the LDS image keeps only the halo steps a row window can straddle
+ *   into (280 / 272 / 256 rows), the sixteen-phase form carries the fused head.  The four-phase form sums in the duo kernel's order (bit-identical); the
+ *   other two in another fp32 order than round 5's 128-time forms (one bf16 ulp on the activation).  1.32 -> 1.26, 1.25 -> 1.19, 1.21 -> 1.03 ms
+ *   (profiles/r06_tcn_whole_sequence_256_tiles_ab.txt). */
 int mst_tcn_set_tuning(MstTcn *tcn, int flags);
 /* the flags in force and whether the handle's LAST forward ran block 0 inside block 1's launch (bit 5 is a request: see its conditions above);
  * either pointer may be null. */
