@@ -261,6 +261,10 @@ namespace {
 
 size_t tcn_elem(int precision) { return precision == MST_PREC_BF16 ? 2 : 4; }      // bf16x3 keeps fp32 activations in HBM
 
+// bf16 mode, tile forms that tcn_run picks beside the phase count (launch_block's bf16_tile)
+enum { TILE_DEFAULT = 0,             // 256-time tiles of P phases (128-time at P = 8)
+       TILE_128_FOUR_PHASES = 1,     // 17 ... 32 steps per phase: 128-time tiles of four phases instead of eight, three workgroups per CU
+       TILE_WHOLE_256 = 3 };         // a phase sequence is exactly one 256-time tile (64 / 32 / 16 steps at 4 / 8 / 16 phases): unrolled loop, trimmed halo
 // phases per tile: P | d.  P = 4 with 256-time tiles (78 KB of LDS, 2 workgroups per CU) whenever a tile's 64 steps
 // fit the segment; for larger dilations P = 8 with 128-time tiles (16 steps per tile, 61 KB, still 2 per CU); P = 16
 // (256-time tiles, 16 steps per tile) only for segments with fewer than 16 steps per phase.
@@ -319,12 +323,12 @@ template <int P, int NQ> int launch_block_duo(TcnBlockArgs a, void *stream, int 
 }
 
 template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int grid, void *stream, int x3_small = 0, int bf16_form = 0,
-                                  int bf16_small4 = 0, int bf16_reuse = 0, int x3_half_cm = 0, int bf16_onetile = 0) {
+                                  int bf16_tile = TILE_DEFAULT, int bf16_reuse = 0, int x3_half_cm = 0, int bf16_onetile = 0) {
     TcnBlockArgs a = a0;
     if constexpr (P == 4) {
         // (the same 128-time form for EVERY block - three workgroups per CU instead of the duo kernel - measured 1.53-1.58 ms per launch
         //  against 1.48-1.53: it only wins where the eight-phase tiles' halo is the alternative)
-        if (precision == MST_PREC_BF16 && bf16_small4 == 1) {          // 128-time tiles of 4 phases (one-tile kernel, three workgroups per CU)
+        if (precision == MST_PREC_BF16 && bf16_tile == TILE_128_FOUR_PHASES) {          // 128-time tiles of 4 phases (one-tile kernel, three workgroups per CU)
             const long nsteps = ((long)a.L + a.d - 1) / a.d;
             a.tiles_step = (int)((nsteps + 128 / P - 1) / (128 / P));
             const long g2 = (long)a.B * a.tiles_phase * a.tiles_step;
@@ -343,7 +347,7 @@ template <int P> int launch_block(int precision, const TcnBlockArgs &a0, int gri
         }
     }
     if constexpr (P == 16 || P == 8 || P == 4) {
-        if (precision == MST_PREC_BF16 && bf16_small4 == 3) {          // one 256-time tile = the whole phase sequence (tcn_run checked the shape)
+        if (precision == MST_PREC_BF16 && bf16_tile == TILE_WHOLE_256) {          // one 256-time tile = the whole phase sequence (tcn_run checked the shape)
             a.tiles_step = 1;
             grid = (int)((long)a.B * a.tiles_phase);
             if (grid % 8 == 0) a.xcd_tiles = grid / 8;
@@ -533,12 +537,12 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         const int x3_small = (precision == MST_PREC_BF16X3 && t->x3_small_tiles && P <= 2) ? 1 : 0;
         // bf16, 17 ... 32 steps per phase (d = 4096 at L = 131072): 128-time tiles of FOUR phases x 32 steps (184 rows staged per 128
         // outputs, three workgroups per CU) instead of eight phases x 16 steps (240 rows, two workgroups per CU)
-        int bf16_small4 = 0;
+        int bf16_tile = TILE_DEFAULT;
         if (precision == MST_PREC_BF16 && P == 8) {
             const long ns = ((long)L + d - 1) / d;
             if (ns > 16 && ns <= 32) {
                 P = 4;
-                bf16_small4 = 1;
+                bf16_tile = TILE_128_FOUR_PHASES;
             }
         }
         // bf16 (tuning bit 7), a block whose phase sequences are EXACTLY one 256-time tile - sixteen phases x 16 steps (d = 8192 at L = 131072, the last
@@ -551,7 +555,7 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
             const bool head = !act_out && n == t->d.nblocks - 1;
             if (Pw && d % Pw == 0 && (long)L == ns * d && (!head || Pw == 16)) {
                 P = Pw;
-                bf16_small4 = 3;
+                bf16_tile = TILE_WHOLE_256;
             }
         }
         TcnBlockArgs a;
@@ -591,11 +595,11 @@ int tcn_run(MstTcn *t, const float *x, float *y, float *act_out, int B, int L, i
         if (grid > 0x7fffffffL) return fail(MST_ERR_ARG, "mst_tcn_forward: grid too large");
         int rc;
         switch (P) {
-            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm, t->bf16_onetile); break;
-            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm, t->bf16_onetile); break;
-            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm, t->bf16_onetile); break;
-            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_small4, t->bf16_reuse, t->x3_half_cm, t->bf16_onetile); break;
-            default: rc = launch_block<16>(precision, a, (int)grid, stream, 0, t->bf16_form, bf16_small4); break;
+            case 1: rc = launch_block<1>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_tile, t->bf16_reuse, t->x3_half_cm, t->bf16_onetile); break;
+            case 2: rc = launch_block<2>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_tile, t->bf16_reuse, t->x3_half_cm, t->bf16_onetile); break;
+            case 4: rc = launch_block<4>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_tile, t->bf16_reuse, t->x3_half_cm, t->bf16_onetile); break;
+            case 8: rc = launch_block<8>(precision, a, (int)grid, stream, x3_small, t->bf16_form, bf16_tile, t->bf16_reuse, t->x3_half_cm, t->bf16_onetile); break;
+            default: rc = launch_block<16>(precision, a, (int)grid, stream, 0, t->bf16_form, bf16_tile); break;
         }
         if (rc) return rc;
         if (ev) MST_HIP_TRY(hipEventRecord(ev[n + 1], (hipStream_t)stream));
