@@ -118,7 +118,8 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
  *
  *   where                          bit / field            default  selects                                                  result  why it is still here
  *   mst_tcn_set_tuning (handle)    bit 0                  1        bf16x3: 128-time tiles of <= 2 phases, 2 workgroups / CU   ~       256-time form needed where < 64 steps per phase
- *                                  bits 1-2 = 2           2        bf16: persistent duo kernel (matrix + loader waves)       ~/=     form 0 runs the blocks the duo form cannot (d >= 4096 at 131072, fused head, odd d)
+ *                                  bits 1-2 = 2           2        bf16: 256-time class-major tiles - the one-tile kernel     ~/=     form 0 (tap-major one-tile kernel) runs what neither takes (odd d, short segments) and is
+ *                                                                  with bit 7, else the persistent duo kernel                         the other side of GPU / emulator tests
  *                                  bit 3, form 1          -        (removed kernels: rejected with MST_ERR_ARG)
  *                                  bit 4                  1        bf16 duo: class-major main loop                           ~       tap-major loop = the P = 1 path and the GPU test's other side
  *                                  bit 5                  1        bf16: block 0 inside the d = 2 block's launch             =       separate block-0 kernel = probes, other precisions, short segments
@@ -145,9 +146,10 @@ int mst_tcn_forward_blocks(MstTcn *tcn, const float *x_dev, float *act_dev, int 
  *   4.09 ms per launch, round 4), the 256-time tiles the tap-major one: results agree to fp32 accumulation rounding (~1e-6).
  * bits 1-2 (bf16 mode), form of the dense block kernel - measured at 32 x 131072, profiles/r03_tcn_block_forms_summary.md:
  *   0 tcn_block_bf16_kernel: one tile per workgroup, two workgroups per CU                                              1.49-1.51 ms
- *   2 (default) tcn_block_bf16_duo_kernel for the blocks with 256-time tiles of <= 4 phases (form 0 for the others and for the last
+ *   2 (default) the blocks with 256-time tiles of <= 4 phases on the class-major family: with bit 7 (default since round 6) the one-tile kernel at
+ *     two workgroups per CU (1.28-1.33 ms, see bit 7), else tcn_block_bf16_duo_kernel (form 0 for the others and for the last
  *     block): persistent, one workgroup of 4 matrix waves + 4 loader waves per CU, two tile buffers, the next tile by LDS-DMA and
- *     the previous tile's row stores during the main loop; with bit 4 off bit-identical to form 0                        1.47-1.48 ms
+ *     the previous tile's row stores during the main loop; with bit 4 off bit-identical to form 0                        1.47-1.48 ms (1.40 with bit 4)
  *   (1 was tcn_block_bf16_stream_kernel, 1.67 ms; bit 3 tcn_block_bf16x3_duo_kernel, 5.45-5.6 ms per launch against 4.09: EXPERIMENTS.md)
  * bit 4 (bf16 mode, form 2; default 1): the duo kernel's main loop runs class-major - taps grouped by j mod (16 / phases), every B
  *   fragment read from LDS once per class and k-step and fed to up to eight MFMAs (304 instead of 960 LDS reads per tile at four phases).
