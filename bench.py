@@ -259,6 +259,12 @@ def roofline(block_ms, nb, B, precision, traffic=None, fused0=False):
            "bound": "mfma", "achieved": achieved, "peak": PEAK[precision], "unit": "TFLOP/s",
            "frac": achieved / PEAK[precision], "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": len(dense),
            "flop_per_launch": flop, "per_block_ms": block_ms}
+    if precision == "bf16" and nb == 14 and SEG_LEN == 131072 and len(block_ms) >= 14:
+        # the nine launches d = 4 ... 1024 run the generic tile form and execute every one of the 2.06 TFLOP; d = 2048 / 4096 / 8192 run whole-sequence tiles
+        # that leave out the multiplications by zero padding (3 % / 10 % / 23 % of their MFMAs) - their share of `frac` is algorithmic work not executed
+        gen = block_ms[2:11]                                 # blocks 2 ... 10 = d = 4 ... 1024
+        out["generic_launch_ms"] = sum(gen) / len(gen)
+        out["frac_generic_launches"] = flop / (out["generic_launch_ms"] * 1e-3) / 1e12 / PEAK[precision]
     if MFMA_PER_FLOP[precision] > 1:      # `achieved` / `frac` count ALGORITHMIC flops; the matrix pipe executes three times as many
         out["mfma_flop_per_algorithmic_flop"] = MFMA_PER_FLOP[precision]
         out["mfma_pipe_frac"] = MFMA_PER_FLOP[precision] * achieved / PEAK[precision]
@@ -268,7 +274,7 @@ def roofline(block_ms, nb, B, precision, traffic=None, fused0=False):
 def slim_roofline(rl):
     """The roofline object of the printed line: numbers only (kernel names shortened, per-block times in the details file)."""
     keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_step", "calib_ms", "frac_of_box_mainloop",
-            "calib_sclk_mhz", "sclk_mhz", "power_w", "traffic_source")
+            "calib_sclk_mhz", "sclk_mhz", "power_w", "traffic_source", "generic_launch_ms", "frac_generic_launches")
     out = {"kernel": rl["kernel"].split(" (")[0]}
     for k in keep:
         if k in rl and rl[k] is not None:
